@@ -1,0 +1,170 @@
+# -*- coding: utf-8 -*-
+"""
+Generates the committed golden fixtures under tests/golden/ by executing the
+REFERENCE's own code (read from /root/reference at run time, build container only):
+
+  * wiring goldens: reference architectures.Text2MelGraph / SSRNGraph (mode
+    'synthesize') -> networks.py -> modules.py, executed over the eager stand-in
+    tests/golden/tf_standin.py (torch CPU primitives), driven by a re-statement of
+    the host loop synthesize.py:150-230 (synthesize.py itself is Python-2-only
+    syntax and cannot be imported).  Reduced max_N / max_T, FULL channel widths.
+  * front-end goldens: reference configuration.load_config + data_load.load_data
+    (mode='synthesis') on the transcript fixture tests/golden/test_transcript.csv.
+
+Only small outputs + seeds are stored; weights are regenerated from the seed by
+oracle.ophelia_oracle.random_weights on both sides.
+
+Usage (from the repo root, in the build container):
+    python -B tests/golden/make_golden.py
+"""
+import io
+import json
+import os
+import sys
+import contextlib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+sys.dont_write_bytecode = True
+
+import numpy as np
+
+import tf_standin as tf
+tf.install()
+sys.path.append(REF)          # AFTER the stand-in's directory
+
+from oracle import ophelia_oracle as O     # only for seeded weights / text generation
+
+import configuration as ref_configuration   # reference
+with contextlib.redirect_stdout(io.StringIO()):
+    import architectures as ref_arch         # reference (imports networks, modules, data_load, utils)
+    import data_load as ref_data_load        # reference
+
+
+def build_t2m(hp, L, mels, prev_max, speakers=None):
+    q = [L]
+    if hp.multispeaker:
+        q.append(speakers)
+    q += [mels, prev_max]
+    tf.PLACEHOLDER_QUEUE[:] = q
+    with contextlib.redirect_stdout(io.StringIO()):
+        g = ref_arch.Text2MelGraph(hp, mode='synthesize')
+    assert not tf.PLACEHOLDER_QUEUE
+    return g
+
+
+def build_ssrn(hp, mels, B, speakers=None):
+    q = [np.zeros((B, hp.max_N), np.int32)]
+    if hp.multispeaker:
+        q.append(speakers)
+    q += [mels, np.zeros((B,), np.int32)]
+    tf.PLACEHOLDER_QUEUE[:] = q
+    with contextlib.redirect_stdout(io.StringIO()):
+        g = ref_arch.SSRNGraph(hp, mode='synthesize')
+    return g
+
+
+def run_case(tag, cfg, B, max_N, max_T, wseed, tseed, min_len, max_len, stop, speaker_ix=None):
+    hp = ref_configuration.load_config(os.path.join(REF, "config", cfg))
+    hp.max_N, hp.max_T = max_N, max_T
+    W = O.random_weights(hp, wseed)
+    tf.VARS.clear(); tf.VARS.update(W); tf.REQUESTED[:] = []
+    L = O.random_text(hp, B, tseed, min_len=min_len, max_len=max_len)
+    speakers = None
+    if hp.multispeaker:
+        speakers = (np.ones((B, 1)) * speaker_ix)           # synthesize.py:499-501 (float64 (B,1))
+    ends = np.array([np.where(L[i] == 0)[0][0] for i in range(B)])   # synthesize.py:242-247
+
+    # --- host loop, restating synthesize.py:150-230 around the REFERENCE graph ---
+    Y = np.zeros((B, hp.max_T, hp.n_mels), np.float32)
+    alignments = np.zeros((B, hp.max_N, hp.max_T), np.float32)
+    prev_max = np.zeros((B,), np.int32)
+    endcounts = np.zeros(ends.shape, dtype=int)
+    t_ends = np.ones(ends.shape, dtype=int) * hp.max_T
+    trace = []
+    K = V = Q0 = None
+    steps = 0
+    for j in range(hp.max_T):
+        g = build_t2m(hp, L, Y, prev_max, speakers)
+        if K is None:
+            K, V = np.asarray(g.K).copy(), np.asarray(g.V).copy()
+            Q0 = np.asarray(g.Q).copy()
+        _Y, _max, _al = np.asarray(g.Y), np.asarray(g.max_attentions), np.asarray(g.alignments)
+        Y[:, j, :] = _Y[:, j, :]
+        alignments[:, :, j] = _al[:, :, j]
+        prev_max = _max[:, j].astype(np.int32)
+        trace.append(prev_max.copy())
+        steps += 1
+        reached_end = (_max[:, j] >= ends)
+        endcounts += reached_end
+        for i in range(B):
+            if t_ends[i] == hp.max_T and endcounts[i] >= 1:
+                t_ends[i] = j
+        if stop and (t_ends < hp.max_T).all():
+            break
+    t2m_names = list(tf.REQUESTED)
+    tf.REQUESTED[:] = []
+    g2 = build_ssrn(hp, Y, B, speakers)
+    Z = np.asarray(g2.Z).copy()
+    ssrn_names = list(tf.REQUESTED)
+
+    # attention-logit margin of the golden run: informational (parity through argmax)
+    out = dict(L=L, ends=ends, K=K, V=V, Q_step0=Q0, Y=Y, alignments=alignments,
+               max_attentions_trace=np.array(trace, np.int32), t_ends=np.array(t_ends, np.int32),
+               steps_run=np.int32(steps), Z=Z)
+    if speakers is not None:
+        out["speakers"] = speakers.astype(np.int32)
+    np.savez_compressed(os.path.join(HERE, "wiring_%s.npz" % tag), **out)
+    meta = dict(tag=tag, cfg=cfg, B=B, max_N=max_N, max_T=max_T, weight_seed=wseed, text_seed=tseed,
+                min_len=min_len, max_len=max_len, stop=bool(stop), speaker_ix=speaker_ix,
+                variables=[[n, list(W[n].shape)] for n in t2m_names + ssrn_names],
+                n_params_t2m=int(sum(W[n].size for n in t2m_names)),
+                n_params_ssrn=int(sum(W[n].size for n in ssrn_names)))
+    with open(os.path.join(HERE, "wiring_%s.json" % tag), "w") as f:
+        json.dump(meta, f, indent=1)
+    print(tag, "steps", steps, "t_ends", t_ends.tolist(), "trace[-1]", trace[-1].tolist(),
+          "nvars", len(meta["variables"]), "params", meta["n_params_t2m"], meta["n_params_ssrn"])
+
+
+def frontend_case():
+    """reference load_config + load_data(mode='synthesis') on the fixture transcript."""
+    out = {}
+    for cfg in ("lj_tutorial.cfg", "lj_test.cfg"):
+        hp = ref_configuration.load_config(os.path.join(REF, "config", cfg))
+        hp.test_transcript = os.path.join(HERE, "test_transcript_%s.csv" % cfg.split(".")[0])
+        with contextlib.redirect_stderr(io.StringIO()):
+            ds = ref_data_load.load_data(hp, mode="synthesis")
+        tag = cfg.split(".")[0]
+        out[tag + "_L"] = ds["texts"]
+        out[tag + "_bases"] = np.array([os.path.basename(p)[:-4] for p in ds["fpaths"]])
+        out[tag + "_text_lengths"] = np.array(ds["text_lengths"], np.int32)
+        print(tag, "front-end:", ds["texts"].shape, ds["text_lengths"])
+    # config attribute snapshot (the drop-in config API): every simple-typed attribute
+    snap = {}
+    for cfg in ("lj_tutorial.cfg", "lj_test.cfg", "vctk_01.cfg"):
+        hp = ref_configuration.load_config(os.path.join(REF, "config", cfg))
+        d = {}
+        for k, v in sorted(hp.__dict__.items()):
+            if isinstance(v, (int, float, str, bool, list, dict, type(None))) and "dir" not in k \
+                    and k not in ("transcript", "test_transcript", "waveforms", "logdir", "topworkdir"):
+                d[k] = v
+        snap[cfg] = d
+    with open(os.path.join(HERE, "config_snapshot.json"), "w") as f:
+        json.dump(snap, f, indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(HERE, "frontend.npz"), **out)
+
+
+if __name__ == "__main__":
+    frontend_case()
+    # free-running, no early stop reached within max_T (long texts)
+    run_case("lj_free", "lj_tutorial.cfg", B=2, max_N=24, max_T=16, wseed=11, tseed=12,
+             min_len=18, max_len=23, stop=True)
+    # short texts so that attention reaches `ends`: exercises t_ends / break / zero tail
+    run_case("lj_stop", "lj_tutorial.cfg", B=3, max_N=12, max_T=24, wseed=21, tseed=22,
+             min_len=2, max_len=5, stop=True)
+    # multispeaker (audio_decoder_input) wiring: vctk_01.cfg
+    run_case("vctk_spk", "vctk_01.cfg", B=2, max_N=16, max_T=12, wseed=31, tseed=32,
+             min_len=8, max_len=15, stop=True, speaker_ix=7)

@@ -1,0 +1,72 @@
+"""Pins the oracle (oracle/ophelia_oracle.py) against golden vectors produced by the
+REFERENCE's own graph code (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import load_wiring_case
+from oracle import ophelia_oracle as O
+
+CASES = ["lj_free", "lj_stop", "vctk_spk"]
+TOL = 2e-5   # fp32 reassociation between numpy-BLAS (oracle) and torch (golden primitives)
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_variable_inventory_matches_reference(tag):
+    hp, meta, g = load_wiring_case(tag)
+    mine = O.variable_shapes(hp)
+    ref = {n: tuple(s) for n, s in meta["variables"]}
+    assert set(mine) == set(ref)
+    for n in ref:
+        assert tuple(mine[n]) == ref[n], n
+    t2m = sum(int(np.prod(s)) for n, s in mine.items() if n.startswith("Text2Mel"))
+    ssrn = sum(int(np.prod(s)) for n, s in mine.items() if n.startswith("SSRN"))
+    assert t2m == meta["n_params_t2m"] and ssrn == meta["n_params_ssrn"]
+
+
+def test_param_totals_lj_tutorial():
+    # SURVEY.md Appendix B sanity anchors
+    hp, meta, g = load_wiring_case("lj_free")
+    assert meta["n_params_t2m"] == 23973488 and meta["n_params_ssrn"] == 28410383
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_text_enc(tag):
+    hp, meta, g = load_wiring_case(tag)
+    W = O.random_weights(hp, meta["weight_seed"], scopes=("Text2Mel/TextEnc",))
+    K, V = O.encode_text(hp, W, g["L"])
+    assert np.abs(K - g["K"]).max() < TOL and np.abs(V - g["V"]).max() < TOL
+
+
+@pytest.mark.parametrize("tag", CASES)
+@pytest.mark.parametrize("algo", ["faithful", "incremental"])
+def test_decode_loop(tag, algo):
+    hp, meta, g = load_wiring_case(tag)
+    W = O.random_weights(hp, meta["weight_seed"], scopes=("Text2Mel/Audio",))
+    fn = O.synth_codedtext2mel if algo == "faithful" else O.synth_codedtext2mel_incremental
+    trace = []
+    Y, t_ends, al = fn(hp, W, g["K"], g["V"], g["ends"], speakers=g.get("speakers"),
+                       stop=meta["stop"], trace=trace)
+    assert np.array_equal(np.array(trace), g["max_attentions_trace"])
+    assert t_ends == g["t_ends"].tolist()
+    assert len(trace) == int(g["steps_run"])
+    assert np.abs(Y - g["Y"]).max() < TOL
+    assert np.abs(al - g["alignments"]).max() < TOL
+    # frames after the break step stay zero (synthesize.py:157,225-228)
+    assert not Y[:, len(trace):].any() and not al[:, :, len(trace):].any()
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_ssrn(tag):
+    hp, meta, g = load_wiring_case(tag)
+    W = O.random_weights(hp, meta["weight_seed"], scopes=("SSRN",))
+    Z = O.synth_mel2mag(hp, W, g["Y"])
+    assert Z.shape == g["Z"].shape == (len(g["Y"]), hp.max_T * hp.r, hp.full_dim)
+    assert np.abs(Z - g["Z"]).max() < TOL
+
+
+def test_mask_is_global_over_time():
+    """The reference tiles ONE mask over all query positions (networks.py:311): a
+    per-layer AudioDec cache is NOT equivalent; the exact incremental form must
+    re-evaluate the 84-frame receptive cone under the current prev_max."""
+    hp, meta, g = load_wiring_case("lj_free")
+    assert O.AUDIODEC_LOOKBACK == 2 * (1 + 3 + 9 + 27 + 1 + 1)
