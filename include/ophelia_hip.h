@@ -1,0 +1,165 @@
+/*
+ * ophelia_hip.h -- C ABI of libophelia_hip.so: MI355X (gfx950) implementation of
+ * Ophelia's Text2Mel + SSRN synthesis hot path.
+ *
+ * The reference (CSTR-Edinburgh/ophelia) has no FFI: its de-facto boundary for this
+ * path is the Python API in synthesize.py around an opaque (graph, session) pair.
+ * Every entry point below names the reference interface it replaces (file:line in
+ * the reference tree).  INTEGRATION.md shows the ctypes binding a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; all tensors float32, channels-last (B, T, C), C-contiguous,
+ *     exactly the layouts of the reference placeholders (architectures.py:69-81).
+ *   - caller allocates every host buffer; the library owns all device memory behind
+ *     the opaque handle.  One handle = one GPU = one host thread (the reference is
+ *     single-threaded around one tf.Session).
+ *   - every call returns 0 on success or a negative oph_status; oph_last_error()
+ *     gives the text.  No exceptions, no callbacks.  There is NO CPU fallback: if
+ *     no gfx950 device is usable, oph_create fails.
+ */
+#ifndef OPHELIA_HIP_H
+#define OPHELIA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OPH_ABI_VERSION 1
+
+typedef enum oph_status {
+    OPH_OK = 0,
+    OPH_ERR_INVALID = -1,      /* bad argument / shape mismatch          */
+    OPH_ERR_STATE = -2,        /* call out of order (e.g. weights missing) */
+    OPH_ERR_DEVICE = -3,       /* HIP runtime error                        */
+    OPH_ERR_UNSUPPORTED = -4   /* config outside the supported hot path    */
+} oph_status;
+
+/* Model dimensions = the hyper-parameters the reference graph reads from `hp`
+ * (config/ *.cfg via configuration.py:60-66). */
+typedef struct oph_dims {
+    int32_t vocab;                  /* len(hp.vocab)            networks.py:136  */
+    int32_t e;                      /* hp.e   embedding          lj_tutorial.cfg:71 */
+    int32_t d;                      /* hp.d   Text2Mel hidden    :72 */
+    int32_t c;                      /* hp.c   SSRN hidden        :73 */
+    int32_t n_mels;                 /* hp.n_mels                 :61 */
+    int32_t full_dim;               /* hp.full_dim = n_fft/2+1   :60 */
+    int32_t r;                      /* hp.r   reduction factor (4 or 8) :69 */
+    int32_t max_N;                  /* hp.max_N                  :41 */
+    int32_t max_T;                  /* hp.max_T                  :42 */
+    int32_t attention_win_size;     /* hp.attention_win_size     :74 */
+    int32_t nspeakers;              /* hp.nspeakers (0 if single speaker) vctk_01.cfg:62 */
+    int32_t speaker_embedding_size; /* hp.speaker_embedding_size vctk_01.cfg:63 */
+    int32_t flags;                  /* OPH_FLAG_* */
+} oph_dims;
+
+#define OPH_FLAG_SPK_AUDIO_DECODER_INPUT 1  /* 'audio_decoder_input' in hp.multispeaker (networks.py:381-389) */
+
+/* stop_mode of the decode loop */
+#define OPH_STOP_REFERENCE 0   /* synthesize.py:218-228: break after the step at which all utterances ended */
+#define OPH_STOP_NEVER     1   /* always run max_T steps (fixed-length timed configuration)                 */
+
+typedef struct oph_handle oph_handle;
+
+/* ---- lifetime -------------------------------------------------------------
+ * replaces: Text2MelGraph(hp, mode="synthesize") + SSRNGraph(hp, mode="synthesize")
+ *           + tf.Session()                    (synthesize.py:511,525,536)        */
+int oph_abi_version(void);
+int oph_create(const oph_dims* dims, int device, oph_handle** out);
+int oph_destroy(oph_handle* h);
+const char* oph_last_error(const oph_handle* h);   /* h may be NULL: last create error */
+
+/* ---- weights ----------------------------------------------------------------
+ * replaces: tf.train.Saver(var_list=TRAINABLE_VARIABLES in scope).restore
+ *           (synthesize.py:302-330).  Variables are addressed by the TF variable
+ *           names the reference creates, e.g. "Text2Mel/TextEnc/HC_4/conv1d/kernel"
+ *           (3,512,1024), "SSRN/D_4/conv2d_transpose/kernel" (1,3,Cout,Cin).      */
+int oph_num_weights(const oph_handle* h);
+int oph_weight_info(const oph_handle* h, int index, char* name, int name_cap,
+                    int64_t* shape /*[4]*/, int* rank);
+int oph_set_weight(oph_handle* h, const char* tf_var_name, const float* data,
+                   const int64_t* shape, int rank);
+int oph_finalize_weights(oph_handle* h);   /* repack to kernel layout + upload */
+
+/* ---- the three session calls of the hot path (host buffers in / out) ----------
+ * oph_encode_text   replaces encode_text()          synthesize.py:232-240
+ *     L (B,max_N) int32, spk (B) int32 or NULL  ->  K,V (B,max_N,d)
+ * oph_text2mel      replaces synth_codedtext2mel()  synthesize.py:150-230
+ *     K,V as returned by oph_encode_text (or any (B,max_N,d) arrays), ends (B) int32
+ *     = get_text_lengths(L) (synthesize.py:242-247), spk (B) int32 or NULL
+ *     -> Y (B,max_T,n_mels), t_ends (B) int32, alignments (B,max_N,max_T),
+ *        *steps_run = number of decoder steps executed.  Frames after the break
+ *        step stay 0, as in the reference.
+ * oph_ssrn          replaces one sess.run(g.Z) of synth_mel2mag()  synthesize.py:250-260
+ *     Y (B,T,n_mels) -> Z (B, r*T, full_dim)      (chunking stays in the caller)   */
+int oph_encode_text(oph_handle* h, const int32_t* L, const int32_t* spk, int B,
+                    float* K, float* V);
+int oph_text2mel(oph_handle* h, const float* K, const float* V, const int32_t* ends,
+                 const int32_t* spk, int B, int stop_mode,
+                 float* Y, int32_t* t_ends, float* alignments, int32_t* steps_run);
+int oph_ssrn(oph_handle* h, const float* Y, int B, int T, float* Z);
+
+/* ---- device-resident pipeline (what bench.py times; no PCIe in the timed region)
+ * oph_stage_text copies L / ends / spk into HBM.  oph_run_resident runs
+ * encode_text -> decode loop -> (optionally) SSRN entirely on the device, leaving
+ * K,V,Y,alignments,Z in HBM; oph_fetch_* copy results out afterwards.
+ * oph_decode_steps continues the decode loop of the staged batch over steps
+ * [t_begin, t_end) (multi-GPU global-stop fix-up).                  */
+int oph_stage_text(oph_handle* h, const int32_t* L, const int32_t* ends,
+                   const int32_t* spk, int B);
+int oph_run_resident(oph_handle* h, int stop_mode, int run_ssrn, int32_t* steps_run);
+int oph_decode_steps(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* steps_run);
+int oph_run_ssrn_resident(oph_handle* h);
+int oph_fetch_kv(oph_handle* h, float* K, float* V);
+int oph_fetch_mel(oph_handle* h, float* Y, int32_t* t_ends, float* alignments);
+int oph_fetch_mag(oph_handle* h, float* Z);
+int oph_synchronize(oph_handle* h);
+
+/* ---- measurement helpers (HIP events on the handle's own stream) ---------------- */
+int oph_timer_start(oph_handle* h);
+int oph_timer_stop(oph_handle* h, float* elapsed_ms);      /* synchronises */
+/* Per-kernel-class accounting: when enabled every launch of each kernel class is
+ * bracketed by HIP events on the launch stream.  oph_profile_get returns, for
+ * class index i, its name, number of launches, summed device time, and the summed
+ * ALGORITHMIC bytes and flops of those launches (DESIGN.md gives the formulas).   */
+int oph_profile_enable(oph_handle* h, int on);
+int oph_profile_reset(oph_handle* h);
+int oph_profile_count(const oph_handle* h);
+int oph_profile_get(oph_handle* h, int index, char* name, int name_cap, int64_t* launches,
+                    double* total_ms, double* alg_bytes, double* alg_flops);
+
+/* ---- per-operator entry points (unit parity; host buffers, (B,T,C) fp32) ---------
+ * Same kernels as the model path.  `padding`: 0 = SAME, 1 = CAUSAL.
+ * `act`: 0 none, 1 relu, 2 sigmoid.
+ * oph_op_embed            modules.py:15-44      table (vocab,units), row 0 zeroed at lookup
+ * oph_op_layernorm        modules.py:47-75      eps 1e-12, biased variance
+ * oph_op_conv1d           modules.py:91-146     kernel (size,Cin,Cout)
+ * oph_op_hc               modules.py:148-207    kernel (size,C,2C)
+ * oph_op_conv1d_transpose modules.py:209-258    kernel (1,3,Cout,Cin), stride 2, 'same'
+ * oph_op_attention        networks.py:286-325   monotonic branch; one mask per utterance
+ */
+int oph_op_embed(int device, const int32_t* ids, int64_t n_ids, const float* table,
+                 int vocab, int units, float* out);
+int oph_op_layernorm(int device, const float* x, int64_t rows, int C, const float* gamma,
+                     const float* beta, float* y);
+int oph_op_conv1d(int device, const float* x, int B, int T, int Cin, int Cout, int size, int rate,
+                  int padding, const float* kernel, const float* bias, const float* gamma,
+                  const float* beta, int act, float* y);
+int oph_op_hc(int device, const float* x, int B, int T, int C, int size, int rate, int padding,
+              const float* kernel, const float* bias, const float* gamma1, const float* beta1,
+              const float* gamma2, const float* beta2, float* y);
+int oph_op_conv1d_transpose(int device, const float* x, int B, int T, int Cin, int Cout,
+                            const float* kernel, const float* bias, const float* gamma,
+                            const float* beta, float* y /* (B,2T,Cout) */);
+int oph_op_attention(int device, const float* Q, const float* K, const float* V,
+                     const int32_t* prev_max, int B, int T, int N, int d, int win,
+                     float* R /*(B,T,2d)*/, float* alignments /*(B,N,T)*/,
+                     int64_t* max_attentions /*(B,T)*/);
+const char* oph_op_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPHELIA_HIP_H */

@@ -1,0 +1,119 @@
+"""ctypes binding of libophelia_hip.so (C ABI: include/ophelia_hip.h).
+
+The library is built in-tree by `build()` (hipcc --offload-arch=gfx950) into
+ophelia_amd/lib/.  Loading fails loudly when it is missing: the product path has
+no CPU fallback."""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIBPATH = os.path.join(LIBDIR, "libophelia_hip.so")
+SOURCES = ["oph_kernels.hip", "oph_api.hip"]
+
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+c_f32p = C.POINTER(C.c_float)
+c_f64p = C.POINTER(C.c_double)
+
+
+class OphDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "vocab", "e", "d", "c", "n_mels", "full_dim", "r", "max_N", "max_T",
+        "attention_win_size", "nspeakers", "speaker_embedding_size", "flags")]
+
+
+FLAG_SPK_AUDIO_DECODER_INPUT = 1
+STOP_REFERENCE, STOP_NEVER = 0, 1
+
+# name -> (restype, argtypes); every symbol declared in include/ophelia_hip.h
+SIGNATURES = {
+    "oph_abi_version": (C.c_int, []),
+    "oph_create": (C.c_int, [C.POINTER(OphDims), C.c_int, C.POINTER(C.c_void_p)]),
+    "oph_destroy": (C.c_int, [C.c_void_p]),
+    "oph_last_error": (C.c_char_p, [C.c_void_p]),
+    "oph_num_weights": (C.c_int, [C.c_void_p]),
+    "oph_weight_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, c_i64p, C.POINTER(C.c_int)]),
+    "oph_set_weight": (C.c_int, [C.c_void_p, C.c_char_p, c_f32p, c_i64p, C.c_int]),
+    "oph_finalize_weights": (C.c_int, [C.c_void_p]),
+    "oph_encode_text": (C.c_int, [C.c_void_p, c_i32p, c_i32p, C.c_int, c_f32p, c_f32p]),
+    "oph_text2mel": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_i32p, c_i32p, C.c_int, C.c_int,
+                               c_f32p, c_i32p, c_f32p, c_i32p]),
+    "oph_ssrn": (C.c_int, [C.c_void_p, c_f32p, C.c_int, C.c_int, c_f32p]),
+    "oph_stage_text": (C.c_int, [C.c_void_p, c_i32p, c_i32p, c_i32p, C.c_int]),
+    "oph_run_resident": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_i32p]),
+    "oph_decode_steps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_i32p]),
+    "oph_run_ssrn_resident": (C.c_int, [C.c_void_p]),
+    "oph_fetch_kv": (C.c_int, [C.c_void_p, c_f32p, c_f32p]),
+    "oph_fetch_mel": (C.c_int, [C.c_void_p, c_f32p, c_i32p, c_f32p]),
+    "oph_fetch_mag": (C.c_int, [C.c_void_p, c_f32p]),
+    "oph_synchronize": (C.c_int, [C.c_void_p]),
+    "oph_timer_start": (C.c_int, [C.c_void_p]),
+    "oph_timer_stop": (C.c_int, [C.c_void_p, c_f32p]),
+    "oph_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "oph_profile_reset": (C.c_int, [C.c_void_p]),
+    "oph_profile_count": (C.c_int, [C.c_void_p]),
+    "oph_profile_get": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, c_i64p, c_f64p, c_f64p, c_f64p]),
+    "oph_op_embed": (C.c_int, [C.c_int, c_i32p, C.c_int64, c_f32p, C.c_int, C.c_int, c_f32p]),
+    "oph_op_layernorm": (C.c_int, [C.c_int, c_f32p, C.c_int64, C.c_int, c_f32p, c_f32p, c_f32p]),
+    "oph_op_conv1d": (C.c_int, [C.c_int, c_f32p] + [C.c_int] * 7 + [c_f32p] * 4 + [C.c_int, c_f32p]),
+    "oph_op_hc": (C.c_int, [C.c_int, c_f32p] + [C.c_int] * 6 + [c_f32p] * 7),
+    "oph_op_conv1d_transpose": (C.c_int, [C.c_int, c_f32p] + [C.c_int] * 4 + [c_f32p] * 5),
+    "oph_op_attention": (C.c_int, [C.c_int, c_f32p, c_f32p, c_f32p, c_i32p] + [C.c_int] * 5 + [c_f32p, c_f32p, c_i64p]),
+    "oph_op_last_error": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+class OpheliaHipError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile the HIP extension for gfx950 in-tree (cross-compiles without a GPU)."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "oph_internal.h"),
+                   os.path.join(os.path.dirname(HERE), "include", "ophelia_hip.h")]
+    if os.path.exists(LIBPATH) and all(os.path.getmtime(LIBPATH) >= os.path.getmtime(d) for d in deps):
+        return LIBPATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wno-unused-value", "-Wno-unused-result"] + srcs + ["-o", LIBPATH]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise OpheliaHipError("hipcc failed building libophelia_hip.so")
+    return LIBPATH
+
+
+def load():
+    """Load the shared library and attach prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIBPATH):
+        raise OpheliaHipError(
+            "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)" % LIBPATH)
+    lib = C.CDLL(LIBPATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    if lib.oph_abi_version() != 1:
+        raise OpheliaHipError("ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def fptr(a):
+    return a.ctypes.data_as(c_f32p)
+
+
+def iptr(a):
+    return a.ctypes.data_as(c_i32p)

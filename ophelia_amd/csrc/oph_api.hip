@@ -1,0 +1,1164 @@
+// libophelia_hip.so -- model assembly, weight packing, decode loop and the C ABI
+// (include/ophelia_hip.h).  Mirrors, for the synthesis path only:
+//   networks.py  TextEnc 121-212, AudioEnc 214-284, Attention 286-325, AudioDec 360-435, SSRN 437-537
+//   architectures.py 69-81, 139-142, 188-239 ; synthesize.py 150-260
+// There is no CPU fallback anywhere in this file: every numeric result comes from the
+// HIP kernels in oph_kernels.hip.
+#include "oph_internal.h"
+#include "../../include/ophelia_hip.h"
+
+#include <algorithm>
+#include <climits>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace oph;
+
+static thread_local std::string g_create_error;
+static thread_local std::string g_op_error;
+
+#define HIPCHK(h, expr)                                                                        \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (h)->fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return OPH_ERR_DEVICE;                                                             \
+        }                                                                                      \
+    } while (0)
+
+namespace {
+
+enum Kind { K_CONV = 0, K_HC = 1, K_CONVT = 2 };
+
+struct Layer {
+    std::string scope;
+    int kind = K_CONV;
+    int cin = 0, cout = 0;       // cout = filters (hc: C ; raw conv output has 2C columns)
+    int size = 1, rate = 1;
+    bool causal = false;
+    int act = ACT_NONE;
+    int ccat = 0;                // speaker-embedding channels concatenated to the input (cin includes them)
+    // packed
+    int kc = 0, N = 0, Nalloc = 0, ntaps = 1;
+    int off[3] = {0, 0, 0};
+    float *Wt = nullptr, *bias = nullptr;       // conv / hc ; convT: even phase (taps x[t], x[t-1])
+    float *Wt2 = nullptr;                        // convT odd phase (tap x[t])
+    float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
+};
+
+struct ProfClass {
+    const char* name;
+    long long launches = 0;
+    double bytes = 0, flops = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t used = 0;
+    double ms = 0;
+};
+enum { PC_GEMM = 0, PC_LN, PC_DEC, PC_ATTN_STEP, PC_ATTN_ROWS, PC_EMIT, PC_MISC, PC_COUNT };
+
+}  // namespace
+
+struct oph_handle {
+    oph_dims dm{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool finalized = false;
+    // expected variables (TF names) and host copies
+    std::vector<std::pair<std::string, std::vector<int64_t>>> inventory;
+    std::map<std::string, std::vector<float>> hostw;
+    // networks
+    std::vector<Layer> textenc, audioenc, audiodec, ssrn;
+    float* emb_text = nullptr;       // (vocab, e)
+    float* emb_spk = nullptr;        // (nspeakers, spk_emb)   AudioDec/embed_2
+    std::vector<void*> allocs;
+    // batched workspaces
+    int capB = 0;
+    float *actA = nullptr, *actB = nullptr, *raw = nullptr;
+    size_t act_elems = 0, raw_elems = 0;
+    // staged batch / resident state
+    int B = 0, Bpad = 0;
+    int *d_L = nullptr, *d_ends = nullptr, *d_spk = nullptr, *d_p = nullptr, *d_tends = nullptr, *d_ctl = nullptr;  // ctl[0]=n_ended ctl[1]=stop_after
+    float *KV = nullptr, *Yout = nullptr, *Ytm = nullptr, *align = nullptr, *Z = nullptr;
+    float *Qhist = nullptr, *Rrow = nullptr;
+    std::vector<float*> ae_hist, ae_raw;          // AudioEnc per-layer input history / raw outputs
+    std::vector<float*> ad_raw, ad_xrow;          // AudioDec row chain
+    // AudioDec history cone
+    int n_hc_dec = 0, dec_pre = 0;                // #hc layers, #k=1 layers before them
+    std::vector<std::vector<int>> Hset;           // Hset[h] sorted offsets (>=1) at which hc layer h's INPUT is needed
+    std::vector<int*> d_tab, d_need, d_res;       // per hc layer h<n-1: tables for computing layer h over Hset[h+1]
+    int* d_off0 = nullptr;                        // Hset[0] on device
+    std::vector<float*> cone;                     // cone[h]: [|Hset[h]|][Bpad][256]
+    float *coneR = nullptr, *coneRaw = nullptr, *coneTmp = nullptr;
+    int ldy = 0;
+    // timing
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool profiling = false;
+    ProfClass prof[PC_COUNT];
+
+    void fail(const char* fmt, ...) {
+        char buf[1024];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+    }
+    template <class T>
+    T* dalloc(size_t n) {
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+        hipMemsetAsync(p, 0, std::max<size_t>(n, 1) * sizeof(T), stream);
+        hipStreamSynchronize(stream);     // setup path only; keeps later copies on any stream ordered
+        allocs.push_back(p);
+        return (T*)p;
+    }
+    // ---- profiling brackets
+    void pbegin(int cls) {
+        if (!profiling) return;
+        ProfClass& pc = prof[cls];
+        if (pc.used == pc.ev.size()) {
+            hipEvent_t a, b;
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            pc.ev.emplace_back(a, b);
+        }
+        hipEventRecord(pc.ev[pc.used].first, stream);
+    }
+    void pend(int cls, double bytes, double flops) {
+        ProfClass& pc = prof[cls];
+        pc.launches++;
+        pc.bytes += bytes;
+        pc.flops += flops;
+        if (!profiling) return;
+        hipEventRecord(pc.ev[pc.used].second, stream);
+        pc.used++;
+    }
+};
+
+namespace {
+
+// ------------------------------------------------------------------ network description
+void add_conv(std::vector<Layer>& v, const std::string& scope, int cin, int cout, bool causal, int act, int ccat = 0) {
+    Layer l;
+    l.scope = scope; l.kind = K_CONV; l.cin = cin; l.cout = cout; l.size = 1; l.rate = 1;
+    l.causal = causal; l.act = act; l.ccat = ccat;
+    v.push_back(l);
+}
+void add_hc(std::vector<Layer>& v, const std::string& scope, int c, int size, int rate, bool causal) {
+    Layer l;
+    l.scope = scope; l.kind = K_HC; l.cin = c; l.cout = c; l.size = size; l.rate = rate; l.causal = causal;
+    v.push_back(l);
+}
+std::string sc(const char* net, const char* pfx, int i) {
+    char b[128];
+    snprintf(b, sizeof b, "%s/%s_%d", net, pfx, i);
+    return b;
+}
+
+void build_networks(oph_handle* h) {
+    const oph_dims& m = h->dm;
+    const int d = m.d, c = m.c;
+    {   // TextEnc  networks.py:121-212
+        const char* n = "Text2Mel/TextEnc";
+        int i = 2;                                    // embed_1 handled separately
+        add_conv(h->textenc, sc(n, "C", i++), m.e, 2 * d, false, ACT_RELU);
+        add_conv(h->textenc, sc(n, "C", i++), 2 * d, 2 * d, false, ACT_NONE);
+        for (int o = 0; o < 2; ++o)
+            for (int j = 0, r = 1; j < 4; ++j, r *= 3) add_hc(h->textenc, sc(n, "HC", i++), 2 * d, 3, r, false);
+        for (int o = 0; o < 2; ++o) add_hc(h->textenc, sc(n, "HC", i++), 2 * d, 3, 1, false);
+        for (int o = 0; o < 2; ++o) add_hc(h->textenc, sc(n, "HC", i++), 2 * d, 1, 1, false);
+    }
+    {   // AudioEnc  networks.py:214-284
+        const char* n = "Text2Mel/AudioEnc";
+        int i = 1;
+        add_conv(h->audioenc, sc(n, "C", i++), m.n_mels, d, true, ACT_RELU);
+        add_conv(h->audioenc, sc(n, "C", i++), d, d, true, ACT_RELU);
+        add_conv(h->audioenc, sc(n, "C", i++), d, d, true, ACT_NONE);
+        for (int o = 0; o < 2; ++o)
+            for (int j = 0, r = 1; j < 4; ++j, r *= 3) add_hc(h->audioenc, sc(n, "HC", i++), d, 3, r, true);
+        for (int o = 0; o < 2; ++o) add_hc(h->audioenc, sc(n, "HC", i++), d, 3, 3, true);
+    }
+    {   // AudioDec  networks.py:360-435
+        const char* n = "Text2Mel/AudioDec";
+        int i = 1;
+        add_conv(h->audiodec, sc(n, "C", i++), 2 * d, d, true, ACT_NONE);
+        h->dec_pre = 1;
+        if (m.flags & OPH_FLAG_SPK_AUDIO_DECODER_INPUT) {
+            i++;                                      // embed_2
+            add_conv(h->audiodec, sc(n, "C", i++), d + m.speaker_embedding_size, d, false, ACT_NONE,
+                     m.speaker_embedding_size);
+            h->dec_pre = 2;
+        }
+        for (int j = 0, r = 1; j < 4; ++j, r *= 3) add_hc(h->audiodec, sc(n, "HC", i++), d, 3, r, true);
+        for (int o = 0; o < 2; ++o) add_hc(h->audiodec, sc(n, "HC", i++), d, 3, 1, true);
+        h->n_hc_dec = 6;
+        for (int o = 0; o < 3; ++o) add_conv(h->audiodec, sc(n, "C", i++), d, d, true, ACT_RELU);
+        add_conv(h->audiodec, sc(n, "C", i++), d, m.n_mels, true, ACT_NONE);   // sigmoid applied by emit (squash_output_t2m)
+    }
+    {   // SSRN  networks.py:437-537
+        const char* n = "SSRN";
+        int i = 1;
+        add_conv(h->ssrn, sc(n, "C", i++), m.n_mels, c, false, ACT_NONE);
+        for (int j = 0, r = 1; j < 2; ++j, r *= 3) add_hc(h->ssrn, sc(n, "HC", i++), c, 3, r, false);
+        const int ntr = m.r == 4 ? 2 : 3;
+        for (int o = 0; o < ntr; ++o) {
+            Layer l;
+            l.scope = sc(n, "D", i++); l.kind = K_CONVT; l.cin = c; l.cout = c; l.size = 3;
+            h->ssrn.push_back(l);
+            for (int j = 0, r = 1; j < 2; ++j, r *= 3) add_hc(h->ssrn, sc(n, "HC", i++), c, 3, r, false);
+        }
+        add_conv(h->ssrn, sc(n, "C", i++), c, 2 * c, false, ACT_NONE);
+        for (int o = 0; o < 2; ++o) add_hc(h->ssrn, sc(n, "HC", i++), 2 * c, 3, 1, false);
+        add_conv(h->ssrn, sc(n, "C", i++), 2 * c, m.full_dim, false, ACT_NONE);
+        for (int o = 0; o < 2; ++o) add_conv(h->ssrn, sc(n, "C", i++), m.full_dim, m.full_dim, false, ACT_RELU);
+        add_conv(h->ssrn, sc(n, "C", i++), m.full_dim, m.full_dim, false, ACT_SIGMOID);   // squash_output_ssrn
+    }
+    // inventory of TF variables, in graph-creation order
+    auto inv = [&](const std::string& name, std::vector<int64_t> shp) { h->inventory.emplace_back(name, shp); };
+    auto inv_layers = [&](const std::vector<Layer>& v) {
+        for (const Layer& l : v) {
+            if (l.kind == K_CONV) {
+                inv(l.scope + "/conv1d/kernel", {1, l.cin, l.cout});
+                inv(l.scope + "/conv1d/bias", {l.cout});
+                inv(l.scope + "/normalize/beta", {l.cout});
+                inv(l.scope + "/normalize/gamma", {l.cout});
+            } else if (l.kind == K_HC) {
+                inv(l.scope + "/conv1d/kernel", {l.size, l.cin, 2 * l.cout});
+                inv(l.scope + "/conv1d/bias", {2 * l.cout});
+                inv(l.scope + "/H1/beta", {l.cout});
+                inv(l.scope + "/H1/gamma", {l.cout});
+                inv(l.scope + "/H2/beta", {l.cout});
+                inv(l.scope + "/H2/gamma", {l.cout});
+            } else {
+                inv(l.scope + "/conv2d_transpose/kernel", {1, 3, l.cout, l.cin});
+                inv(l.scope + "/conv2d_transpose/bias", {l.cout});
+                inv(l.scope + "/normalize/beta", {l.cout});
+                inv(l.scope + "/normalize/gamma", {l.cout});
+            }
+        }
+    };
+    inv("Text2Mel/TextEnc/embed_1/lookup_table", {m.vocab, m.e});
+    inv_layers(h->textenc);
+    inv_layers(h->audioenc);
+    if (m.flags & OPH_FLAG_SPK_AUDIO_DECODER_INPUT) {
+        // creation order inside AudioDec: C_1, embed_2, C_3, ...
+        std::vector<Layer> first(h->audiodec.begin(), h->audiodec.begin() + 1), rest(h->audiodec.begin() + 1, h->audiodec.end());
+        inv_layers(first);
+        inv("Text2Mel/AudioDec/embed_2/lookup_table", {m.nspeakers, m.speaker_embedding_size});
+        inv_layers(rest);
+    } else {
+        inv_layers(h->audiodec);
+    }
+    inv_layers(h->ssrn);
+}
+
+// ------------------------------------------------------------------ weight packing
+const std::vector<float>* getw(oph_handle* h, const std::string& name) {
+    auto it = h->hostw.find(name);
+    return it == h->hostw.end() ? nullptr : &it->second;
+}
+
+float* upload(oph_handle* h, const std::vector<float>& v) {
+    float* p = h->dalloc<float>(v.size());
+    if (p) hipMemcpyAsync(p, v.data(), v.size() * 4, hipMemcpyHostToDevice, h->stream);
+    hipStreamSynchronize(h->stream);     // host vector may be a temporary
+    return p;
+}
+float* upload_padded(oph_handle* h, const std::vector<float>& v, int padto) {
+    std::vector<float> t((size_t)round_up((int)v.size(), padto), 0.f);
+    std::copy(v.begin(), v.end(), t.begin());
+    return upload(h, t);
+}
+
+// conv kernel (size, cin, cout) -> Wt[Nalloc][size*kc], k contiguous; tap order = kernel order
+std::vector<float> pack_conv(const float* k, int size, int cin, int cout, int kc, int Nalloc) {
+    std::vector<float> w((size_t)Nalloc * size * kc, 0.f);
+    for (int t = 0; t < size; ++t)
+        for (int c = 0; c < cin; ++c) {
+            const float* src = k + ((size_t)t * cin + c) * cout;
+            for (int n = 0; n < cout; ++n) w[(size_t)n * size * kc + (size_t)t * kc + c] = src[n];
+        }
+    return w;
+}
+
+int pack_layer(oph_handle* h, Layer& l) {
+    l.kc = round_up(l.cin, 32);
+    if (l.kind == K_CONVT) {
+        // [TF-sem] o[2t] = x[t].Kt[0,0]^T + x[t-1].Kt[0,2]^T ; o[2t+1] = x[t].Kt[0,1]^T   (modules.py:242-250)
+        const std::vector<float>& kt = *getw(h, l.scope + "/conv2d_transpose/kernel");   // (1,3,cout,cin)
+        l.N = l.cout; l.Nalloc = round_up(l.N, 128); l.ntaps = 2; l.off[0] = 0; l.off[1] = -1;
+        std::vector<float> we((size_t)l.Nalloc * 2 * l.kc, 0.f), wo((size_t)l.Nalloc * l.kc, 0.f);
+        for (int n = 0; n < l.cout; ++n)
+            for (int c = 0; c < l.cin; ++c) {
+                we[(size_t)n * 2 * l.kc + c] = kt[((size_t)0 * l.cout + n) * l.cin + c];
+                we[(size_t)n * 2 * l.kc + l.kc + c] = kt[((size_t)2 * l.cout + n) * l.cin + c];
+                wo[(size_t)n * l.kc + c] = kt[((size_t)1 * l.cout + n) * l.cin + c];
+            }
+        l.Wt = upload(h, we);
+        l.Wt2 = upload(h, wo);
+        l.bias = upload_padded(h, *getw(h, l.scope + "/conv2d_transpose/bias"), l.Nalloc);
+        l.g1 = upload_padded(h, *getw(h, l.scope + "/normalize/gamma"), 256);
+        l.b1 = upload_padded(h, *getw(h, l.scope + "/normalize/beta"), 256);
+        return (l.Wt && l.Wt2 && l.bias && l.g1 && l.b1) ? 0 : -1;
+    }
+    l.N = l.kind == K_HC ? 2 * l.cout : l.cout;
+    l.Nalloc = round_up(l.N, 128);
+    l.ntaps = l.size;
+    for (int t = 0; t < l.size; ++t)   // causal: x[t-(size-1-k)*rate] (modules.py:123-127); SAME: centred [TF-sem]
+        l.off[t] = l.causal ? -(l.size - 1 - t) * l.rate : (t - (l.size - 1) / 2) * l.rate;
+    const std::vector<float>& k = *getw(h, l.scope + "/conv1d/kernel");
+    l.Wt = upload(h, pack_conv(k.data(), l.size, l.cin, l.N, l.kc, l.Nalloc));
+    l.bias = upload_padded(h, *getw(h, l.scope + "/conv1d/bias"), l.Nalloc);
+    if (l.kind == K_HC) {
+        l.g1 = upload_padded(h, *getw(h, l.scope + "/H1/gamma"), 256);
+        l.b1 = upload_padded(h, *getw(h, l.scope + "/H1/beta"), 256);
+        l.g2 = upload_padded(h, *getw(h, l.scope + "/H2/gamma"), 256);
+        l.b2 = upload_padded(h, *getw(h, l.scope + "/H2/beta"), 256);
+        if (!l.g2 || !l.b2) return -1;
+    } else {
+        l.g1 = upload_padded(h, *getw(h, l.scope + "/normalize/gamma"), 256);
+        l.b1 = upload_padded(h, *getw(h, l.scope + "/normalize/beta"), 256);
+    }
+    return (l.Wt && l.bias && l.g1 && l.b1) ? 0 : -1;
+}
+
+// ------------------------------------------------------------------ launch wrappers with accounting
+void run_gemm(oph_handle* h, const GemmArgs& a, int cin_true) {
+    h->pbegin(PC_GEMM);
+    launch_conv_gemm(a, h->stream);
+    const double K = (double)a.ntaps * cin_true;
+    h->pend(PC_GEMM, ((double)a.M * cin_true + (double)a.M * a.N + (double)a.N * K) * 4.0, 2.0 * a.M * a.N * K);
+}
+void run_epi(oph_handle* h, const EpiArgs& a) {
+    h->pbegin(PC_LN);
+    launch_epilogue(a, h->stream);
+    const double cols = a.mode == PRE_HC ? 4.0 * a.C : 2.0 * a.C;    // read raw (+res), write out
+    h->pend(PC_LN, (double)a.M * cols * 4.0, (double)a.M * a.C * 10.0);
+}
+void run_dec(oph_handle* h, const DecArgs& a, const Layer& l) {
+    h->pbegin(PC_DEC);
+    launch_dec_layer(a, round_up(l.N, 16), h->stream);
+    const double K = (double)l.ntaps * l.cin;
+    h->pend(PC_DEC, ((double)l.N * K + (double)a.B * (K + l.N)) * 4.0, 2.0 * a.B * l.N * K);
+}
+
+// ------------------------------------------------------------------ batched networks (TextEnc, SSRN, ops)
+// Runs `layers` over dense rows (B utterances x T frames).  in: [B*T][ld_in] padded rows.
+// final_out/final_ld: where the LAST layer's epilogue writes (e.g. Z with ld = full_dim).
+// Returns pointer to the final activation rows and their ld via *out_ld; rows via *out_rows.
+float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, int ld_in, int B, int T,
+                   float* final_out, int final_ld, int final_pad, int* out_ld, long long* out_rows) {
+    float* x = in;
+    int ldx = ld_in;
+    int Tcur = T;
+    float* bufs[2] = {h->actA, h->actB};
+    int flip = (in == h->actA) ? 1 : 0;
+    for (size_t li = 0; li < layers.size(); ++li) {
+        const Layer& l = layers[li];
+        const bool last = li + 1 == layers.size();
+        const int M = B * Tcur;
+        float* y = (last && final_out) ? final_out : bufs[flip];
+        const int cout_pad = round_up(l.cout, 32);
+        const int ldy = (last && final_out) ? final_ld : cout_pad;
+        const int ypad = (last && final_out) ? final_pad : cout_pad;
+        GemmArgs g{};
+        g.X = x; g.ldx = ldx; g.bias = l.bias; g.H = h->raw; g.kc = l.kc; g.mode = 0; g.T = Tcur;
+        g.stop_after = nullptr;
+        EpiArgs e{};
+        e.g1 = l.g1; e.b1 = l.b1; e.g2 = l.g2; e.b2 = l.b2; e.act = l.act; e.Y = y; e.ldy = ldy; e.ypad = ypad;
+        e.H = h->raw; e.stop_after = nullptr;
+        if (l.kind == K_CONVT) {
+            // even rows: taps (x[t], x[t-1]); odd rows: tap x[t]; raw rows interleaved 2t / 2t+1
+            g.N = l.N; g.ldh = 2 * l.Nalloc; g.M = M;
+            g.Wt = l.Wt; g.ldw = 2 * l.kc; g.ntaps = 2; g.off[0] = 0; g.off[1] = -1;
+            run_gemm(h, g, l.cin);
+            g.Wt = l.Wt2; g.ldw = l.kc; g.ntaps = 1; g.off[0] = 0; g.H = h->raw + l.Nalloc;
+            run_gemm(h, g, l.cin);
+            Tcur *= 2;
+            e.ldh = l.Nalloc; e.M = B * Tcur; e.C = l.cout; e.mode = PRE_CONV; e.act = ACT_NONE;
+            run_epi(h, e);
+        } else {
+            g.N = l.N; g.ldh = l.Nalloc; g.M = M; g.Wt = l.Wt; g.ldw = l.ntaps * l.kc; g.ntaps = l.ntaps;
+            for (int t = 0; t < 3; ++t) g.off[t] = l.off[t];
+            run_gemm(h, g, l.cin);
+            e.ldh = l.Nalloc; e.M = M; e.C = l.cout;
+            if (l.kind == K_HC) { e.mode = PRE_HC; e.Xres = x; e.ldres = ldx; }
+            else e.mode = PRE_CONV;
+            run_epi(h, e);
+        }
+        x = y; ldx = ldy;
+        flip ^= 1;
+    }
+    if (out_ld) *out_ld = ldx;
+    if (out_rows) *out_rows = (long long)B * Tcur;
+    return x;
+}
+
+int ensure_batched_capacity(oph_handle* h, int B) {
+    if (B <= h->capB) return 0;
+    const oph_dims& m = h->dm;
+    const long long rows_ssrn = (long long)B * m.max_T * m.r, rows_text = (long long)B * m.max_N;
+    const long long rows = std::max(rows_ssrn, rows_text);
+    const int ld_act = round_up(std::max({2 * m.c, m.full_dim, 2 * m.d}), 32);
+    const int ld_raw = round_up(std::max({4 * m.c, m.full_dim, 4 * m.d}), 128);
+    h->act_elems = (size_t)rows * ld_act;
+    h->raw_elems = (size_t)rows * ld_raw;
+    h->actA = h->dalloc<float>(h->act_elems);
+    h->actB = h->dalloc<float>(h->act_elems);
+    h->raw = h->dalloc<float>(h->raw_elems);
+    if (!h->actA || !h->actB || !h->raw) { h->fail("out of device memory for batch %d", B); return OPH_ERR_DEVICE; }
+    h->capB = B;
+    return 0;
+}
+
+// ------------------------------------------------------------------ decoder state
+int idx_of(const std::vector<int>& v, int x) {
+    auto it = std::lower_bound(v.begin(), v.end(), x);
+    return (it != v.end() && *it == x) ? (int)(it - v.begin()) : -1;
+}
+
+int ensure_decode_state(oph_handle* h, int B) {
+    const int Bpad = round_up(B, 16);
+    if (h->Bpad == Bpad && h->KV) { h->B = B; return 0; }
+    if (h->KV) { h->fail("batch size changed from %d to %d rows: create a new handle", h->Bpad, Bpad); return OPH_ERR_STATE; }
+    const oph_dims& m = h->dm;
+    const int d = m.d;
+    h->B = B; h->Bpad = Bpad;
+    h->ldy = round_up(m.n_mels, 32);
+    h->d_L = h->dalloc<int>((size_t)Bpad * m.max_N);
+    h->d_ends = h->dalloc<int>(Bpad);
+    h->d_spk = h->dalloc<int>(Bpad);
+    h->d_p = h->dalloc<int>(2 * Bpad);
+    h->d_tends = h->dalloc<int>(Bpad);
+    h->d_ctl = h->dalloc<int>(4);
+    h->KV = h->dalloc<float>((size_t)Bpad * m.max_N * 2 * d);
+    h->Yout = h->dalloc<float>((size_t)Bpad * m.max_T * h->ldy);
+    h->Ytm = h->dalloc<float>((size_t)(m.max_T + 1) * Bpad * h->ldy);
+    h->align = h->dalloc<float>((size_t)Bpad * m.max_N * m.max_T);
+    h->Z = h->dalloc<float>((size_t)Bpad * m.max_T * m.r * m.full_dim);
+    h->Qhist = h->dalloc<float>((size_t)m.max_T * Bpad * d);
+    h->Rrow = h->dalloc<float>((size_t)Bpad * 2 * d);
+    for (const Layer& l : h->audioenc) {
+        h->ae_hist.push_back(l.kind == K_HC ? h->dalloc<float>((size_t)m.max_T * Bpad * l.kc) : nullptr);
+        h->ae_raw.push_back(h->dalloc<float>((size_t)Bpad * l.Nalloc));
+    }
+    for (const Layer& l : h->audiodec) {
+        h->ad_raw.push_back(h->dalloc<float>((size_t)Bpad * l.Nalloc));
+        h->ad_xrow.push_back(l.kind == K_HC ? h->dalloc<float>((size_t)Bpad * l.kc) : nullptr);
+    }
+    // ---- history cone position sets (offsets back from the current step)
+    const int nh = h->n_hc_dec, pre = h->dec_pre;
+    std::vector<std::vector<int>> I(nh);
+    for (int k = nh - 1; k >= 0; --k) {
+        const int r = h->audiodec[pre + k].rate;
+        std::vector<int> outs = (k == nh - 1) ? std::vector<int>{0} : I[k + 1];
+        std::vector<int> s;
+        for (int o : outs) { s.push_back(o); s.push_back(o + r); s.push_back(o + 2 * r); }
+        std::sort(s.begin(), s.end());
+        s.erase(std::unique(s.begin(), s.end()), s.end());
+        I[k] = s;
+    }
+    h->Hset.assign(nh, {});
+    for (int k = 0; k < nh; ++k)
+        for (int o : I[k]) if (o >= 1) h->Hset[k].push_back(o);
+    h->d_off0 = h->dalloc<int>(h->Hset[0].size());
+    hipMemcpyAsync(h->d_off0, h->Hset[0].data(), h->Hset[0].size() * 4, hipMemcpyHostToDevice, h->stream);
+    hipStreamSynchronize(h->stream);
+    size_t maxrows = h->Hset[0].size();
+    for (int k = 0; k < nh; ++k) {
+        h->cone.push_back(h->dalloc<float>(h->Hset[k].size() * Bpad * (size_t)h->audiodec[pre + k].kc));
+        if (k + 1 < nh) {
+            // hc layer k evaluated at output offsets Hset[k+1]: taps (oldest first) read Hset[k]
+            const int r = h->audiodec[pre + k].rate, n_out = (int)h->Hset[k + 1].size();
+            std::vector<int> tab(3 * n_out), need(3 * n_out), res(n_out);
+            for (int i = 0; i < n_out; ++i) {
+                const int o = h->Hset[k + 1][i];
+                for (int t = 0; t < 3; ++t) {
+                    const int so = o + (2 - t) * r;
+                    tab[t * n_out + i] = idx_of(h->Hset[k], so);
+                    need[t * n_out + i] = so;
+                    if (tab[t * n_out + i] < 0) { h->fail("internal: cone table hole"); return OPH_ERR_STATE; }
+                }
+                res[i] = idx_of(h->Hset[k], o);
+            }
+            int* dt = h->dalloc<int>(tab.size()); int* dn = h->dalloc<int>(need.size()); int* dr = h->dalloc<int>(res.size());
+            hipMemcpyAsync(dt, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, h->stream);
+            hipMemcpyAsync(dn, need.data(), need.size() * 4, hipMemcpyHostToDevice, h->stream);
+            hipMemcpyAsync(dr, res.data(), res.size() * 4, hipMemcpyHostToDevice, h->stream);
+            hipStreamSynchronize(h->stream);
+            h->d_tab.push_back(dt); h->d_need.push_back(dn); h->d_res.push_back(dr);
+        }
+    }
+    const int ld_cat = round_up(d + m.speaker_embedding_size, 32);
+    h->coneR = h->dalloc<float>(maxrows * Bpad * 2 * d);
+    h->coneRaw = h->dalloc<float>(maxrows * Bpad * (size_t)round_up(2 * d, 128));
+    h->coneTmp = h->dalloc<float>(maxrows * Bpad * (size_t)ld_cat);
+    hipStreamSynchronize(h->stream);
+    if (!h->coneTmp || !h->Z) { h->fail("out of device memory for decode state"); return OPH_ERR_DEVICE; }
+    return ensure_batched_capacity(h, B);
+}
+
+// reset per-utterance decode state (synthesize.py:157-166)
+void reset_decode(oph_handle* h) {
+    const oph_dims& m = h->dm;
+    hipMemsetAsync(h->d_p, 0, 2 * h->Bpad * 4, h->stream);
+    hipMemsetAsync(h->Yout, 0, (size_t)h->Bpad * m.max_T * h->ldy * 4, h->stream);
+    hipMemsetAsync(h->Ytm, 0, (size_t)(m.max_T + 1) * h->Bpad * h->ldy * 4, h->stream);
+    hipMemsetAsync(h->align, 0, (size_t)h->Bpad * m.max_N * m.max_T * 4, h->stream);
+    launch_fill_int(h->d_tends, m.max_T, h->Bpad, h->stream);
+    const int ctl[4] = {0, INT_MAX, 0, 0};
+    hipMemcpyAsync(h->d_ctl, ctl, sizeof ctl, hipMemcpyHostToDevice, h->stream);
+    hipStreamSynchronize(h->stream);
+}
+
+// one decoder step t (all launches on h->stream)
+void decode_step(oph_handle* h, int t, int stop_mode) {
+    const oph_dims& m = h->dm;
+    const int d = m.d, Bpad = h->Bpad, B = h->B;
+    int* stop_after = h->d_ctl + 1;
+    // ---------------- AudioEnc, incremental (causal, mask-free => cacheable)
+    const Layer* prev = nullptr;
+    const float* prev_raw = nullptr;
+    const float* prev_x = nullptr;    // previous layer's input rows at time t (highway residual)
+    for (size_t li = 0; li < h->audioenc.size(); ++li) {
+        const Layer& l = h->audioenc[li];
+        DecArgs a{};
+        if (li == 0) { a.pre = PRE_COPY; a.src = h->Ytm + (size_t)t * Bpad * h->ldy; a.ldsrc = h->ldy; a.cin = m.n_mels; }
+        else if (prev->kind == K_CONV) { a.pre = PRE_CONV; a.src = prev_raw; a.ldsrc = prev->Nalloc; a.g1 = prev->g1; a.b1 = prev->b1; a.act = prev->act; a.cin = prev->cout; }
+        else { a.pre = PRE_HC; a.src = prev_raw; a.ldsrc = prev->Nalloc; a.g1 = prev->g1; a.b1 = prev->b1; a.g2 = prev->g2; a.b2 = prev->b2; a.xres = prev_x; a.ldres = prev->kc; a.cin = prev->cout; }
+        a.ntaps = l.ntaps; a.kc = l.kc;
+        if (l.kind == K_HC) {
+            float* hist = h->ae_hist[li];
+            a.xstore = hist + (size_t)t * Bpad * l.kc; a.ldstore = l.kc; a.ldtap = l.kc;
+            const int o0 = -l.off[0], o1 = -l.off[1];
+            a.tap0 = t - o0 >= 0 ? hist + (size_t)(t - o0) * Bpad * l.kc : nullptr;
+            a.tap1 = t - o1 >= 0 ? hist + (size_t)(t - o1) * Bpad * l.kc : nullptr;
+        }
+        a.Wt = l.Wt; a.ldw = l.ntaps * l.kc; a.bias = l.bias; a.H = h->ae_raw[li]; a.ldh = l.Nalloc; a.B = B;
+        a.stop_after = stop_after; a.t = t;
+        run_dec(h, a, l);
+        prev = &l; prev_raw = h->ae_raw[li];
+        prev_x = l.kind == K_HC ? h->ae_hist[li] + (size_t)t * Bpad * l.kc : nullptr;
+    }
+    // ---------------- attention at row t (networks.py:286-325) + bookkeeping (synthesize.py:204-228)
+    {
+        AttnStepArgs a{};
+        a.hraw = prev_raw; a.ldh = prev->Nalloc; a.g1 = prev->g1; a.b1 = prev->b1; a.g2 = prev->g2; a.b2 = prev->b2;
+        a.xres = prev_x; a.ldres = prev->kc;
+        a.KV = h->KV; a.N = m.max_N; a.d = d; a.win = m.attention_win_size; a.B = B; a.Bpad = Bpad; a.max_T = m.max_T; a.t = t;
+        a.pcur = h->d_p + (t & 1) * Bpad; a.pnext = h->d_p + ((t + 1) & 1) * Bpad;
+        a.ends = h->d_ends; a.t_ends = h->d_tends; a.n_ended = h->d_ctl; a.stop_after = stop_after; a.stop_mode = stop_mode;
+        a.Qhist = h->Qhist; a.Rrow = h->Rrow; a.ldr = 2 * d; a.align = h->align;
+        h->pbegin(PC_ATTN_STEP);
+        launch_attn_step(a, h->stream);
+        h->pend(PC_ATTN_STEP, (double)B * (6.0 * d + 2.0 * m.attention_win_size * d) * 4.0, (double)B * 4.0 * m.attention_win_size * d);
+    }
+    const int* pcur = h->d_p + (t & 1) * Bpad;
+    // ---------------- AudioDec history cone under the CURRENT mask (the reference
+    // re-evaluates R[t'] for all t' <= t with prev_max(t), networks.py:311, so AudioDec history
+    // cannot be cached across steps)
+    const int pre = h->dec_pre, nh = h->n_hc_dec;
+    if (t >= 1) {
+        const int n0 = (int)h->Hset[0].size();
+        AttnRowsArgs ar{};
+        ar.mode = 0; ar.Q = h->Qhist; ar.ldq = d; ar.K = h->KV; ar.V = h->KV + d; ar.ldkv = 2 * d; ar.N = m.max_N; ar.d = d;
+        ar.win = m.attention_win_size; ar.p = pcur; ar.B = B; ar.Bpad = Bpad; ar.nrows = n0 * Bpad; ar.off = h->d_off0; ar.j = t;
+        ar.R = h->coneR; ar.ldr = 2 * d; ar.stop_after = stop_after; ar.t = t;
+        h->pbegin(PC_ATTN_ROWS);
+        launch_attn_rows(ar, h->stream);
+        h->pend(PC_ATTN_ROWS, (double)n0 * B * 3.0 * d * 4.0, (double)n0 * B * 4.0 * m.attention_win_size * d);
+        // k=1 layers before the highway stack, on all Hset[0] positions
+        const float* x = h->coneR; int ldx = 2 * d;
+        for (int k = 0; k < pre; ++k) {
+            const Layer& l = h->audiodec[k];
+            GemmArgs g{};
+            g.X = x; g.ldx = ldx; g.Wt = l.Wt; g.ldw = l.kc; g.bias = l.bias; g.H = h->coneRaw; g.ldh = l.Nalloc;
+            g.M = n0 * Bpad; g.N = l.N; g.kc = l.kc; g.ntaps = 1; g.mode = 0; g.T = g.M; g.off[0] = 0;
+            g.stop_after = stop_after; g.t = t;
+            run_gemm(h, g, l.cin);
+            EpiArgs e{};
+            e.H = h->coneRaw; e.ldh = l.Nalloc; e.M = g.M; e.C = l.cout; e.mode = PRE_CONV; e.act = l.act; e.g1 = l.g1; e.b1 = l.b1;
+            e.Bpad = Bpad; e.stop_after = stop_after; e.t = t;
+            const bool spk_next = (k + 1 < pre) && h->audiodec[k + 1].ccat > 0;
+            if (spk_next) {
+                const Layer& nx = h->audiodec[k + 1];
+                e.Y = h->coneTmp; e.ldy = nx.kc; e.ypad = nx.kc;
+                e.spk_table = h->emb_spk; e.spk_ids = h->d_spk; e.spk_dim = nx.ccat; e.spk_T = 0;
+                x = h->coneTmp; ldx = nx.kc;
+            } else {
+                const Layer& hc0 = h->audiodec[pre];
+                e.Y = h->cone[0]; e.ldy = hc0.kc; e.ypad = hc0.kc;
+                x = h->cone[0]; ldx = hc0.kc;
+            }
+            run_epi(h, e);
+        }
+        for (int k = 0; k + 1 < nh; ++k) {
+            const Layer& l = h->audiodec[pre + k];
+            const int n_out = (int)h->Hset[k + 1].size();
+            GemmArgs g{};
+            g.X = h->cone[k]; g.ldx = l.kc; g.Wt = l.Wt; g.ldw = 3 * l.kc; g.bias = l.bias; g.H = h->coneRaw; g.ldh = l.Nalloc;
+            g.M = n_out * Bpad; g.N = l.N; g.kc = l.kc; g.ntaps = 3; g.mode = 1; g.Bpad = Bpad; g.n_out = n_out; g.j = t;
+            g.tab = h->d_tab[k]; g.need = h->d_need[k]; g.stop_after = stop_after; g.t = t;
+            run_gemm(h, g, l.cin);
+            EpiArgs e{};
+            e.H = h->coneRaw; e.ldh = l.Nalloc; e.M = g.M; e.C = l.cout; e.mode = PRE_HC;
+            e.g1 = l.g1; e.b1 = l.b1; e.g2 = l.g2; e.b2 = l.b2; e.Xres = h->cone[k]; e.ldres = l.kc; e.restab = h->d_res[k]; e.Bpad = Bpad;
+            const Layer& nx = h->audiodec[pre + k + 1];
+            e.Y = h->cone[k + 1]; e.ldy = nx.kc; e.ypad = nx.kc; e.stop_after = stop_after; e.t = t;
+            run_epi(h, e);
+        }
+    }
+    // ---------------- AudioDec row t
+    prev = nullptr; prev_raw = nullptr; prev_x = nullptr;
+    for (size_t li = 0; li < h->audiodec.size(); ++li) {
+        const Layer& l = h->audiodec[li];
+        DecArgs a{};
+        if (li == 0) { a.pre = PRE_COPY; a.src = h->Rrow; a.ldsrc = 2 * d; a.cin = 2 * d; }
+        else if (prev->kind == K_CONV) { a.pre = PRE_CONV; a.src = prev_raw; a.ldsrc = prev->Nalloc; a.g1 = prev->g1; a.b1 = prev->b1; a.act = prev->act; a.cin = prev->cout; }
+        else { a.pre = PRE_HC; a.src = prev_raw; a.ldsrc = prev->Nalloc; a.g1 = prev->g1; a.b1 = prev->b1; a.g2 = prev->g2; a.b2 = prev->b2; a.xres = prev_x; a.ldres = prev->kc; a.cin = prev->cout; }
+        if (l.ccat > 0) { a.cat_table = h->emb_spk; a.cat_ids = h->d_spk; a.ccat = l.ccat; }
+        a.ntaps = l.ntaps; a.kc = l.kc;
+        if (l.kind == K_HC) {
+            const int k = (int)li - pre;
+            a.xstore = h->ad_xrow[li]; a.ldstore = l.kc; a.ldtap = l.kc;
+            const int o0 = -l.off[0], o1 = -l.off[1];
+            a.tap0 = t - o0 >= 0 ? h->cone[k] + (size_t)idx_of(h->Hset[k], o0) * Bpad * l.kc : nullptr;
+            a.tap1 = t - o1 >= 0 ? h->cone[k] + (size_t)idx_of(h->Hset[k], o1) * Bpad * l.kc : nullptr;
+        }
+        a.Wt = l.Wt; a.ldw = l.ntaps * l.kc; a.bias = l.bias; a.H = h->ad_raw[li]; a.ldh = l.Nalloc; a.B = B;
+        a.stop_after = stop_after; a.t = t;
+        run_dec(h, a, l);
+        prev = &l; prev_raw = h->ad_raw[li];
+        prev_x = l.kind == K_HC ? h->ad_xrow[li] : nullptr;
+    }
+    {
+        EmitArgs e{};
+        e.hraw = prev_raw; e.ldh = prev->Nalloc; e.g = prev->g1; e.b = prev->b1; e.C = m.n_mels; e.squash = 1;
+        e.Yout = h->Yout; e.ldy = h->ldy; e.max_T = m.max_T; e.Ytm = h->Ytm; e.ldtm = h->ldy; e.Bpad = Bpad; e.B = B;
+        e.stop_after = stop_after; e.t = t;
+        h->pbegin(PC_EMIT);
+        launch_emit_mel(e, h->stream);
+        h->pend(PC_EMIT, (double)B * m.n_mels * 12.0, (double)B * m.n_mels * 10.0);
+    }
+}
+
+int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* steps_run) {
+    const oph_dims& m = h->dm;
+    t_end = std::min(t_end, (int)m.max_T);
+    int ctl[4] = {0, INT_MAX, 0, 0};
+    int last = t_begin;
+    for (int t = t_begin; t < t_end; ++t) {
+        decode_step(h, t, stop_mode);
+        last = t + 1;
+        // bounded look-ahead: poll the device-side stop flag every 8 steps (reference semantics keep
+        // frames after the break step at zero because later steps early-out on the device)
+        if (stop_mode == OPH_STOP_REFERENCE && ((t & 7) == 7)) {
+            HIPCHK(h, hipMemcpyAsync(ctl, h->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (ctl[1] != INT_MAX) break;
+        }
+    }
+    HIPCHK(h, hipMemcpyAsync(ctl, h->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (steps_run) *steps_run = ctl[1] != INT_MAX ? ctl[1] + 1 : last;
+    HIPCHK(h, hipGetLastError());
+    return OPH_OK;
+}
+
+int run_encode(oph_handle* h) {
+    const oph_dims& m = h->dm;
+    const int B = h->B;
+    // embed_1 (modules.py:15-44) -> rows [B*max_N][e]
+    h->pbegin(PC_MISC);
+    launch_embed(h->d_L, (long long)B * m.max_N, h->emb_text, m.e, h->actA, round_up(m.e, 32), h->stream);
+    h->pend(PC_MISC, (double)B * m.max_N * m.e * 4.0, 0);
+    // last highway layer writes K|V rows straight into the resident KV buffer [B][N][2d]
+    run_batched(h, h->textenc, h->actA, round_up(m.e, 32), B, m.max_N, h->KV, 2 * m.d, 2 * m.d, nullptr, nullptr);
+    HIPCHK(h, hipGetLastError());
+    return OPH_OK;
+}
+
+int run_ssrn_on(oph_handle* h, const float* Yrows, int ldy, int B, int T, float* Zout) {
+    const oph_dims& m = h->dm;
+    run_batched(h, h->ssrn, const_cast<float*>(Yrows), ldy, B, T, Zout, m.full_dim, m.full_dim, nullptr, nullptr);
+    HIPCHK(h, hipGetLastError());
+    return OPH_OK;
+}
+
+}  // namespace
+
+// ====================================================================================== C ABI
+extern "C" {
+
+int oph_abi_version(void) { return OPH_ABI_VERSION; }
+
+const char* oph_last_error(const oph_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int oph_create(const oph_dims* dims, int device, oph_handle** out) {
+    if (!dims || !out) { g_create_error = "null argument"; return OPH_ERR_INVALID; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_create_error = "no HIP device available (libophelia_hip has no CPU fallback)";
+        return OPH_ERR_DEVICE;
+    }
+    if (device < 0 || device >= ndev) { g_create_error = "device index out of range"; return OPH_ERR_INVALID; }
+    const oph_dims& m = *dims;
+    if (m.r != 4 && m.r != 8) { g_create_error = "reduction factor not handled by SSRN (networks.py:474-479)"; return OPH_ERR_UNSUPPORTED; }
+    if (m.d % 4 || m.d > 256 || m.c % 4 || 2 * m.c > 1024 || m.n_mels > 256 || m.full_dim > 1280 || m.e % 4 ||
+        m.attention_win_size < 1 || m.attention_win_size > 8 || m.max_N < 1 || m.max_T < 1 || m.vocab < 1) {
+        g_create_error = "dimensions outside the supported hot path (d<=256, c<=512, n_mels<=256, full_dim<=1280, win<=8)";
+        return OPH_ERR_UNSUPPORTED;
+    }
+    if ((m.flags & OPH_FLAG_SPK_AUDIO_DECODER_INPUT) && (m.nspeakers < 1 || m.speaker_embedding_size < 1 || m.speaker_embedding_size % 4)) {
+        g_create_error = "multispeaker flag set but nspeakers/speaker_embedding_size invalid";
+        return OPH_ERR_INVALID;
+    }
+    if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return OPH_ERR_DEVICE; }
+    oph_handle* h = new oph_handle();
+    h->dm = m;
+    h->device = device;
+    static const char* names[PC_COUNT] = {"conv_gemm_f32", "ln_rows", "dec_layer16", "attn_step", "attn_rows", "emit_mel", "misc"};
+    for (int i = 0; i < PC_COUNT; ++i) h->prof[i].name = names[i];
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+        g_create_error = "stream/event creation failed";
+        delete h;
+        return OPH_ERR_DEVICE;
+    }
+    build_networks(h);
+    *out = h;
+    return OPH_OK;
+}
+
+int oph_destroy(oph_handle* h) {
+    if (!h) return OPH_OK;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    for (void* p : h->allocs) hipFree(p);
+    for (auto& pc : h->prof)
+        for (auto& e : pc.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    hipEventDestroy(h->ev0);
+    hipEventDestroy(h->ev1);
+    hipStreamDestroy(h->stream);
+    delete h;
+    return OPH_OK;
+}
+
+int oph_num_weights(const oph_handle* h) { return h ? (int)h->inventory.size() : OPH_ERR_INVALID; }
+
+int oph_weight_info(const oph_handle* h, int index, char* name, int name_cap, int64_t* shape, int* rank) {
+    if (!h || index < 0 || index >= (int)h->inventory.size()) return OPH_ERR_INVALID;
+    const auto& it = h->inventory[index];
+    if (name && name_cap > 0) { strncpy(name, it.first.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (rank) *rank = (int)it.second.size();
+    if (shape) for (size_t i = 0; i < it.second.size() && i < 4; ++i) shape[i] = it.second[i];
+    return OPH_OK;
+}
+
+int oph_set_weight(oph_handle* h, const char* name, const float* data, const int64_t* shape, int rank) {
+    if (!h) return OPH_ERR_INVALID;
+    if (!name || !data || !shape) { h->fail("null argument"); return OPH_ERR_INVALID; }
+    if (h->finalized) { h->fail("weights already finalized"); return OPH_ERR_STATE; }
+    for (const auto& it : h->inventory) {
+        if (it.first != name) continue;
+        if ((int)it.second.size() != rank) { h->fail("variable %s: rank %d, expected %d", name, rank, (int)it.second.size()); return OPH_ERR_INVALID; }
+        size_t n = 1;
+        for (int i = 0; i < rank; ++i) {
+            if (shape[i] != it.second[i]) { h->fail("variable %s: dim %d is %lld, expected %lld", name, i, (long long)shape[i], (long long)it.second[i]); return OPH_ERR_INVALID; }
+            n *= (size_t)shape[i];
+        }
+        h->hostw[name].assign(data, data + n);
+        return OPH_OK;
+    }
+    h->fail("unknown variable %s", name);
+    return OPH_ERR_INVALID;
+}
+
+int oph_finalize_weights(oph_handle* h) {
+    if (!h) return OPH_ERR_INVALID;
+    if (h->finalized) return OPH_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    for (const auto& it : h->inventory)
+        if (!h->hostw.count(it.first)) { h->fail("missing variable %s", it.first.c_str()); return OPH_ERR_STATE; }
+    for (auto* net : {&h->textenc, &h->audioenc, &h->audiodec, &h->ssrn})
+        for (Layer& l : *net)
+            if (pack_layer(h, l) != 0) { h->fail("out of device memory packing %s", l.scope.c_str()); return OPH_ERR_DEVICE; }
+    h->emb_text = upload(h, h->hostw["Text2Mel/TextEnc/embed_1/lookup_table"]);
+    if (h->dm.flags & OPH_FLAG_SPK_AUDIO_DECODER_INPUT) h->emb_spk = upload(h, h->hostw["Text2Mel/AudioDec/embed_2/lookup_table"]);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    h->hostw.clear();
+    h->finalized = true;
+    return OPH_OK;
+}
+
+static int check_ready(oph_handle* h, int B) {
+    if (!h) return OPH_ERR_INVALID;
+    if (!h->finalized) { h->fail("weights not finalized"); return OPH_ERR_STATE; }
+    if (B < 1) { h->fail("batch must be >= 1"); return OPH_ERR_INVALID; }
+    if (hipSetDevice(h->device) != hipSuccess) { h->fail("hipSetDevice failed"); return OPH_ERR_DEVICE; }
+    return OPH_OK;
+}
+
+int oph_stage_text(oph_handle* h, const int32_t* L, const int32_t* ends, const int32_t* spk, int B) {
+    int rc = check_ready(h, B);
+    if (rc) return rc;
+    if (!L || !ends) { h->fail("null argument"); return OPH_ERR_INVALID; }
+    const bool ms = h->dm.flags & OPH_FLAG_SPK_AUDIO_DECODER_INPUT;
+    if (ms && !spk) { h->fail("multispeaker model needs speaker ids"); return OPH_ERR_INVALID; }
+    const oph_dims& m = h->dm;
+    for (long long i = 0; i < (long long)B * m.max_N; ++i)
+        if (L[i] < 0 || L[i] >= m.vocab) { h->fail("text id %d out of range at %lld", L[i], i); return OPH_ERR_INVALID; }
+    if (ms) for (int b = 0; b < B; ++b) if (spk[b] < 0 || spk[b] >= m.nspeakers) { h->fail("speaker id out of range"); return OPH_ERR_INVALID; }
+    if ((rc = ensure_decode_state(h, B))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_L, L, (size_t)B * m.max_N * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_ends, ends, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    if (ms) HIPCHK(h, hipMemcpyAsync(h->d_spk, spk, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return OPH_OK;
+}
+
+int oph_decode_steps(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* steps_run) {
+    if (!h || !h->KV) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (t_begin == 0) reset_decode(h);
+    else {   // resume (multi-GPU global stop): clear the local stop so later steps execute
+        const int ctl1 = INT_MAX;
+        HIPCHK(h, hipMemcpyAsync(h->d_ctl + 1, &ctl1, 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return decode_range(h, t_begin, t_end, stop_mode, steps_run);
+}
+
+int oph_run_ssrn_resident(oph_handle* h) {
+    if (!h || !h->KV) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
+    HIPCHK(h, hipSetDevice(h->device));
+    return run_ssrn_on(h, h->Yout, h->ldy, h->B, h->dm.max_T, h->Z);
+}
+
+int oph_run_resident(oph_handle* h, int stop_mode, int run_ssrn, int32_t* steps_run) {
+    if (!h || !h->KV) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = run_encode(h);
+    if (rc) return rc;
+    reset_decode(h);
+    if ((rc = decode_range(h, 0, h->dm.max_T, stop_mode, steps_run))) return rc;
+    if (run_ssrn) rc = oph_run_ssrn_resident(h);
+    return rc;
+}
+
+int oph_synchronize(oph_handle* h) {
+    if (!h) return OPH_ERR_INVALID;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    return OPH_OK;
+}
+
+int oph_fetch_kv(oph_handle* h, float* K, float* V) {
+    if (!h || !h->KV) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
+    const oph_dims& m = h->dm;
+    const size_t rows = (size_t)h->B * m.max_N, w = (size_t)m.d * 4;
+    if (K) HIPCHK(h, hipMemcpy2DAsync(K, w, h->KV, 2 * w, w, rows, hipMemcpyDeviceToHost, h->stream));
+    if (V) HIPCHK(h, hipMemcpy2DAsync(V, w, h->KV + m.d, 2 * w, w, rows, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return OPH_OK;
+}
+
+int oph_fetch_mel(oph_handle* h, float* Y, int32_t* t_ends, float* alignments) {
+    if (!h || !h->KV) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
+    const oph_dims& m = h->dm;
+    if (Y) HIPCHK(h, hipMemcpy2DAsync(Y, (size_t)m.n_mels * 4, h->Yout, (size_t)h->ldy * 4, (size_t)m.n_mels * 4,
+                                      (size_t)h->B * m.max_T, hipMemcpyDeviceToHost, h->stream));
+    if (t_ends) HIPCHK(h, hipMemcpyAsync(t_ends, h->d_tends, (size_t)h->B * 4, hipMemcpyDeviceToHost, h->stream));
+    if (alignments) HIPCHK(h, hipMemcpyAsync(alignments, h->align, (size_t)h->B * m.max_N * m.max_T * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return OPH_OK;
+}
+
+int oph_fetch_mag(oph_handle* h, float* Z) {
+    if (!h || !h->KV || !Z) { if (h) h->fail("no staged batch / null"); return OPH_ERR_STATE; }
+    const oph_dims& m = h->dm;
+    HIPCHK(h, hipMemcpyAsync(Z, h->Z, (size_t)h->B * m.max_T * m.r * m.full_dim * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return OPH_OK;
+}
+
+// ---- host-buffer session calls ---------------------------------------------------------------
+int oph_encode_text(oph_handle* h, const int32_t* L, const int32_t* spk, int B, float* K, float* V) {
+    int rc = check_ready(h, B);
+    if (rc) return rc;
+    if (!L || !K || !V) { h->fail("null argument"); return OPH_ERR_INVALID; }
+    // ends are not needed by TextEnc; stage zeros (get_text_lengths stays with the caller, synthesize.py:556)
+    std::vector<int32_t> ends(B, 0), spk0(B, 0);
+    if ((rc = oph_stage_text(h, L, ends.data(), spk ? spk : spk0.data(), B))) return rc;
+    if ((rc = run_encode(h))) return rc;
+    return oph_fetch_kv(h, K, V);
+}
+
+int oph_text2mel(oph_handle* h, const float* K, const float* V, const int32_t* ends, const int32_t* spk, int B,
+                 int stop_mode, float* Y, int32_t* t_ends, float* alignments, int32_t* steps_run) {
+    int rc = check_ready(h, B);
+    if (rc) return rc;
+    if (!K || !V || !ends) { h->fail("null argument"); return OPH_ERR_INVALID; }
+    const bool ms = h->dm.flags & OPH_FLAG_SPK_AUDIO_DECODER_INPUT;
+    if (ms && !spk) { h->fail("multispeaker model needs speaker ids"); return OPH_ERR_INVALID; }
+    if ((rc = ensure_decode_state(h, B))) return rc;
+    const oph_dims& m = h->dm;
+    const size_t rows = (size_t)B * m.max_N, w = (size_t)m.d * 4;
+    HIPCHK(h, hipMemcpy2DAsync(h->KV, 2 * w, K, w, w, rows, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpy2DAsync(h->KV + m.d, 2 * w, V, w, w, rows, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_ends, ends, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    if (ms) {
+        for (int b = 0; b < B; ++b) if (spk[b] < 0 || spk[b] >= m.nspeakers) { h->fail("speaker id out of range"); return OPH_ERR_INVALID; }
+        HIPCHK(h, hipMemcpyAsync(h->d_spk, spk, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    reset_decode(h);
+    if ((rc = decode_range(h, 0, m.max_T, stop_mode, steps_run))) return rc;
+    return oph_fetch_mel(h, Y, t_ends, alignments);
+}
+
+int oph_ssrn(oph_handle* h, const float* Y, int B, int T, float* Z) {
+    int rc = check_ready(h, B);
+    if (rc) return rc;
+    if (!Y || !Z || T < 1) { h->fail("bad argument"); return OPH_ERR_INVALID; }
+    const oph_dims& m = h->dm;
+    if (T > m.max_T) { h->fail("T=%d exceeds max_T=%d", T, m.max_T); return OPH_ERR_INVALID; }
+    if ((rc = ensure_batched_capacity(h, B))) return rc;
+    const int ldy = round_up(m.n_mels, 32);
+    float* dY = nullptr; float* dZ = nullptr;
+    const size_t zn = (size_t)B * T * m.r * m.full_dim;
+    HIPCHK(h, hipMalloc((void**)&dY, (size_t)B * T * m.n_mels * 4));
+    HIPCHK(h, hipMalloc((void**)&dZ, zn * 4));
+    hipMemcpyAsync(dY, Y, (size_t)B * T * m.n_mels * 4, hipMemcpyHostToDevice, h->stream);
+    launch_pad_rows(dY, m.n_mels, h->actB, ldy, (long long)B * T, m.n_mels, h->stream);
+    rc = run_ssrn_on(h, h->actB, ldy, B, T, dZ);
+    hipMemcpyAsync(Z, dZ, zn * 4, hipMemcpyDeviceToHost, h->stream);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    hipFree(dY); hipFree(dZ);
+    if (e != hipSuccess) { h->fail("ssrn failed: %s", hipGetErrorString(e)); return OPH_ERR_DEVICE; }
+    return rc;
+}
+
+// ---- measurement ----------------------------------------------------------------------------
+int oph_timer_start(oph_handle* h) {
+    if (!h) return OPH_ERR_INVALID;
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    return OPH_OK;
+}
+int oph_timer_stop(oph_handle* h, float* ms) {
+    if (!h || !ms) return OPH_ERR_INVALID;
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipEventSynchronize(h->ev1));
+    HIPCHK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return OPH_OK;
+}
+int oph_profile_enable(oph_handle* h, int on) { if (!h) return OPH_ERR_INVALID; h->profiling = on != 0; return OPH_OK; }
+int oph_profile_reset(oph_handle* h) {
+    if (!h) return OPH_ERR_INVALID;
+    hipStreamSynchronize(h->stream);
+    for (auto& pc : h->prof) { pc.launches = 0; pc.bytes = pc.flops = pc.ms = 0; pc.used = 0; }
+    return OPH_OK;
+}
+int oph_profile_count(const oph_handle* h) { return h ? PC_COUNT : OPH_ERR_INVALID; }
+int oph_profile_get(oph_handle* h, int index, char* name, int name_cap, int64_t* launches, double* total_ms,
+                    double* alg_bytes, double* alg_flops) {
+    if (!h || index < 0 || index >= PC_COUNT) return OPH_ERR_INVALID;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    ProfClass& pc = h->prof[index];
+    double ms = 0;
+    for (size_t i = 0; i < pc.used; ++i) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, pc.ev[i].first, pc.ev[i].second) == hipSuccess) ms += t;
+    }
+    pc.ms = ms;
+    if (name && name_cap > 0) { strncpy(name, pc.name, name_cap - 1); name[name_cap - 1] = 0; }
+    if (launches) *launches = pc.launches;
+    if (total_ms) *total_ms = ms;
+    if (alg_bytes) *alg_bytes = pc.bytes;
+    if (alg_flops) *alg_flops = pc.flops;
+    return OPH_OK;
+}
+
+// ---- per-operator entry points (unit parity) ---------------------------------------------------
+const char* oph_op_last_error(void) { return g_op_error.c_str(); }
+
+}  // extern "C"
+
+namespace {
+struct OpCtx {
+    hipStream_t s = nullptr;
+    std::vector<void*> bufs;
+    bool ok = true;
+    explicit OpCtx(int device) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n || hipSetDevice(device) != hipSuccess ||
+            hipStreamCreate(&s) != hipSuccess) { ok = false; g_op_error = "no usable HIP device (no CPU fallback)"; }
+    }
+    ~OpCtx() { for (void* p : bufs) hipFree(p); if (s) hipStreamDestroy(s); }
+    template <class T> T* alloc(size_t n) {
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) { ok = false; g_op_error = "hipMalloc failed"; return nullptr; }
+        hipMemsetAsync(p, 0, std::max<size_t>(n, 1) * sizeof(T), s);
+        bufs.push_back(p);
+        return (T*)p;
+    }
+    template <class T> T* up(const T* src, size_t n) {
+        T* p = alloc<T>(n);
+        if (p) hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, s);
+        return p;
+    }
+    float* up_pad(const float* src, size_t n, size_t padto) {
+        std::vector<float> t((n + padto - 1) / padto * padto, 0.f);
+        std::copy(src, src + n, t.begin());
+        float* p = up(t.data(), t.size());
+        hipStreamSynchronize(s);
+        return p;
+    }
+    int finish() {
+        hipError_t e = hipStreamSynchronize(s);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) { g_op_error = hipGetErrorString(e); return OPH_ERR_DEVICE; }
+        return ok ? OPH_OK : OPH_ERR_DEVICE;
+    }
+};
+}  // namespace
+
+extern "C" {
+
+int oph_op_embed(int device, const int32_t* ids, int64_t n, const float* table, int vocab, int units, float* out) {
+    OpCtx c(device);
+    if (!c.ok) return OPH_ERR_DEVICE;
+    for (int64_t i = 0; i < n; ++i) if (ids[i] < 0 || ids[i] >= vocab) { g_op_error = "id out of range"; return OPH_ERR_INVALID; }
+    const int ldo = round_up(units, 4);
+    int* dids = c.up(ids, (size_t)n);
+    float* dt = c.up(table, (size_t)vocab * units);
+    float* dout = c.alloc<float>((size_t)n * ldo);
+    if (!c.ok) return OPH_ERR_DEVICE;
+    launch_embed(dids, n, dt, units, dout, ldo, c.s);
+    hipMemcpy2DAsync(out, (size_t)units * 4, dout, (size_t)ldo * 4, (size_t)units * 4, (size_t)n, hipMemcpyDeviceToHost, c.s);
+    return c.finish();
+}
+
+int oph_op_layernorm(int device, const float* x, int64_t rows, int C, const float* gamma, const float* beta, float* y) {
+    OpCtx c(device);
+    if (!c.ok) return OPH_ERR_DEVICE;
+    if (C < 1 || C > 1280) { g_op_error = "C out of range (<=1280)"; return OPH_ERR_UNSUPPORTED; }
+    const int ld = round_up(C, 128);
+    float* dx = c.up(x, (size_t)rows * C);
+    float* dh = c.alloc<float>((size_t)rows * ld);
+    float* dy = c.alloc<float>((size_t)rows * C);
+    float* g = c.up_pad(gamma, C, 256); float* b = c.up_pad(beta, C, 256);
+    if (!c.ok) return OPH_ERR_DEVICE;
+    launch_pad_rows(dx, C, dh, ld, rows, C, c.s);
+    EpiArgs e{};
+    e.H = dh; e.ldh = ld; e.M = (int)rows; e.C = C; e.mode = PRE_CONV; e.act = ACT_NONE; e.g1 = g; e.b1 = b; e.Y = dy; e.ldy = C; e.ypad = C;
+    launch_epilogue(e, c.s);
+    hipMemcpyAsync(y, dy, (size_t)rows * C * 4, hipMemcpyDeviceToHost, c.s);
+    return c.finish();
+}
+
+static int op_conv_common(int device, const float* x, int B, int T, int Cin, int Cout, int size, int rate, int padding,
+                          const float* kernel, const float* bias, const float* g1, const float* b1, const float* g2,
+                          const float* b2, int act, bool is_hc, float* y) {
+    OpCtx c(device);
+    if (!c.ok) return OPH_ERR_DEVICE;
+    if (size != 1 && size != 3) { g_op_error = "size must be 1 or 3"; return OPH_ERR_UNSUPPORTED; }
+    if (Cout > 1280 || (is_hc && (Cout > 1024 || Cout % 4 || Cin != Cout))) { g_op_error = "channels out of range"; return OPH_ERR_UNSUPPORTED; }
+    const int kc = round_up(Cin, 32), N = is_hc ? 2 * Cout : Cout, Nalloc = round_up(N, 128), M = B * T;
+    std::vector<float> wt = pack_conv(kernel, size, Cin, N, kc, Nalloc);
+    float* dx = c.up(x, (size_t)M * Cin);
+    float* dxp = c.alloc<float>((size_t)M * kc);
+    float* dw = c.up(wt.data(), wt.size());
+    float* dbias = c.up_pad(bias, N, Nalloc);
+    float* dh = c.alloc<float>((size_t)M * Nalloc);
+    float* dy = c.alloc<float>((size_t)M * Cout);
+    float* dg1 = c.up_pad(g1, Cout, 256); float* db1 = c.up_pad(b1, Cout, 256);
+    float* dg2 = is_hc ? c.up_pad(g2, Cout, 256) : nullptr; float* db2 = is_hc ? c.up_pad(b2, Cout, 256) : nullptr;
+    if (!c.ok) return OPH_ERR_DEVICE;
+    launch_pad_rows(dx, Cin, dxp, kc, M, Cin, c.s);
+    GemmArgs g{};
+    g.X = dxp; g.ldx = kc; g.Wt = dw; g.ldw = size * kc; g.bias = dbias; g.H = dh; g.ldh = Nalloc; g.M = M; g.N = N; g.kc = kc;
+    g.ntaps = size; g.mode = 0; g.T = T;
+    for (int t = 0; t < size; ++t) g.off[t] = padding == 1 ? -(size - 1 - t) * rate : (t - (size - 1) / 2) * rate;
+    launch_conv_gemm(g, c.s);
+    EpiArgs e{};
+    e.H = dh; e.ldh = Nalloc; e.M = M; e.C = Cout; e.mode = is_hc ? PRE_HC : PRE_CONV; e.act = act;
+    e.g1 = dg1; e.b1 = db1; e.g2 = dg2; e.b2 = db2; e.Xres = dxp; e.ldres = kc; e.Y = dy; e.ldy = Cout; e.ypad = Cout;
+    launch_epilogue(e, c.s);
+    hipMemcpyAsync(y, dy, (size_t)M * Cout * 4, hipMemcpyDeviceToHost, c.s);
+    return c.finish();
+}
+
+int oph_op_conv1d(int device, const float* x, int B, int T, int Cin, int Cout, int size, int rate, int padding,
+                  const float* kernel, const float* bias, const float* gamma, const float* beta, int act, float* y) {
+    return op_conv_common(device, x, B, T, Cin, Cout, size, rate, padding, kernel, bias, gamma, beta, nullptr, nullptr, act, false, y);
+}
+int oph_op_hc(int device, const float* x, int B, int T, int C, int size, int rate, int padding, const float* kernel,
+              const float* bias, const float* gamma1, const float* beta1, const float* gamma2, const float* beta2, float* y) {
+    return op_conv_common(device, x, B, T, C, C, size, rate, padding, kernel, bias, gamma1, beta1, gamma2, beta2, ACT_NONE, true, y);
+}
+
+int oph_op_conv1d_transpose(int device, const float* x, int B, int T, int Cin, int Cout, const float* kernel,
+                            const float* bias, const float* gamma, const float* beta, float* y) {
+    OpCtx c(device);
+    if (!c.ok) return OPH_ERR_DEVICE;
+    if (Cout > 1280) { g_op_error = "channels out of range"; return OPH_ERR_UNSUPPORTED; }
+    const int kc = round_up(Cin, 32), Nalloc = round_up(Cout, 128), M = B * T;
+    std::vector<float> we((size_t)Nalloc * 2 * kc, 0.f), wo((size_t)Nalloc * kc, 0.f);
+    for (int n = 0; n < Cout; ++n)
+        for (int ci = 0; ci < Cin; ++ci) {
+            we[(size_t)n * 2 * kc + ci] = kernel[((size_t)0 * Cout + n) * Cin + ci];
+            we[(size_t)n * 2 * kc + kc + ci] = kernel[((size_t)2 * Cout + n) * Cin + ci];
+            wo[(size_t)n * kc + ci] = kernel[((size_t)1 * Cout + n) * Cin + ci];
+        }
+    float* dx = c.up(x, (size_t)M * Cin);
+    float* dxp = c.alloc<float>((size_t)M * kc);
+    float* dwe = c.up(we.data(), we.size()); float* dwo = c.up(wo.data(), wo.size());
+    float* dbias = c.up_pad(bias, Cout, Nalloc);
+    float* dh = c.alloc<float>((size_t)2 * M * Nalloc);
+    float* dy = c.alloc<float>((size_t)2 * M * Cout);
+    float* dg = c.up_pad(gamma, Cout, 256); float* db = c.up_pad(beta, Cout, 256);
+    if (!c.ok) return OPH_ERR_DEVICE;
+    launch_pad_rows(dx, Cin, dxp, kc, M, Cin, c.s);
+    GemmArgs g{};
+    g.X = dxp; g.ldx = kc; g.bias = dbias; g.ldh = 2 * Nalloc; g.M = M; g.N = Cout; g.kc = kc; g.mode = 0; g.T = T;
+    g.Wt = dwe; g.ldw = 2 * kc; g.ntaps = 2; g.off[0] = 0; g.off[1] = -1; g.H = dh;
+    launch_conv_gemm(g, c.s);
+    g.Wt = dwo; g.ldw = kc; g.ntaps = 1; g.off[0] = 0; g.H = dh + Nalloc;
+    launch_conv_gemm(g, c.s);
+    EpiArgs e{};
+    e.H = dh; e.ldh = Nalloc; e.M = 2 * M; e.C = Cout; e.mode = PRE_CONV; e.act = ACT_NONE; e.g1 = dg; e.b1 = db; e.Y = dy; e.ldy = Cout; e.ypad = Cout;
+    launch_epilogue(e, c.s);
+    hipMemcpyAsync(y, dy, (size_t)2 * M * Cout * 4, hipMemcpyDeviceToHost, c.s);
+    return c.finish();
+}
+
+int oph_op_attention(int device, const float* Q, const float* K, const float* V, const int32_t* prev_max, int B, int T,
+                     int N, int d, int win, float* R, float* alignments, int64_t* max_attentions) {
+    OpCtx c(device);
+    if (!c.ok) return OPH_ERR_DEVICE;
+    if (d % 4 || d > 512 || win < 1 || win > 8) { g_op_error = "d/win out of range"; return OPH_ERR_UNSUPPORTED; }
+    for (int b = 0; b < B; ++b) if (prev_max[b] < 0 || prev_max[b] >= N) { g_op_error = "prev_max out of range"; return OPH_ERR_INVALID; }
+    float* dq = c.up(Q, (size_t)B * T * d); float* dk = c.up(K, (size_t)B * N * d); float* dv = c.up(V, (size_t)B * N * d);
+    int* dp = c.up(prev_max, (size_t)B);
+    float* dr = c.alloc<float>((size_t)B * T * 2 * d); float* da = c.alloc<float>((size_t)B * N * T);
+    long long* dm = c.alloc<long long>((size_t)B * T);
+    if (!c.ok) return OPH_ERR_DEVICE;
+    AttnRowsArgs a{};
+    a.mode = 1; a.Q = dq; a.ldq = d; a.K = dk; a.V = dv; a.ldkv = d; a.N = N; a.d = d; a.win = win; a.p = dp; a.B = B; a.Bpad = B;
+    a.nrows = B * T; a.T = T; a.R = dr; a.ldr = 2 * d; a.align = da; a.amax = dm;
+    launch_attn_rows(a, c.s);
+    hipMemcpyAsync(R, dr, (size_t)B * T * 2 * d * 4, hipMemcpyDeviceToHost, c.s);
+    hipMemcpyAsync(alignments, da, (size_t)B * N * T * 4, hipMemcpyDeviceToHost, c.s);
+    hipMemcpyAsync(max_attentions, dm, (size_t)B * T * 8, hipMemcpyDeviceToHost, c.s);
+    return c.finish();
+}
+
+}  // extern "C"

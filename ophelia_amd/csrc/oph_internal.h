@@ -1,0 +1,113 @@
+// Internal declarations shared by the kernel and API translation units of
+// libophelia_hip.so.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace oph {
+
+constexpr int ROWT = 16;        // decode row tile = one 16x16x4 f32 MFMA tile of utterances
+constexpr float LN_EPS = 1e-12f;            // tf.contrib.layers.layer_norm epsilon (modules.py:65)
+constexpr float MASK_VALUE = -4294967296.0f; // -2**32+1 rounded to fp32 (networks.py:312)
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
+enum Pre { PRE_COPY = 0, PRE_CONV = 1, PRE_HC = 2 };
+
+// ---- batched conv-as-GEMM (fp32 MFMA), H[m][n] = sum_tap X[src(m,tap)][:] . Wt[n][tap*kc + :] + bias[n]
+struct GemmArgs {
+    const float* X; int ldx;        // input activations, row stride (floats)
+    const float* Wt; int ldw;       // packed weights [Nalloc][ntaps*kc], k contiguous
+    const float* bias;              // [Nalloc]
+    float* H; int ldh;              // raw conv output rows (bias added, pre-LayerNorm)
+    int M;                          // output rows
+    int N;                          // output columns actually needed (tiles cover round_up(N,BN))
+    int kc;                         // per-tap K (padded Cin, multiple of 32)
+    int ntaps;
+    int mode;                       // 0 dense (b,t) rows, 1 table-mapped rows (decoder cone)
+    int T; int off[3];              // dense: time length per utterance, per-tap time offsets
+    int Bpad; int n_out; int j;     // table: rows = i*Bpad + b ; current decoder step j
+    const int* tab;                 // table: [ntaps][n_out] source position index in X (rows idx*Bpad+b)
+    const int* need;                // table: [ntaps][n_out] source valid iff j >= need
+    const int* stop_after; int t;   // early-out when t > *stop_after (decode loop); stop_after may be null
+};
+
+// ---- LayerNorm epilogues over raw conv rows (one wavefront per row)
+struct EpiArgs {
+    const float* H; int ldh;        // raw rows
+    int M; int C;                   // rows ; channels of the OUTPUT (hc: raw has 2C)
+    int mode;                       // PRE_CONV (LN + act) or PRE_HC (2xLN + gate + highway)
+    int act;
+    const float *g1, *b1, *g2, *b2; // gamma/beta (conv: g1,b1 ; hc: H1 -> g1,b1, H2 -> g2,b2)
+    const float* Xres; int ldres;   // hc residual rows
+    const int* restab; int Bpad;    // if non-null: residual row = restab[m / Bpad]*Bpad + m % Bpad
+    float* Y; int ldy; int ypad;    // output rows; columns [Ctot, ypad) are zero-filled
+    // optional speaker-embedding append (AudioDec 'audio_decoder_input', networks.py:381-387)
+    const float* spk_table; const int* spk_ids; int spk_dim; int spk_T; // utterance of row m: spk_T>0 ? m / spk_T : m % Bpad
+    const int* stop_after; int t;
+};
+
+// ---- fused M=16 decode layer (prologue = previous layer's LN/gate, then 16xK . KxN slice)
+struct DecArgs {
+    int pre;                        // PRE_COPY / PRE_CONV / PRE_HC : how x[t] is produced
+    const float* src; int ldsrc;    // PRE_COPY: x rows ; else raw rows of the previous layer
+    const float *g1, *b1, *g2, *b2; int act;
+    const float* xres; int ldres;   // PRE_HC residual rows (previous layer's input at t)
+    int cin;                        // channels produced by the prologue
+    const float* cat_table; const int* cat_ids; int ccat;  // optional speaker embedding concat
+    float* xstore; int ldstore;     // block x==0 stores x[t] rows here (this layer's input history), may be null
+    int ntaps; int kc;              // kc = padded per-tap K (multiple of 16) >= cin + ccat
+    const float* tap0; const float* tap1; int ldtap;        // older taps (x[t-2r], x[t-r]) rows or null = zeros
+    const float* Wt; int ldw; const float* bias;
+    float* H; int ldh;              // raw output rows [Bpad][ldh]
+    int B;
+    const int* stop_after; int t;
+};
+
+struct AttnStepArgs {
+    // query = gate(LN(H1), LN(H2), xres) of AudioEnc's last highway layer
+    const float* hraw; int ldh; const float *g1, *b1, *g2, *b2; const float* xres; int ldres;
+    const float* KV; int N; int d;  // [B][N][2d] : K cols [0,d), V cols [d,2d)
+    int win; int B; int Bpad; int max_T; int t;
+    const int* pcur; int* pnext;    // prev_max_attentions ping-pong
+    const int* ends; int* t_ends; int* n_ended; int* stop_after;
+    int stop_mode;
+    float* Qhist;                   // [max_T][Bpad][d]
+    float* Rrow; int ldr;           // [Bpad][2d]
+    float* align;                   // (B, N, max_T)
+};
+
+struct AttnRowsArgs {
+    int mode;                       // 0: decoder history rows (position-major), 1: batched op (b,t) rows
+    const float* Q; int ldq;
+    const float* K; const float* V; int ldkv; int N; int d; int win;
+    const int* p;                   // per-utterance window start
+    int B; int Bpad; int nrows;
+    const int* off; int j;          // mode 0: row i*Bpad+b reads Qhist[(j-off[i])*Bpad+b]
+    int T;                          // mode 1
+    float* R; int ldr;
+    float* align; long long* amax;  // mode 1 outputs (B,N,T) and (B,T)
+    const int* stop_after; int t;
+};
+
+struct EmitArgs {
+    const float* hraw; int ldh; const float *g, *b; int C; int squash;
+    float* Yout; int ldy; int max_T;    // [B][max_T][ldy]
+    float* Ytm;  int ldtm; int Bpad;    // [max_T+1][Bpad][ldtm], row t+1 receives Y[t]
+    int B; const int* stop_after; int t;
+};
+
+// launchers (oph_kernels.hip)
+void launch_conv_gemm(const GemmArgs& a, hipStream_t s);
+int  conv_gemm_tile_m(int M, int N);          // tile size chosen for a problem (64 or 128)
+void launch_epilogue(const EpiArgs& a, hipStream_t s);
+void launch_dec_layer(const DecArgs& a, int Npad16, hipStream_t s);
+void launch_attn_step(const AttnStepArgs& a, hipStream_t s);
+void launch_attn_rows(const AttnRowsArgs& a, hipStream_t s);
+void launch_emit_mel(const EmitArgs& a, hipStream_t s);
+void launch_embed(const int* ids, long long n, const float* table, int units, float* out, int ldo, hipStream_t s);
+void launch_pad_rows(const float* src, int lds_, float* dst, int ldd, long long rows, int C, hipStream_t s);
+void launch_fill_int(int* p, int v, int n, hipStream_t s);
+
+}  // namespace oph

@@ -1,0 +1,748 @@
+// HIP kernels for Ophelia's Text2Mel + SSRN synthesis path on MI355X (gfx950, CDNA4).
+// Wave = 64 lanes.  All arithmetic fp32; contractions on the fp32-input MFMA
+// (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32: exact fp32, bitwise an fmaf chain).
+//
+// Kernels
+//   conv_gemm_f32<BM,BN>  batched conv-as-GEMM (TextEnc, SSRN, AudioDec history cone)
+//   ln_rows<NV>           LayerNorm epilogues: conv(LN+act) and highway (2xLN+gate+mix)
+//   dec_layer16           fused M=16 decoder layer: previous layer's LN/gate as prologue,
+//                         then a 16 x K . K x 16 slice per workgroup, K split over 4 waves
+//   attn_step / attn_rows windowed monotonic attention (networks.py:286-325)
+//   emit_mel, embed_rows, pad_rows
+#include "oph_internal.h"
+
+namespace oph {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float apply_act(float x, int act) {
+    return act == ACT_RELU ? fmaxf(x, 0.0f) : (act == ACT_SIGMOID ? sigmoidf_(x) : x);
+}
+__device__ __forceinline__ bool stopped(const int* stop_after, int t) {
+    return stop_after != nullptr && t > *stop_after;
+}
+
+// =====================================================================================
+// conv_gemm_f32: H[m][n] = bias[n] + sum_{tap} sum_{c<kc} X[src(m,tap)][c] * Wt[n][tap*kc+c]
+// 256 threads = 4 waves (2x2), each wave owns a (BM/2)x(BN/2) block of 32x32 MFMA tiles.
+// Both operands are K-contiguous ("TN"): tiles are staged global -> regs -> LDS [row][32+4]
+// (pad 4 floats => conflict-free ds_read_b128 fragment reads) and double-buffered.
+// K order inside an 8-wide chunk is permuted (lanes<32 take k..k+3, lanes>=32 take k+4..k+7,
+// MFMA e pairs k+e with k+4+e) identically for A and B, so the sum is unchanged.
+// =====================================================================================
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_f32(GemmArgs a) {
+    if (stopped(a.stop_after, a.t)) return;
+    constexpr int BK = 32, LD = 36;
+    constexpr int AR = BM / 32, BR = BN / 32;     // float4 staging loads per thread
+    constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 tiles per wave
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                      // [2][BM*LD]
+    float* Bs = smem + 2 * BM * LD;        // [2][BN*LD]
+    int* srow_s = (int*)(smem + 2 * (BM + BN) * LD);   // [3][BM] source row per tap (-1 = zeros)
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
+    const int ntiles = MT * NT;
+    // XCD-aware bijective remap (blocks b, b+8, .. share an XCD/L2): contiguous tile chunk per XCD
+    int id;
+    {
+        const int bid = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    // grouped ordering: 8 m-tiles x all n-tiles per group keeps A and W panels L2-resident
+    constexpr int GM = 8;
+    const int width = GM * NT, g = id / width, first_m = g * GM;
+    const int gsz = min(MT - first_m, GM);
+    const int tm = first_m + (id % width) % gsz, tn = (id % width) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    for (int i = tid; i < BM * a.ntaps; i += 256) {
+        const int tap = i / BM, m = m0 + (i - tap * BM);
+        int src = -1;
+        if (m < a.M) {
+            if (a.mode == 0) {
+                const int b = m / a.T, t = m - b * a.T, tt = t + a.off[tap];
+                if (tt >= 0 && tt < a.T) src = m + a.off[tap];
+            } else {
+                const int ip = m / a.Bpad, b = m - ip * a.Bpad;
+                if (a.j >= a.need[tap * a.n_out + ip]) src = a.tab[tap * a.n_out + ip] * a.Bpad + b;
+            }
+        }
+        srow_s[i] = src;
+    }
+    __syncthreads();
+
+    const int lrow = tid >> 3, kq = tid & 7;
+    const int kpt = a.kc / BK, nk = a.ntaps * kpt;
+    f32x4 ra[AR], rb[BR];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    auto load_global = [&](int s) {
+        const int tap = s / kpt, ko = (s - tap * kpt) * BK + kq * 4;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int src = srow_s[tap * BM + lrow + 32 * i];
+            ra[i] = src >= 0 ? *(const f32x4*)(a.X + (size_t)src * a.ldx + ko) : zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+            rb[i] = *(const f32x4*)(a.Wt + (size_t)(n0 + lrow + 32 * i) * a.ldw + tap * a.kc + ko);
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) *(f32x4*)(As + buf * BM * LD + (lrow + 32 * i) * LD + kq * 4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BR; ++i) *(f32x4*)(Bs + buf * BN * LD + (lrow + 32 * i) * LD + kq * 4) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
+
+    const int wr = w >> 1, wc = w & 1, r32 = lane & 31, kh = lane >> 5;
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+    for (int s = 0; s < nk; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nk) load_global(s + 1);
+        const float* Ab = As + buf * BM * LD + (wr * (BM / 2) + r32) * LD + kh * 4;
+        const float* Bb = Bs + buf * BN * LD + (wc * (BN / 2) + r32) * LD + kh * 4;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(Ab + i * 32 * LD + kk * 8);
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) bf[jn] = *(const f32x4*)(Bb + jn * 32 * LD + kk * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < TN; ++jn)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[jn][e], acc[i][jn], 0, 0, 0);
+        }
+        if (s + 1 < nk) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+    // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+            const int col = n0 + wc * (BN / 2) + jn * 32 + r32;
+            const float bv = a.bias[col];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                if (row < a.M) a.H[(size_t)row * a.ldh + col] = acc[i][jn][e] + bv;
+            }
+        }
+}
+
+int conv_gemm_tile_m(int M, int N) {
+    const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
+    return t128 >= 384 ? 128 : 64;
+}
+
+template <int BM, int BN>
+static void launch_conv_gemm_t(const GemmArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)(2 * (BM + BN) * 36) * 4 + (size_t)3 * BM * 4;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv_gemm_f32<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
+    hipLaunchKernelGGL((conv_gemm_f32<BM, BN>), dim3(MT * NT), dim3(256), lds, s, a);
+}
+void launch_conv_gemm(const GemmArgs& a, hipStream_t s) {
+    if (conv_gemm_tile_m(a.M, a.N) == 128) launch_conv_gemm_t<128, 128>(a, s);
+    else launch_conv_gemm_t<64, 64>(a, s);
+}
+
+// =====================================================================================
+// ln_rows<NV>: one wavefront per row; the row (<= NV*256 channels) lives in registers.
+// [TF-sem] tf.contrib.layers.layer_norm: mean, biased variance, eps 1e-12 (modules.py:65).
+//   conv : y = act(LN(h))                                     (modules.py:137-139)
+//   hc   : g = sigmoid(LN1(h[:C])), u = LN2(h[C:]), y = g*u + (1-g)*x   (modules.py:194-203)
+// =====================================================================================
+template <int NV>
+__device__ __forceinline__ void ln_vec(f32x4 (&x)[NV], int C, int lane, const float* gam, const float* bet) {
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += ((v * 64 + lane) * 4 + e < C) ? x[v][e] : 0.f;
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float dlt = ((v * 64 + lane) * 4 + e < C) ? x[v][e] - mean : 0.f;
+            x[v][e] = dlt;
+            q += dlt * dlt;
+        }
+    const float var = wave_sum(q) / (float)C;
+    const float rstd = 1.0f / sqrtf(var + LN_EPS);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        if (c < C) {
+            const f32x4 gv = *(const f32x4*)(gam + c), bv = *(const f32x4*)(bet + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[v][e] = x[v][e] * rstd * gv[e] + bv[e];
+        }
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_rows(EpiArgs a) {
+    if (stopped(a.stop_after, a.t)) return;
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= a.M) return;
+    const int C = a.C;
+    const float* h = a.H + (size_t)m * a.ldh;
+    f32x4 x[NV];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        x[v] = c < C ? *(const f32x4*)(h + c) : zero4;
+    }
+    ln_vec<NV>(x, C, lane, a.g1, a.b1);
+    if (a.mode == PRE_HC) {
+        f32x4 u[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            u[v] = c < C ? *(const f32x4*)(h + C + c) : zero4;
+        }
+        ln_vec<NV>(u, C, lane, a.g2, a.b2);
+        size_t rrow = m;
+        if (a.restab) rrow = (size_t)a.restab[m / a.Bpad] * a.Bpad + (m % a.Bpad);
+        const float* xr = a.Xres + rrow * a.ldres;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (c < C) {
+                const f32x4 xv = *(const f32x4*)(xr + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gte = sigmoidf_(x[v][e]);
+                    x[v][e] = gte * u[v][e] + (1.0f - gte) * xv[e];
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[v][e] = apply_act(x[v][e], a.act);
+    }
+    float* y = a.Y + (size_t)m * a.ldy;
+    const bool vec_ok = (a.ldy & 3) == 0;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        if (c + 3 < C && vec_ok) *(f32x4*)(y + c) = x[v];
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < C) y[c + e] = x[v][e];
+        }
+    }
+    int ctot = C;
+    if (a.spk_table) {
+        const int u = a.spk_T > 0 ? m / a.spk_T : m % a.Bpad;
+        const int id = a.spk_ids[u];
+        for (int c = lane; c < a.spk_dim; c += 64)
+            y[C + c] = id == 0 ? 0.f : a.spk_table[(size_t)id * a.spk_dim + c];   // row 0 zeroed at lookup (modules.py:38-40)
+        ctot += a.spk_dim;
+    }
+    for (int c = ctot + lane; c < a.ypad; c += 64) y[c] = 0.f;
+}
+
+void launch_epilogue(const EpiArgs& a, hipStream_t s) {
+    const dim3 grid((a.M + 3) / 4), block(256);
+    if (a.C <= 256) hipLaunchKernelGGL(ln_rows<1>, grid, block, 0, s, a);
+    else if (a.C <= 512) hipLaunchKernelGGL(ln_rows<2>, grid, block, 0, s, a);
+    else if (a.C <= 1024) hipLaunchKernelGGL(ln_rows<4>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(ln_rows<5>, grid, block, 0, s, a);   // <= 1280 (full_dim 1025)
+}
+
+// =====================================================================================
+// dec_layer16: one decoder layer for a tile of 16 utterances at ONE time step.
+//   grid = (Npad/16, Bpad/16), 256 threads.  Every workgroup redundantly runs the cheap
+//   prologue (the previous layer's LayerNorm / gate / highway mix for its 16 rows) into LDS,
+//   gathers the dilated taps x[t-2r], x[t-r] from the layer's history rows, then computes a
+//   16x16 output slice on v_mfma_f32_16x16x4_f32 with K split round-robin over the 4 waves;
+//   weight fragments (Wt is [n][k], k contiguous) are fetched straight from L2 into
+//   registers and are issued BEFORE the prologue so their latency hides behind it.
+//   Output = raw conv rows (bias added); the consumer kernel applies this layer's LN.
+// =====================================================================================
+constexpr int DEC_NVMAX = 4;      // prologue channels <= 1024
+constexpr int DEC_PF = 12;        // 16-wide k-chunks prefetched per wave per pass (K <= 768 in one pass)
+
+__global__ __launch_bounds__(256) void dec_layer16(DecArgs a) {
+    if (stopped(a.stop_after, a.t)) return;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Ktot = a.ntaps * a.kc, ldxs = Ktot + 4;
+    float* xs = smem;                 // [16][ldxs]
+    float* part = smem + 16 * ldxs;   // [4][256]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n0 = blockIdx.x * 16, row0 = blockIdx.y * 16;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int nchunks = Ktot >> 4;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    const float* wrow = a.Wt + (size_t)(n0 + r16) * a.ldw + kq * 4;
+    f32x4 bfrag[DEC_PF];
+#pragma unroll
+    for (int i = 0; i < DEC_PF; ++i) {
+        const int c = w + 4 * i;
+        bfrag[i] = c < nchunks ? *(const f32x4*)(wrow + c * 16) : zero4;
+    }
+
+    // ---- prologue: wave w produces rows 4w..4w+3
+    const int cur = (a.ntaps - 1) * a.kc;
+    for (int rr = 0; rr < 4; ++rr) {
+        const int row = 4 * w + rr, grow = row0 + row;
+        float* xrow = xs + row * ldxs;
+        f32x4 x[DEC_NVMAX];
+        if (a.pre == PRE_COPY) {
+            const float* sp = a.src + (size_t)grow * a.ldsrc;
+#pragma unroll
+            for (int v = 0; v < DEC_NVMAX; ++v) {
+                const int c = (v * 64 + lane) * 4;
+                x[v] = c < a.cin ? *(const f32x4*)(sp + c) : zero4;
+            }
+        } else {
+            const float* hp = a.src + (size_t)grow * a.ldsrc;
+            // generic (runtime cin) LayerNorm over <= 1024 channels held in registers
+            auto ln = [&](f32x4 (&z)[DEC_NVMAX], const float* base, const float* gam, const float* bet) {
+                float s = 0.f;
+#pragma unroll
+                for (int v = 0; v < DEC_NVMAX; ++v) {
+                    const int c = (v * 64 + lane) * 4;
+                    z[v] = c < a.cin ? *(const f32x4*)(base + c) : zero4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s += (c + e < a.cin) ? z[v][e] : 0.f;
+                }
+                const float mean = wave_sum(s) / (float)a.cin;
+                float q = 0.f;
+#pragma unroll
+                for (int v = 0; v < DEC_NVMAX; ++v)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float dlt = ((v * 64 + lane) * 4 + e < a.cin) ? z[v][e] - mean : 0.f;
+                        z[v][e] = dlt;
+                        q += dlt * dlt;
+                    }
+                const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)a.cin + LN_EPS);
+#pragma unroll
+                for (int v = 0; v < DEC_NVMAX; ++v) {
+                    const int c = (v * 64 + lane) * 4;
+                    if (c < a.cin) {
+                        const f32x4 gv = *(const f32x4*)(gam + c), bv = *(const f32x4*)(bet + c);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) z[v][e] = z[v][e] * rstd * gv[e] + bv[e];
+                    }
+                }
+            };
+            ln(x, hp, a.g1, a.b1);
+            if (a.pre == PRE_HC) {
+                f32x4 u[DEC_NVMAX];
+                ln(u, hp + a.cin, a.g2, a.b2);
+                const float* xr = a.xres + (size_t)grow * a.ldres;
+#pragma unroll
+                for (int v = 0; v < DEC_NVMAX; ++v) {
+                    const int c = (v * 64 + lane) * 4;
+                    if (c < a.cin) {
+                        const f32x4 xv = *(const f32x4*)(xr + c);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float gte = sigmoidf_(x[v][e]);
+                            x[v][e] = gte * u[v][e] + (1.0f - gte) * xv[e];
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < DEC_NVMAX; ++v)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[v][e] = apply_act(x[v][e], a.act);
+            }
+        }
+        // current tap block: [0,cin) = x, [cin, cin+ccat) = speaker embedding, rest zero
+#pragma unroll
+        for (int v = 0; v < DEC_NVMAX; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (c < a.kc) {
+                f32x4 val = x[v];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e >= a.cin) val[e] = 0.f;
+                *(f32x4*)(xrow + cur + c) = val;
+            }
+        }
+        if (a.ccat > 0) {
+            const int id = a.cat_ids[grow < a.B ? grow : 0];
+            for (int c = lane; c < a.ccat; c += 64)
+                xrow[cur + a.cin + c] = id == 0 ? 0.f : a.cat_table[(size_t)id * a.ccat + c];
+        }
+        // older taps from this layer's input history (rows have ld >= kc with zero pads)
+        if (a.ntaps == 3) {
+            const float* t0 = a.tap0 ? a.tap0 + (size_t)grow * a.ldtap : nullptr;
+            const float* t1 = a.tap1 ? a.tap1 + (size_t)grow * a.ldtap : nullptr;
+            for (int c = lane * 4; c < a.kc; c += 256) {
+                *(f32x4*)(xrow + c) = t0 ? *(const f32x4*)(t0 + c) : zero4;
+                *(f32x4*)(xrow + a.kc + c) = t1 ? *(const f32x4*)(t1 + c) : zero4;
+            }
+        }
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && a.xstore) {     // publish x[t] (this layer's input) for later steps / residual
+        for (int i = tid * 4; i < 16 * a.kc; i += 1024) {
+            const int row = i / a.kc, c = i - row * a.kc;
+            *(f32x4*)(a.xstore + (size_t)(row0 + row) * a.ldstore + c) = *(const f32x4*)(xs + row * ldxs + cur + c);
+        }
+    }
+
+    // ---- 16x16 slice, K split over waves
+    f32x4 acc0 = zero4, acc1 = zero4;
+    const float* xa = xs + r16 * ldxs + kq * 4;
+    for (int base = 0; base < nchunks; base += 4 * DEC_PF) {
+        if (base > 0) {
+#pragma unroll
+            for (int i = 0; i < DEC_PF; ++i) {
+                const int c = base + w + 4 * i;
+                bfrag[i] = c < nchunks ? *(const f32x4*)(wrow + c * 16) : zero4;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < DEC_PF; ++i) {
+            const int c = base + w + 4 * i;
+            if (c < nchunks) {
+                const f32x4 av = *(const f32x4*)(xa + c * 16);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bfrag[i][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bfrag[i][1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bfrag[i][2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bfrag[i][3], acc1, 0, 0, 0);
+            }
+        }
+    }
+    // C/D layout of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[w * 256 + (kq * 4 + e) * 16 + r16] = acc0[e] + acc1[e];
+    __syncthreads();
+    {
+        const int row = tid >> 4, col = tid & 15;
+        const float v = part[tid] + part[256 + tid] + part[512 + tid] + part[768 + tid] + a.bias[n0 + col];
+        a.H[(size_t)(row0 + row) * a.ldh + n0 + col] = v;
+    }
+}
+
+void launch_dec_layer(const DecArgs& a, int Npad16, hipStream_t s) {
+    const int Ktot = a.ntaps * a.kc;
+    const size_t lds = (size_t)(16 * (Ktot + 4) + 1024) * 4;
+    static size_t attr = 0;
+    if (lds > attr) {
+        hipFuncSetAttribute((const void*)dec_layer16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = lds;
+    }
+    const int Bpad = round_up(a.B, 16);
+    hipLaunchKernelGGL(dec_layer16, dim3(Npad16 / 16, Bpad / 16), dim3(256), lds, s, a);
+}
+
+// =====================================================================================
+// Attention (networks.py:286-325, monotonic synthesis branch).
+// With prev_max = p the unmasked keys are [p, min(p+win, N)): keys n<p (key_masks) and
+// n>=p+win (reverse_masks, only when N-win-p>0) receive -2**32+1 and their softmax terms
+// are exactly 0 in fp32, so only the window is evaluated; outputs are identical.
+// One wavefront per (utterance, query row); lane holds d/64 channels.
+// =====================================================================================
+constexpr int ATT_NV = 2;     // d <= 512
+constexpr int ATT_WMAX = 8;   // attention_win_size <= 8
+
+struct AttnOut { float prob[ATT_WMAX]; int nwin; int arg; };
+
+__device__ __forceinline__ AttnOut attend_window(const f32x4 (&q)[ATT_NV], const float* Kb, const float* Vb, int ldkv,
+                                                 int p, int N, int win, int d, int lane, f32x4 (&ctx)[ATT_NV]) {
+    AttnOut o;
+    o.nwin = min(win, N - p);
+    const float scale = 1.0f / sqrtf((float)d);      // tf.rsqrt(tf.to_float(hp.d))  networks.py:300
+    float sc[ATT_WMAX];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < ATT_WMAX; ++i) {
+        sc[i] = -INFINITY;
+        if (i < o.nwin) {
+            const float* kr = Kb + (size_t)(p + i) * ldkv;
+            float s = 0.f;
+#pragma unroll
+            for (int v = 0; v < ATT_NV; ++v) {
+                const int c = (v * 64 + lane) * 4;
+                if (c < d) {
+                    const f32x4 kv = *(const f32x4*)(kr + c);
+                    s += q[v][0] * kv[0] + q[v][1] * kv[1] + q[v][2] * kv[2] + q[v][3] * kv[3];
+                }
+            }
+            sc[i] = wave_sum(s) * scale;
+            mx = fmaxf(mx, sc[i]);
+        }
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int i = 0; i < ATT_WMAX; ++i) {
+        o.prob[i] = i < o.nwin ? expf(sc[i] - mx) : 0.f;
+        den += o.prob[i];
+    }
+    o.arg = 0;
+    float best = -1.f;
+#pragma unroll
+    for (int i = 0; i < ATT_WMAX; ++i) {
+        o.prob[i] = o.prob[i] / den;
+        if (i < o.nwin && o.prob[i] > best) { best = o.prob[i]; o.arg = i; }   // first max on ties
+    }
+#pragma unroll
+    for (int v = 0; v < ATT_NV; ++v) {
+        ctx[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int c = (v * 64 + lane) * 4;
+        if (c < d) {
+#pragma unroll
+            for (int i = 0; i < ATT_WMAX; ++i)
+                if (i < o.nwin) {
+                    const f32x4 vv = *(const f32x4*)(Vb + (size_t)(p + i) * ldkv + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ctx[v][e] += o.prob[i] * vv[e];
+                }
+        }
+    }
+    return o;
+}
+
+// attn_step: grid = Bpad/16 blocks of 16 waves; wave = utterance.
+__global__ __launch_bounds__(1024) void attn_step(AttnStepArgs a) {
+    if (a.t > *a.stop_after) return;
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 16 + (threadIdx.x >> 6);
+    if (b >= a.B) return;
+    const int d = a.d;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // query = highway output of AudioEnc's last layer
+    f32x4 q[ATT_NV], u[ATT_NV];
+    const float* h = a.hraw + (size_t)b * a.ldh;
+    auto ln = [&](f32x4 (&z)[ATT_NV], const float* base, const float* gam, const float* bet) {
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < ATT_NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            z[v] = c < d ? *(const f32x4*)(base + c) : zero4;
+            s += z[v][0] + z[v][1] + z[v][2] + z[v][3];
+        }
+        const float mean = wave_sum(s) / (float)d;
+        float qq = 0.f;
+#pragma unroll
+        for (int v = 0; v < ATT_NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dlt = c < d ? z[v][e] - mean : 0.f;
+                z[v][e] = dlt;
+                qq += dlt * dlt;
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(qq) / (float)d + LN_EPS);
+#pragma unroll
+        for (int v = 0; v < ATT_NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (c < d) {
+                const f32x4 gv = *(const f32x4*)(gam + c), bv = *(const f32x4*)(bet + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[v][e] = z[v][e] * rstd * gv[e] + bv[e];
+            }
+        }
+    };
+    ln(q, h, a.g1, a.b1);
+    ln(u, h + d, a.g2, a.b2);
+    const float* xr = a.xres + (size_t)b * a.ldres;
+    float* qh = a.Qhist + ((size_t)a.t * a.Bpad + b) * d;
+    float* rr = a.Rrow + (size_t)b * a.ldr;
+#pragma unroll
+    for (int v = 0; v < ATT_NV; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        if (c < d) {
+            const f32x4 xv = *(const f32x4*)(xr + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gte = sigmoidf_(q[v][e]);
+                q[v][e] = gte * u[v][e] + (1.0f - gte) * xv[e];
+            }
+            *(f32x4*)(qh + c) = q[v];
+            *(f32x4*)(rr + d + c) = q[v];       // R' = concat(R, Q)  networks.py:317-319
+        }
+    }
+    const int p = a.pcur[b];
+    const float* KVb = a.KV + (size_t)b * a.N * 2 * d;
+    f32x4 ctx[ATT_NV];
+    const AttnOut o = attend_window(q, KVb, KVb + d, 2 * d, p, a.N, a.win, d, lane, ctx);
+#pragma unroll
+    for (int v = 0; v < ATT_NV; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        if (c < d) *(f32x4*)(rr + c) = ctx[v];
+    }
+    if (lane == 0) {
+        float* al = a.align + (size_t)b * a.N * a.max_T + a.t;      // alignments[b, n, t]
+#pragma unroll
+        for (int i = 0; i < ATT_WMAX; ++i)
+            if (i < o.nwin) al[(size_t)(p + i) * a.max_T] = o.prob[i];
+        const int m = p + o.arg;                                    // max_attentions[b, t]
+        a.pnext[b] = m;
+        // synthesize.py:218-228: first step at which attention sits on/after the text end
+        if (a.t_ends[b] == a.max_T && m >= a.ends[b]) {
+            a.t_ends[b] = a.t;
+            const int old = atomicAdd(a.n_ended, 1);
+            if (old + 1 == a.B && a.stop_mode == 0) *a.stop_after = a.t;
+        }
+    }
+}
+
+void launch_attn_step(const AttnStepArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(attn_step, dim3(a.Bpad / 16), dim3(1024), 0, s, a);
+}
+
+// attn_rows: generic rows.  mode 0 = decoder history rows (position-major, current mask p);
+// mode 1 = batched operator over (b,t) with alignments + argmax outputs.
+__global__ __launch_bounds__(256) void attn_rows(AttnRowsArgs a) {
+    if (stopped(a.stop_after, a.t)) return;
+    const int lane = threadIdx.x & 63;
+    const int rid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (rid >= a.nrows) return;
+    int b, tq = 0;
+    const float* qp;
+    if (a.mode == 0) {
+        const int i = rid / a.Bpad;
+        b = rid - i * a.Bpad;
+        const int t = a.j - a.off[i];
+        if (b >= a.B || t < 0) return;
+        qp = a.Q + ((size_t)t * a.Bpad + b) * a.ldq;
+    } else {
+        b = rid / a.T;
+        tq = rid - b * a.T;
+        qp = a.Q + (size_t)rid * a.ldq;
+    }
+    const int d = a.d;
+    f32x4 q[ATT_NV], ctx[ATT_NV];
+#pragma unroll
+    for (int v = 0; v < ATT_NV; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        q[v] = c < d ? *(const f32x4*)(qp + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int p = a.p[b];
+    const float* Kb = a.K + (size_t)b * a.N * a.ldkv;
+    const float* Vb = a.V + (size_t)b * a.N * a.ldkv;
+    const AttnOut o = attend_window(q, Kb, Vb, a.ldkv, p, a.N, a.win, d, lane, ctx);
+    float* rr = a.R + (size_t)rid * a.ldr;
+#pragma unroll
+    for (int v = 0; v < ATT_NV; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        if (c < d) {
+            *(f32x4*)(rr + c) = ctx[v];
+            *(f32x4*)(rr + d + c) = q[v];
+        }
+    }
+    if (a.mode == 1) {
+        float* al = a.align + (size_t)b * a.N * a.T + tq;
+        for (int n = lane; n < a.N; n += 64) {
+            float pv = 0.f;
+#pragma unroll
+            for (int i = 0; i < ATT_WMAX; ++i)
+                if (i < o.nwin && n == p + i) pv = o.prob[i];
+            al[(size_t)n * a.T] = pv;
+        }
+        if (lane == 0) a.amax[rid] = p + o.arg;
+    }
+}
+
+void launch_attn_rows(const AttnRowsArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(attn_rows, dim3((a.nrows + 3) / 4), dim3(256), 0, s, a);
+}
+
+// emit_mel: Y[b, t, :] = sigmoid(LN(logits))  (networks.py:421-431); also feeds S[t+1] (architectures.py:191)
+__global__ __launch_bounds__(256) void emit_mel(EmitArgs a) {
+    if (stopped(a.stop_after, a.t)) return;
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= a.B) return;
+    f32x4 x[1];
+    const int c = lane * 4;
+    x[0] = c < a.C ? *(const f32x4*)(a.hraw + (size_t)b * a.ldh + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    ln_vec<1>(x, a.C, lane, a.g, a.b);
+    float* yo = a.Yout + ((size_t)b * a.max_T + a.t) * a.ldy;
+    float* yt = a.Ytm + ((size_t)(a.t + 1) * a.Bpad + b) * a.ldtm;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float v = c + e < a.C ? (a.squash ? sigmoidf_(x[0][e]) : x[0][e]) : 0.f;
+        if (c + e < a.ldy) yo[c + e] = v;
+        if (c + e < a.ldtm) yt[c + e] = v;
+    }
+}
+void launch_emit_mel(const EmitArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(emit_mel, dim3((a.B + 3) / 4), dim3(256), 0, s, a);
+}
+
+// embed_rows: modules.py:15-44 (row 0 replaced by zeros at lookup time); pads to ldo with zeros
+__global__ void embed_rows(const int* ids, long long n, const float* table, int units, float* out, int ldo) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = ldo / 4;
+    if (i >= n * per) return;
+    const long long row = i / per;
+    const int c = (int)(i - row * per) * 4;
+    const int id = ids[row];
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (id != 0 && c + e < units) v[e] = table[(size_t)id * units + c + e];
+    *(f32x4*)(out + row * ldo + c) = v;
+}
+void launch_embed(const int* ids, long long n, const float* table, int units, float* out, int ldo, hipStream_t s) {
+    const long long tot = n * (ldo / 4);
+    hipLaunchKernelGGL(embed_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ids, n, table, units, out, ldo);
+}
+
+// pad_rows: dst[r][0:ldd) = src[r][0:C) then zeros
+__global__ void pad_rows_k(const float* src, int lds_, float* dst, int ldd, long long rows, int C) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * ldd) return;
+    const long long r = i / ldd;
+    const int c = (int)(i - r * ldd);
+    dst[i] = c < C ? src[r * lds_ + c] : 0.f;
+}
+void launch_pad_rows(const float* src, int lds_, float* dst, int ldd, long long rows, int C, hipStream_t s) {
+    const long long tot = rows * ldd;
+    hipLaunchKernelGGL(pad_rows_k, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, lds_, dst, ldd, rows, C);
+}
+
+__global__ void fill_int_k(int* p, int v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+void launch_fill_int(int* p, int v, int n, hipStream_t s) {
+    hipLaunchKernelGGL(fill_int_k, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n);
+}
+
+}  // namespace oph

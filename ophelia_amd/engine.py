@@ -1,0 +1,192 @@
+"""Engine: one handle of libophelia_hip.so (= one GPU, one host thread).  It plays the
+role of the reference's (graph, session) pair (synthesize.py:511-537): built from `hp`,
+loaded with variables by TF name, then driven through encode_text / text2mel / ssrn."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def dims_from_hp(hp, max_N=None, max_T=None):
+    ms = list(getattr(hp, "multispeaker", []) or [])
+    unsupported = [p for p in ms if p != "audio_decoder_input"]
+    if unsupported:
+        raise NotImplementedError("multispeaker positions %s are outside the hot-path scope "
+                                  "(SURVEY.md 8f-4)" % unsupported)
+    for attr, want in (("norm", "layer"), ("text_encoder_type", "DCTTS_standard"),
+                       ("history_type", "DCTTS_standard"), ("use_external_durations", False),
+                       ("concatenate_query", True), ("turn_off_monotonic_for_synthesis", False),
+                       ("squash_output_t2m", True), ("squash_output_ssrn", True)):
+        if getattr(hp, attr, want) != want:
+            raise NotImplementedError("hp.%s=%r is outside the hot-path scope" % (attr, getattr(hp, attr)))
+    d = _lib.OphDims()
+    d.vocab = len(hp.vocab)
+    d.e, d.d, d.c = hp.e, hp.d, hp.c
+    d.n_mels, d.full_dim, d.r = hp.n_mels, hp.full_dim, hp.r
+    d.max_N = hp.max_N if max_N is None else max_N
+    d.max_T = hp.max_T if max_T is None else max_T
+    d.attention_win_size = hp.attention_win_size
+    d.nspeakers = getattr(hp, "nspeakers", 0) if ms else 0
+    d.speaker_embedding_size = getattr(hp, "speaker_embedding_size", 0) if ms else 0
+    d.flags = _lib.FLAG_SPK_AUDIO_DECODER_INPUT if ms else 0
+    return d
+
+
+class Engine(object):
+    def __init__(self, hp, device=0, max_N=None, max_T=None):
+        self.lib = _lib.load()
+        self.dims = dims_from_hp(hp, max_N, max_T)
+        self.hp = hp
+        self._h = C.c_void_p()
+        rc = self.lib.oph_create(C.byref(self.dims), int(device), C.byref(self._h))
+        if rc != 0:
+            raise _lib.OpheliaHipError("oph_create failed (%d): %s" % (rc, self.lib.oph_last_error(None).decode()))
+        self.multispeaker = bool(self.dims.flags & _lib.FLAG_SPK_AUDIO_DECODER_INPUT)
+        self.B = 0
+
+    # -- plumbing
+    def _chk(self, rc):
+        if rc != 0:
+            raise _lib.OpheliaHipError("libophelia_hip error %d: %s" % (rc, self.lib.oph_last_error(self._h).decode()))
+
+    def close(self):
+        if self._h:
+            self.lib.oph_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights
+    def inventory(self):
+        out = []
+        name = C.create_string_buffer(256)
+        shape = (C.c_int64 * 4)()
+        rank = C.c_int()
+        for i in range(self.lib.oph_num_weights(self._h)):
+            self._chk(self.lib.oph_weight_info(self._h, i, name, 256, shape, C.byref(rank)))
+            out.append((name.value.decode(), tuple(int(shape[k]) for k in range(rank.value))))
+        return out
+
+    def load_weights(self, W):
+        for name, shape in self.inventory():
+            if name not in W:
+                raise KeyError("missing variable %s" % name)
+            a = np.ascontiguousarray(W[name], dtype=np.float32)
+            shp = (C.c_int64 * 4)(*a.shape)
+            self._chk(self.lib.oph_set_weight(self._h, name.encode(), _lib.fptr(a), shp, a.ndim))
+        self._chk(self.lib.oph_finalize_weights(self._h))
+
+    # -- the three session calls (host arrays in/out), synthesize.py:232-260
+    def _spk(self, speaker_data, B):
+        if not self.multispeaker:
+            return None, None
+        if speaker_data is None:
+            raise ValueError("multispeaker model: speaker_data (B,1) required (synthesize.py:496-503)")
+        s = np.ascontiguousarray(np.asarray(speaker_data).reshape(B), dtype=np.int32)
+        return s, _lib.iptr(s)
+
+    def encode_text(self, L, speaker_data=None):
+        L = np.ascontiguousarray(L, dtype=np.int32)
+        B, N = L.shape
+        assert N == self.dims.max_N, (N, self.dims.max_N)
+        K = np.empty((B, N, self.dims.d), np.float32)
+        V = np.empty_like(K)
+        s, sp = self._spk(speaker_data, B)
+        self._chk(self.lib.oph_encode_text(self._h, _lib.iptr(L), sp, B, _lib.fptr(K), _lib.fptr(V)))
+        return K, V
+
+    def text2mel(self, K, V, ends, speaker_data=None, stop_mode=_lib.STOP_REFERENCE):
+        K = np.ascontiguousarray(K, dtype=np.float32)
+        V = np.ascontiguousarray(V, dtype=np.float32)
+        B = K.shape[0]
+        assert K.shape == V.shape == (B, self.dims.max_N, self.dims.d)
+        ends = np.ascontiguousarray(ends, dtype=np.int32)
+        Y = np.empty((B, self.dims.max_T, self.dims.n_mels), np.float32)
+        t_ends = np.empty((B,), np.int32)
+        al = np.empty((B, self.dims.max_N, self.dims.max_T), np.float32)
+        steps = C.c_int32()
+        s, sp = self._spk(speaker_data, B)
+        self._chk(self.lib.oph_text2mel(self._h, _lib.fptr(K), _lib.fptr(V), _lib.iptr(ends), sp, B, int(stop_mode),
+                                        _lib.fptr(Y), _lib.iptr(t_ends), _lib.fptr(al), C.byref(steps)))
+        return Y, t_ends, al, steps.value
+
+    def ssrn(self, Y):
+        Y = np.ascontiguousarray(Y, dtype=np.float32)
+        B, T, nm = Y.shape
+        assert nm == self.dims.n_mels
+        Z = np.empty((B, T * self.dims.r, self.dims.full_dim), np.float32)
+        self._chk(self.lib.oph_ssrn(self._h, _lib.fptr(Y), B, T, _lib.fptr(Z)))
+        return Z
+
+    # -- device-resident pipeline
+    def stage_text(self, L, ends, speaker_data=None):
+        L = np.ascontiguousarray(L, dtype=np.int32)
+        ends = np.ascontiguousarray(ends, dtype=np.int32)
+        B = L.shape[0]
+        s, sp = self._spk(speaker_data, B)
+        self._chk(self.lib.oph_stage_text(self._h, _lib.iptr(L), _lib.iptr(ends), sp, B))
+        self.B = B
+
+    def run_resident(self, stop_mode=_lib.STOP_NEVER, run_ssrn=True):
+        steps = C.c_int32()
+        self._chk(self.lib.oph_run_resident(self._h, int(stop_mode), int(bool(run_ssrn)), C.byref(steps)))
+        return steps.value
+
+    def decode_steps(self, t_begin, t_end, stop_mode):
+        steps = C.c_int32()
+        self._chk(self.lib.oph_decode_steps(self._h, int(t_begin), int(t_end), int(stop_mode), C.byref(steps)))
+        return steps.value
+
+    def run_ssrn_resident(self):
+        self._chk(self.lib.oph_run_ssrn_resident(self._h))
+
+    def fetch_kv(self):
+        K = np.empty((self.B, self.dims.max_N, self.dims.d), np.float32)
+        V = np.empty_like(K)
+        self._chk(self.lib.oph_fetch_kv(self._h, _lib.fptr(K), _lib.fptr(V)))
+        return K, V
+
+    def fetch_mel(self):
+        Y = np.empty((self.B, self.dims.max_T, self.dims.n_mels), np.float32)
+        t_ends = np.empty((self.B,), np.int32)
+        al = np.empty((self.B, self.dims.max_N, self.dims.max_T), np.float32)
+        self._chk(self.lib.oph_fetch_mel(self._h, _lib.fptr(Y), _lib.iptr(t_ends), _lib.fptr(al)))
+        return Y, t_ends, al
+
+    def fetch_mag(self):
+        Z = np.empty((self.B, self.dims.max_T * self.dims.r, self.dims.full_dim), np.float32)
+        self._chk(self.lib.oph_fetch_mag(self._h, _lib.fptr(Z)))
+        return Z
+
+    def synchronize(self):
+        self._chk(self.lib.oph_synchronize(self._h))
+
+    # -- measurement
+    def timer_start(self):
+        self._chk(self.lib.oph_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._chk(self.lib.oph_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
+    def profile_enable(self, on=True):
+        self._chk(self.lib.oph_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        self._chk(self.lib.oph_profile_reset(self._h))
+
+    def profile(self):
+        out = []
+        name = C.create_string_buffer(64)
+        n, ms, by, fl = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+        for i in range(self.lib.oph_profile_count(self._h)):
+            self._chk(self.lib.oph_profile_get(self._h, i, name, 64, C.byref(n), C.byref(ms), C.byref(by), C.byref(fl)))
+            out.append(dict(name=name.value.decode(), launches=n.value, total_ms=ms.value,
+                            alg_bytes=by.value, alg_flops=fl.value))
+        return out
