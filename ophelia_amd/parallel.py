@@ -1,0 +1,71 @@
+"""Multi-GPU plumbing (one process per GPU, torch.distributed; backend "nccl" = RCCL on
+ROCm, "gloo" on CPU in tests).  The hot path shards by utterance -- there is NO data-path
+collective (every op is per-utterance).  Collectives are used only for
+  * the start-up weight broadcast (one flat fp32 tensor, root -> peers over xGMI), and
+  * the one-integer MAX exchange that reproduces the reference's batch-coupled early stop
+    (synthesize.py:225-228 breaks when ALL utterances of the global batch have ended).
+"""
+import numpy as np
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous utterance shard of `rank`: sizes differ by at most one, order preserved."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+def broadcast_weights(W, inventory, src=0, device=None):
+    """Broadcast the weight dict from `src` as ONE flat fp32 tensor (RCCL when device is a GPU)."""
+    import torch
+    from . import weights as WT
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1:
+        return W
+    n = int(sum(int(np.prod(s)) for _, s in inventory))
+    dev = torch.device("cuda", device) if (device is not None and torch.cuda.is_available()) else torch.device("cpu")
+    if dist.get_rank() == src:
+        flat = torch.from_numpy(WT.flatten(W, inventory)).to(dev)
+    else:
+        flat = torch.empty(n, dtype=torch.float32, device=dev)
+    dist.broadcast(flat, src=src)
+    return W if dist.get_rank() == src else WT.unflatten(flat.cpu().numpy(), inventory)
+
+
+def global_max_int(value, device=None):
+    """MAX over ranks of one integer (the global stop step)."""
+    import torch
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1:
+        return int(value)
+    dev = torch.device("cuda", device) if (device is not None and torch.cuda.is_available()) else torch.device("cpu")
+    t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
+def gather_arrays(arr):
+    """Concatenate per-rank numpy arrays on every rank, in rank order (host side)."""
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1:
+        return arr
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, arr)
+    return np.concatenate(out, axis=0)
+
+
+def sharded_text2mel(decode_local, resume_local, steps_local, max_T, device=None):
+    """Batch-coupled early stop across shards.  Each rank first decodes its shard
+    until ITS utterances have all ended (`decode_local()` -> steps run); ranks then agree on the
+    global number of steps (MAX) and the ones that stopped earlier resume to it
+    (`resume_local(t_begin, t_end)`), so every shard's Y equals the single-batch reference run."""
+    steps = decode_local()
+    g = global_max_int(steps, device)
+    if g > steps:
+        resume_local(steps, g)
+    return g
