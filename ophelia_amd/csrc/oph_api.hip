@@ -58,6 +58,7 @@ struct ProfClass {
     size_t used = 0;
     double ms = 0;
 };
+constexpr int CONE_KSPLIT = 4;   // split-K of the latency-bound decoder-cone GEMMs (partials summed by ln_rows)
 enum { PC_GEMM = 0, PC_LN, PC_DEC, PC_ATTN_STEP, PC_ATTN_ROWS, PC_EMIT, PC_MISC, PC_COUNT };
 
 }  // namespace
@@ -496,7 +497,7 @@ int ensure_decode_state(oph_handle* h, int B) {
     }
     const int ld_cat = round_up(d + m.speaker_embedding_size, 32);
     h->coneR = h->dalloc<float>(maxrows * Bpad * 2 * d);
-    h->coneRaw = h->dalloc<float>(maxrows * Bpad * (size_t)round_up(2 * d, 128));
+    h->coneRaw = h->dalloc<float>((size_t)CONE_KSPLIT * maxrows * Bpad * (size_t)round_up(2 * d, 128));
     h->coneTmp = h->dalloc<float>(maxrows * Bpad * (size_t)ld_cat);
     hipStreamSynchronize(h->stream);
     if (!h->coneTmp || !h->Z) { h->fail("out of device memory for decode state"); return OPH_ERR_DEVICE; }
@@ -580,8 +581,10 @@ void decode_step(oph_handle* h, int t, int stop_mode) {
             g.X = x; g.ldx = ldx; g.Wt = l.Wt; g.ldw = l.kc; g.bias = l.bias; g.H = h->coneRaw; g.ldh = l.Nalloc;
             g.M = n0 * Bpad; g.N = l.N; g.kc = l.kc; g.ntaps = 1; g.mode = 0; g.T = g.M; g.off[0] = 0;
             g.stop_after = stop_after; g.t = t;
+            g.ksplit = CONE_KSPLIT; g.split_stride = (long long)g.M * l.Nalloc;
             run_gemm(h, g, l.cin);
             EpiArgs e{};
+            e.nsplit = g.ksplit; e.split_stride = g.split_stride;
             e.H = h->coneRaw; e.ldh = l.Nalloc; e.M = g.M; e.C = l.cout; e.mode = PRE_CONV; e.act = l.act; e.g1 = l.g1; e.b1 = l.b1;
             e.Bpad = Bpad; e.stop_after = stop_after; e.t = t;
             const bool spk_next = (k + 1 < pre) && h->audiodec[k + 1].ccat > 0;
@@ -604,8 +607,10 @@ void decode_step(oph_handle* h, int t, int stop_mode) {
             g.X = h->cone[k]; g.ldx = l.kc; g.Wt = l.Wt; g.ldw = 3 * l.kc; g.bias = l.bias; g.H = h->coneRaw; g.ldh = l.Nalloc;
             g.M = n_out * Bpad; g.N = l.N; g.kc = l.kc; g.ntaps = 3; g.mode = 1; g.Bpad = Bpad; g.n_out = n_out; g.j = t;
             g.tab = h->d_tab[k]; g.need = h->d_need[k]; g.stop_after = stop_after; g.t = t;
+            g.ksplit = CONE_KSPLIT; g.split_stride = (long long)g.M * l.Nalloc;
             run_gemm(h, g, l.cin);
             EpiArgs e{};
+            e.nsplit = g.ksplit; e.split_stride = g.split_stride;
             e.H = h->coneRaw; e.ldh = l.Nalloc; e.M = g.M; e.C = l.cout; e.mode = PRE_HC;
             e.g1 = l.g1; e.b1 = l.b1; e.g2 = l.g2; e.b2 = l.b2; e.Xres = h->cone[k]; e.ldres = l.kc; e.restab = h->d_res[k]; e.Bpad = Bpad;
             const Layer& nx = h->audiodec[pre + k + 1];

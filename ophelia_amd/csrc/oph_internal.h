@@ -31,11 +31,13 @@ struct GemmArgs {
     const int* tab;                 // table: [ntaps][n_out] source position index in X (rows idx*Bpad+b)
     const int* need;                // table: [ntaps][n_out] source valid iff j >= need
     const int* stop_after; int t;   // early-out when t > *stop_after (decode loop); stop_after may be null
+    int ksplit; long long split_stride;  // split-K over K-steps: grid.y = ksplit, partial s written at H + s*split_stride (bias in split 0)
 };
 
 // ---- LayerNorm epilogues over raw conv rows (one wavefront per row)
 struct EpiArgs {
     const float* H; int ldh;        // raw rows
+    int nsplit; long long split_stride;   // raw = sum of nsplit partial buffers (split-K GEMM)
     int M; int C;                   // rows ; channels of the OUTPUT (hc: raw has 2C)
     int mode;                       // PRE_CONV (LN + act) or PRE_HC (2xLN + gate + highway)
     int act;

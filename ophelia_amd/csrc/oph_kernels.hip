@@ -11,6 +11,8 @@
 //   emit_mel, embed_rows, pad_rows
 #include "oph_internal.h"
 
+#include <map>
+
 namespace oph {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -81,11 +83,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32(GemmArgs a) {
     __syncthreads();
 
     const int lrow = tid >> 3, kq = tid & 7;
-    const int kpt = a.kc / BK, nk = a.ntaps * kpt;
+    const int kpt = a.kc / BK, nk_all = a.ntaps * kpt;
+    const int ksplit = a.ksplit > 1 ? a.ksplit : 1, split = blockIdx.y;
+    const int ks0 = split * nk_all / ksplit, nk = (split + 1) * nk_all / ksplit - ks0;
     f32x4 ra[AR], rb[BR];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    auto load_global = [&](int s) {
+    auto load_global = [&](int sl) {
+        const int s = ks0 + sl;
         const int tap = s / kpt, ko = (s - tap * kpt) * BK + kq * 4;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
@@ -144,11 +149,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32(GemmArgs a) {
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn) {
             const int col = n0 + wc * (BN / 2) + jn * 32 + r32;
-            const float bv = a.bias[col];
+            const float bv = split == 0 ? a.bias[col] : 0.f;
+            float* Hs = a.H + (size_t)split * a.split_stride;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-                if (row < a.M) a.H[(size_t)row * a.ldh + col] = acc[i][jn][e] + bv;
+                if (row < a.M) Hs[(size_t)row * a.ldh + col] = acc[i][jn][e] + bv;
             }
         }
 }
@@ -167,7 +173,7 @@ static void launch_conv_gemm_t(const GemmArgs& a, hipStream_t s) {
         attr_set = true;
     }
     const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL((conv_gemm_f32<BM, BN>), dim3(MT * NT), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_gemm_f32<BM, BN>), dim3(MT * NT, a.ksplit > 1 ? a.ksplit : 1), dim3(256), lds, s, a);
 }
 void launch_conv_gemm(const GemmArgs& a, hipStream_t s) {
     if (conv_gemm_tile_m(a.M, a.N) == 128) launch_conv_gemm_t<128, 128>(a, s);
@@ -224,6 +230,8 @@ __global__ __launch_bounds__(256) void ln_rows(EpiArgs a) {
     for (int v = 0; v < NV; ++v) {
         const int c = (v * 64 + lane) * 4;
         x[v] = c < C ? *(const f32x4*)(h + c) : zero4;
+        for (int sp = 1; sp < a.nsplit; ++sp)
+            if (c < C) x[v] += *(const f32x4*)(h + sp * a.split_stride + c);
     }
     ln_vec<NV>(x, C, lane, a.g1, a.b1);
     if (a.mode == PRE_HC) {
@@ -232,6 +240,8 @@ __global__ __launch_bounds__(256) void ln_rows(EpiArgs a) {
         for (int v = 0; v < NV; ++v) {
             const int c = (v * 64 + lane) * 4;
             u[v] = c < C ? *(const f32x4*)(h + C + c) : zero4;
+            for (int sp = 1; sp < a.nsplit; ++sp)
+                if (c < C) u[v] += *(const f32x4*)(h + sp * a.split_stride + C + c);
         }
         ln_vec<NV>(u, C, lane, a.g2, a.b2);
         size_t rrow = m;
@@ -296,13 +306,18 @@ void launch_epilogue(const EpiArgs& a, hipStream_t s) {
 //   registers and are issued BEFORE the prologue so their latency hides behind it.
 //   Output = raw conv rows (bias added); the consumer kernel applies this layer's LN.
 // =====================================================================================
-constexpr int DEC_NVMAX = 4;      // prologue channels <= 1024
 constexpr int DEC_PF = 12;        // 16-wide k-chunks prefetched per wave per pass (K <= 768 in one pass)
 
+// Latency engineering (profiles/r01): a step is ~25 dependent launches, so what matters is the
+// number of dependent memory round trips inside each one.  Everything that does not depend on
+// computed data -- weight fragments, the 16 raw rows, residual rows, dilated-tap rows, LN
+// gamma/beta, bias, the stop flag -- is requested up front in ONE batch (rows unrolled 4-wide
+// per wave), the LayerNorm reductions of the 4 rows are interleaved, and the stop flag only
+// predicates the final stores instead of gating the kernel.
+template <int NV, int PRE, int NTAPS>
 __global__ __launch_bounds__(256) void dec_layer16(DecArgs a) {
-    if (stopped(a.stop_after, a.t)) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int Ktot = a.ntaps * a.kc, ldxs = Ktot + 4;
+    const int Ktot = NTAPS * a.kc, ldxs = Ktot + 4;
     float* xs = smem;                 // [16][ldxs]
     float* part = smem + 16 * ldxs;   // [4][256]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -310,7 +325,9 @@ __global__ __launch_bounds__(256) void dec_layer16(DecArgs a) {
     const int r16 = lane & 15, kq = lane >> 4;
     const int nchunks = Ktot >> 4;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int KV = 2;             // tap vectors per lane per row: kc <= 512
 
+    // ---- 1. every independent global request, issued back to back
     const float* wrow = a.Wt + (size_t)(n0 + r16) * a.ldw + kq * 4;
     f32x4 bfrag[DEC_PF];
 #pragma unroll
@@ -318,113 +335,153 @@ __global__ __launch_bounds__(256) void dec_layer16(DecArgs a) {
         const int c = w + 4 * i;
         bfrag[i] = c < nchunks ? *(const f32x4*)(wrow + c * 16) : zero4;
     }
-
-    // ---- prologue: wave w produces rows 4w..4w+3
-    const int cur = (a.ntaps - 1) * a.kc;
+    const int stop_v = a.stop_after ? *a.stop_after : 0x7fffffff;
+    const float bias_v = a.bias[n0 + (tid & 15)];
+    f32x4 x[4][NV], u[4][NV], xr[4][NV], tp0[4][KV], tp1[4][KV];
+    f32x4 g1v[NV], b1v[NV], g2v[NV], b2v[NV];
+#pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-        const int row = 4 * w + rr, grow = row0 + row;
-        float* xrow = xs + row * ldxs;
-        f32x4 x[DEC_NVMAX];
-        if (a.pre == PRE_COPY) {
-            const float* sp = a.src + (size_t)grow * a.ldsrc;
+        const int grow = row0 + 4 * w + rr;
+        const float* sp = a.src + (size_t)grow * a.ldsrc;
 #pragma unroll
-            for (int v = 0; v < DEC_NVMAX; ++v) {
-                const int c = (v * 64 + lane) * 4;
-                x[v] = c < a.cin ? *(const f32x4*)(sp + c) : zero4;
-            }
-        } else {
-            const float* hp = a.src + (size_t)grow * a.ldsrc;
-            // generic (runtime cin) LayerNorm over <= 1024 channels held in registers
-            auto ln = [&](f32x4 (&z)[DEC_NVMAX], const float* base, const float* gam, const float* bet) {
-                float s = 0.f;
-#pragma unroll
-                for (int v = 0; v < DEC_NVMAX; ++v) {
-                    const int c = (v * 64 + lane) * 4;
-                    z[v] = c < a.cin ? *(const f32x4*)(base + c) : zero4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) s += (c + e < a.cin) ? z[v][e] : 0.f;
-                }
-                const float mean = wave_sum(s) / (float)a.cin;
-                float q = 0.f;
-#pragma unroll
-                for (int v = 0; v < DEC_NVMAX; ++v)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float dlt = ((v * 64 + lane) * 4 + e < a.cin) ? z[v][e] - mean : 0.f;
-                        z[v][e] = dlt;
-                        q += dlt * dlt;
-                    }
-                const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)a.cin + LN_EPS);
-#pragma unroll
-                for (int v = 0; v < DEC_NVMAX; ++v) {
-                    const int c = (v * 64 + lane) * 4;
-                    if (c < a.cin) {
-                        const f32x4 gv = *(const f32x4*)(gam + c), bv = *(const f32x4*)(bet + c);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) z[v][e] = z[v][e] * rstd * gv[e] + bv[e];
-                    }
-                }
-            };
-            ln(x, hp, a.g1, a.b1);
-            if (a.pre == PRE_HC) {
-                f32x4 u[DEC_NVMAX];
-                ln(u, hp + a.cin, a.g2, a.b2);
-                const float* xr = a.xres + (size_t)grow * a.ldres;
-#pragma unroll
-                for (int v = 0; v < DEC_NVMAX; ++v) {
-                    const int c = (v * 64 + lane) * 4;
-                    if (c < a.cin) {
-                        const f32x4 xv = *(const f32x4*)(xr + c);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float gte = sigmoidf_(x[v][e]);
-                            x[v][e] = gte * u[v][e] + (1.0f - gte) * xv[e];
-                        }
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int v = 0; v < DEC_NVMAX; ++v)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) x[v][e] = apply_act(x[v][e], a.act);
-            }
-        }
-        // current tap block: [0,cin) = x, [cin, cin+ccat) = speaker embedding, rest zero
-#pragma unroll
-        for (int v = 0; v < DEC_NVMAX; ++v) {
+        for (int v = 0; v < NV; ++v) {
             const int c = (v * 64 + lane) * 4;
-            if (c < a.kc) {
-                f32x4 val = x[v];
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (c + e >= a.cin) val[e] = 0.f;
-                *(f32x4*)(xrow + cur + c) = val;
+            x[rr][v] = c < a.cin ? *(const f32x4*)(sp + c) : zero4;
+            if (PRE == PRE_HC) {
+                u[rr][v] = c < a.cin ? *(const f32x4*)(sp + a.cin + c) : zero4;
+                xr[rr][v] = c < a.cin ? *(const f32x4*)(a.xres + (size_t)grow * a.ldres + c) : zero4;
             }
         }
-        if (a.ccat > 0) {
-            const int id = a.cat_ids[grow < a.B ? grow : 0];
-            for (int c = lane; c < a.ccat; c += 64)
-                xrow[cur + a.cin + c] = id == 0 ? 0.f : a.cat_table[(size_t)id * a.ccat + c];
-        }
-        // older taps from this layer's input history (rows have ld >= kc with zero pads)
-        if (a.ntaps == 3) {
-            const float* t0 = a.tap0 ? a.tap0 + (size_t)grow * a.ldtap : nullptr;
-            const float* t1 = a.tap1 ? a.tap1 + (size_t)grow * a.ldtap : nullptr;
-            for (int c = lane * 4; c < a.kc; c += 256) {
-                *(f32x4*)(xrow + c) = t0 ? *(const f32x4*)(t0 + c) : zero4;
-                *(f32x4*)(xrow + a.kc + c) = t1 ? *(const f32x4*)(t1 + c) : zero4;
+        if (NTAPS == 3) {
+#pragma unroll
+            for (int v = 0; v < KV; ++v) {
+                const int c = (v * 64 + lane) * 4;
+                tp0[rr][v] = (a.tap0 && c < a.kc) ? *(const f32x4*)(a.tap0 + (size_t)grow * a.ldtap + c) : zero4;
+                tp1[rr][v] = (a.tap1 && c < a.kc) ? *(const f32x4*)(a.tap1 + (size_t)grow * a.ldtap + c) : zero4;
             }
         }
     }
+    if (PRE != PRE_COPY) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            g1v[v] = c < a.cin ? *(const f32x4*)(a.g1 + c) : zero4;
+            b1v[v] = c < a.cin ? *(const f32x4*)(a.b1 + c) : zero4;
+            if (PRE == PRE_HC) {
+                g2v[v] = c < a.cin ? *(const f32x4*)(a.g2 + c) : zero4;
+                b2v[v] = c < a.cin ? *(const f32x4*)(a.b2 + c) : zero4;
+            }
+        }
+    }
+    int cat_id[4] = {0, 0, 0, 0};
+    if (a.ccat > 0) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int grow = row0 + 4 * w + rr;
+            cat_id[rr] = a.cat_ids[grow < a.B ? grow : 0];
+        }
+    }
+
+    // ---- 2. prologue math: LayerNorm(s) of 4 rows interleaved, gate / activation
+    if (PRE != PRE_COPY) {
+        const float invc = 1.0f / (float)a.cin;
+        auto ln4 = [&](f32x4 (&z)[4][NV], const f32x4 (&gv)[NV], const f32x4 (&bv)[NV]) {
+            float s[4], q[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                s[rr] = 0.f;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) s[rr] += z[rr][v][0] + z[rr][v][1] + z[rr][v][2] + z[rr][v][3];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) s[rr] += __shfl_xor(s[rr], o, 64);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const float mean = s[rr] * invc;
+                q[rr] = 0.f;
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float dlt = ((v * 64 + lane) * 4 + e < a.cin) ? z[rr][v][e] - mean : 0.f;
+                        z[rr][v][e] = dlt;
+                        q[rr] += dlt * dlt;
+                    }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) q[rr] += __shfl_xor(q[rr], o, 64);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const float rstd = 1.0f / sqrtf(q[rr] * invc + LN_EPS);
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) z[rr][v][e] = z[rr][v][e] * rstd * gv[v][e] + bv[v][e];
+            }
+        };
+        ln4(x, g1v, b1v);
+        if (PRE == PRE_HC) {
+            ln4(u, g2v, b2v);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float gte = sigmoidf_(x[rr][v][e]);
+                        x[rr][v][e] = gte * u[rr][v][e] + (1.0f - gte) * xr[rr][v][e];
+                    }
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[rr][v][e] = apply_act(x[rr][v][e], a.act);
+        }
+    }
+    // ---- 3. stage the 16 x Ktot operand in LDS: [taps (oldest first) | current]
+    const int cur = (NTAPS - 1) * a.kc;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        float* xrow = xs + (4 * w + rr) * ldxs;
+#pragma unroll
+        for (int v = 0; v < KV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (c < a.kc) {
+                f32x4 val = zero4;
+                if (v < NV) {
+                    val = x[rr][v < NV ? v : 0];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e >= a.cin) val[e] = 0.f;
+                }
+                *(f32x4*)(xrow + cur + c) = val;
+                if (NTAPS == 3) {
+                    *(f32x4*)(xrow + c) = tp0[rr][v];
+                    *(f32x4*)(xrow + a.kc + c) = tp1[rr][v];
+                }
+            }
+        }
+        if (a.ccat > 0) {
+            for (int c = lane; c < a.ccat; c += 64)
+                xrow[cur + a.cin + c] = cat_id[rr] == 0 ? 0.f : a.cat_table[(size_t)cat_id[rr] * a.ccat + c];
+        }
+    }
     __syncthreads();
-    if (blockIdx.x == 0 && a.xstore) {     // publish x[t] (this layer's input) for later steps / residual
+    const bool live = a.t <= stop_v;
+    if (blockIdx.x == 0 && a.xstore && live) {     // publish x[t] (this layer's input) for later steps / residual
         for (int i = tid * 4; i < 16 * a.kc; i += 1024) {
             const int row = i / a.kc, c = i - row * a.kc;
             *(f32x4*)(a.xstore + (size_t)(row0 + row) * a.ldstore + c) = *(const f32x4*)(xs + row * ldxs + cur + c);
         }
     }
 
-    // ---- 16x16 slice, K split over waves
+    // ---- 4. 16x16 slice, K split over waves
     f32x4 acc0 = zero4, acc1 = zero4;
     const float* xa = xs + r16 * ldxs + kq * 4;
     for (int base = 0; base < nchunks; base += 4 * DEC_PF) {
@@ -451,23 +508,32 @@ __global__ __launch_bounds__(256) void dec_layer16(DecArgs a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) part[w * 256 + (kq * 4 + e) * 16 + r16] = acc0[e] + acc1[e];
     __syncthreads();
-    {
+    if (live) {
         const int row = tid >> 4, col = tid & 15;
-        const float v = part[tid] + part[256 + tid] + part[512 + tid] + part[768 + tid] + a.bias[n0 + col];
+        const float v = part[tid] + part[256 + tid] + part[512 + tid] + part[768 + tid] + bias_v;
         a.H[(size_t)(row0 + row) * a.ldh + n0 + col] = v;
     }
+}
+
+template <int NV, int PRE>
+static void launch_dec_t(const DecArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+    auto set = [&](const void* f) {
+        static std::map<const void*, size_t> done;
+        if (done[f] < lds) { (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done[f] = lds; }
+    };
+    if (a.ntaps == 3) { set((const void*)dec_layer16<NV, PRE, 3>); hipLaunchKernelGGL((dec_layer16<NV, PRE, 3>), grid, dim3(256), lds, s, a); }
+    else              { set((const void*)dec_layer16<NV, PRE, 1>); hipLaunchKernelGGL((dec_layer16<NV, PRE, 1>), grid, dim3(256), lds, s, a); }
 }
 
 void launch_dec_layer(const DecArgs& a, int Npad16, hipStream_t s) {
     const int Ktot = a.ntaps * a.kc;
     const size_t lds = (size_t)(16 * (Ktot + 4) + 1024) * 4;
-    static size_t attr = 0;
-    if (lds > attr) {
-        hipFuncSetAttribute((const void*)dec_layer16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = lds;
-    }
     const int Bpad = round_up(a.B, 16);
-    hipLaunchKernelGGL(dec_layer16, dim3(Npad16 / 16, Bpad / 16), dim3(256), lds, s, a);
+    const dim3 grid(Npad16 / 16, Bpad / 16);
+    const bool wide = a.cin > 256;          // NV = 2 (cin <= 512)
+    if (a.pre == PRE_COPY) { if (wide) launch_dec_t<2, PRE_COPY>(a, grid, lds, s); else launch_dec_t<1, PRE_COPY>(a, grid, lds, s); }
+    else if (a.pre == PRE_CONV) { if (wide) launch_dec_t<2, PRE_CONV>(a, grid, lds, s); else launch_dec_t<1, PRE_CONV>(a, grid, lds, s); }
+    else { if (wide) launch_dec_t<2, PRE_HC>(a, grid, lds, s); else launch_dec_t<1, PRE_HC>(a, grid, lds, s); }
 }
 
 // =====================================================================================

@@ -22,11 +22,33 @@ def lib():
     if _lib is None:
         l = C.CDLL(build_oracle.build())
         l.oph_cpu_threads.restype = C.c_int
+        l.oph_cpu_set_threads.argtypes = [C.c_int]
         l.oph_cpu_text_enc.argtypes = [C.POINTER(CpuDims), _f, _i, C.c_int, _f, _f]
         l.oph_cpu_text2mel.argtypes = [C.POINTER(CpuDims), _f, _f, _f, _i, _i, C.c_int, C.c_int, C.c_int, _f, _i, _f, _i]
         l.oph_cpu_ssrn.argtypes = [C.POINTER(CpuDims), _f, _f, C.c_int, C.c_int, _f]
         _lib = l
     return _lib
+
+
+def usable_cores():
+    """Cores this process may actually use: min(affinity mask, cgroup cpu quota)."""
+    import math
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, math.floor(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
 
 
 def dims(hp):
@@ -46,10 +68,12 @@ def _p(a, t=_f):
 
 
 class CpuModel(object):
-    def __init__(self, hp, W):
+    def __init__(self, hp, W, threads=None):
         self.hp, self.d = hp, dims(hp)
         self.w_t2m = flat(hp, W, "Text2Mel")
         self.w_ssrn = flat(hp, W, "SSRN")
+        if threads:
+            lib().oph_cpu_set_threads(int(threads))
         self.threads = lib().oph_cpu_threads()
 
     def encode_text(self, L):

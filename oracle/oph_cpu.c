@@ -33,6 +33,14 @@ typedef struct {
 #define LN_EPS 1e-12f
 #define MASK_VALUE (-4294967296.0f)
 
+void oph_cpu_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int oph_cpu_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
