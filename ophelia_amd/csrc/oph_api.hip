@@ -11,6 +11,7 @@
 #include <climits>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -66,7 +67,17 @@ enum { PC_GEMM = 0, PC_LN, PC_DEC, PC_ATTN_STEP, PC_ATTN_ROWS, PC_EMIT, PC_MISC,
 struct oph_handle {
     oph_dims dm{};
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // API stream (unmasked): TextEnc / SSRN, timers, copies
+    hipStream_t sdec = nullptr;        // decode critical path: CU-masked to a private slice of every XCD
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    // captured decode loop (all max_T steps, both streams) per stop_mode; replayed by hipGraphLaunch
+    hipGraphExec_t dec_graph[2] = {nullptr, nullptr};
+    int dec_graph_B[2] = {0, 0};
+    bool capturing = false;
+    bool use_graph = true;
+    hipStream_t stream2 = nullptr;     // side stream: AudioDec history cone, overlapped with the AudioEnc chain
+    hipStream_t cur = nullptr;         // stream the launch wrappers currently target
+    hipEvent_t ev_attn = nullptr, ev_cone = nullptr;
     std::string err;
     bool finalized = false;
     // expected variables (TF names) and host copies
@@ -93,7 +104,7 @@ struct oph_handle {
     std::vector<std::vector<int>> Hset;           // Hset[h] sorted offsets (>=1) at which hc layer h's INPUT is needed
     std::vector<int*> d_tab, d_need, d_res;       // per hc layer h<n-1: tables for computing layer h over Hset[h+1]
     int* d_off0 = nullptr;                        // Hset[0] on device
-    std::vector<float*> cone;                     // cone[h]: [|Hset[h]|][Bpad][256]
+    std::vector<float*> cone[2];                  // cone[t&1][h]: [|Hset[h]|][Bpad][256], ping-pong over steps
     float *coneR = nullptr, *coneRaw = nullptr, *coneTmp = nullptr;
     int ldy = 0;
     // timing
@@ -120,7 +131,7 @@ struct oph_handle {
     }
     // ---- profiling brackets
     void pbegin(int cls) {
-        if (!profiling) return;
+        if (!profiling || capturing) return;
         ProfClass& pc = prof[cls];
         if (pc.used == pc.ev.size()) {
             hipEvent_t a, b;
@@ -128,15 +139,15 @@ struct oph_handle {
             hipEventCreate(&b);
             pc.ev.emplace_back(a, b);
         }
-        hipEventRecord(pc.ev[pc.used].first, stream);
+        hipEventRecord(pc.ev[pc.used].first, cur);
     }
     void pend(int cls, double bytes, double flops) {
         ProfClass& pc = prof[cls];
         pc.launches++;
         pc.bytes += bytes;
         pc.flops += flops;
-        if (!profiling) return;
-        hipEventRecord(pc.ev[pc.used].second, stream);
+        if (!profiling || capturing) return;
+        hipEventRecord(pc.ev[pc.used].second, cur);
         pc.used++;
     }
 };
@@ -331,19 +342,19 @@ int pack_layer(oph_handle* h, Layer& l) {
 // ------------------------------------------------------------------ launch wrappers with accounting
 void run_gemm(oph_handle* h, const GemmArgs& a, int cin_true) {
     h->pbegin(PC_GEMM);
-    launch_conv_gemm(a, h->stream);
+    launch_conv_gemm(a, h->cur);
     const double K = (double)a.ntaps * cin_true;
     h->pend(PC_GEMM, ((double)a.M * cin_true + (double)a.M * a.N + (double)a.N * K) * 4.0, 2.0 * a.M * a.N * K);
 }
 void run_epi(oph_handle* h, const EpiArgs& a) {
     h->pbegin(PC_LN);
-    launch_epilogue(a, h->stream);
+    launch_epilogue(a, h->cur);
     const double cols = a.mode == PRE_HC ? 4.0 * a.C : 2.0 * a.C;    // read raw (+res), write out
     h->pend(PC_LN, (double)a.M * cols * 4.0, (double)a.M * a.C * 10.0);
 }
 void run_dec(oph_handle* h, const DecArgs& a, const Layer& l) {
     h->pbegin(PC_DEC);
-    launch_dec_layer(a, round_up(l.N, 16), h->stream);
+    launch_dec_layer(a, round_up(l.N, 16), h->cur);
     const double K = (double)l.ntaps * l.cin;
     h->pend(PC_DEC, ((double)l.N * K + (double)a.B * (K + l.N)) * 4.0, 2.0 * a.B * l.N * K);
 }
@@ -472,7 +483,8 @@ int ensure_decode_state(oph_handle* h, int B) {
     hipStreamSynchronize(h->stream);
     size_t maxrows = h->Hset[0].size();
     for (int k = 0; k < nh; ++k) {
-        h->cone.push_back(h->dalloc<float>(h->Hset[k].size() * Bpad * (size_t)h->audiodec[pre + k].kc));
+        for (int pp = 0; pp < 2; ++pp)
+            h->cone[pp].push_back(h->dalloc<float>(h->Hset[k].size() * Bpad * (size_t)h->audiodec[pre + k].kc));
         if (k + 1 < nh) {
             // hc layer k evaluated at output offsets Hset[k+1]: taps (oldest first) read Hset[k]
             const int r = h->audiodec[pre + k].rate, n_out = (int)h->Hset[k + 1].size();
@@ -517,11 +529,84 @@ void reset_decode(oph_handle* h) {
     hipStreamSynchronize(h->stream);
 }
 
-// one decoder step t (all launches on h->stream)
-void decode_step(oph_handle* h, int t, int stop_mode) {
+// AudioDec history cone for step t under the mask p_t (= max_attentions of step t-1).
+// The reference re-evaluates R[t'] for ALL t' <= t with the current prev_max (networks.py:311
+// tiles one mask over max_T), so AudioDec's hidden history cannot be cached across steps; what is
+// recomputed here is the sparse receptive cone of row t: the highway-layer inputs at the history
+// offsets Hset[k] (84, 82, 44, 14, 4, 2 positions for rates 1,3,9,27,1,1).  It depends only on
+// p_t and Q[<t], both known right after attn_step(t-1): it runs on the SIDE stream, concurrently
+// with the AudioEnc chain of step t, into the ping-pong buffer cone[t&1].
+void launch_cone(oph_handle* h, int t) {
     const oph_dims& m = h->dm;
     const int d = m.d, Bpad = h->Bpad, B = h->B;
     int* stop_after = h->d_ctl + 1;
+    const int* pcur = h->d_p + (t & 1) * Bpad;
+    const int pre = h->dec_pre, nh = h->n_hc_dec;
+    std::vector<float*>& cone = h->cone[t & 1];
+    hipStream_t saved = h->cur;
+    h->cur = h->stream2;
+    const int n0 = (int)h->Hset[0].size();
+    AttnRowsArgs ar{};
+    ar.mode = 0; ar.Q = h->Qhist; ar.ldq = d; ar.K = h->KV; ar.V = h->KV + d; ar.ldkv = 2 * d; ar.N = m.max_N; ar.d = d;
+    ar.win = m.attention_win_size; ar.p = pcur; ar.B = B; ar.Bpad = Bpad; ar.nrows = n0 * Bpad; ar.off = h->d_off0; ar.j = t;
+    ar.R = h->coneR; ar.ldr = 2 * d; ar.stop_after = stop_after; ar.t = t;
+    h->pbegin(PC_ATTN_ROWS);
+    launch_attn_rows(ar, h->cur);
+    h->pend(PC_ATTN_ROWS, (double)n0 * B * 3.0 * d * 4.0, (double)n0 * B * 4.0 * m.attention_win_size * d);
+    // k=1 layers before the highway stack, on all Hset[0] positions
+    const float* x = h->coneR; int ldx = 2 * d;
+    for (int k = 0; k < pre; ++k) {
+        const Layer& l = h->audiodec[k];
+        GemmArgs g{};
+        g.X = x; g.ldx = ldx; g.Wt = l.Wt; g.ldw = l.kc; g.bias = l.bias; g.H = h->coneRaw; g.ldh = l.Nalloc;
+        g.M = n0 * Bpad; g.N = l.N; g.kc = l.kc; g.ntaps = 1; g.mode = 0; g.T = g.M; g.off[0] = 0;
+        g.stop_after = stop_after; g.t = t;
+        g.ksplit = CONE_KSPLIT; g.split_stride = (long long)g.M * l.Nalloc;
+        run_gemm(h, g, l.cin);
+        EpiArgs e{};
+        e.nsplit = g.ksplit; e.split_stride = g.split_stride;
+        e.H = h->coneRaw; e.ldh = l.Nalloc; e.M = g.M; e.C = l.cout; e.mode = PRE_CONV; e.act = l.act; e.g1 = l.g1; e.b1 = l.b1;
+        e.Bpad = Bpad; e.stop_after = stop_after; e.t = t;
+        const bool spk_next = (k + 1 < pre) && h->audiodec[k + 1].ccat > 0;
+        if (spk_next) {
+            const Layer& nx = h->audiodec[k + 1];
+            e.Y = h->coneTmp; e.ldy = nx.kc; e.ypad = nx.kc;
+            e.spk_table = h->emb_spk; e.spk_ids = h->d_spk; e.spk_dim = nx.ccat; e.spk_T = 0;
+            x = h->coneTmp; ldx = nx.kc;
+        } else {
+            const Layer& hc0 = h->audiodec[pre];
+            e.Y = cone[0]; e.ldy = hc0.kc; e.ypad = hc0.kc;
+            x = cone[0]; ldx = hc0.kc;
+        }
+        run_epi(h, e);
+    }
+    for (int k = 0; k + 1 < nh; ++k) {
+        const Layer& l = h->audiodec[pre + k];
+        const int n_out = (int)h->Hset[k + 1].size();
+        GemmArgs g{};
+        g.X = cone[k]; g.ldx = l.kc; g.Wt = l.Wt; g.ldw = 3 * l.kc; g.bias = l.bias; g.H = h->coneRaw; g.ldh = l.Nalloc;
+        g.M = n_out * Bpad; g.N = l.N; g.kc = l.kc; g.ntaps = 3; g.mode = 1; g.Bpad = Bpad; g.n_out = n_out; g.j = t;
+        g.tab = h->d_tab[k]; g.need = h->d_need[k]; g.stop_after = stop_after; g.t = t;
+        g.ksplit = CONE_KSPLIT; g.split_stride = (long long)g.M * l.Nalloc;
+        run_gemm(h, g, l.cin);
+        EpiArgs e{};
+        e.nsplit = g.ksplit; e.split_stride = g.split_stride;
+        e.H = h->coneRaw; e.ldh = l.Nalloc; e.M = g.M; e.C = l.cout; e.mode = PRE_HC;
+        e.g1 = l.g1; e.b1 = l.b1; e.g2 = l.g2; e.b2 = l.b2; e.Xres = cone[k]; e.ldres = l.kc; e.restab = h->d_res[k]; e.Bpad = Bpad;
+        const Layer& nx = h->audiodec[pre + k + 1];
+        e.Y = cone[k + 1]; e.ldy = nx.kc; e.ypad = nx.kc; e.stop_after = stop_after; e.t = t;
+        run_epi(h, e);
+    }
+    h->cur = saved;
+}
+
+// one decoder step t.  Main stream: AudioEnc chain -> attention -> [wait cone(t)] -> AudioDec row t
+// -> emit.  Side stream: cone(t+1), released by the event recorded right after attn_step(t).
+void decode_step(oph_handle* h, int t, int t_last, int stop_mode) {
+    const oph_dims& m = h->dm;
+    const int d = m.d, Bpad = h->Bpad, B = h->B;
+    int* stop_after = h->d_ctl + 1;
+    h->cur = h->sdec;
     // ---------------- AudioEnc, incremental (causal, mask-free => cacheable)
     const Layer* prev = nullptr;
     const float* prev_raw = nullptr;
@@ -556,68 +641,20 @@ void decode_step(oph_handle* h, int t, int stop_mode) {
         a.ends = h->d_ends; a.t_ends = h->d_tends; a.n_ended = h->d_ctl; a.stop_after = stop_after; a.stop_mode = stop_mode;
         a.Qhist = h->Qhist; a.Rrow = h->Rrow; a.ldr = 2 * d; a.align = h->align;
         h->pbegin(PC_ATTN_STEP);
-        launch_attn_step(a, h->stream);
+        launch_attn_step(a, h->sdec);
         h->pend(PC_ATTN_STEP, (double)B * (6.0 * d + 2.0 * m.attention_win_size * d) * 4.0, (double)B * 4.0 * m.attention_win_size * d);
     }
-    const int* pcur = h->d_p + (t & 1) * Bpad;
-    // ---------------- AudioDec history cone under the CURRENT mask (the reference
-    // re-evaluates R[t'] for all t' <= t with prev_max(t), networks.py:311, so AudioDec history
-    // cannot be cached across steps)
-    const int pre = h->dec_pre, nh = h->n_hc_dec;
-    if (t >= 1) {
-        const int n0 = (int)h->Hset[0].size();
-        AttnRowsArgs ar{};
-        ar.mode = 0; ar.Q = h->Qhist; ar.ldq = d; ar.K = h->KV; ar.V = h->KV + d; ar.ldkv = 2 * d; ar.N = m.max_N; ar.d = d;
-        ar.win = m.attention_win_size; ar.p = pcur; ar.B = B; ar.Bpad = Bpad; ar.nrows = n0 * Bpad; ar.off = h->d_off0; ar.j = t;
-        ar.R = h->coneR; ar.ldr = 2 * d; ar.stop_after = stop_after; ar.t = t;
-        h->pbegin(PC_ATTN_ROWS);
-        launch_attn_rows(ar, h->stream);
-        h->pend(PC_ATTN_ROWS, (double)n0 * B * 3.0 * d * 4.0, (double)n0 * B * 4.0 * m.attention_win_size * d);
-        // k=1 layers before the highway stack, on all Hset[0] positions
-        const float* x = h->coneR; int ldx = 2 * d;
-        for (int k = 0; k < pre; ++k) {
-            const Layer& l = h->audiodec[k];
-            GemmArgs g{};
-            g.X = x; g.ldx = ldx; g.Wt = l.Wt; g.ldw = l.kc; g.bias = l.bias; g.H = h->coneRaw; g.ldh = l.Nalloc;
-            g.M = n0 * Bpad; g.N = l.N; g.kc = l.kc; g.ntaps = 1; g.mode = 0; g.T = g.M; g.off[0] = 0;
-            g.stop_after = stop_after; g.t = t;
-            g.ksplit = CONE_KSPLIT; g.split_stride = (long long)g.M * l.Nalloc;
-            run_gemm(h, g, l.cin);
-            EpiArgs e{};
-            e.nsplit = g.ksplit; e.split_stride = g.split_stride;
-            e.H = h->coneRaw; e.ldh = l.Nalloc; e.M = g.M; e.C = l.cout; e.mode = PRE_CONV; e.act = l.act; e.g1 = l.g1; e.b1 = l.b1;
-            e.Bpad = Bpad; e.stop_after = stop_after; e.t = t;
-            const bool spk_next = (k + 1 < pre) && h->audiodec[k + 1].ccat > 0;
-            if (spk_next) {
-                const Layer& nx = h->audiodec[k + 1];
-                e.Y = h->coneTmp; e.ldy = nx.kc; e.ypad = nx.kc;
-                e.spk_table = h->emb_spk; e.spk_ids = h->d_spk; e.spk_dim = nx.ccat; e.spk_T = 0;
-                x = h->coneTmp; ldx = nx.kc;
-            } else {
-                const Layer& hc0 = h->audiodec[pre];
-                e.Y = h->cone[0]; e.ldy = hc0.kc; e.ypad = hc0.kc;
-                x = h->cone[0]; ldx = hc0.kc;
-            }
-            run_epi(h, e);
-        }
-        for (int k = 0; k + 1 < nh; ++k) {
-            const Layer& l = h->audiodec[pre + k];
-            const int n_out = (int)h->Hset[k + 1].size();
-            GemmArgs g{};
-            g.X = h->cone[k]; g.ldx = l.kc; g.Wt = l.Wt; g.ldw = 3 * l.kc; g.bias = l.bias; g.H = h->coneRaw; g.ldh = l.Nalloc;
-            g.M = n_out * Bpad; g.N = l.N; g.kc = l.kc; g.ntaps = 3; g.mode = 1; g.Bpad = Bpad; g.n_out = n_out; g.j = t;
-            g.tab = h->d_tab[k]; g.need = h->d_need[k]; g.stop_after = stop_after; g.t = t;
-            g.ksplit = CONE_KSPLIT; g.split_stride = (long long)g.M * l.Nalloc;
-            run_gemm(h, g, l.cin);
-            EpiArgs e{};
-            e.nsplit = g.ksplit; e.split_stride = g.split_stride;
-            e.H = h->coneRaw; e.ldh = l.Nalloc; e.M = g.M; e.C = l.cout; e.mode = PRE_HC;
-            e.g1 = l.g1; e.b1 = l.b1; e.g2 = l.g2; e.b2 = l.b2; e.Xres = h->cone[k]; e.ldres = l.kc; e.restab = h->d_res[k]; e.Bpad = Bpad;
-            const Layer& nx = h->audiodec[pre + k + 1];
-            e.Y = h->cone[k + 1]; e.ldy = nx.kc; e.ypad = nx.kc; e.stop_after = stop_after; e.t = t;
-            run_epi(h, e);
-        }
+    const int pre = h->dec_pre;
+    // cone(t) (launched during step t-1, or by decode_range for the first step) must have landed
+    if (t >= 1) hipStreamWaitEvent(h->sdec, h->ev_cone, 0);
+    // release cone(t+1) on the side stream: needs p_{t+1} and Q[t], both written by attn_step(t)
+    if (t + 1 < t_last) {
+        hipEventRecord(h->ev_attn, h->sdec);
+        hipStreamWaitEvent(h->stream2, h->ev_attn, 0);
+        launch_cone(h, t + 1);
+        hipEventRecord(h->ev_cone, h->stream2);
     }
+    const std::vector<float*>& cone = h->cone[t & 1];
     // ---------------- AudioDec row t
     prev = nullptr; prev_raw = nullptr; prev_x = nullptr;
     for (size_t li = 0; li < h->audiodec.size(); ++li) {
@@ -632,8 +669,8 @@ void decode_step(oph_handle* h, int t, int stop_mode) {
             const int k = (int)li - pre;
             a.xstore = h->ad_xrow[li]; a.ldstore = l.kc; a.ldtap = l.kc;
             const int o0 = -l.off[0], o1 = -l.off[1];
-            a.tap0 = t - o0 >= 0 ? h->cone[k] + (size_t)idx_of(h->Hset[k], o0) * Bpad * l.kc : nullptr;
-            a.tap1 = t - o1 >= 0 ? h->cone[k] + (size_t)idx_of(h->Hset[k], o1) * Bpad * l.kc : nullptr;
+            a.tap0 = t - o0 >= 0 ? cone[k] + (size_t)idx_of(h->Hset[k], o0) * Bpad * l.kc : nullptr;
+            a.tap1 = t - o1 >= 0 ? cone[k] + (size_t)idx_of(h->Hset[k], o1) * Bpad * l.kc : nullptr;
         }
         a.Wt = l.Wt; a.ldw = l.ntaps * l.kc; a.bias = l.bias; a.H = h->ad_raw[li]; a.ldh = l.Nalloc; a.B = B;
         a.stop_after = stop_after; a.t = t;
@@ -647,7 +684,7 @@ void decode_step(oph_handle* h, int t, int stop_mode) {
         e.Yout = h->Yout; e.ldy = h->ldy; e.max_T = m.max_T; e.Ytm = h->Ytm; e.ldtm = h->ldy; e.Bpad = Bpad; e.B = B;
         e.stop_after = stop_after; e.t = t;
         h->pbegin(PC_EMIT);
-        launch_emit_mel(e, h->stream);
+        launch_emit_mel(e, h->sdec);
         h->pend(PC_EMIT, (double)B * m.n_mels * 12.0, (double)B * m.n_mels * 10.0);
     }
 }
@@ -657,19 +694,65 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
     t_end = std::min(t_end, (int)m.max_T);
     int ctl[4] = {0, INT_MAX, 0, 0};
     int last = t_begin;
+    // fork: the decode streams start after everything queued on the API stream (encode, resets)
+    hipEventRecord(h->ev_in, h->stream);
+    hipStreamWaitEvent(h->sdec, h->ev_in, 0);
+    h->cur = h->sdec;
+    // ---- whole-loop hipGraph: a step is ~39 launches on two streams; enqueued eagerly the host
+    // (~5 us per launch) is slower than the device (profiles/r01 trace: the critical stream idles
+    // while the host enqueues the cone).  Capture all max_T steps once per (stop_mode, B) and replay.
+    // After the stop step every node early-outs on the device, so outputs are identical.
+    const bool graphable = h->use_graph && !h->profiling && t_begin == 0 && t_end == m.max_T && stop_mode >= 0 && stop_mode <= 1;
+    if (graphable) {
+        hipGraphExec_t& ge = h->dec_graph[stop_mode];
+        if (ge && h->dec_graph_B[stop_mode] != h->B) { hipGraphExecDestroy(ge); ge = nullptr; }
+        if (!ge) {
+            hipGraph_t g = nullptr;
+            bool ok = hipStreamBeginCapture(h->sdec, hipStreamCaptureModeRelaxed) == hipSuccess;
+            if (ok) {
+                h->capturing = true;
+                for (int t = 0; t < t_end; ++t) decode_step(h, t, t_end, stop_mode);
+                h->capturing = false;
+                ok = hipStreamEndCapture(h->sdec, &g) == hipSuccess && g != nullptr;
+            }
+            if (ok) ok = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess;
+            if (g) hipGraphDestroy(g);
+            if (!ok) { ge = nullptr; h->use_graph = false; (void)hipGetLastError(); }
+            else h->dec_graph_B[stop_mode] = h->B;
+        }
+        if (ge) {
+            HIPCHK(h, hipGraphLaunch(ge, h->sdec));
+            last = t_end;
+            t_begin = t_end;      // skip the eager loop below
+        }
+    }
+    if (t_begin >= 1 && t_begin < t_end) {      // resuming mid-utterance: cone(t_begin) has not been launched yet
+        hipEventRecord(h->ev_attn, h->sdec);
+        hipStreamWaitEvent(h->stream2, h->ev_attn, 0);
+        launch_cone(h, t_begin);
+        hipEventRecord(h->ev_cone, h->stream2);
+    }
     for (int t = t_begin; t < t_end; ++t) {
-        decode_step(h, t, stop_mode);
+        decode_step(h, t, t_end, stop_mode);
         last = t + 1;
         // bounded look-ahead: poll the device-side stop flag every 8 steps (reference semantics keep
         // frames after the break step at zero because later steps early-out on the device)
         if (stop_mode == OPH_STOP_REFERENCE && ((t & 7) == 7)) {
-            HIPCHK(h, hipMemcpyAsync(ctl, h->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipStreamSynchronize(h->stream));
+            HIPCHK(h, hipMemcpyAsync(ctl, h->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, h->sdec));
+            HIPCHK(h, hipStreamSynchronize(h->sdec));
             if (ctl[1] != INT_MAX) break;
         }
     }
-    HIPCHK(h, hipMemcpyAsync(ctl, h->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // join: the API stream continues (SSRN, fetches) only after both decode streams drained
+    hipEventRecord(h->ev_out, h->sdec);
+    hipStreamWaitEvent(h->stream, h->ev_out, 0);
+    hipEventRecord(h->ev_out, h->stream2);
+    hipStreamWaitEvent(h->stream, h->ev_out, 0);
+    h->cur = h->stream;
+    if (steps_run || stop_mode == OPH_STOP_REFERENCE) {
+        HIPCHK(h, hipMemcpyAsync(ctl, h->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     if (steps_run) *steps_run = ctl[1] != INT_MAX ? ctl[1] + 1 : last;
     HIPCHK(h, hipGetLastError());
     return OPH_OK;
@@ -730,12 +813,41 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
     h->device = device;
     static const char* names[PC_COUNT] = {"conv_gemm_f32", "ln_rows", "dec_layer16", "attn_step", "attn_rows", "emit_mel", "misc"};
     for (int i = 0; i < PC_COUNT; ++i) h->prof[i].name = names[i];
+    // CU partition for the decode loop (MI355X: 256 CUs, mask bit i -> XCD i%8): the ~25 dependent
+    // tiny launches of a step get a private slice of 8 CUs in every XCD so the concurrently running
+    // history-cone GEMMs (the other 24 CUs per XCD) cannot delay their dispatch.
+    {
+        hipDeviceProp_t prop;
+        uint32_t m_dec[16] = {0}, m_cone[16] = {0};
+        int ncu = 0;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) ncu = prop.multiProcessorCount;
+        const int words = (ncu + 31) / 32, ndec = ncu / 4;
+        const char* nomask = getenv("OPH_NO_CU_MASK");
+        if (ncu >= 64 && words <= 16 && !nomask) {
+            const char* onex = getenv("OPH_DEC_ONE_XCD");      // experiment: critical chain on ONE XCD (bit i -> XCD i%8)
+            for (int i = 0; i < ncu; ++i) {
+                const bool dec = onex ? (i % 8 == 0) : (i < ndec);
+                (dec ? m_dec : m_cone)[i / 32] |= 1u << (i % 32);
+            }
+            if (hipExtStreamCreateWithCUMask(&h->sdec, words, m_dec) != hipSuccess) h->sdec = nullptr;
+            if (hipExtStreamCreateWithCUMask(&h->stream2, words, m_cone) != hipSuccess) h->stream2 = nullptr;
+        }
+        (void)hipGetLastError();
+    }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        (!h->sdec && hipStreamCreateWithFlags(&h->sdec, hipStreamNonBlocking) != hipSuccess) ||
+        (!h->stream2 && hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) ||
+        hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_attn, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_cone, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
         g_create_error = "stream/event creation failed";
         delete h;
         return OPH_ERR_DEVICE;
     }
+    h->cur = h->stream;
+    h->use_graph = getenv("OPH_USE_GRAPH") != nullptr;   // replay measured slower than eager launches
     build_networks(h);
     *out = h;
     return OPH_OK;
@@ -750,6 +862,15 @@ int oph_destroy(oph_handle* h) {
         for (auto& e : pc.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     hipEventDestroy(h->ev0);
     hipEventDestroy(h->ev1);
+    hipEventDestroy(h->ev_attn);
+    hipEventDestroy(h->ev_cone);
+    for (auto& ge : h->dec_graph) if (ge) hipGraphExecDestroy(ge);
+    hipEventDestroy(h->ev_in);
+    hipEventDestroy(h->ev_out);
+    hipStreamSynchronize(h->stream2);
+    hipStreamDestroy(h->stream2);
+    hipStreamSynchronize(h->sdec);
+    hipStreamDestroy(h->sdec);
     hipStreamDestroy(h->stream);
     delete h;
     return OPH_OK;
@@ -976,6 +1097,8 @@ int oph_profile_get(oph_handle* h, int index, char* name, int name_cap, int64_t*
                     double* alg_bytes, double* alg_flops) {
     if (!h || index < 0 || index >= PC_COUNT) return OPH_ERR_INVALID;
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream2));
+    HIPCHK(h, hipStreamSynchronize(h->sdec));
     ProfClass& pc = h->prof[index];
     double ms = 0;
     for (size_t i = 0; i < pc.used; ++i) {
