@@ -1,0 +1,283 @@
+#!/usr/bin/env python
+"""Synthesis driver with the reference's interface: counterpart of synthesize.py
+(main_work 635-683, synthesize 442-632, encode_text 232-240, synth_codedtext2mel 150-230,
+synth_text2mel 62-132, synth_mel2mag 250-260, get_text_lengths 242-247, split_batch 263-268,
+make_mel_batch 270-285, list2batch 287-299, restore_* 302-330, synth_wave 433-440).
+
+    python -m ophelia_amd.synthesize -c config/X.cfg [-N n] [-speaker id] [-odir d]
+           [-t2m_epoch e] [-ssrn_epoch e] [-max_N n] [-max_T t] [-tr transcript] [-ncores k]
+
+Same flags, same output directory naming ({sampledir|odir/cfg}/t2m{E}_ssrn{E}[_speaker-{id}]/),
+same trimming rules.  Scope differences: Griffin-Lim / WORLD vocoding, alignment
+plots and the CDP/Ain diagnostics are not part of the hot path -- the driver writes the trimmed
+magnitude spectrogram {base}.npy (what hp.store_synth_features stores, synthesize.py:436-437)
+and the trimmed mel {base}.mel.npy instead of a .wav.  Under torchrun (WORLD_SIZE>1) the
+utterances are sharded over the GPUs of the node (ophelia_amd.parallel).
+"""
+from __future__ import print_function
+
+import os
+import sys
+import timeit
+from argparse import ArgumentParser
+
+import numpy as np
+
+from . import _lib
+from . import parallel
+from .architectures import (SSRNGraph, Session, Text2MelGraph, restore_archived_model_parameters,
+                            restore_latest_model_parameters)
+from .configuration import load_config
+from .data_load import load_data
+from .libutil import basename, safe_makedir
+
+
+def start_clock(comment):
+    print("%s... " % (comment), end="")
+    return (timeit.default_timer(), comment)
+
+
+def stop_clock(clock, width=40):
+    start_time, comment = clock
+    padding = (width - len(comment)) * " "
+    print("%s--> took %.2f seconds" % (padding, (timeit.default_timer() - start_time)))
+
+
+def _check_scope(hp):
+    if getattr(hp, "use_external_durations", False) or getattr(hp, "merlin_label_dir", "") \
+            or "position_in_phone" in getattr(hp, "history_type", ""):
+        raise NotImplementedError("external durations / Merlin labels / position-in-phone history are outside the hot path")
+
+
+def get_text_lengths(L):
+    """Index of the first padding id (0) in each row; IndexError if a row has no padding."""
+    ends = []
+    for i in range(len(L)):
+        ends.append((np.where(L[i, :] == 0)[0][0]))
+    return np.array(ends)
+
+
+def encode_text(hp, L, g, sess, speaker_data=None, labels=None):
+    """K, V = sess.run([g.K, g.V], {g.L: L [, g.speakers]})"""
+    _check_scope(hp)
+    return sess.ensure_ready().encode_text(L, speaker_data)
+
+
+def synth_codedtext2mel(hp, K, V, ends, g, sess, speaker_data=None, duration_data=None,
+                        labels=None, position_in_phone_data=None):
+    """Autoregressive decode of the coded text.  Returns (Y, t_ends list, alignments) exactly as the
+    reference: Y (B,max_T,n_mels) with frames after the break step left at 0, t_ends[i] = first step at
+    which the attention peak reached the end of text i (max_T if never), alignments (B,max_N,max_T)."""
+    _check_scope(hp)
+    eng = sess.ensure_ready()
+    dist_on = parallel._dist() is not None
+    if not dist_on:
+        Y, t_ends, alignments, _ = eng.text2mel(K, V, ends, speaker_data, _lib.STOP_REFERENCE)
+        return (Y, [int(t) for t in t_ends], alignments)
+    # sharded batch: reproduce the batch-coupled break (synthesize.py:225-228) across ranks
+    state = {}
+
+    def local():
+        Y, t_ends, al, steps = eng.text2mel(K, V, ends, speaker_data, _lib.STOP_REFERENCE)
+        state["out"] = (Y, t_ends, al)
+        return steps
+
+    def resume(t0, t1):
+        eng.B = len(K)
+        eng.decode_steps(t0, t1, _lib.STOP_NEVER)
+        state["out"] = eng.fetch_mel()
+
+    parallel.sharded_text2mel(local, resume, None, hp.max_T, device=sess.device)
+    Y, t_ends, alignments = state["out"]
+    return (Y, [int(t) for t in t_ends], alignments)
+
+
+def synth_text2mel(hp, L, g, sess, speaker_data=None, duration_data=None, labels=None, position_in_phone_data=None):
+    """The reference keeps this slower variant (K/V recomputed every step) for validation; results are
+    identical to encode_text + synth_codedtext2mel, which is what runs here.  Returns (Y, t_ends)."""
+    K, V = encode_text(hp, L, g, sess, speaker_data=speaker_data, labels=labels)
+    Y, t_ends, _ = synth_codedtext2mel(hp, K, V, get_text_lengths(L), g, sess, speaker_data=speaker_data)
+    return (Y, t_ends)
+
+
+def synth_mel2mag(hp, Y, g, sess, batchsize=128):
+    if batchsize > 0:
+        nbatches = max(1, len(Y) // batchsize)       # the reference's Python-2 integer division
+        batches = np.array_split(Y, nbatches)
+    else:
+        batches = [Y]
+    eng = sess.ensure_ready()
+    return np.concatenate([eng.ssrn(Y_batch) for Y_batch in batches])
+
+
+def split_batch(synth_batch, end_indices):
+    return [predmel[:end_indices[i], :] for i, predmel in enumerate(synth_batch)]
+
+
+def make_mel_batch(hp, fnames, oracle=True):
+    if oracle:
+        mels = [os.path.join(hp.coarse_audio_dir, basename(fname) + ".npy") for fname in fnames]
+    else:
+        mels = fnames
+    mels = [np.load(melfile) for melfile in mels]
+    mel_batch = np.zeros((len(mels), hp.max_T, hp.n_mels), np.float32)
+    lengths = []
+    for (i, mel) in enumerate(mels):
+        length, n = mel.shape
+        mel_batch[i, :length, :] = mel
+        lengths.append(length * hp.r)
+    return mel_batch, lengths
+
+
+def list2batch(inlist, pad_length):
+    m, dim = inlist[0].shape
+    if pad_length == 0:
+        pad_length = max([a.shape[0] for a in inlist])
+    batch = np.zeros((len(inlist), pad_length, dim), np.float32)
+    for (i, array) in enumerate(inlist):
+        length, n = array.shape
+        assert length <= pad_length
+        assert n == dim
+        batch[i, :length, :] = array
+    return batch
+
+
+def synth_wave(hp, mag, outfile):
+    """Vocoding is outside the hot path: store the trimmed magnitudes the reference stores when
+    hp.store_synth_features is set (same file name: {base}.npy)."""
+    assert hp.vocoder in ["griffin_lim", "world"], "Other vocoders than griffin_lim/world not yet supported"
+    np.save(outfile.replace(".wav", ".npy"), mag)
+
+
+def synthesize(hp, speaker_id="", num_sentences=0, ncores=1, topoutdir="", t2m_epoch=-1, ssrn_epoch=-1,
+               weights=None, device=None):
+    """topoutdir: store samples under here; defaults to hp.sampledir.
+    t2m_epoch / ssrn_epoch: -1 = latest, else archived epoch.
+    weights: optional {TF name: array} bypassing the checkpoint lookup (tests / random-init runs)."""
+    assert hp.vocoder in ["griffin_lim", "world"], "Other vocoders than griffin_lim/world not yet supported"
+    _check_scope(hp)
+    dist = parallel._dist()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist else (0, 1)
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+
+    dataset = load_data(hp, mode="synthesis")
+    fpaths, L = dataset["fpaths"], dataset["texts"]
+    if num_sentences > 0:
+        assert num_sentences <= len(fpaths)
+        L = L[:num_sentences, :]
+        fpaths = fpaths[:num_sentences]
+    bases = [basename(fpath) for fpath in fpaths]
+    lo, hi = parallel.shard_range(len(L), rank, world)       # contiguous utterance shard of this GPU
+    L, bases = L[lo:hi], bases[lo:hi]
+
+    if speaker_id:
+        speaker2ix = dict(zip(hp.speaker_list, range(len(hp.speaker_list))))
+        speaker_data = np.ones((len(L), 1)) * speaker2ix[speaker_id]
+    else:
+        speaker_data = None
+
+    g1 = Text2MelGraph(hp, mode="synthesize"); print("Graph 1 (t2m) loaded")
+    g2 = SSRNGraph(hp, mode="synthesize"); print("Graph 2 (ssrn) loaded")
+
+    with Session(hp, device=device) as sess:
+        if weights is not None:
+            if world > 1:
+                weights = parallel.broadcast_weights(weights if rank == 0 else None, sess.inventory(), src=0, device=device)
+            sess.assign(weights)
+            t2m_epoch = ssrn_epoch = "rand" if t2m_epoch == -1 else t2m_epoch
+        else:
+            if t2m_epoch > -1:
+                restore_archived_model_parameters(sess, hp, "t2m", t2m_epoch)
+            else:
+                t2m_epoch = restore_latest_model_parameters(sess, hp, "t2m")
+            if ssrn_epoch > -1:
+                restore_archived_model_parameters(sess, hp, "ssrn", ssrn_epoch)
+            else:
+                ssrn_epoch = restore_latest_model_parameters(sess, hp, "ssrn")
+
+        t = start_clock("Text2Mel generating...")
+        text_lengths = get_text_lengths(L)
+        K, V = encode_text(hp, L, g1, sess, speaker_data=speaker_data)
+        Y, lengths, alignments = synth_codedtext2mel(hp, K, V, text_lengths, g1, sess, speaker_data=speaker_data)
+        stop_clock(t)
+
+        t = start_clock("Mel2Mag generating...")
+        Z = synth_mel2mag(hp, Y, g2, sess)
+        stop_clock(t)
+        if (np.isnan(Z).any()):
+            Z = np.nan_to_num(Z)
+
+        if not topoutdir:
+            topoutdir = hp.sampledir
+        outdir = os.path.join(topoutdir, "t2m%s_ssrn%s" % (t2m_epoch, ssrn_epoch))
+        if speaker_id:
+            outdir += "_speaker-%s" % (speaker_id)
+        safe_makedir(outdir)
+        print("Generating feature files, will save to following dir: %s" % (outdir))
+        for i, mag in enumerate(Z):
+            outfile = os.path.join(outdir, bases[i] + ".wav")
+            mag = mag[:lengths[i] * hp.r, :]                   # trim to generated length
+            synth_wave(hp, mag, outfile)
+            np.save(os.path.join(outdir, bases[i] + ".mel.npy"), Y[i, :lengths[i], :])
+    return outdir
+
+
+def main_work():
+    a = ArgumentParser()
+    a.add_argument("-c", dest="config", required=True, type=str)
+    a.add_argument("-speaker", default="", type=str)
+    a.add_argument("-N", dest="num_sentences", default=0, type=int)
+    a.add_argument("-babble", action="store_true")
+    a.add_argument("-ncores", type=int, default=1, help="Number of CPUs for Griffin-Lim stage (unused: vocoding is out of scope)")
+    a.add_argument("-odir", type=str, default="", help="Alternative place to put output samples")
+    a.add_argument("-t2m_epoch", default=-1, type=int, help="Default: use latest (-1)")
+    a.add_argument("-ssrn_epoch", default=-1, type=int, help="Default: use latest (-1)")
+    a.add_argument("-max_N", default=-1, type=int, help="Default: use max_N from config")
+    a.add_argument("-max_T", default=-1, type=int, help="Default: use max_T from config")
+    a.add_argument("-tr", default="", type=str, help="Default:use test_transcript from config")
+    a.add_argument("-random_init", default=-1, type=int, metavar="SEED",
+                   help="(extension) seeded random-init weights instead of a checkpoint")
+    opts = a.parse_args()
+
+    hp = load_config(opts.config)
+    if (opts.max_N != -1):
+        hp.max_N = opts.max_N
+    if (opts.max_T != -1):
+        hp.max_T = opts.max_T
+    if (opts.tr != ""):
+        hp.test_transcript = opts.tr
+    print("max_N=" + str(hp.max_N))
+    print("max_T=" + str(hp.max_T))
+    print("test_transcript=" + str(hp.test_transcript))
+
+    outdir = opts.odir
+    if outdir:
+        outdir = os.path.join(outdir, basename(opts.config))
+    if hp.multispeaker:
+        assert opts.speaker, "Please specify a speaker from speaker_list with -speaker flag"
+        assert opts.speaker in hp.speaker_list
+    if opts.babble:
+        sys.exit("babbling is outside the hot-path scope")
+
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch
+        import torch.distributed as dist
+        use_gpu = torch.cuda.is_available()
+        if use_gpu:
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl" if use_gpu else "gloo")
+
+    weights = None
+    if opts.random_init >= 0:
+        from .engine import Engine
+        from . import weights as WT
+        probe = Engine(hp, device=int(os.environ.get("LOCAL_RANK", "0")))
+        weights = WT.random_weights(probe.inventory(), opts.random_init)
+        probe.close()
+    synthesize(hp, speaker_id=opts.speaker, num_sentences=opts.num_sentences, ncores=opts.ncores,
+               topoutdir=outdir, t2m_epoch=opts.t2m_epoch, ssrn_epoch=opts.ssrn_epoch, weights=weights)
+
+
+if __name__ == "__main__":
+    main_work()

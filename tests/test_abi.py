@@ -1,0 +1,53 @@
+"""The C-ABI library loads and exports every symbol include/ophelia_hip.h declares, and the
+product path fails loudly without a GPU (no CPU fallback).  CPU only: no compute calls."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "ophelia_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(oph_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ophelia_amd import _lib
+    _lib.build()
+    lib = C.CDLL(_lib.LIBPATH)
+    syms = _declared_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert set(syms) == set(_lib.SIGNATURES), set(syms) ^ set(_lib.SIGNATURES)
+    assert lib.oph_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ophelia_amd import _lib
+    from ophelia_amd.engine import Engine
+    from conftest import hp_from_snapshot
+    with pytest.raises(_lib.OpheliaHipError, match="no HIP device"):
+        Engine(hp_from_snapshot("lj_tutorial.cfg"))
+    from ophelia_amd import modules as M
+    import numpy as np
+    with pytest.raises(_lib.OpheliaHipError):
+        M.embed(np.zeros((1, 2), np.int32), np.zeros((4, 4), np.float32))
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under ophelia_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "ophelia_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "oph_cpu" not in src, f
