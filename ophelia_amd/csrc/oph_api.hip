@@ -131,7 +131,7 @@ struct oph_handle {
     }
     // ---- profiling brackets
     void pbegin(int cls) {
-        if (!profiling || capturing) return;
+        if (!profiling || capturing || group_cls == cls) return;
         ProfClass& pc = prof[cls];
         if (pc.used == pc.ev.size()) {
             hipEvent_t a, b;
@@ -141,12 +141,23 @@ struct oph_handle {
         }
         hipEventRecord(pc.ev[pc.used].first, cur);
     }
+    // group bracket: ONE event pair around a run of consecutive launches of class `cls` on `cur`
+    // (per-launch event records would add ~3 us to 5-9 us kernels and disagree with rocprof)
+    int group_cls = -1;
+    void gbegin(int cls) { pbegin(cls); group_cls = cls; }
+    void gend(int cls) {
+        group_cls = -1;
+        if (!profiling || capturing) return;
+        ProfClass& pc = prof[cls];
+        hipEventRecord(pc.ev[pc.used].second, cur);
+        pc.used++;
+    }
     void pend(int cls, double bytes, double flops) {
         ProfClass& pc = prof[cls];
         pc.launches++;
         pc.bytes += bytes;
         pc.flops += flops;
-        if (!profiling || capturing) return;
+        if (!profiling || capturing || group_cls == cls) return;
         hipEventRecord(pc.ev[pc.used].second, cur);
         pc.used++;
     }
@@ -611,6 +622,7 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode) {
     const Layer* prev = nullptr;
     const float* prev_raw = nullptr;
     const float* prev_x = nullptr;    // previous layer's input rows at time t (highway residual)
+    h->gbegin(PC_DEC);
     for (size_t li = 0; li < h->audioenc.size(); ++li) {
         const Layer& l = h->audioenc[li];
         DecArgs a{};
@@ -631,6 +643,7 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode) {
         prev = &l; prev_raw = h->ae_raw[li];
         prev_x = l.kind == K_HC ? h->ae_hist[li] + (size_t)t * Bpad * l.kc : nullptr;
     }
+    h->gend(PC_DEC);
     // ---------------- attention at row t (networks.py:286-325) + bookkeeping (synthesize.py:204-228)
     {
         AttnStepArgs a{};
@@ -657,6 +670,7 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode) {
     const std::vector<float*>& cone = h->cone[t & 1];
     // ---------------- AudioDec row t
     prev = nullptr; prev_raw = nullptr; prev_x = nullptr;
+    h->gbegin(PC_DEC);
     for (size_t li = 0; li < h->audiodec.size(); ++li) {
         const Layer& l = h->audiodec[li];
         DecArgs a{};
@@ -678,6 +692,7 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode) {
         prev = &l; prev_raw = h->ad_raw[li];
         prev_x = l.kind == K_HC ? h->ad_xrow[li] : nullptr;
     }
+    h->gend(PC_DEC);
     {
         EmitArgs e{};
         e.hraw = prev_raw; e.ldh = prev->Nalloc; e.g = prev->g1; e.b = prev->b1; e.C = m.n_mels; e.squash = 1;
