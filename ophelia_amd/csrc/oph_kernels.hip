@@ -306,7 +306,9 @@ void launch_epilogue(const EpiArgs& a, hipStream_t s) {
 //   registers and are issued BEFORE the prologue so their latency hides behind it.
 //   Output = raw conv rows (bias added); the consumer kernel applies this layer's LN.
 // =====================================================================================
-constexpr int DEC_PF = 12;        // 16-wide k-chunks prefetched per wave per pass (K <= 768 in one pass)
+constexpr int DEC_WAVES = 16;     // waves per workgroup (prologue rows and K-chunks are split over them)
+constexpr int DEC_RPW = 16 / DEC_WAVES;   // prologue rows per wave
+constexpr int DEC_PF = 48 / DEC_WAVES;    // 16-wide k-chunks prefetched per wave per pass (K <= 768 in one pass)
 
 // Latency engineering (profiles/r01): a step is ~25 dependent launches, so what matters is the
 // number of dependent memory round trips inside each one.  Everything that does not depend on
@@ -315,11 +317,11 @@ constexpr int DEC_PF = 12;        // 16-wide k-chunks prefetched per wave per pa
 // per wave), the LayerNorm reductions of the 4 rows are interleaved, and the stop flag only
 // predicates the final stores instead of gating the kernel.
 template <int NV, int PRE, int NTAPS>
-__global__ __launch_bounds__(256) void dec_layer16(DecArgs a) {
+__global__ __launch_bounds__(64 * DEC_WAVES) void dec_layer16(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Ktot = NTAPS * a.kc, ldxs = Ktot + 4;
     float* xs = smem;                 // [16][ldxs]
-    float* part = smem + 16 * ldxs;   // [4][256]
+    float* part = smem + 16 * ldxs;   // [DEC_WAVES][256]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int n0 = blockIdx.x * 16, row0 = blockIdx.y * 16;
     const int r16 = lane & 15, kq = lane >> 4;
@@ -332,16 +334,16 @@ __global__ __launch_bounds__(256) void dec_layer16(DecArgs a) {
     f32x4 bfrag[DEC_PF];
 #pragma unroll
     for (int i = 0; i < DEC_PF; ++i) {
-        const int c = w + 4 * i;
+        const int c = w + DEC_WAVES * i;
         bfrag[i] = c < nchunks ? *(const f32x4*)(wrow + c * 16) : zero4;
     }
     const int stop_v = a.stop_after ? *a.stop_after : 0x7fffffff;
     const float bias_v = a.bias[n0 + (tid & 15)];
-    f32x4 x[4][NV], u[4][NV], xr[4][NV], tp0[4][KV], tp1[4][KV];
+    f32x4 x[DEC_RPW][NV], u[DEC_RPW][NV], xr[DEC_RPW][NV], tp0[DEC_RPW][KV], tp1[DEC_RPW][KV];
     f32x4 g1v[NV], b1v[NV], g2v[NV], b2v[NV];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int grow = row0 + 4 * w + rr;
+    for (int rr = 0; rr < DEC_RPW; ++rr) {
+        const int grow = row0 + DEC_RPW * w + rr;
         const float* sp = a.src + (size_t)grow * a.ldsrc;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -373,11 +375,11 @@ __global__ __launch_bounds__(256) void dec_layer16(DecArgs a) {
             }
         }
     }
-    int cat_id[4] = {0, 0, 0, 0};
+    int cat_id[DEC_RPW] = {};
     if (a.ccat > 0) {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int grow = row0 + 4 * w + rr;
+        for (int rr = 0; rr < DEC_RPW; ++rr) {
+            const int grow = row0 + DEC_RPW * w + rr;
             cat_id[rr] = a.cat_ids[grow < a.B ? grow : 0];
         }
     }
@@ -385,10 +387,10 @@ __global__ __launch_bounds__(256) void dec_layer16(DecArgs a) {
     // ---- 2. prologue math: LayerNorm(s) of 4 rows interleaved, gate / activation
     if (PRE != PRE_COPY) {
         const float invc = 1.0f / (float)a.cin;
-        auto ln4 = [&](f32x4 (&z)[4][NV], const f32x4 (&gv)[NV], const f32x4 (&bv)[NV]) {
-            float s[4], q[4];
+        auto ln4 = [&](f32x4 (&z)[DEC_RPW][NV], const f32x4 (&gv)[NV], const f32x4 (&bv)[NV]) {
+            float s[DEC_RPW], q[DEC_RPW];
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
+            for (int rr = 0; rr < DEC_RPW; ++rr) {
                 s[rr] = 0.f;
 #pragma unroll
                 for (int v = 0; v < NV; ++v) s[rr] += z[rr][v][0] + z[rr][v][1] + z[rr][v][2] + z[rr][v][3];
@@ -396,9 +398,9 @@ __global__ __launch_bounds__(256) void dec_layer16(DecArgs a) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) s[rr] += __shfl_xor(s[rr], o, 64);
+                for (int rr = 0; rr < DEC_RPW; ++rr) s[rr] += __shfl_xor(s[rr], o, 64);
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
+            for (int rr = 0; rr < DEC_RPW; ++rr) {
                 const float mean = s[rr] * invc;
                 q[rr] = 0.f;
 #pragma unroll
@@ -413,9 +415,9 @@ __global__ __launch_bounds__(256) void dec_layer16(DecArgs a) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) q[rr] += __shfl_xor(q[rr], o, 64);
+                for (int rr = 0; rr < DEC_RPW; ++rr) q[rr] += __shfl_xor(q[rr], o, 64);
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
+            for (int rr = 0; rr < DEC_RPW; ++rr) {
                 const float rstd = 1.0f / sqrtf(q[rr] * invc + LN_EPS);
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(256) void dec_layer16(DecArgs a) {
         if (PRE == PRE_HC) {
             ln4(u, g2v, b2v);
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
+            for (int rr = 0; rr < DEC_RPW; ++rr)
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
 #pragma unroll
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(256) void dec_layer16(DecArgs a) {
                     }
         } else {
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
+            for (int rr = 0; rr < DEC_RPW; ++rr)
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
 #pragma unroll
@@ -447,8 +449,8 @@ __global__ __launch_bounds__(256) void dec_layer16(DecArgs a) {
     // ---- 3. stage the 16 x Ktot operand in LDS: [taps (oldest first) | current]
     const int cur = (NTAPS - 1) * a.kc;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        float* xrow = xs + (4 * w + rr) * ldxs;
+    for (int rr = 0; rr < DEC_RPW; ++rr) {
+        float* xrow = xs + (DEC_RPW * w + rr) * ldxs;
 #pragma unroll
         for (int v = 0; v < KV; ++v) {
             const int c = (v * 64 + lane) * 4;
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(256) void dec_layer16(DecArgs a) {
     __syncthreads();
     const bool live = a.t <= stop_v;
     if (blockIdx.x == 0 && a.xstore && live) {     // publish x[t] (this layer's input) for later steps / residual
-        for (int i = tid * 4; i < 16 * a.kc; i += 1024) {
+        for (int i = tid * 4; i < 16 * a.kc; i += 256 * DEC_WAVES) {
             const int row = i / a.kc, c = i - row * a.kc;
             *(f32x4*)(a.xstore + (size_t)(row0 + row) * a.ldstore + c) = *(const f32x4*)(xs + row * ldxs + cur + c);
         }
@@ -484,17 +486,17 @@ __global__ __launch_bounds__(256) void dec_layer16(DecArgs a) {
     // ---- 4. 16x16 slice, K split over waves
     f32x4 acc0 = zero4, acc1 = zero4;
     const float* xa = xs + r16 * ldxs + kq * 4;
-    for (int base = 0; base < nchunks; base += 4 * DEC_PF) {
+    for (int base = 0; base < nchunks; base += DEC_WAVES * DEC_PF) {
         if (base > 0) {
 #pragma unroll
             for (int i = 0; i < DEC_PF; ++i) {
-                const int c = base + w + 4 * i;
+                const int c = base + w + DEC_WAVES * i;
                 bfrag[i] = c < nchunks ? *(const f32x4*)(wrow + c * 16) : zero4;
             }
         }
 #pragma unroll
         for (int i = 0; i < DEC_PF; ++i) {
-            const int c = base + w + 4 * i;
+            const int c = base + w + DEC_WAVES * i;
             if (c < nchunks) {
                 const f32x4 av = *(const f32x4*)(xa + c * 16);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bfrag[i][0], acc0, 0, 0, 0);
@@ -508,9 +510,11 @@ __global__ __launch_bounds__(256) void dec_layer16(DecArgs a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) part[w * 256 + (kq * 4 + e) * 16 + r16] = acc0[e] + acc1[e];
     __syncthreads();
-    if (live) {
+    if (live && tid < 256) {
         const int row = tid >> 4, col = tid & 15;
-        const float v = part[tid] + part[256 + tid] + part[512 + tid] + part[768 + tid] + bias_v;
+        float v = bias_v;
+#pragma unroll
+        for (int ww = 0; ww < DEC_WAVES; ++ww) v += part[ww * 256 + tid];
         a.H[(size_t)(row0 + row) * a.ldh + n0 + col] = v;
     }
 }
@@ -521,13 +525,13 @@ static void launch_dec_t(const DecArgs& a, dim3 grid, size_t lds, hipStream_t s)
         static std::map<const void*, size_t> done;
         if (done[f] < lds) { (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done[f] = lds; }
     };
-    if (a.ntaps == 3) { set((const void*)dec_layer16<NV, PRE, 3>); hipLaunchKernelGGL((dec_layer16<NV, PRE, 3>), grid, dim3(256), lds, s, a); }
-    else              { set((const void*)dec_layer16<NV, PRE, 1>); hipLaunchKernelGGL((dec_layer16<NV, PRE, 1>), grid, dim3(256), lds, s, a); }
+    if (a.ntaps == 3) { set((const void*)dec_layer16<NV, PRE, 3>); hipLaunchKernelGGL((dec_layer16<NV, PRE, 3>), grid, dim3(64 * DEC_WAVES), lds, s, a); }
+    else              { set((const void*)dec_layer16<NV, PRE, 1>); hipLaunchKernelGGL((dec_layer16<NV, PRE, 1>), grid, dim3(64 * DEC_WAVES), lds, s, a); }
 }
 
 void launch_dec_layer(const DecArgs& a, int Npad16, hipStream_t s) {
     const int Ktot = a.ntaps * a.kc;
-    const size_t lds = (size_t)(16 * (Ktot + 4) + 1024) * 4;
+    const size_t lds = (size_t)(16 * (Ktot + 4) + 256 * DEC_WAVES) * 4;
     const int Bpad = round_up(a.B, 16);
     const dim3 grid(Npad16 / 16, Bpad / 16);
     const bool wide = a.cin > 256;          // NV = 2 (cin <= 512)
