@@ -8,6 +8,10 @@
 #include "../../include/ophelia_hip.h"
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <climits>
 #include <cstdarg>
 #include <cstdio>
@@ -20,6 +24,8 @@
 using namespace oph;
 
 static thread_local std::string g_create_error;
+static thread_local hipStream_t g_cur = nullptr;    // stream the launch wrappers of THIS host thread target
+static thread_local int g_group_cls = -1;
 static thread_local std::string g_op_error;
 
 #define HIPCHK(h, expr)                                                                        \
@@ -75,8 +81,16 @@ struct oph_handle {
     int dec_graph_B[2] = {0, 0};
     bool capturing = false;
     bool use_graph = true;
+    // second host thread: enqueues the side-stream cone while this thread enqueues the critical chain
+    bool use_threads = true;
+    std::thread worker;
+    std::mutex wmu;
+    std::condition_variable wcv, wcv_done;
+    bool job_pending = false, job_done = true, quit = false;
+    int job_t0 = 0, job_t1 = 0;
+    std::atomic<int> attn_posted{-1}, cone_posted{0}, limit{INT_MAX};
+    std::vector<hipEvent_t> ev_attn_v, ev_cone_v;     // per-step events (threaded mode)
     hipStream_t stream2 = nullptr;     // side stream: AudioDec history cone, overlapped with the AudioEnc chain
-    hipStream_t cur = nullptr;         // stream the launch wrappers currently target
     hipEvent_t ev_attn = nullptr, ev_cone = nullptr;
     std::string err;
     bool finalized = false;
@@ -131,7 +145,7 @@ struct oph_handle {
     }
     // ---- profiling brackets
     void pbegin(int cls) {
-        if (!profiling || capturing || group_cls == cls) return;
+        if (!profiling || capturing || g_group_cls == cls) return;
         ProfClass& pc = prof[cls];
         if (pc.used == pc.ev.size()) {
             hipEvent_t a, b;
@@ -139,17 +153,16 @@ struct oph_handle {
             hipEventCreate(&b);
             pc.ev.emplace_back(a, b);
         }
-        hipEventRecord(pc.ev[pc.used].first, cur);
+        hipEventRecord(pc.ev[pc.used].first, g_cur);
     }
     // group bracket: ONE event pair around a run of consecutive launches of class `cls` on `cur`
     // (per-launch event records would add ~3 us to 5-9 us kernels and disagree with rocprof)
-    int group_cls = -1;
-    void gbegin(int cls) { pbegin(cls); group_cls = cls; }
+    void gbegin(int cls) { pbegin(cls); g_group_cls = cls; }
     void gend(int cls) {
-        group_cls = -1;
+        g_group_cls = -1;
         if (!profiling || capturing) return;
         ProfClass& pc = prof[cls];
-        hipEventRecord(pc.ev[pc.used].second, cur);
+        hipEventRecord(pc.ev[pc.used].second, g_cur);
         pc.used++;
     }
     void pend(int cls, double bytes, double flops) {
@@ -157,8 +170,8 @@ struct oph_handle {
         pc.launches++;
         pc.bytes += bytes;
         pc.flops += flops;
-        if (!profiling || capturing || group_cls == cls) return;
-        hipEventRecord(pc.ev[pc.used].second, cur);
+        if (!profiling || capturing || g_group_cls == cls) return;
+        hipEventRecord(pc.ev[pc.used].second, g_cur);
         pc.used++;
     }
 };
@@ -353,19 +366,19 @@ int pack_layer(oph_handle* h, Layer& l) {
 // ------------------------------------------------------------------ launch wrappers with accounting
 void run_gemm(oph_handle* h, const GemmArgs& a, int cin_true) {
     h->pbegin(PC_GEMM);
-    launch_conv_gemm(a, h->cur);
+    launch_conv_gemm(a, g_cur);
     const double K = (double)a.ntaps * cin_true;
     h->pend(PC_GEMM, ((double)a.M * cin_true + (double)a.M * a.N + (double)a.N * K) * 4.0, 2.0 * a.M * a.N * K);
 }
 void run_epi(oph_handle* h, const EpiArgs& a) {
     h->pbegin(PC_LN);
-    launch_epilogue(a, h->cur);
+    launch_epilogue(a, g_cur);
     const double cols = a.mode == PRE_HC ? 4.0 * a.C : 2.0 * a.C;    // read raw (+res), write out
     h->pend(PC_LN, (double)a.M * cols * 4.0, (double)a.M * a.C * 10.0);
 }
 void run_dec(oph_handle* h, const DecArgs& a, const Layer& l) {
     h->pbegin(PC_DEC);
-    launch_dec_layer(a, round_up(l.N, 16), h->cur);
+    launch_dec_layer(a, round_up(l.N, 16), g_cur);
     const double K = (double)l.ntaps * l.cin;
     h->pend(PC_DEC, ((double)l.N * K + (double)a.B * (K + l.N)) * 4.0, 2.0 * a.B * l.N * K);
 }
@@ -554,15 +567,15 @@ void launch_cone(oph_handle* h, int t) {
     const int* pcur = h->d_p + (t & 1) * Bpad;
     const int pre = h->dec_pre, nh = h->n_hc_dec;
     std::vector<float*>& cone = h->cone[t & 1];
-    hipStream_t saved = h->cur;
-    h->cur = h->stream2;
+    hipStream_t saved = g_cur;
+    g_cur = h->stream2;
     const int n0 = (int)h->Hset[0].size();
     AttnRowsArgs ar{};
     ar.mode = 0; ar.Q = h->Qhist; ar.ldq = d; ar.K = h->KV; ar.V = h->KV + d; ar.ldkv = 2 * d; ar.N = m.max_N; ar.d = d;
     ar.win = m.attention_win_size; ar.p = pcur; ar.B = B; ar.Bpad = Bpad; ar.nrows = n0 * Bpad; ar.off = h->d_off0; ar.j = t;
     ar.R = h->coneR; ar.ldr = 2 * d; ar.stop_after = stop_after; ar.t = t;
     h->pbegin(PC_ATTN_ROWS);
-    launch_attn_rows(ar, h->cur);
+    launch_attn_rows(ar, g_cur);
     h->pend(PC_ATTN_ROWS, (double)n0 * B * 3.0 * d * 4.0, (double)n0 * B * 4.0 * m.attention_win_size * d);
     // k=1 layers before the highway stack, on all Hset[0] positions
     const float* x = h->coneR; int ldx = 2 * d;
@@ -608,16 +621,16 @@ void launch_cone(oph_handle* h, int t) {
         e.Y = cone[k + 1]; e.ldy = nx.kc; e.ypad = nx.kc; e.stop_after = stop_after; e.t = t;
         run_epi(h, e);
     }
-    h->cur = saved;
+    g_cur = saved;
 }
 
 // one decoder step t.  Main stream: AudioEnc chain -> attention -> [wait cone(t)] -> AudioDec row t
 // -> emit.  Side stream: cone(t+1), released by the event recorded right after attn_step(t).
-void decode_step(oph_handle* h, int t, int t_last, int stop_mode) {
+void decode_step(oph_handle* h, int t, int t_last, int stop_mode, bool threaded = false) {
     const oph_dims& m = h->dm;
     const int d = m.d, Bpad = h->Bpad, B = h->B;
     int* stop_after = h->d_ctl + 1;
-    h->cur = h->sdec;
+    g_cur = h->sdec;
     // ---------------- AudioEnc, incremental (causal, mask-free => cacheable)
     const Layer* prev = nullptr;
     const float* prev_raw = nullptr;
@@ -658,10 +671,19 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode) {
         h->pend(PC_ATTN_STEP, (double)B * (6.0 * d + 2.0 * m.attention_win_size * d) * 4.0, (double)B * 4.0 * m.attention_win_size * d);
     }
     const int pre = h->dec_pre;
+    if (threaded) {
+        // the worker thread enqueues cone(t+1) as soon as it sees attn(t) recorded
+        hipEventRecord(h->ev_attn_v[t], h->sdec);
+        h->attn_posted.store(t, std::memory_order_release);
+        if (t >= 1) {
+            while (h->cone_posted.load(std::memory_order_acquire) < t) __builtin_ia32_pause();
+            hipStreamWaitEvent(h->sdec, h->ev_cone_v[t], 0);
+        }
+    }
     // cone(t) (launched during step t-1, or by decode_range for the first step) must have landed
-    if (t >= 1) hipStreamWaitEvent(h->sdec, h->ev_cone, 0);
+    if (!threaded && t >= 1) hipStreamWaitEvent(h->sdec, h->ev_cone, 0);
     // release cone(t+1) on the side stream: needs p_{t+1} and Q[t], both written by attn_step(t)
-    if (t + 1 < t_last) {
+    if (!threaded && t + 1 < t_last) {
         hipEventRecord(h->ev_attn, h->sdec);
         hipStreamWaitEvent(h->stream2, h->ev_attn, 0);
         launch_cone(h, t + 1);
@@ -704,6 +726,39 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode) {
     }
 }
 
+// Side-stream enqueue thread: for t in [t0,t1): wait until attn(t-1) has been RECORDED by the main
+// thread, make stream2 wait on it, enqueue cone(t), record its completion event.
+void worker_main(oph_handle* h) {
+    (void)hipSetDevice(h->device);
+    for (;;) {
+        int t0, t1;
+        {
+            std::unique_lock<std::mutex> lk(h->wmu);
+            h->wcv.wait(lk, [&] { return h->job_pending || h->quit; });
+            if (h->quit) return;
+            t0 = h->job_t0; t1 = h->job_t1; h->job_pending = false;
+        }
+        g_cur = h->stream2;
+        for (int t = t0; t < t1; ++t) {
+            bool stop = false;
+            while (h->attn_posted.load(std::memory_order_acquire) < t - 1) {
+                if (h->limit.load(std::memory_order_acquire) < t) { stop = true; break; }
+                __builtin_ia32_pause();
+            }
+            if (stop || h->limit.load(std::memory_order_acquire) < t) break;
+            hipStreamWaitEvent(h->stream2, h->ev_attn_v[t - 1], 0);
+            launch_cone(h, t);
+            hipEventRecord(h->ev_cone_v[t], h->stream2);
+            h->cone_posted.store(t, std::memory_order_release);
+        }
+        {
+            std::lock_guard<std::mutex> lk(h->wmu);
+            h->job_done = true;
+        }
+        h->wcv_done.notify_all();
+    }
+}
+
 int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* steps_run) {
     const oph_dims& m = h->dm;
     t_end = std::min(t_end, (int)m.max_T);
@@ -712,7 +767,7 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
     // fork: the decode streams start after everything queued on the API stream (encode, resets)
     hipEventRecord(h->ev_in, h->stream);
     hipStreamWaitEvent(h->sdec, h->ev_in, 0);
-    h->cur = h->sdec;
+    g_cur = h->sdec;
     // ---- whole-loop hipGraph: a step is ~39 launches on two streams; enqueued eagerly the host
     // (~5 us per launch) is slower than the device (profiles/r01 trace: the critical stream idles
     // while the host enqueues the cone).  Capture all max_T steps once per (stop_mode, B) and replay.
@@ -741,29 +796,54 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
             t_begin = t_end;      // skip the eager loop below
         }
     }
-    if (t_begin >= 1 && t_begin < t_end) {      // resuming mid-utterance: cone(t_begin) has not been launched yet
+    const bool threaded = h->use_threads && !h->profiling && t_begin < t_end;
+    if (threaded) {
+        if ((int)h->ev_attn_v.size() < m.max_T + 1) {
+            h->ev_attn_v.resize(m.max_T + 1); h->ev_cone_v.resize(m.max_T + 1);
+            for (auto& e : h->ev_attn_v) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            for (auto& e : h->ev_cone_v) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        }
+        if (!h->worker.joinable()) h->worker = std::thread(worker_main, h);
+        h->limit.store(INT_MAX);
+        h->cone_posted.store(t_begin >= 1 ? t_begin - 1 : 0);
+        if (t_begin >= 1) hipEventRecord(h->ev_attn_v[t_begin - 1], h->sdec);   // resuming: cone(t_begin) may start now
+        h->attn_posted.store(t_begin - 1, std::memory_order_release);
+        {
+            std::lock_guard<std::mutex> lk(h->wmu);
+            h->job_t0 = std::max(1, t_begin); h->job_t1 = t_end; h->job_pending = true; h->job_done = false;
+        }
+        h->wcv.notify_all();
+    } else if (t_begin >= 1 && t_begin < t_end) {      // resuming mid-utterance: cone(t_begin) has not been launched yet
         hipEventRecord(h->ev_attn, h->sdec);
         hipStreamWaitEvent(h->stream2, h->ev_attn, 0);
         launch_cone(h, t_begin);
         hipEventRecord(h->ev_cone, h->stream2);
     }
+    int rc_loop = OPH_OK;
     for (int t = t_begin; t < t_end; ++t) {
-        decode_step(h, t, t_end, stop_mode);
+        decode_step(h, t, t_end, stop_mode, threaded);
         last = t + 1;
         // bounded look-ahead: poll the device-side stop flag every 8 steps (reference semantics keep
         // frames after the break step at zero because later steps early-out on the device)
         if (stop_mode == OPH_STOP_REFERENCE && ((t & 7) == 7)) {
-            HIPCHK(h, hipMemcpyAsync(ctl, h->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, h->sdec));
-            HIPCHK(h, hipStreamSynchronize(h->sdec));
+            if (hipMemcpyAsync(ctl, h->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, h->sdec) != hipSuccess ||
+                hipStreamSynchronize(h->sdec) != hipSuccess) { rc_loop = OPH_ERR_DEVICE; break; }
             if (ctl[1] != INT_MAX) break;
         }
     }
+    if (threaded) {      // the worker must have stopped enqueuing before stream2 is joined
+        h->limit.store(last - 1, std::memory_order_release);
+        std::unique_lock<std::mutex> lk(h->wmu);
+        h->wcv_done.wait(lk, [&] { return h->job_done; });
+    }
+    g_cur = h->sdec;
+    if (rc_loop != OPH_OK) { h->fail("device error while polling the stop flag"); return rc_loop; }
     // join: the API stream continues (SSRN, fetches) only after both decode streams drained
     hipEventRecord(h->ev_out, h->sdec);
     hipStreamWaitEvent(h->stream, h->ev_out, 0);
     hipEventRecord(h->ev_out, h->stream2);
     hipStreamWaitEvent(h->stream, h->ev_out, 0);
-    h->cur = h->stream;
+    g_cur = h->stream;
     if (steps_run || stop_mode == OPH_STOP_REFERENCE) {
         HIPCHK(h, hipMemcpyAsync(ctl, h->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -861,8 +941,9 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
         delete h;
         return OPH_ERR_DEVICE;
     }
-    h->cur = h->stream;
-    h->use_graph = getenv("OPH_USE_GRAPH") != nullptr;   // replay measured slower than eager launches
+    g_cur = h->stream;
+    h->use_graph = getenv("OPH_USE_GRAPH") != nullptr;
+    h->use_threads = getenv("OPH_USE_THREADS") != nullptr && !h->use_graph;   // measured slower (HIP serialises launches across threads)   // replay measured slower than eager launches
     build_networks(h);
     *out = h;
     return OPH_OK;
@@ -879,6 +960,13 @@ int oph_destroy(oph_handle* h) {
     hipEventDestroy(h->ev1);
     hipEventDestroy(h->ev_attn);
     hipEventDestroy(h->ev_cone);
+    if (h->worker.joinable()) {
+        { std::lock_guard<std::mutex> lk(h->wmu); h->quit = true; }
+        h->wcv.notify_all();
+        h->worker.join();
+    }
+    for (auto e : h->ev_attn_v) hipEventDestroy(e);
+    for (auto e : h->ev_cone_v) hipEventDestroy(e);
     for (auto& ge : h->dec_graph) if (ge) hipGraphExecDestroy(ge);
     hipEventDestroy(h->ev_in);
     hipEventDestroy(h->ev_out);

@@ -1,0 +1,104 @@
+"""GPU parity at the edges: ragged batch sizes (1, 10, 20 = two 16-row tiles), the other BASELINE
+dimension sets (C1 lj_test: V=65, max_N=180, max_T=210, B=10; C5 vctk_01 multispeaker B=8), the
+host-polled early stop (stop after >8 steps), argument validation and handle re-use across batches."""
+import numpy as np
+import pytest
+
+from conftest import hp_from_snapshot
+from oracle import ophelia_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _run(hp, W, L, spk=None, stop=True):
+    from ophelia_amd.engine import Engine
+    eng = Engine(hp, device=0)
+    eng.load_weights(W)
+    ends = O.get_text_lengths(L)
+    K, V = eng.encode_text(L, spk)
+    Y, t_ends, al, steps = eng.text2mel(K, V, ends, spk, stop_mode=0 if stop else 1)
+    Z = eng.ssrn(Y)
+    eng.close()
+    return K, V, Y, t_ends, al, steps, Z
+
+
+def _check(hp, W, L, spk=None, stop=True):
+    K, V, Y, t_ends, al, steps, Z = _run(hp, W, L, spk, stop)
+    ends = O.get_text_lengths(L)
+    K0, V0 = O.encode_text(hp, W, L)
+    trace = []
+    Y0, t0, al0 = O.synth_codedtext2mel_incremental(hp, W, K0, V0, ends, speakers=spk, stop=stop, trace=trace)
+    Z0 = O.synth_mel2mag(hp, W, Y0)
+    assert steps == len(trace) and t_ends.tolist() == t0
+    assert np.abs(K - K0).max() < TOL and np.abs(V - V0).max() < TOL
+    assert np.abs(Y - Y0).max() < TOL and np.abs(al - al0).max() < TOL and np.abs(Z - Z0).max() < TOL
+    assert not Y[:, steps:].any() and not al[:, :, steps:].any()
+    return steps, t0
+
+
+@pytest.mark.parametrize("B", [1, 10, 20])
+def test_ragged_batch_sizes(B):
+    hp = hp_from_snapshot("lj_tutorial.cfg", max_N=40, max_T=30)
+    W = O.random_weights(hp, 51)
+    L = O.random_text(hp, B, 52, min_len=5, max_len=35)
+    _check(hp, W, L, stop=False)
+
+
+def test_c1_lj_test_dims_full_size():
+    hp = hp_from_snapshot("lj_test.cfg")                     # V=65, max_N=180, max_T=210
+    assert (len(hp.vocab), hp.max_N, hp.max_T) == (65, 180, 210)
+    W = O.random_weights(hp, 1)
+    L = O.random_text(hp, 10, 53, min_len=30, max_len=170)   # the 10-line test transcript case
+    _check(hp, W, L, stop=False)
+
+
+def test_c5_vctk_multispeaker_dims():
+    hp = hp_from_snapshot("vctk_01.cfg")                     # max_N=80, max_T=100, 209 speakers, emb 128
+    assert hp.multispeaker == ["audio_decoder_input"] and hp.nspeakers == 209
+    W = O.random_weights(hp, 5)
+    L = O.random_text(hp, 8, 54, min_len=20, max_len=79)
+    spk = np.random.default_rng(5).integers(1, 109, size=(8, 1)).astype(np.int32)
+    _check(hp, W, L, spk=spk, stop=False)
+    # speaker id 0 is the padding speaker: its embedding row is zeroed at lookup (modules.py:38-40)
+    spk[0, 0] = 0
+    _check(hp, W, L, spk=spk, stop=False)
+
+
+def test_host_polled_early_stop_after_many_steps():
+    """short texts -> every utterance ends; the break step is past the first 8-step poll boundary"""
+    hp = hp_from_snapshot("lj_tutorial.cfg", max_N=64, max_T=60)
+    W = O.random_weights(hp, 43)
+    rng = np.random.default_rng(1)
+    L = np.zeros((6, hp.max_N), np.int32)
+    for i, n in enumerate((2, 3, 4, 6, 8, 10)):
+        L[i, :n] = rng.integers(1, len(hp.vocab), n)
+    steps, t_ends = _check(hp, W, L, stop=True)
+    assert 8 < steps < hp.max_T and max(t_ends) == steps - 1
+
+
+def test_engine_reuse_across_batches_and_validation():
+    from ophelia_amd.engine import Engine
+    from ophelia_amd import _lib
+    hp = hp_from_snapshot("lj_tutorial.cfg", max_N=32, max_T=20)
+    W = O.random_weights(hp, 61)
+    eng = Engine(hp, device=0)
+    with pytest.raises(_lib.OpheliaHipError, match="not finalized"):
+        eng.encode_text(np.zeros((2, 32), np.int32))
+    bad = dict(W); bad.pop("SSRN/C_1/conv1d/bias")
+    with pytest.raises(KeyError):
+        eng.load_weights(bad)
+    eng.load_weights(W)
+    for seed in (1, 2):                  # same handle, two different batches: state is fully reset between them
+        L = O.random_text(hp, 5, seed, min_len=4, max_len=30)
+        ends = O.get_text_lengths(L)
+        K, V = eng.encode_text(L)
+        Y, t_ends, al, steps = eng.text2mel(K, V, ends, stop_mode=1)
+        K0, V0 = O.encode_text(hp, W, L)
+        Y0, t0, al0 = O.synth_codedtext2mel_incremental(hp, W, K0, V0, ends, stop=False)
+        assert np.abs(Y - Y0).max() < TOL and t_ends.tolist() == t0
+    with pytest.raises(_lib.OpheliaHipError, match="out of range"):
+        eng.encode_text(np.full((2, 32), 999, np.int32))
+    with pytest.raises(_lib.OpheliaHipError):
+        eng.ssrn(np.zeros((2, hp.max_T + 5, hp.n_mels), np.float32))
+    eng.close()
