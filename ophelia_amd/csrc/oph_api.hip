@@ -54,6 +54,7 @@ struct Layer {
     int off[3] = {0, 0, 0};
     float *Wt = nullptr, *bias = nullptr;       // conv / hc ; convT: even phase (taps x[t], x[t-1])
     float *Wt2 = nullptr;                        // convT odd phase (tap x[t])
+    float *Wkn = nullptr; int ldn = 0;           // k=1 layers with N<=256: [kc][ldn] n-contiguous copy for row_chain
     float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
 };
 
@@ -66,7 +67,7 @@ struct ProfClass {
     double ms = 0;
 };
 constexpr int CONE_KSPLIT = 4;   // split-K of the latency-bound decoder-cone GEMMs (partials summed by ln_rows)
-enum { PC_GEMM = 0, PC_LN, PC_DEC, PC_ATTN_STEP, PC_ATTN_ROWS, PC_EMIT, PC_MISC, PC_COUNT };
+enum { PC_GEMM = 0, PC_LN, PC_DEC, PC_ROWCHAIN, PC_ATTN_ROWS, PC_MISC, PC_COUNT };
 
 }  // namespace
 
@@ -349,6 +350,14 @@ int pack_layer(oph_handle* h, Layer& l) {
         l.off[t] = l.causal ? -(l.size - 1 - t) * l.rate : (t - (l.size - 1) / 2) * l.rate;
     const std::vector<float>& k = *getw(h, l.scope + "/conv1d/kernel");
     l.Wt = upload(h, pack_conv(k.data(), l.size, l.cin, l.N, l.kc, l.Nalloc));
+    if (l.kind == K_CONV && l.size == 1 && l.N <= 256) {
+        l.ldn = round_up(l.N, 4);
+        std::vector<float> wk((size_t)l.kc * l.ldn, 0.f);
+        for (int c = 0; c < l.cin; ++c)
+            for (int n = 0; n < l.N; ++n) wk[(size_t)c * l.ldn + n] = k[(size_t)c * l.N + n];
+        l.Wkn = upload(h, wk);
+        if (!l.Wkn) return -1;
+    }
     l.bias = upload_padded(h, *getw(h, l.scope + "/conv1d/bias"), l.Nalloc);
     if (l.kind == K_HC) {
         l.g1 = upload_padded(h, *getw(h, l.scope + "/H1/gamma"), 256);
@@ -624,55 +633,93 @@ void launch_cone(oph_handle* h, int t) {
     g_cur = saved;
 }
 
-// one decoder step t.  Main stream: AudioEnc chain -> attention -> [wait cone(t)] -> AudioDec row t
-// -> emit.  Side stream: cone(t+1), released by the event recorded right after attn_step(t).
+RowLayer row_layer(const Layer& l) {
+    RowLayer r{};
+    r.W = l.Wkn; r.ldn = l.ldn; r.bias = l.bias; r.g = l.g1; r.b = l.b1; r.kc = l.kc; r.N = l.cout; r.act = l.act; r.ccat = l.ccat;
+    return r;
+}
+void run_row_chain(oph_handle* h, RowChainArgs& a, int first_is_attn) {
+    double wbytes = 0, flops = 0;
+    for (int i = 0; i < a.nlayers; ++i) { wbytes += (double)a.L[i].kc * a.L[i].N * 4.0; flops += 2.0 * a.B * a.L[i].kc * a.L[i].N; }
+    h->pbegin(PC_ROWCHAIN);
+    launch_row_chain(a, g_cur);
+    h->pend(PC_ROWCHAIN, wbytes + (double)a.B * 4096.0 + (first_is_attn ? (double)a.B * 8.0 * a.d * 4.0 : 0.0), flops);
+}
+
+// dec_layer16 arguments of decoder layer `l` whose input rows x[t] are produced by `prev`'s raw output
+void fill_pre(DecArgs& a, const Layer* prev, const float* prev_raw, const float* prev_x) {
+    if (prev->kind == K_CONV) { a.pre = PRE_CONV; a.src = prev_raw; a.ldsrc = prev->Nalloc; a.g1 = prev->g1; a.b1 = prev->b1; a.act = prev->act; a.cin = prev->cout; }
+    else { a.pre = PRE_HC; a.src = prev_raw; a.ldsrc = prev->Nalloc; a.g1 = prev->g1; a.b1 = prev->b1; a.g2 = prev->g2; a.b2 = prev->b2; a.xres = prev_x; a.ldres = prev->kc; a.cin = prev->cout; }
+}
+
+// one decoder step t.  Critical stream (19 dependent launches):
+//   row_chain A  : S[t] -> AudioEnc C_1..C_3 (k=1, row-local LN)            -> x of the first highway layer
+//   dec_layer16  : AudioEnc highway layers (column-split, dilated taps from the cached history)
+//   row_chain B  : gate of the last highway layer -> attention row t (+ alignments, prev_max, end
+//                  detection, stop flag) -> AudioDec C_1 [-> speaker concat -> C_3]
+//   dec_layer16  : AudioDec highway layers (taps from the cone of this step)
+//   row_chain C  : gate -> AudioDec C_8..C_11 -> LN -> sigmoid -> Y[:, t] (and S[t+1])
+// Side stream: cone(t+1), released by the event recorded right after row_chain B of step t.
 void decode_step(oph_handle* h, int t, int t_last, int stop_mode, bool threaded = false) {
     const oph_dims& m = h->dm;
     const int d = m.d, Bpad = h->Bpad, B = h->B;
     int* stop_after = h->d_ctl + 1;
     g_cur = h->sdec;
-    // ---------------- AudioEnc, incremental (causal, mask-free => cacheable)
+    const int pre = h->dec_pre, nh = h->n_hc_dec;
+    // ---------------- row_chain A: AudioEnc k=1 head
+    size_t nk1 = 0;
+    while (nk1 < h->audioenc.size() && h->audioenc[nk1].kind == K_CONV) ++nk1;
+    {
+        const Layer& hc0 = h->audioenc[nk1];
+        RowChainArgs a{};
+        a.pro = ROW_COPY; a.src = h->Ytm + (size_t)t * Bpad * h->ldy; a.ldsrc = h->ldy; a.cin = m.n_mels;
+        a.nlayers = (int)nk1;
+        for (size_t i = 0; i < nk1; ++i) a.L[i] = row_layer(h->audioenc[i]);
+        a.xout = h->ae_hist[nk1] + (size_t)t * Bpad * hc0.kc; a.ldout = hc0.kc;
+        a.B = B; a.Bpad = Bpad; a.stop_after = stop_after; a.t = t; a.d = d;
+        run_row_chain(h, a, 0);
+    }
+    // ---------------- AudioEnc highway layers, incremental (causal, mask-free => cacheable)
     const Layer* prev = nullptr;
     const float* prev_raw = nullptr;
     const float* prev_x = nullptr;    // previous layer's input rows at time t (highway residual)
     h->gbegin(PC_DEC);
-    for (size_t li = 0; li < h->audioenc.size(); ++li) {
+    for (size_t li = nk1; li < h->audioenc.size(); ++li) {
         const Layer& l = h->audioenc[li];
+        float* hist = h->ae_hist[li];
         DecArgs a{};
-        if (li == 0) { a.pre = PRE_COPY; a.src = h->Ytm + (size_t)t * Bpad * h->ldy; a.ldsrc = h->ldy; a.cin = m.n_mels; }
-        else if (prev->kind == K_CONV) { a.pre = PRE_CONV; a.src = prev_raw; a.ldsrc = prev->Nalloc; a.g1 = prev->g1; a.b1 = prev->b1; a.act = prev->act; a.cin = prev->cout; }
-        else { a.pre = PRE_HC; a.src = prev_raw; a.ldsrc = prev->Nalloc; a.g1 = prev->g1; a.b1 = prev->b1; a.g2 = prev->g2; a.b2 = prev->b2; a.xres = prev_x; a.ldres = prev->kc; a.cin = prev->cout; }
-        a.ntaps = l.ntaps; a.kc = l.kc;
-        if (l.kind == K_HC) {
-            float* hist = h->ae_hist[li];
-            a.xstore = hist + (size_t)t * Bpad * l.kc; a.ldstore = l.kc; a.ldtap = l.kc;
-            const int o0 = -l.off[0], o1 = -l.off[1];
-            a.tap0 = t - o0 >= 0 ? hist + (size_t)(t - o0) * Bpad * l.kc : nullptr;
-            a.tap1 = t - o1 >= 0 ? hist + (size_t)(t - o1) * Bpad * l.kc : nullptr;
-        }
+        if (li == nk1) { a.pre = PRE_COPY; a.src = hist + (size_t)t * Bpad * l.kc; a.ldsrc = l.kc; a.cin = l.cin; }
+        else { fill_pre(a, prev, prev_raw, prev_x); a.xstore = hist + (size_t)t * Bpad * l.kc; a.ldstore = l.kc; }
+        a.ntaps = l.ntaps; a.kc = l.kc; a.ldtap = l.kc;
+        const int o0 = -l.off[0], o1 = -l.off[1];
+        a.tap0 = t - o0 >= 0 ? hist + (size_t)(t - o0) * Bpad * l.kc : nullptr;
+        a.tap1 = t - o1 >= 0 ? hist + (size_t)(t - o1) * Bpad * l.kc : nullptr;
         a.Wt = l.Wt; a.ldw = l.ntaps * l.kc; a.bias = l.bias; a.H = h->ae_raw[li]; a.ldh = l.Nalloc; a.B = B;
         a.stop_after = stop_after; a.t = t;
         run_dec(h, a, l);
         prev = &l; prev_raw = h->ae_raw[li];
-        prev_x = l.kind == K_HC ? h->ae_hist[li] + (size_t)t * Bpad * l.kc : nullptr;
+        prev_x = hist + (size_t)t * Bpad * l.kc;
     }
     h->gend(PC_DEC);
-    // ---------------- attention at row t (networks.py:286-325) + bookkeeping (synthesize.py:204-228)
+    // ---------------- row_chain B: attention at row t + AudioDec k=1 head
     {
-        AttnStepArgs a{};
-        a.hraw = prev_raw; a.ldh = prev->Nalloc; a.g1 = prev->g1; a.b1 = prev->b1; a.g2 = prev->g2; a.b2 = prev->b2;
-        a.xres = prev_x; a.ldres = prev->kc;
-        a.KV = h->KV; a.N = m.max_N; a.d = d; a.win = m.attention_win_size; a.B = B; a.Bpad = Bpad; a.max_T = m.max_T; a.t = t;
+        const Layer& hca = h->audiodec[pre];
+        RowChainArgs a{};
+        a.pro = ROW_ATTN; a.src = prev_raw; a.ldsrc = prev->Nalloc; a.cin = d;
+        a.g1 = prev->g1; a.b1 = prev->b1; a.g2 = prev->g2; a.b2 = prev->b2; a.xres = prev_x; a.ldres = prev->kc;
+        a.KV = h->KV; a.N_keys = m.max_N; a.d = d; a.win = m.attention_win_size; a.max_T = m.max_T;
         a.pcur = h->d_p + (t & 1) * Bpad; a.pnext = h->d_p + ((t + 1) & 1) * Bpad;
-        a.ends = h->d_ends; a.t_ends = h->d_tends; a.n_ended = h->d_ctl; a.stop_after = stop_after; a.stop_mode = stop_mode;
-        a.Qhist = h->Qhist; a.Rrow = h->Rrow; a.ldr = 2 * d; a.align = h->align;
-        h->pbegin(PC_ATTN_STEP);
-        launch_attn_step(a, h->sdec);
-        h->pend(PC_ATTN_STEP, (double)B * (6.0 * d + 2.0 * m.attention_win_size * d) * 4.0, (double)B * 4.0 * m.attention_win_size * d);
+        a.ends = h->d_ends; a.t_ends = h->d_tends; a.n_ended = h->d_ctl; a.stop_flag = stop_after; a.stop_mode = stop_mode;
+        a.Qhist = h->Qhist; a.align = h->align; a.Bpad = Bpad;
+        a.nlayers = pre;
+        for (int i = 0; i < pre; ++i) a.L[i] = row_layer(h->audiodec[i]);
+        a.cat_table = h->emb_spk; a.cat_ids = h->d_spk;
+        a.xout = h->ad_xrow[pre]; a.ldout = hca.kc;
+        a.B = B; a.stop_after = stop_after; a.t = t;
+        run_row_chain(h, a, 1);
     }
-    const int pre = h->dec_pre;
     if (threaded) {
-        // the worker thread enqueues cone(t+1) as soon as it sees attn(t) recorded
+        // the worker thread enqueues cone(t+1) as soon as it sees attention(t) recorded
         hipEventRecord(h->ev_attn_v[t], h->sdec);
         h->attn_posted.store(t, std::memory_order_release);
         if (t >= 1) {
@@ -682,7 +729,7 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode, bool threaded 
     }
     // cone(t) (launched during step t-1, or by decode_range for the first step) must have landed
     if (!threaded && t >= 1) hipStreamWaitEvent(h->sdec, h->ev_cone, 0);
-    // release cone(t+1) on the side stream: needs p_{t+1} and Q[t], both written by attn_step(t)
+    // release cone(t+1) on the side stream: needs p_{t+1} and Q[t], both written by row_chain B of step t
     if (!threaded && t + 1 < t_last) {
         hipEventRecord(h->ev_attn, h->sdec);
         hipStreamWaitEvent(h->stream2, h->ev_attn, 0);
@@ -690,39 +737,36 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode, bool threaded 
         hipEventRecord(h->ev_cone, h->stream2);
     }
     const std::vector<float*>& cone = h->cone[t & 1];
-    // ---------------- AudioDec row t
+    // ---------------- AudioDec highway layers, row t (taps from the cone)
     prev = nullptr; prev_raw = nullptr; prev_x = nullptr;
     h->gbegin(PC_DEC);
-    for (size_t li = 0; li < h->audiodec.size(); ++li) {
+    for (int k = 0; k < nh; ++k) {
+        const size_t li = pre + k;
         const Layer& l = h->audiodec[li];
         DecArgs a{};
-        if (li == 0) { a.pre = PRE_COPY; a.src = h->Rrow; a.ldsrc = 2 * d; a.cin = 2 * d; }
-        else if (prev->kind == K_CONV) { a.pre = PRE_CONV; a.src = prev_raw; a.ldsrc = prev->Nalloc; a.g1 = prev->g1; a.b1 = prev->b1; a.act = prev->act; a.cin = prev->cout; }
-        else { a.pre = PRE_HC; a.src = prev_raw; a.ldsrc = prev->Nalloc; a.g1 = prev->g1; a.b1 = prev->b1; a.g2 = prev->g2; a.b2 = prev->b2; a.xres = prev_x; a.ldres = prev->kc; a.cin = prev->cout; }
-        if (l.ccat > 0) { a.cat_table = h->emb_spk; a.cat_ids = h->d_spk; a.ccat = l.ccat; }
-        a.ntaps = l.ntaps; a.kc = l.kc;
-        if (l.kind == K_HC) {
-            const int k = (int)li - pre;
-            a.xstore = h->ad_xrow[li]; a.ldstore = l.kc; a.ldtap = l.kc;
-            const int o0 = -l.off[0], o1 = -l.off[1];
-            a.tap0 = t - o0 >= 0 ? cone[k] + (size_t)idx_of(h->Hset[k], o0) * Bpad * l.kc : nullptr;
-            a.tap1 = t - o1 >= 0 ? cone[k] + (size_t)idx_of(h->Hset[k], o1) * Bpad * l.kc : nullptr;
-        }
+        if (k == 0) { a.pre = PRE_COPY; a.src = h->ad_xrow[li]; a.ldsrc = l.kc; a.cin = l.cin; }
+        else { fill_pre(a, prev, prev_raw, prev_x); a.xstore = h->ad_xrow[li]; a.ldstore = l.kc; }
+        a.ntaps = l.ntaps; a.kc = l.kc; a.ldtap = l.kc;
+        const int o0 = -l.off[0], o1 = -l.off[1];
+        a.tap0 = t - o0 >= 0 ? cone[k] + (size_t)idx_of(h->Hset[k], o0) * Bpad * l.kc : nullptr;
+        a.tap1 = t - o1 >= 0 ? cone[k] + (size_t)idx_of(h->Hset[k], o1) * Bpad * l.kc : nullptr;
         a.Wt = l.Wt; a.ldw = l.ntaps * l.kc; a.bias = l.bias; a.H = h->ad_raw[li]; a.ldh = l.Nalloc; a.B = B;
         a.stop_after = stop_after; a.t = t;
         run_dec(h, a, l);
-        prev = &l; prev_raw = h->ad_raw[li];
-        prev_x = l.kind == K_HC ? h->ad_xrow[li] : nullptr;
+        prev = &l; prev_raw = h->ad_raw[li]; prev_x = h->ad_xrow[li];
     }
     h->gend(PC_DEC);
+    // ---------------- row_chain C: AudioDec k=1 tail + mel frame t
     {
-        EmitArgs e{};
-        e.hraw = prev_raw; e.ldh = prev->Nalloc; e.g = prev->g1; e.b = prev->b1; e.C = m.n_mels; e.squash = 1;
-        e.Yout = h->Yout; e.ldy = h->ldy; e.max_T = m.max_T; e.Ytm = h->Ytm; e.ldtm = h->ldy; e.Bpad = Bpad; e.B = B;
-        e.stop_after = stop_after; e.t = t;
-        h->pbegin(PC_EMIT);
-        launch_emit_mel(e, h->sdec);
-        h->pend(PC_EMIT, (double)B * m.n_mels * 12.0, (double)B * m.n_mels * 10.0);
+        RowChainArgs a{};
+        a.pro = ROW_HC; a.src = prev_raw; a.ldsrc = prev->Nalloc; a.cin = d;
+        a.g1 = prev->g1; a.b1 = prev->b1; a.g2 = prev->g2; a.b2 = prev->b2; a.xres = prev_x; a.ldres = prev->kc;
+        a.nlayers = (int)h->audiodec.size() - pre - nh;
+        for (int i = 0; i < a.nlayers; ++i) a.L[i] = row_layer(h->audiodec[pre + nh + i]);
+        a.L[a.nlayers - 1].act = ACT_SIGMOID;           // squash_output_t2m (networks.py:430-431)
+        a.emit = 1; a.Yout = h->Yout; a.ldy = h->ldy; a.Ytm = h->Ytm; a.ldtm = h->ldy; a.max_T = m.max_T;
+        a.B = B; a.Bpad = Bpad; a.stop_after = stop_after; a.t = t; a.d = d;
+        run_row_chain(h, a, 0);
     }
 }
 
@@ -906,7 +950,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
     oph_handle* h = new oph_handle();
     h->dm = m;
     h->device = device;
-    static const char* names[PC_COUNT] = {"conv_gemm_f32", "ln_rows", "dec_layer16", "attn_step", "attn_rows", "emit_mel", "misc"};
+    static const char* names[PC_COUNT] = {"conv_gemm_f32", "ln_rows", "dec_layer16", "row_chain", "attn_rows", "misc"};
     for (int i = 0; i < PC_COUNT; ++i) h->prof[i].name = names[i];
     // CU partition for the decode loop (MI355X: 256 CUs, mask bit i -> XCD i%8): the ~25 dependent
     // tiny launches of a step get a private slice of 8 CUs in every XCD so the concurrently running

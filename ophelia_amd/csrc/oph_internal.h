@@ -100,7 +100,31 @@ struct EmitArgs {
     int B; const int* stop_after; int t;
 };
 
+// ---- row-parallel fused chain of k=1 layers (LayerNorm is row-local, so a run of k=1 convs needs no
+// cross-workgroup exchange): one workgroup per utterance streams each layer's full [K][N] weights.
+struct RowLayer {
+    const float* W; int ldn;        // weights [kc][ldn], n contiguous (second packed copy of the k=1 layers)
+    const float* bias; const float* g; const float* b;
+    int kc; int N; int act; int ccat;   // ccat: speaker-embedding channels appended to this layer's INPUT
+};
+enum RowPro { ROW_COPY = 0, ROW_HC = 1, ROW_ATTN = 2 };
+struct RowChainArgs {
+    int pro;                        // how the chain input is produced
+    const float* src; int ldsrc; int cin;       // ROW_COPY: x rows ; else raw rows of the previous highway layer
+    const float *g1, *b1, *g2, *b2; const float* xres; int ldres;
+    // ROW_ATTN: attention at row t + bookkeeping (networks.py:286-325, synthesize.py:204-228)
+    const float* KV; int N_keys; int d; int win; int max_T;
+    const int* pcur; int* pnext; const int* ends; int* t_ends; int* n_ended; int* stop_flag; int stop_mode;
+    float* Qhist; float* align; int Bpad;
+    int nlayers; RowLayer L[4];
+    const float* cat_table; const int* cat_ids;
+    float* xout; int ldout;         // final activation rows (zero padded to ldout) or null
+    int emit; float* Yout; int ldy; float* Ytm; int ldtm;    // emit: final = mel frame t -> Yout[b][t], Ytm[t+1][b]
+    int B; const int* stop_after; int t;
+};
+
 // launchers (oph_kernels.hip)
+void launch_row_chain(const RowChainArgs& a, hipStream_t s);
 void launch_conv_gemm(const GemmArgs& a, hipStream_t s);
 int  conv_gemm_tile_m(int M, int N);          // tile size chosen for a problem (64 or 128)
 void launch_epilogue(const EpiArgs& a, hipStream_t s);

@@ -753,6 +753,190 @@ void launch_attn_rows(const AttnRowsArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(attn_rows, dim3((a.nrows + 3) / 4), dim3(256), 0, s, a);
 }
 
+// =====================================================================================
+// row_chain: grid = B workgroups (one utterance each), 1024 threads = 16 waves.
+// Stage = one k=1 conv + LayerNorm + activation on ONE row: wave w takes K/16 of the reduction,
+// lane l the 4 output columns 4l..4l+3 (coalesced 1 KB weight rows, all 16 loads of a pass in
+// flight), partials meet in LDS, wave 0 normalises and writes the next stage's input.
+// Prologues: copy a row / highway gate of the previous layer / gate + attention + bookkeeping.
+// =====================================================================================
+constexpr int RC_WAVES = 16;
+constexpr int RC_XMAX = 1024;
+
+__global__ __launch_bounds__(64 * RC_WAVES) void row_chain(RowChainArgs a) {
+    __shared__ __attribute__((aligned(16))) float xs[2][RC_XMAX];
+    __shared__ __attribute__((aligned(16))) float part[RC_WAVES][256];
+    __shared__ __attribute__((aligned(16))) float ys[256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b = blockIdx.x;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int stop_v = a.stop_after ? *a.stop_after : 0x7fffffff;
+    const bool live = a.t <= stop_v;
+    int cur = 0;
+    // ---------------- prologue -> xs[0][0 .. kc0)
+    const int kc0 = a.L[0].kc;
+    if (a.pro == ROW_COPY) {
+        const float* sp = a.src + (size_t)b * a.ldsrc;
+        for (int c = tid; c < kc0; c += 64 * RC_WAVES) xs[0][c] = c < a.cin ? sp[c] : 0.f;
+    } else if (w == 0) {
+        const int d = a.cin;
+        f32x4 q[ATT_NV], u[ATT_NV];
+        const float* h = a.src + (size_t)b * a.ldsrc;
+        const float* xr = a.xres + (size_t)b * a.ldres;
+        f32x4 xv[ATT_NV], g1v[ATT_NV], b1v[ATT_NV], g2v[ATT_NV], b2v[ATT_NV];
+        const int p = a.pro == ROW_ATTN ? a.pcur[b] : 0;
+#pragma unroll
+        for (int v = 0; v < ATT_NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            const bool ok = c < d;
+            q[v] = ok ? *(const f32x4*)(h + c) : zero4;
+            u[v] = ok ? *(const f32x4*)(h + d + c) : zero4;
+            xv[v] = ok ? *(const f32x4*)(xr + c) : zero4;
+            g1v[v] = ok ? *(const f32x4*)(a.g1 + c) : zero4; b1v[v] = ok ? *(const f32x4*)(a.b1 + c) : zero4;
+            g2v[v] = ok ? *(const f32x4*)(a.g2 + c) : zero4; b2v[v] = ok ? *(const f32x4*)(a.b2 + c) : zero4;
+        }
+        auto ln = [&](f32x4 (&z)[ATT_NV], const f32x4 (&gv)[ATT_NV], const f32x4 (&bv)[ATT_NV]) {
+            float s = 0.f;
+#pragma unroll
+            for (int v = 0; v < ATT_NV; ++v) s += z[v][0] + z[v][1] + z[v][2] + z[v][3];
+            const float mean = wave_sum(s) / (float)d;
+            float qq = 0.f;
+#pragma unroll
+            for (int v = 0; v < ATT_NV; ++v)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dlt = ((v * 64 + lane) * 4 < d) ? z[v][e] - mean : 0.f;
+                    z[v][e] = dlt;
+                    qq += dlt * dlt;
+                }
+            const float rstd = 1.0f / sqrtf(wave_sum(qq) / (float)d + LN_EPS);
+#pragma unroll
+            for (int v = 0; v < ATT_NV; ++v)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[v][e] = z[v][e] * rstd * gv[v][e] + bv[v][e];
+        };
+        ln(q, g1v, b1v);
+        ln(u, g2v, b2v);
+#pragma unroll
+        for (int v = 0; v < ATT_NV; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gte = sigmoidf_(q[v][e]);
+                q[v][e] = gte * u[v][e] + (1.0f - gte) * xv[v][e];
+            }
+        if (a.pro == ROW_HC) {
+#pragma unroll
+            for (int v = 0; v < ATT_NV; ++v) {
+                const int c = (v * 64 + lane) * 4;
+                if (c < kc0) *(f32x4*)(&xs[0][c]) = c < d ? q[v] : zero4;
+            }
+        } else {
+            // R' = concat(softmax(QK^T/sqrt(d)) V, Q) for row t under the current mask
+            const float* KVb = a.KV + (size_t)b * a.N_keys * 2 * d;
+            f32x4 ctx[ATT_NV];
+            const AttnOut o = attend_window(q, KVb, KVb + d, 2 * d, p, a.N_keys, a.win, d, lane, ctx);
+            float* qh = a.Qhist + ((size_t)a.t * a.Bpad + b) * d;
+#pragma unroll
+            for (int v = 0; v < ATT_NV; ++v) {
+                const int c = (v * 64 + lane) * 4;
+                if (c < d) {
+                    *(f32x4*)(&xs[0][c]) = ctx[v];
+                    *(f32x4*)(&xs[0][d + c]) = q[v];
+                    if (live) *(f32x4*)(qh + c) = q[v];
+                }
+            }
+            if (lane == 0 && live) {
+                float* al = a.align + (size_t)b * a.N_keys * a.max_T + a.t;
+#pragma unroll
+                for (int i = 0; i < ATT_WMAX; ++i)
+                    if (i < o.nwin) al[(size_t)(p + i) * a.max_T] = o.prob[i];
+                const int m = p + o.arg;
+                a.pnext[b] = m;
+                if (a.t_ends[b] == a.max_T && m >= a.ends[b]) {
+                    a.t_ends[b] = a.t;
+                    const int old = atomicAdd(a.n_ended, 1);
+                    if (old + 1 == a.B && a.stop_mode == 0) *a.stop_flag = a.t;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---------------- stages
+    for (int li = 0; li < a.nlayers; ++li) {
+        const RowLayer& L = a.L[li];
+        const int kr = L.kc / RC_WAVES, k0 = w * kr, col = lane * 4;
+        f32x4 acc = zero4;
+        if (col < L.N) {
+            const float* wp = L.W + (size_t)k0 * L.ldn + col;
+            for (int base = 0; base < kr; base += 8) {
+                f32x4 wv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wv[i] = base + i < kr ? *(const f32x4*)(wp + (size_t)(base + i) * L.ldn) : zero4;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float xk = base + i < kr ? xs[cur][k0 + base + i] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += xk * wv[i][e];
+                }
+            }
+            *(f32x4*)(&part[w][col]) = acc;
+        }
+        __syncthreads();
+        if (tid < L.N) {
+            float y = L.bias[tid];
+#pragma unroll
+            for (int ww = 0; ww < RC_WAVES; ++ww) y += part[ww][tid];
+            ys[tid] = y;
+        }
+        __syncthreads();
+        const int nxt = cur ^ 1;
+        const bool last = li + 1 == a.nlayers;
+        const int kc_next = last ? (a.xout ? a.ldout : L.N) : a.L[li + 1].kc;
+        if (w == 0) {
+            f32x4 v = zero4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = col + e < L.N ? ys[col + e] : 0.f;
+            float s = v[0] + v[1] + v[2] + v[3];
+            const float mean = wave_sum(s) / (float)L.N;
+            float qq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float dlt = col + e < L.N ? v[e] - mean : 0.f; v[e] = dlt; qq += dlt * dlt; }
+            const float rstd = 1.0f / sqrtf(wave_sum(qq) / (float)L.N + LN_EPS);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                v[e] = col + e < L.N ? apply_act(v[e] * rstd * L.g[col + e] + L.b[col + e], L.act) : 0.f;
+            if (col < RC_XMAX && col < ((kc_next + 3) & ~3)) *(f32x4*)(&xs[nxt][col]) = v;
+            for (int c = 256 + lane; c < kc_next; c += 64) xs[nxt][c] = 0.f;
+            if (!last && a.L[li + 1].ccat > 0) {     // speaker embedding appended to the next layer's input
+                const int id = a.cat_ids[b];
+                for (int c = lane; c < a.L[li + 1].ccat; c += 64)
+                    xs[nxt][L.N + c] = id == 0 ? 0.f : a.cat_table[(size_t)id * a.L[li + 1].ccat + c];
+            }
+        }
+        __syncthreads();
+        cur = nxt;
+    }
+    // ---------------- epilogue
+    if (!live) return;
+    if (a.xout) {
+        float* xo = a.xout + (size_t)b * a.ldout;
+        for (int c = tid; c < a.ldout; c += 64 * RC_WAVES) xo[c] = xs[cur][c];
+    }
+    if (a.emit) {
+        const int nm = a.L[a.nlayers - 1].N;
+        float* yo = a.Yout + ((size_t)b * a.max_T + a.t) * a.ldy;
+        float* yt = a.Ytm + ((size_t)(a.t + 1) * a.Bpad + b) * a.ldtm;
+        for (int c = tid; c < a.ldy; c += 64 * RC_WAVES) {
+            const float v = c < nm ? xs[cur][c] : 0.f;
+            yo[c] = v;
+            if (c < a.ldtm) yt[c] = v;
+        }
+    }
+}
+
+void launch_row_chain(const RowChainArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(row_chain, dim3(a.B), dim3(64 * RC_WAVES), 0, s, a);
+}
+
 // emit_mel: Y[b, t, :] = sigmoid(LN(logits))  (networks.py:421-431); also feeds S[t+1] (architectures.py:191)
 __global__ __launch_bounds__(256) void emit_mel(EmitArgs a) {
     if (stopped(a.stop_after, a.t)) return;
