@@ -18,10 +18,22 @@ namespace oph {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Wave-wide sum, result uniform in all 64 lanes.  A __shfl_xor butterfly is 6 dependent
+// ds_bpermute round trips (~60 cycles each); profiles/r01 ablation: 1.4 us of a 8 us decoder layer
+// was LayerNorm reductions.  DPP does the 16-lane row reduction in 4 VALU ops (xor 1, xor 2,
+// half-mirror, mirror), and the 4 row totals are combined through v_readlane (scalar).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);     // row_half_mirror
+    v += dpp_mov<0x140>(v);     // row_mirror  -> every lane holds its 16-lane row total
+    const int iv = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float apply_act(float x, int act) {
@@ -396,9 +408,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void dec_layer16(DecArgs a) {
                 for (int v = 0; v < NV; ++v) s[rr] += z[rr][v][0] + z[rr][v][1] + z[rr][v][2] + z[rr][v][3];
             }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-                for (int rr = 0; rr < DEC_RPW; ++rr) s[rr] += __shfl_xor(s[rr], o, 64);
+            for (int rr = 0; rr < DEC_RPW; ++rr) s[rr] = wave_sum(s[rr]);
 #pragma unroll
             for (int rr = 0; rr < DEC_RPW; ++rr) {
                 const float mean = s[rr] * invc;
@@ -413,9 +423,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void dec_layer16(DecArgs a) {
                     }
             }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-                for (int rr = 0; rr < DEC_RPW; ++rr) q[rr] += __shfl_xor(q[rr], o, 64);
+            for (int rr = 0; rr < DEC_RPW; ++rr) q[rr] = wave_sum(q[rr]);
 #pragma unroll
             for (int rr = 0; rr < DEC_RPW; ++rr) {
                 const float rstd = 1.0f / sqrtf(q[rr] * invc + LN_EPS);
