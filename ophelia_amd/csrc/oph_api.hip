@@ -26,6 +26,8 @@ using namespace oph;
 static thread_local std::string g_create_error;
 static thread_local hipStream_t g_cur = nullptr;    // stream the launch wrappers of THIS host thread target
 static thread_local int g_group_cls = -1;
+static const bool g_trace = getenv("OPH_TRACE") != nullptr;
+#define TRACE(...) do { if (g_trace) { fprintf(stderr, "[oph] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 static thread_local std::string g_op_error;
 
 #define HIPCHK(h, expr)                                                                        \
@@ -77,6 +79,12 @@ struct oph_handle {
     hipStream_t stream = nullptr;      // API stream (unmasked): TextEnc / SSRN, timers, copies
     hipStream_t sdec = nullptr;        // decode critical path: CU-masked to a private slice of every XCD
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    hipStream_t sssrn = nullptr;       // pipelined SSRN: own CU partition, overlaps the NEXT batch's decode
+    hipEvent_t ev_dec_done = nullptr, ev_ssrn_done[2] = {nullptr, nullptr};
+    bool ssrn_inflight[2] = {false, false};
+    float *Yout2[2] = {nullptr, nullptr}, *Z2[2] = {nullptr, nullptr};
+    int buf = 0; bool pipelined = false;
+    uint32_t m_cone[16] = {0}, m_conep[16] = {0}, m_ssrn[16] = {0}; int mask_words = 0;   // CU partitions (0 words = no masking)
     // captured decode loop (all max_T steps, both streams) per stop_mode; replayed by hipGraphLaunch
     hipGraphExec_t dec_graph[2] = {nullptr, nullptr};
     int dec_graph_B[2] = {0, 0};
@@ -91,7 +99,7 @@ struct oph_handle {
     int job_t0 = 0, job_t1 = 0;
     std::atomic<int> attn_posted{-1}, cone_posted{0}, limit{INT_MAX};
     std::vector<hipEvent_t> ev_attn_v, ev_cone_v;     // per-step events (threaded mode)
-    hipStream_t stream2 = nullptr;     // side stream: AudioDec history cone, overlapped with the AudioEnc chain
+    hipStream_t scone = nullptr;       // side stream in use: AudioDec history cone, overlapped with the AudioEnc chain
     hipEvent_t ev_attn = nullptr, ev_cone = nullptr;
     std::string err;
     bool finalized = false;
@@ -105,7 +113,8 @@ struct oph_handle {
     std::vector<void*> allocs;
     // batched workspaces
     int capB = 0;
-    float *actA = nullptr, *actB = nullptr, *raw = nullptr;
+    float *actA = nullptr, *actB = nullptr, *raw = nullptr;   // workspace of the API stream (TextEnc, host-buffer SSRN)
+    float *actA2 = nullptr, *actB2 = nullptr, *raw2 = nullptr; // workspace of the pipelined SSRN stream
     size_t act_elems = 0, raw_elems = 0;
     // staged batch / resident state
     int B = 0, Bpad = 0;
@@ -396,13 +405,14 @@ void run_dec(oph_handle* h, const DecArgs& a, const Layer& l) {
 // Runs `layers` over dense rows (B utterances x T frames).  in: [B*T][ld_in] padded rows.
 // final_out/final_ld: where the LAST layer's epilogue writes (e.g. Z with ld = full_dim).
 // Returns pointer to the final activation rows and their ld via *out_ld; rows via *out_rows.
-float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, int ld_in, int B, int T,
+float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, int ld_in, int B, int T, int wsi,
                    float* final_out, int final_ld, int final_pad, int* out_ld, long long* out_rows) {
     float* x = in;
     int ldx = ld_in;
     int Tcur = T;
-    float* bufs[2] = {h->actA, h->actB};
-    int flip = (in == h->actA) ? 1 : 0;
+    float* const wsA = wsi ? h->actA2 : h->actA; float* const wsB = wsi ? h->actB2 : h->actB; float* const wsraw = wsi ? h->raw2 : h->raw;
+    float* bufs[2] = {wsA, wsB};
+    int flip = (in == wsA) ? 1 : 0;
     for (size_t li = 0; li < layers.size(); ++li) {
         const Layer& l = layers[li];
         const bool last = li + 1 == layers.size();
@@ -412,17 +422,17 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
         const int ldy = (last && final_out) ? final_ld : cout_pad;
         const int ypad = (last && final_out) ? final_pad : cout_pad;
         GemmArgs g{};
-        g.X = x; g.ldx = ldx; g.bias = l.bias; g.H = h->raw; g.kc = l.kc; g.mode = 0; g.T = Tcur;
+        g.X = x; g.ldx = ldx; g.bias = l.bias; g.H = wsraw; g.kc = l.kc; g.mode = 0; g.T = Tcur;
         g.stop_after = nullptr;
         EpiArgs e{};
         e.g1 = l.g1; e.b1 = l.b1; e.g2 = l.g2; e.b2 = l.b2; e.act = l.act; e.Y = y; e.ldy = ldy; e.ypad = ypad;
-        e.H = h->raw; e.stop_after = nullptr;
+        e.H = wsraw; e.stop_after = nullptr;
         if (l.kind == K_CONVT) {
             // even rows: taps (x[t], x[t-1]); odd rows: tap x[t]; raw rows interleaved 2t / 2t+1
             g.N = l.N; g.ldh = 2 * l.Nalloc; g.M = M;
             g.Wt = l.Wt; g.ldw = 2 * l.kc; g.ntaps = 2; g.off[0] = 0; g.off[1] = -1;
             run_gemm(h, g, l.cin);
-            g.Wt = l.Wt2; g.ldw = l.kc; g.ntaps = 1; g.off[0] = 0; g.H = h->raw + l.Nalloc;
+            g.Wt = l.Wt2; g.ldw = l.kc; g.ntaps = 1; g.off[0] = 0; g.H = wsraw + l.Nalloc;
             run_gemm(h, g, l.cin);
             Tcur *= 2;
             e.ldh = l.Nalloc; e.M = B * Tcur; e.C = l.cout; e.mode = PRE_CONV; e.act = ACT_NONE;
@@ -456,7 +466,10 @@ int ensure_batched_capacity(oph_handle* h, int B) {
     h->actA = h->dalloc<float>(h->act_elems);
     h->actB = h->dalloc<float>(h->act_elems);
     h->raw = h->dalloc<float>(h->raw_elems);
-    if (!h->actA || !h->actB || !h->raw) { h->fail("out of device memory for batch %d", B); return OPH_ERR_DEVICE; }
+    h->actA2 = h->dalloc<float>(h->act_elems);
+    h->actB2 = h->dalloc<float>(h->act_elems);
+    h->raw2 = h->dalloc<float>(h->raw_elems);
+    if (!h->actA || !h->actB || !h->raw || !h->actA2 || !h->actB2 || !h->raw2) { h->fail("out of device memory for batch %d", B); return OPH_ERR_DEVICE; }
     h->capB = B;
     return 0;
 }
@@ -482,10 +495,12 @@ int ensure_decode_state(oph_handle* h, int B) {
     h->d_tends = h->dalloc<int>(Bpad);
     h->d_ctl = h->dalloc<int>(4);
     h->KV = h->dalloc<float>((size_t)Bpad * m.max_N * 2 * d);
-    h->Yout = h->dalloc<float>((size_t)Bpad * m.max_T * h->ldy);
+    for (int i = 0; i < 2; ++i) h->Yout2[i] = h->dalloc<float>((size_t)Bpad * m.max_T * h->ldy);
+    h->Yout = h->Yout2[0];
     h->Ytm = h->dalloc<float>((size_t)(m.max_T + 1) * Bpad * h->ldy);
     h->align = h->dalloc<float>((size_t)Bpad * m.max_N * m.max_T);
-    h->Z = h->dalloc<float>((size_t)Bpad * m.max_T * m.r * m.full_dim);
+    for (int i = 0; i < 2; ++i) h->Z2[i] = h->dalloc<float>((size_t)Bpad * m.max_T * m.r * m.full_dim);
+    h->Z = h->Z2[0];
     h->Qhist = h->dalloc<float>((size_t)m.max_T * Bpad * d);
     h->Rrow = h->dalloc<float>((size_t)Bpad * 2 * d);
     for (const Layer& l : h->audioenc) {
@@ -545,13 +560,18 @@ int ensure_decode_state(oph_handle* h, int B) {
     h->coneRaw = h->dalloc<float>((size_t)CONE_KSPLIT * maxrows * Bpad * (size_t)round_up(2 * d, 128));
     h->coneTmp = h->dalloc<float>(maxrows * Bpad * (size_t)ld_cat);
     hipStreamSynchronize(h->stream);
-    if (!h->coneTmp || !h->Z) { h->fail("out of device memory for decode state"); return OPH_ERR_DEVICE; }
+    if (!h->coneTmp || !h->Z2[1] || !h->Yout2[1]) { h->fail("out of device memory for decode state"); return OPH_ERR_DEVICE; }
     return ensure_batched_capacity(h, B);
 }
 
 // reset per-utterance decode state (synthesize.py:157-166)
 void reset_decode(oph_handle* h) {
     const oph_dims& m = h->dm;
+    if (h->pipelined) {       // ping-pong Y/Z so that SSRN of the previous batch can still read its Y
+        h->buf ^= 1;
+        h->Yout = h->Yout2[h->buf]; h->Z = h->Z2[h->buf];
+        if (h->ssrn_inflight[h->buf]) { hipStreamWaitEvent(h->stream, h->ev_ssrn_done[h->buf], 0); h->ssrn_inflight[h->buf] = false; }
+    }
     hipMemsetAsync(h->d_p, 0, 2 * h->Bpad * 4, h->stream);
     hipMemsetAsync(h->Yout, 0, (size_t)h->Bpad * m.max_T * h->ldy * 4, h->stream);
     hipMemsetAsync(h->Ytm, 0, (size_t)(m.max_T + 1) * h->Bpad * h->ldy * 4, h->stream);
@@ -577,7 +597,7 @@ void launch_cone(oph_handle* h, int t) {
     const int pre = h->dec_pre, nh = h->n_hc_dec;
     std::vector<float*>& cone = h->cone[t & 1];
     hipStream_t saved = g_cur;
-    g_cur = h->stream2;
+    g_cur = h->scone;
     const int n0 = (int)h->Hset[0].size();
     AttnRowsArgs ar{};
     ar.mode = 0; ar.Q = h->Qhist; ar.ldq = d; ar.K = h->KV; ar.V = h->KV + d; ar.ldkv = 2 * d; ar.N = m.max_N; ar.d = d;
@@ -732,9 +752,9 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode, bool threaded 
     // release cone(t+1) on the side stream: needs p_{t+1} and Q[t], both written by row_chain B of step t
     if (!threaded && t + 1 < t_last) {
         hipEventRecord(h->ev_attn, h->sdec);
-        hipStreamWaitEvent(h->stream2, h->ev_attn, 0);
+        hipStreamWaitEvent(h->scone, h->ev_attn, 0);
         launch_cone(h, t + 1);
-        hipEventRecord(h->ev_cone, h->stream2);
+        hipEventRecord(h->ev_cone, h->scone);
     }
     const std::vector<float*>& cone = h->cone[t & 1];
     // ---------------- AudioDec highway layers, row t (taps from the cone)
@@ -782,7 +802,7 @@ void worker_main(oph_handle* h) {
             if (h->quit) return;
             t0 = h->job_t0; t1 = h->job_t1; h->job_pending = false;
         }
-        g_cur = h->stream2;
+        g_cur = h->scone;
         for (int t = t0; t < t1; ++t) {
             bool stop = false;
             while (h->attn_posted.load(std::memory_order_acquire) < t - 1) {
@@ -790,9 +810,9 @@ void worker_main(oph_handle* h) {
                 __builtin_ia32_pause();
             }
             if (stop || h->limit.load(std::memory_order_acquire) < t) break;
-            hipStreamWaitEvent(h->stream2, h->ev_attn_v[t - 1], 0);
+            hipStreamWaitEvent(h->scone, h->ev_attn_v[t - 1], 0);
             launch_cone(h, t);
-            hipEventRecord(h->ev_cone_v[t], h->stream2);
+            hipEventRecord(h->ev_cone_v[t], h->scone);
             h->cone_posted.store(t, std::memory_order_release);
         }
         {
@@ -859,9 +879,9 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
         h->wcv.notify_all();
     } else if (t_begin >= 1 && t_begin < t_end) {      // resuming mid-utterance: cone(t_begin) has not been launched yet
         hipEventRecord(h->ev_attn, h->sdec);
-        hipStreamWaitEvent(h->stream2, h->ev_attn, 0);
+        hipStreamWaitEvent(h->scone, h->ev_attn, 0);
         launch_cone(h, t_begin);
-        hipEventRecord(h->ev_cone, h->stream2);
+        hipEventRecord(h->ev_cone, h->scone);
     }
     int rc_loop = OPH_OK;
     for (int t = t_begin; t < t_end; ++t) {
@@ -882,10 +902,11 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
     }
     g_cur = h->sdec;
     if (rc_loop != OPH_OK) { h->fail("device error while polling the stop flag"); return rc_loop; }
+    TRACE("decode loop enqueued, last=%d", last);
     // join: the API stream continues (SSRN, fetches) only after both decode streams drained
     hipEventRecord(h->ev_out, h->sdec);
     hipStreamWaitEvent(h->stream, h->ev_out, 0);
-    hipEventRecord(h->ev_out, h->stream2);
+    hipEventRecord(h->ev_out, h->scone);
     hipStreamWaitEvent(h->stream, h->ev_out, 0);
     g_cur = h->stream;
     if (steps_run || stop_mode == OPH_STOP_REFERENCE) {
@@ -905,14 +926,14 @@ int run_encode(oph_handle* h) {
     launch_embed(h->d_L, (long long)B * m.max_N, h->emb_text, m.e, h->actA, round_up(m.e, 32), h->stream);
     h->pend(PC_MISC, (double)B * m.max_N * m.e * 4.0, 0);
     // last highway layer writes K|V rows straight into the resident KV buffer [B][N][2d]
-    run_batched(h, h->textenc, h->actA, round_up(m.e, 32), B, m.max_N, h->KV, 2 * m.d, 2 * m.d, nullptr, nullptr);
+    run_batched(h, h->textenc, h->actA, round_up(m.e, 32), B, m.max_N, 0, h->KV, 2 * m.d, 2 * m.d, nullptr, nullptr);
     HIPCHK(h, hipGetLastError());
     return OPH_OK;
 }
 
-int run_ssrn_on(oph_handle* h, const float* Yrows, int ldy, int B, int T, float* Zout) {
+int run_ssrn_on(oph_handle* h, const float* Yrows, int ldy, int B, int T, float* Zout, int wsi = 0) {
     const oph_dims& m = h->dm;
-    run_batched(h, h->ssrn, const_cast<float*>(Yrows), ldy, B, T, Zout, m.full_dim, m.full_dim, nullptr, nullptr);
+    run_batched(h, h->ssrn, const_cast<float*>(Yrows), ldy, B, T, wsi, Zout, m.full_dim, m.full_dim, nullptr, nullptr);
     HIPCHK(h, hipGetLastError());
     return OPH_OK;
 }
@@ -957,25 +978,40 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
     // history-cone GEMMs (the other 24 CUs per XCD) cannot delay their dispatch.
     {
         hipDeviceProp_t prop;
-        uint32_t m_dec[16] = {0}, m_cone[16] = {0};
+        uint32_t m_dec[16] = {0};
+        uint32_t* m_cone = h->m_cone; uint32_t* m_conep = h->m_conep; uint32_t* m_ssrn = h->m_ssrn;
         int ncu = 0;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) ncu = prop.multiProcessorCount;
-        const int words = (ncu + 31) / 32, ndec = ncu / 4;
-        const char* nomask = getenv("OPH_NO_CU_MASK");
-        if (ncu >= 64 && words <= 16 && !nomask) {
-            const char* onex = getenv("OPH_DEC_ONE_XCD");      // experiment: critical chain on ONE XCD (bit i -> XCD i%8)
+        const int words = (ncu + 31) / 32;
+        int ndec = ncu / 4, nconep = ncu * 3 / 8;           // 64 | 96 | 96 of 256 CUs (sweep in DESIGN.md)
+        if (const char* sp = getenv("OPH_CU_SPLIT")) { int a_ = 0, b_ = 0; if (sscanf(sp, "%d,%d", &a_, &b_) == 2 && a_ > 0 && b_ > 0 && a_ + b_ < ncu) { ndec = a_; nconep = b_; } }
+        if (ncu >= 64 && words <= 16 && !getenv("OPH_NO_CU_MASK")) {
             for (int i = 0; i < ncu; ++i) {
-                const bool dec = onex ? (i % 8 == 0) : (i < ndec);
-                (dec ? m_dec : m_cone)[i / 32] |= 1u << (i % 32);
+                const uint32_t bit = 1u << (i % 32);
+                if (i < ndec) m_dec[i / 32] |= bit;
+                else {
+                    m_cone[i / 32] |= bit;
+                    (i < ndec + nconep ? m_conep : m_ssrn)[i / 32] |= bit;
+                }
             }
-            if (hipExtStreamCreateWithCUMask(&h->sdec, words, m_dec) != hipSuccess) h->sdec = nullptr;
-            if (hipExtStreamCreateWithCUMask(&h->stream2, words, m_cone) != hipSuccess) h->stream2 = nullptr;
+            // CU-masked queues are a scarce resource: with four alive the queues get time-sliced and even
+            // sequential batches run 2x slower (measured); never keep more than three (see set_pipelined()).
+            // (and re-creating masked streams after destroying one hung hipStreamSynchronize), so exactly three
+            // are created here, once: critical chain | cone | SSRN partitions.
+            h->mask_words = words;
+            if (hipExtStreamCreateWithCUMask(&h->sdec, words, m_dec) != hipSuccess) { h->sdec = nullptr; h->mask_words = 0; }
+            if (h->mask_words && hipExtStreamCreateWithCUMask(&h->scone, words, m_conep) != hipSuccess) h->scone = nullptr;
+            if (h->mask_words && hipExtStreamCreateWithCUMask(&h->sssrn, words, m_ssrn) != hipSuccess) h->sssrn = nullptr;
         }
         (void)hipGetLastError();
     }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         (!h->sdec && hipStreamCreateWithFlags(&h->sdec, hipStreamNonBlocking) != hipSuccess) ||
-        (!h->stream2 && hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) ||
+        (!h->scone && hipStreamCreateWithFlags(&h->scone, hipStreamNonBlocking) != hipSuccess) ||
+        (!h->sssrn && hipStreamCreateWithFlags(&h->sssrn, hipStreamNonBlocking) != hipSuccess) ||
+        hipEventCreateWithFlags(&h->ev_dec_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_ssrn_done[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_ssrn_done[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_attn, hipEventDisableTiming) != hipSuccess ||
@@ -996,29 +1032,26 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
 int oph_destroy(oph_handle* h) {
     if (!h) return OPH_OK;
     hipSetDevice(h->device);
-    hipStreamSynchronize(h->stream);
-    for (void* p : h->allocs) hipFree(p);
-    for (auto& pc : h->prof)
-        for (auto& e : pc.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    hipEventDestroy(h->ev0);
-    hipEventDestroy(h->ev1);
-    hipEventDestroy(h->ev_attn);
-    hipEventDestroy(h->ev_cone);
     if (h->worker.joinable()) {
         { std::lock_guard<std::mutex> lk(h->wmu); h->quit = true; }
         h->wcv.notify_all();
         h->worker.join();
     }
+    TRACE("destroy: sync streams");
+    for (hipStream_t st : {h->stream, h->sdec, h->scone, h->sssrn}) if (st) hipStreamSynchronize(st);
+    TRACE("destroy: graphs/events");
+    for (auto& ge : h->dec_graph) if (ge) hipGraphExecDestroy(ge);
+    for (auto& pc : h->prof)
+        for (auto& e : pc.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (hipEvent_t e : {h->ev0, h->ev1, h->ev_attn, h->ev_cone, h->ev_in, h->ev_out, h->ev_dec_done, h->ev_ssrn_done[0], h->ev_ssrn_done[1]})
+        if (e) hipEventDestroy(e);
     for (auto e : h->ev_attn_v) hipEventDestroy(e);
     for (auto e : h->ev_cone_v) hipEventDestroy(e);
-    for (auto& ge : h->dec_graph) if (ge) hipGraphExecDestroy(ge);
-    hipEventDestroy(h->ev_in);
-    hipEventDestroy(h->ev_out);
-    hipStreamSynchronize(h->stream2);
-    hipStreamDestroy(h->stream2);
-    hipStreamSynchronize(h->sdec);
-    hipStreamDestroy(h->sdec);
-    hipStreamDestroy(h->stream);
+    TRACE("destroy: free");
+    for (void* p : h->allocs) hipFree(p);
+    TRACE("destroy: streams");
+    for (hipStream_t st : {h->scone, h->sssrn, h->sdec, h->stream}) if (st) { TRACE("  destroy stream %p", (void*)st); hipStreamDestroy(st); }
+    TRACE("destroy: done");
     delete h;
     return OPH_OK;
 }
@@ -1115,19 +1148,51 @@ int oph_run_ssrn_resident(oph_handle* h) {
     return run_ssrn_on(h, h->Yout, h->ldy, h->B, h->dm.max_T, h->Z);
 }
 
+// Switch between sequential batches (SSRN on the whole chip, joined) and pipelined batches (SSRN on its
+// own CU partition, overlapping the next batch).
+static int set_pipelined(oph_handle* h, bool pipe) {
+    if (pipe == h->pipelined) return OPH_OK;
+    for (hipStream_t st : {h->stream, h->sdec, h->scone, h->sssrn}) HIPCHK(h, hipStreamSynchronize(st));
+    if (!pipe) { h->buf = 0; h->Yout = h->Yout2[0]; h->Z = h->Z2[0]; }
+    h->pipelined = pipe;
+    h->ssrn_inflight[0] = h->ssrn_inflight[1] = false;
+    return OPH_OK;
+}
+
 int oph_run_resident(oph_handle* h, int stop_mode, int run_ssrn, int32_t* steps_run) {
     if (!h || !h->KV) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
-    int rc = run_encode(h);
+    // run_ssrn == 2: pipelined batches -- SSRN of THIS batch is queued on its own CU partition and is not
+    // joined here, so the next call's TextEnc + decode overlap it (Y/Z ping-pong, separate workspace);
+    // oph_synchronize / oph_fetch_* / oph_timer_stop join it.
+    const bool pipe = run_ssrn == 2;
+    TRACE("run_resident pipe=%d", (int)pipe);
+    int rc = set_pipelined(h, pipe);
     if (rc) return rc;
+    TRACE("mode set; encode");
+    g_cur = h->stream;
+    if ((rc = run_encode(h))) return rc;
+    TRACE("encode queued; reset");
     reset_decode(h);
+    TRACE("reset done; decode");
     if ((rc = decode_range(h, 0, h->dm.max_T, stop_mode, steps_run))) return rc;
-    if (run_ssrn) rc = oph_run_ssrn_resident(h);
+    TRACE("decode done");
+    if (pipe) {
+        HIPCHK(h, hipEventRecord(h->ev_dec_done, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->sssrn, h->ev_dec_done, 0));
+        g_cur = h->sssrn;
+        rc = run_ssrn_on(h, h->Yout, h->ldy, h->B, h->dm.max_T, h->Z, 1);
+        g_cur = h->stream;
+        HIPCHK(h, hipEventRecord(h->ev_ssrn_done[h->buf], h->sssrn));
+        h->ssrn_inflight[h->buf] = true;
+        TRACE("ssrn queued");
+    } else if (run_ssrn) rc = oph_run_ssrn_resident(h);
     return rc;
 }
 
 int oph_synchronize(oph_handle* h) {
     if (!h) return OPH_ERR_INVALID;
+    if (h->sssrn) HIPCHK(h, hipStreamSynchronize(h->sssrn));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     return OPH_OK;
@@ -1156,6 +1221,7 @@ int oph_fetch_mel(oph_handle* h, float* Y, int32_t* t_ends, float* alignments) {
 
 int oph_fetch_mag(oph_handle* h, float* Z) {
     if (!h || !h->KV || !Z) { if (h) h->fail("no staged batch / null"); return OPH_ERR_STATE; }
+    if (h->sssrn) HIPCHK(h, hipStreamSynchronize(h->sssrn));
     const oph_dims& m = h->dm;
     HIPCHK(h, hipMemcpyAsync(Z, h->Z, (size_t)h->B * m.max_T * m.r * m.full_dim * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1227,6 +1293,10 @@ int oph_timer_start(oph_handle* h) {
 }
 int oph_timer_stop(oph_handle* h, float* ms) {
     if (!h || !ms) return OPH_ERR_INVALID;
+    if (h->pipelined && h->sssrn) {      // join the pipelined SSRN stream first
+        HIPCHK(h, hipEventRecord(h->ev_dec_done, h->sssrn));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_dec_done, 0));
+    }
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipEventSynchronize(h->ev1));
     HIPCHK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
@@ -1244,8 +1314,9 @@ int oph_profile_get(oph_handle* h, int index, char* name, int name_cap, int64_t*
                     double* alg_bytes, double* alg_flops) {
     if (!h || index < 0 || index >= PC_COUNT) return OPH_ERR_INVALID;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream2));
+    HIPCHK(h, hipStreamSynchronize(h->scone));
     HIPCHK(h, hipStreamSynchronize(h->sdec));
+    if (h->sssrn) HIPCHK(h, hipStreamSynchronize(h->sssrn));
     ProfClass& pc = h->prof[index];
     double ms = 0;
     for (size_t i = 0; i < pc.used; ++i) {

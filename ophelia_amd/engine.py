@@ -132,9 +132,12 @@ class Engine(object):
         self._chk(self.lib.oph_stage_text(self._h, _lib.iptr(L), _lib.iptr(ends), sp, B))
         self.B = B
 
-    def run_resident(self, stop_mode=_lib.STOP_NEVER, run_ssrn=True):
+    def run_resident(self, stop_mode=_lib.STOP_NEVER, run_ssrn=True, pipelined=False):
+        """encode -> decode -> SSRN on the staged batch, everything staying in HBM.  pipelined=True queues
+        this batch's SSRN on its own CU partition without joining it, so the next call overlaps it."""
         steps = C.c_int32()
-        self._chk(self.lib.oph_run_resident(self._h, int(stop_mode), int(bool(run_ssrn)), C.byref(steps)))
+        mode = 2 if (run_ssrn and pipelined) else int(bool(run_ssrn))
+        self._chk(self.lib.oph_run_resident(self._h, int(stop_mode), mode, C.byref(steps)))
         return steps.value
 
     def decode_steps(self, t_begin, t_end, stop_mode):

@@ -103,3 +103,30 @@ def test_c3_ssrn_full_size(c2):
     Yr, _, _ = eng.fetch_mel()
     Zr = eng.fetch_mag()
     assert np.abs(Yr - Y0).max() < TOL and np.abs(Zr - Z0).max() < TOL
+
+
+def test_pipelined_batches_equal_sequential(c2):
+    """SSRN of batch i overlapping decode of batch i+1 (own CU partition, Y/Z ping-pong) changes nothing."""
+    hp, W, L, eng = c2
+    ends = O.get_text_lengths(L)
+    L2 = O.random_text(hp, 16, 77, min_len=75, max_len=149)
+    ends2 = O.get_text_lengths(L2)
+    eng.stage_text(L2, ends2)
+    eng.run_resident(stop_mode=1, run_ssrn=True, pipelined=False)
+    Yb, _, _ = eng.fetch_mel(); Zb = eng.fetch_mag()
+    eng.stage_text(L, ends)
+    eng.run_resident(stop_mode=1, run_ssrn=True, pipelined=False)
+    Ya, _, _ = eng.fetch_mel(); Za = eng.fetch_mag()
+    # pipelined: A then B back to back without a join in between
+    eng.stage_text(L, ends)
+    eng.run_resident(stop_mode=1, run_ssrn=True, pipelined=True)
+    eng.stage_text(L2, ends2)
+    eng.run_resident(stop_mode=1, run_ssrn=True, pipelined=True)
+    Y2, _, _ = eng.fetch_mel(); Z2 = eng.fetch_mag()
+    assert np.array_equal(Y2, Yb) and np.array_equal(Z2, Zb)
+    eng.stage_text(L, ends)
+    eng.run_resident(stop_mode=1, run_ssrn=True, pipelined=True)
+    Y3, _, _ = eng.fetch_mel(); Z3 = eng.fetch_mag()
+    assert np.array_equal(Y3, Ya) and np.array_equal(Z3, Za)
+    eng.run_resident(stop_mode=1, run_ssrn=True, pipelined=False)      # switch back
+    assert np.array_equal(eng.fetch_mag(), Za)
