@@ -5,7 +5,7 @@
 set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r01; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile"
+CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-pipeline"
 # 1. kernel trace + stats (per-kernel durations)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o r01 -- $CMD > $O/trace.log 2>&1
 # 2./3. HBM traffic counters, each in its own pass (TCC slots: FETCH_SIZE costs 3, WRITE_SIZE 2)
