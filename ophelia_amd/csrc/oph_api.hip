@@ -69,7 +69,7 @@ struct ProfClass {
     double ms = 0;
 };
 constexpr int CONE_KSPLIT = 4;   // split-K of the latency-bound decoder-cone GEMMs (partials summed by ln_rows)
-enum { PC_GEMM = 0, PC_LN, PC_DEC, PC_ROWCHAIN, PC_ATTN_ROWS, PC_MISC, PC_COUNT };
+enum { PC_GEMM = 0, PC_GEMM64, PC_LN, PC_DEC, PC_ROWCHAIN, PC_ATTN_ROWS, PC_MISC, PC_COUNT };   // PC_GEMM = the <128,128> instance
 
 }  // namespace
 
@@ -383,10 +383,11 @@ int pack_layer(oph_handle* h, Layer& l) {
 
 // ------------------------------------------------------------------ launch wrappers with accounting
 void run_gemm(oph_handle* h, const GemmArgs& a, int cin_true) {
-    h->pbegin(PC_GEMM);
+    const int cls = conv_gemm_tile_m(a.M, a.N) == 128 ? PC_GEMM : PC_GEMM64;
+    h->pbegin(cls);
     launch_conv_gemm(a, g_cur);
     const double K = (double)a.ntaps * cin_true;
-    h->pend(PC_GEMM, ((double)a.M * cin_true + (double)a.M * a.N + (double)a.N * K) * 4.0, 2.0 * a.M * a.N * K);
+    h->pend(cls, ((double)a.M * cin_true + (double)a.M * a.N + (double)a.N * K) * 4.0, 2.0 * a.M * a.N * K);
 }
 void run_epi(oph_handle* h, const EpiArgs& a) {
     h->pbegin(PC_LN);
@@ -971,7 +972,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
     oph_handle* h = new oph_handle();
     h->dm = m;
     h->device = device;
-    static const char* names[PC_COUNT] = {"conv_gemm_f32", "ln_rows", "dec_layer16", "row_chain", "attn_rows", "misc"};
+    static const char* names[PC_COUNT] = {"conv_gemm_f32<128,128>", "conv_gemm_f32<64,64>", "ln_rows", "dec_layer16", "row_chain", "attn_rows", "misc"};
     for (int i = 0; i < PC_COUNT; ++i) h->prof[i].name = names[i];
     // CU partition for the decode loop (MI355X: 256 CUs, mask bit i -> XCD i%8): the ~25 dependent
     // tiny launches of a step get a private slice of 8 CUs in every XCD so the concurrently running

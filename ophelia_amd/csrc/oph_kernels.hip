@@ -98,10 +98,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32(GemmArgs a) {
     const int kpt = a.kc / BK, nk_all = a.ntaps * kpt;
     const int ksplit = a.ksplit > 1 ? a.ksplit : 1, split = blockIdx.y;
     const int ks0 = split * nk_all / ksplit, nk = (split + 1) * nk_all / ksplit - ks0;
-    f32x4 ra[AR], rb[BR];
+    // Software pipeline, prefetch distance 2: while tile s is multiplied out of LDS buffer s&1, tile s+1
+    // sits in one register set (written to the other LDS buffer at the end of the step) and the global
+    // loads of tile s+2 are already in flight into the second register set.  One K-step of MFMAs
+    // (0.45 us for a 64x64 tile) does not cover an L2/MALL round trip; two do.
+    f32x4 ra0[AR], rb0[BR], ra1[AR], rb1[BR];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    auto load_global = [&](int sl) {
+    auto load_global = [&](int sl, f32x4 (&ra)[AR], f32x4 (&rb)[BR]) {
         const int s = ks0 + sl;
         const int tap = s / kpt, ko = (s - tap * kpt) * BK + kq * 4;
 #pragma unroll
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32(GemmArgs a) {
         for (int i = 0; i < BR; ++i)
             rb[i] = *(const f32x4*)(a.Wt + (size_t)(n0 + lrow + 32 * i) * a.ldw + tap * a.kc + ko);
     };
-    auto store_lds = [&](int buf) {
+    auto store_lds = [&](int buf, const f32x4 (&ra)[AR], const f32x4 (&rb)[BR]) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) *(f32x4*)(As + buf * BM * LD + (lrow + 32 * i) * LD + kq * 4) = ra[i];
 #pragma unroll
@@ -129,12 +133,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32(GemmArgs a) {
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
 
     const int wr = w >> 1, wc = w & 1, r32 = lane & 31, kh = lane >> 5;
-    load_global(0);
-    store_lds(0);
-    __syncthreads();
-    for (int s = 0; s < nk; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nk) load_global(s + 1);
+    auto compute = [&](int buf) {
         const float* Ab = As + buf * BM * LD + (wr * (BM / 2) + r32) * LD + kh * 4;
         const float* Bb = Bs + buf * BN * LD + (wc * (BN / 2) + r32) * LD + kh * 4;
 #pragma unroll
@@ -152,7 +151,23 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32(GemmArgs a) {
                     for (int jn = 0; jn < TN; ++jn)
                         acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[jn][e], acc[i][jn], 0, 0, 0);
         }
-        if (s + 1 < nk) store_lds(buf ^ 1);
+    };
+    load_global(0, ra0, rb0);
+    if (nk > 1) load_global(1, ra1, rb1);
+    store_lds(0, ra0, rb0);
+    __syncthreads();
+    // steps are processed in pairs so that the two register sets are addressed statically
+    for (int s = 0; s < nk; s += 2) {
+        // even step s: LDS buffer 0; set1 holds tile s+1; set0 is free -> prefetch tile s+2
+        if (s + 2 < nk) load_global(s + 2, ra0, rb0);
+        compute(0);
+        if (s + 1 < nk) store_lds(1, ra1, rb1);
+        __syncthreads();
+        if (s + 1 >= nk) break;
+        // odd step s+1: LDS buffer 1; set0 holds tile s+2; set1 is free -> prefetch tile s+3
+        if (s + 3 < nk) load_global(s + 3, ra1, rb1);
+        compute(1);
+        if (s + 2 < nk) store_lds(0, ra0, rb0);
         __syncthreads();
     }
     // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)

@@ -25,7 +25,7 @@ def broadcast_weights(W, inventory, src=0, device=None):
     import torch
     from . import weights as WT
     dist = _dist()
-    if dist is None or dist.get_world_size() == 1:
+    if dist is None:
         return W
     n = int(sum(int(np.prod(s)) for _, s in inventory))
     dev = torch.device("cuda", device) if (device is not None and torch.cuda.is_available()) else torch.device("cpu")
