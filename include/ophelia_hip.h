@@ -116,6 +116,10 @@ int oph_fetch_kv(oph_handle* h, float* K, float* V);
 int oph_fetch_mel(oph_handle* h, float* Y, int32_t* t_ends, float* alignments);
 int oph_fetch_mag(oph_handle* h, float* Z);
 int oph_synchronize(oph_handle* h);
+/* SSRN contraction arithmetic: 1 (default) = each fp32 operand split into hi+lo bf16, a.b ~ ah.bh+ah.bl+al.bh on the
+ * bf16 MFMA with fp32 accumulation (~1e-5 relative); 0 = exact fp32 MFMA.  Text2Mel is always exact fp32 (its
+ * attention argmax feeds back into the decode). */
+int oph_set_ssrn_precision(oph_handle* h, int mode);
 
 /* ---- measurement helpers (HIP events on the handle's own stream) ---------------- */
 int oph_timer_start(oph_handle* h);

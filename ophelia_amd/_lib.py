@@ -50,6 +50,7 @@ SIGNATURES = {
     "oph_fetch_mel": (C.c_int, [C.c_void_p, c_f32p, c_i32p, c_f32p]),
     "oph_fetch_mag": (C.c_int, [C.c_void_p, c_f32p]),
     "oph_synchronize": (C.c_int, [C.c_void_p]),
+    "oph_set_ssrn_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "oph_timer_start": (C.c_int, [C.c_void_p]),
     "oph_timer_stop": (C.c_int, [C.c_void_p, c_f32p]),
     "oph_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

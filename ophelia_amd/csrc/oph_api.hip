@@ -69,7 +69,7 @@ struct ProfClass {
     double ms = 0;
 };
 constexpr int CONE_KSPLIT = 4;   // split-K of the latency-bound decoder-cone GEMMs (partials summed by ln_rows)
-enum { PC_GEMM = 0, PC_GEMM64, PC_LN, PC_DEC, PC_ROWCHAIN, PC_ATTN_ROWS, PC_MISC, PC_COUNT };   // PC_GEMM = the <128,128> instance
+enum { PC_GEMM = 0, PC_GEMM64, PC_GEMM_BF16, PC_LN, PC_DEC, PC_ROWCHAIN, PC_ATTN_ROWS, PC_MISC, PC_COUNT };   // PC_GEMM = the <128,128> instance
 
 }  // namespace
 
@@ -89,6 +89,7 @@ struct oph_handle {
     hipGraphExec_t dec_graph[2] = {nullptr, nullptr};
     int dec_graph_B[2] = {0, 0};
     bool capturing = false;
+    int ssrn_prec = 1;                 // SSRN contractions: 1 = split-bf16 x3 (fp32 accumulate), 0 = exact fp32 MFMA
     bool use_graph = true;
     // second host thread: enqueues the side-stream cone while this thread enqueues the critical chain
     bool use_threads = true;
@@ -382,10 +383,11 @@ int pack_layer(oph_handle* h, Layer& l) {
 }
 
 // ------------------------------------------------------------------ launch wrappers with accounting
-void run_gemm(oph_handle* h, const GemmArgs& a, int cin_true) {
-    const int cls = conv_gemm_tile_m(a.M, a.N) == 128 ? PC_GEMM : PC_GEMM64;
+void run_gemm(oph_handle* h, const GemmArgs& a, int cin_true, int prec = 0) {
+    const int cls = prec ? PC_GEMM_BF16 : (conv_gemm_tile_m(a.M, a.N) == 128 ? PC_GEMM : PC_GEMM64);
     h->pbegin(cls);
-    launch_conv_gemm(a, g_cur);
+    if (prec) launch_conv_gemm_bf16x3(a, g_cur);
+    else launch_conv_gemm(a, g_cur);
     const double K = (double)a.ntaps * cin_true;
     h->pend(cls, ((double)a.M * cin_true + (double)a.M * a.N + (double)a.N * K) * 4.0, 2.0 * a.M * a.N * K);
 }
@@ -406,7 +408,7 @@ void run_dec(oph_handle* h, const DecArgs& a, const Layer& l) {
 // Runs `layers` over dense rows (B utterances x T frames).  in: [B*T][ld_in] padded rows.
 // final_out/final_ld: where the LAST layer's epilogue writes (e.g. Z with ld = full_dim).
 // Returns pointer to the final activation rows and their ld via *out_ld; rows via *out_rows.
-float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, int ld_in, int B, int T, int wsi,
+float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, int ld_in, int B, int T, int wsi, int prec,
                    float* final_out, int final_ld, int final_pad, int* out_ld, long long* out_rows) {
     float* x = in;
     int ldx = ld_in;
@@ -432,16 +434,16 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
             // even rows: taps (x[t], x[t-1]); odd rows: tap x[t]; raw rows interleaved 2t / 2t+1
             g.N = l.N; g.ldh = 2 * l.Nalloc; g.M = M;
             g.Wt = l.Wt; g.ldw = 2 * l.kc; g.ntaps = 2; g.off[0] = 0; g.off[1] = -1;
-            run_gemm(h, g, l.cin);
+            run_gemm(h, g, l.cin, prec);
             g.Wt = l.Wt2; g.ldw = l.kc; g.ntaps = 1; g.off[0] = 0; g.H = wsraw + l.Nalloc;
-            run_gemm(h, g, l.cin);
+            run_gemm(h, g, l.cin, prec);
             Tcur *= 2;
             e.ldh = l.Nalloc; e.M = B * Tcur; e.C = l.cout; e.mode = PRE_CONV; e.act = ACT_NONE;
             run_epi(h, e);
         } else {
             g.N = l.N; g.ldh = l.Nalloc; g.M = M; g.Wt = l.Wt; g.ldw = l.ntaps * l.kc; g.ntaps = l.ntaps;
             for (int t = 0; t < 3; ++t) g.off[t] = l.off[t];
-            run_gemm(h, g, l.cin);
+            run_gemm(h, g, l.cin, prec);
             e.ldh = l.Nalloc; e.M = M; e.C = l.cout;
             if (l.kind == K_HC) { e.mode = PRE_HC; e.Xres = x; e.ldres = ldx; }
             else e.mode = PRE_CONV;
@@ -927,14 +929,14 @@ int run_encode(oph_handle* h) {
     launch_embed(h->d_L, (long long)B * m.max_N, h->emb_text, m.e, h->actA, round_up(m.e, 32), h->stream);
     h->pend(PC_MISC, (double)B * m.max_N * m.e * 4.0, 0);
     // last highway layer writes K|V rows straight into the resident KV buffer [B][N][2d]
-    run_batched(h, h->textenc, h->actA, round_up(m.e, 32), B, m.max_N, 0, h->KV, 2 * m.d, 2 * m.d, nullptr, nullptr);
+    run_batched(h, h->textenc, h->actA, round_up(m.e, 32), B, m.max_N, 0, 0, h->KV, 2 * m.d, 2 * m.d, nullptr, nullptr);
     HIPCHK(h, hipGetLastError());
     return OPH_OK;
 }
 
 int run_ssrn_on(oph_handle* h, const float* Yrows, int ldy, int B, int T, float* Zout, int wsi = 0) {
     const oph_dims& m = h->dm;
-    run_batched(h, h->ssrn, const_cast<float*>(Yrows), ldy, B, T, wsi, Zout, m.full_dim, m.full_dim, nullptr, nullptr);
+    run_batched(h, h->ssrn, const_cast<float*>(Yrows), ldy, B, T, wsi, h->ssrn_prec, Zout, m.full_dim, m.full_dim, nullptr, nullptr);
     HIPCHK(h, hipGetLastError());
     return OPH_OK;
 }
@@ -972,7 +974,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
     oph_handle* h = new oph_handle();
     h->dm = m;
     h->device = device;
-    static const char* names[PC_COUNT] = {"conv_gemm_f32<128,128>", "conv_gemm_f32<64,64>", "ln_rows", "dec_layer16", "row_chain", "attn_rows", "misc"};
+    static const char* names[PC_COUNT] = {"conv_gemm_f32<128,128>", "conv_gemm_f32<64,64>", "conv_gemm_bf16x3", "ln_rows", "dec_layer16", "row_chain", "attn_rows", "misc"};
     for (int i = 0; i < PC_COUNT; ++i) h->prof[i].name = names[i];
     // CU partition for the decode loop (MI355X: 256 CUs, mask bit i -> XCD i%8): the ~25 dependent
     // tiny launches of a step get a private slice of 8 CUs in every XCD so the concurrently running
@@ -1023,6 +1025,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
         return OPH_ERR_DEVICE;
     }
     g_cur = h->stream;
+    h->ssrn_prec = getenv("OPH_SSRN_FP32") ? 0 : 1;
     h->use_graph = getenv("OPH_USE_GRAPH") != nullptr;
     h->use_threads = getenv("OPH_USE_THREADS") != nullptr && !h->use_graph;   // measured slower (HIP serialises launches across threads)   // replay measured slower than eager launches
     build_networks(h);
@@ -1189,6 +1192,12 @@ int oph_run_resident(oph_handle* h, int stop_mode, int run_ssrn, int32_t* steps_
         TRACE("ssrn queued");
     } else if (run_ssrn) rc = oph_run_ssrn_resident(h);
     return rc;
+}
+
+int oph_set_ssrn_precision(oph_handle* h, int mode) {
+    if (!h || mode < 0 || mode > 1) return OPH_ERR_INVALID;
+    h->ssrn_prec = mode;
+    return OPH_OK;
 }
 
 int oph_synchronize(oph_handle* h) {

@@ -126,6 +126,7 @@ struct RowChainArgs {
 // launchers (oph_kernels.hip)
 void launch_row_chain(const RowChainArgs& a, hipStream_t s);
 void launch_conv_gemm(const GemmArgs& a, hipStream_t s);
+void launch_conv_gemm_bf16x3(const GemmArgs& a, hipStream_t s);   // split-bf16 contraction (dense rows only)
 int  conv_gemm_tile_m(int M, int N);          // tile size chosen for a problem (64 or 128)
 void launch_epilogue(const EpiArgs& a, hipStream_t s);
 void launch_dec_layer(const DecArgs& a, int Npad16, hipStream_t s);

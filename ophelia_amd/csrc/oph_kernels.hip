@@ -208,6 +208,171 @@ void launch_conv_gemm(const GemmArgs& a, hipStream_t s) {
 }
 
 // =====================================================================================
+// conv_gemm_bf16x3: same contract as conv_gemm_f32, but every fp32 operand is split on the fly into
+// hi = bf16(x), lo = bf16(x - hi) while it is staged into LDS, and the contraction runs as
+//     a.b ~= ah.bh + ah.bl + al.bh          (dropped al.bl <= 2^-18 |a.b|)
+// on v_mfma_f32_32x32x16_bf16 (16x the fp32-MFMA rate => ~5x effective) with fp32 accumulation.
+// Used for SSRN only (no argmax feedback there); measured error vs the fp32 oracle is reported by
+// tests/test_gpu_model.py.  LDS tile = hi and lo planes [row][32 bf16 + 8 pad] (80-B rows =>
+// conflict-free ds_read_b128 of the 8-element MFMA fragments).
+// =====================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split_bf16(const f32x4& x, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 h = (__bf16)x[e];
+        hi[e] = h;
+        lo[e] = (__bf16)(x[e] - (float)h);
+    }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3(GemmArgs a) {
+    constexpr int BK = 32, LDH = 40;               // bf16 elements per LDS row (32 + 8 pad)
+    constexpr int AR = BM / 32, BR = BN / 32;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* Ah = (__bf16*)smem;                    // [2][BM*LDH]
+    __bf16* Al = Ah + 2 * BM * LDH;
+    __bf16* Bh = Al + 2 * BM * LDH;                // [2][BN*LDH]
+    __bf16* Bl = Bh + 2 * BN * LDH;
+    int* srow_s = (int*)(Bl + 2 * BN * LDH);       // [3][BM]
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
+    const int ntiles = MT * NT;
+    int id;
+    {
+        const int bid = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    constexpr int GM = 8;
+    const int width = GM * NT, g = id / width, first_m = g * GM;
+    const int gsz = min(MT - first_m, GM);
+    const int tm = first_m + (id % width) % gsz, tn = (id % width) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    for (int i = tid; i < BM * a.ntaps; i += 256) {
+        const int tap = i / BM, m = m0 + (i - tap * BM);
+        int src = -1;
+        if (m < a.M) {
+            const int b = m / a.T, t = m - b * a.T, tt = t + a.off[tap];
+            if (tt >= 0 && tt < a.T) src = m + a.off[tap];
+        }
+        srow_s[i] = src;
+    }
+    __syncthreads();
+
+    const int lrow = tid >> 3, kq = tid & 7;
+    const int kpt = a.kc / BK, nk = a.ntaps * kpt;
+    f32x4 ra[AR], rb[BR];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto load_global = [&](int s) {
+        const int tap = s / kpt, ko = (s - tap * kpt) * BK + kq * 4;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int src = srow_s[tap * BM + lrow + 32 * i];
+            ra[i] = src >= 0 ? *(const f32x4*)(a.X + (size_t)src * a.ldx + ko) : zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+            rb[i] = *(const f32x4*)(a.Wt + (size_t)(n0 + lrow + 32 * i) * a.ldw + tap * a.kc + ko);
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            bf16x4 hi, lo;
+            split_bf16(ra[i], hi, lo);
+            const int o = buf * BM * LDH + (lrow + 32 * i) * LDH + kq * 4;
+            *(bf16x4*)(Ah + o) = hi;
+            *(bf16x4*)(Al + o) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            bf16x4 hi, lo;
+            split_bf16(rb[i], hi, lo);
+            const int o = buf * BN * LDH + (lrow + 32 * i) * LDH + kq * 4;
+            *(bf16x4*)(Bh + o) = hi;
+            *(bf16x4*)(Bl + o) = lo;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
+
+    // 32x32x16 bf16 fragment: lane l holds row (l&31), k = 8*(l>>5) .. +7 of the 16-wide chunk
+    const int wr = w >> 1, wc = w & 1, r32 = lane & 31, kh = lane >> 5;
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+    for (int s = 0; s < nk; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nk) load_global(s + 1);
+        const int ao = buf * BM * LDH + (wr * (BM / 2) + r32) * LDH + kh * 8;
+        const int bo = buf * BN * LDH + (wc * (BN / 2) + r32) * LDH + kh * 8;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *(const bf16x8*)(Ah + ao + i * 32 * LDH + kc * 16);
+                al[i] = *(const bf16x8*)(Al + ao + i * 32 * LDH + kc * 16);
+            }
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+                bh[jn] = *(const bf16x8*)(Bh + bo + jn * 32 * LDH + kc * 16);
+                bl[jn] = *(const bf16x8*)(Bl + bo + jn * 32 * LDH + kc * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) {
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[jn], acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[jn], acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[jn], acc[i][jn], 0, 0, 0);
+                }
+        }
+        if (s + 1 < nk) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+            const int col = n0 + wc * (BN / 2) + jn * 32 + r32;
+            const float bv = a.bias[col];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                if (row < a.M) a.H[(size_t)row * a.ldh + col] = acc[i][jn][e] + bv;
+            }
+        }
+}
+
+template <int BM, int BN>
+static void launch_conv_gemm_bf16x3_t(const GemmArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)(2 * 2 * (BM + BN) * 40) * 2 + (size_t)3 * BM * 4;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_gemm_bf16x3<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
+    hipLaunchKernelGGL((conv_gemm_bf16x3<BM, BN>), dim3(MT * NT), dim3(256), lds, s, a);
+}
+void launch_conv_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {     // dense rows, no split-K
+    if (conv_gemm_tile_m(a.M, a.N) == 128) launch_conv_gemm_bf16x3_t<128, 128>(a, s);
+    else launch_conv_gemm_bf16x3_t<64, 64>(a, s);
+}
+
+// =====================================================================================
 // ln_rows<NV>: one wavefront per row; the row (<= NV*256 channels) lives in registers.
 // [TF-sem] tf.contrib.layers.layer_norm: mean, biased variance, eps 1e-12 (modules.py:65).
 //   conv : y = act(LN(h))                                     (modules.py:137-139)

@@ -166,6 +166,10 @@ class Engine(object):
         self._chk(self.lib.oph_fetch_mag(self._h, _lib.fptr(Z)))
         return Z
 
+    def set_ssrn_precision(self, mode):
+        """1 = split-bf16 x3 contractions with fp32 accumulate (default), 0 = exact fp32 MFMA."""
+        self._chk(self.lib.oph_set_ssrn_precision(self._h, int(mode)))
+
     def synchronize(self):
         self._chk(self.lib.oph_synchronize(self._h))
 

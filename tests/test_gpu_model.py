@@ -34,9 +34,11 @@ def test_golden_cases(tag):
     assert np.abs(Y - g["Y"]).max() < TOL
     assert np.abs(al - g["alignments"]).max() < TOL
     assert not Y[:, steps:].any() and not al[:, :, steps:].any()      # zero tail after the break step
-    Z = eng.ssrn(g["Y"])
-    assert Z.shape == g["Z"].shape
-    assert np.abs(Z - g["Z"]).max() < TOL
+    for mode, tol in ((0, TOL), (1, 1e-3 / 4)):
+        eng.set_ssrn_precision(mode)
+        Z = eng.ssrn(g["Y"])
+        assert Z.shape == g["Z"].shape
+        assert np.abs(Z - g["Z"]).max() < tol, mode
     eng.close()
 
 
@@ -91,18 +93,23 @@ def test_c3_ssrn_full_size(c2):
     Y0 = c2_Y[0]
     if Y0 is None:
         Y0 = np.random.default_rng(4).random((16, hp.max_T, hp.n_mels), dtype=np.float32)
-    Z = eng.ssrn(Y0)
     Z0 = O.synth_mel2mag(hp, W, Y0)
-    print("C3 max-abs: Z %.3e" % np.abs(Z - Z0).max())
+    eng.set_ssrn_precision(0)                       # exact fp32 MFMA
+    Z = eng.ssrn(Y0)
+    print("C3 max-abs (fp32 MFMA): Z %.3e" % np.abs(Z - Z0).max())
     assert Z.shape == (16, hp.max_T * hp.r, hp.full_dim)
     assert np.abs(Z - Z0).max() < TOL
+    eng.set_ssrn_precision(1)                       # default: split-bf16 x3, fp32 accumulate
+    Zb = eng.ssrn(Y0)
+    print("C3 max-abs (bf16x3): Z %.3e   (bar: 1e-3 max-abs on mag, BASELINE.json north_star)" % np.abs(Zb - Z0).max())
+    assert np.abs(Zb - Z0).max() < 1e-3 / 4
     # resident pipeline == host-buffer pipeline
     ends = O.get_text_lengths(L)
     eng.stage_text(L, ends)
     assert eng.run_resident(stop_mode=1, run_ssrn=True) == hp.max_T
     Yr, _, _ = eng.fetch_mel()
     Zr = eng.fetch_mag()
-    assert np.abs(Yr - Y0).max() < TOL and np.abs(Zr - Z0).max() < TOL
+    assert np.abs(Yr - Y0).max() < TOL and np.abs(Zr - Z0).max() < 1e-3 / 4
 
 
 def test_pipelined_batches_equal_sequential(c2):
