@@ -8,10 +8,6 @@
 #include "../../include/ophelia_hip.h"
 
 #include <algorithm>
-#include <atomic>
-#include <condition_variable>
-#include <mutex>
-#include <thread>
 #include <climits>
 #include <cstdarg>
 #include <cstdio>
@@ -91,15 +87,6 @@ struct oph_handle {
     bool capturing = false;
     int ssrn_prec = 1;                 // SSRN contractions: 1 = split-bf16 x3 (fp32 accumulate), 0 = exact fp32 MFMA
     bool use_graph = true;
-    // second host thread: enqueues the side-stream cone while this thread enqueues the critical chain
-    bool use_threads = true;
-    std::thread worker;
-    std::mutex wmu;
-    std::condition_variable wcv, wcv_done;
-    bool job_pending = false, job_done = true, quit = false;
-    int job_t0 = 0, job_t1 = 0;
-    std::atomic<int> attn_posted{-1}, cone_posted{0}, limit{INT_MAX};
-    std::vector<hipEvent_t> ev_attn_v, ev_cone_v;     // per-step events (threaded mode)
     hipStream_t scone = nullptr;       // side stream in use: AudioDec history cone, overlapped with the AudioEnc chain
     hipEvent_t ev_attn = nullptr, ev_cone = nullptr;
     std::string err;
@@ -683,7 +670,7 @@ void fill_pre(DecArgs& a, const Layer* prev, const float* prev_raw, const float*
 //   dec_layer16  : AudioDec highway layers (taps from the cone of this step)
 //   row_chain C  : gate -> AudioDec C_8..C_11 -> LN -> sigmoid -> Y[:, t] (and S[t+1])
 // Side stream: cone(t+1), released by the event recorded right after row_chain B of step t.
-void decode_step(oph_handle* h, int t, int t_last, int stop_mode, bool threaded = false) {
+void decode_step(oph_handle* h, int t, int t_last, int stop_mode) {
     const oph_dims& m = h->dm;
     const int d = m.d, Bpad = h->Bpad, B = h->B;
     int* stop_after = h->d_ctl + 1;
@@ -741,19 +728,10 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode, bool threaded 
         a.B = B; a.stop_after = stop_after; a.t = t;
         run_row_chain(h, a, 1);
     }
-    if (threaded) {
-        // the worker thread enqueues cone(t+1) as soon as it sees attention(t) recorded
-        hipEventRecord(h->ev_attn_v[t], h->sdec);
-        h->attn_posted.store(t, std::memory_order_release);
-        if (t >= 1) {
-            while (h->cone_posted.load(std::memory_order_acquire) < t) __builtin_ia32_pause();
-            hipStreamWaitEvent(h->sdec, h->ev_cone_v[t], 0);
-        }
-    }
     // cone(t) (launched during step t-1, or by decode_range for the first step) must have landed
-    if (!threaded && t >= 1) hipStreamWaitEvent(h->sdec, h->ev_cone, 0);
+    if (t >= 1) hipStreamWaitEvent(h->sdec, h->ev_cone, 0);
     // release cone(t+1) on the side stream: needs p_{t+1} and Q[t], both written by row_chain B of step t
-    if (!threaded && t + 1 < t_last) {
+    if (t + 1 < t_last) {
         hipEventRecord(h->ev_attn, h->sdec);
         hipStreamWaitEvent(h->scone, h->ev_attn, 0);
         launch_cone(h, t + 1);
@@ -790,39 +768,6 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode, bool threaded 
         a.emit = 1; a.Yout = h->Yout; a.ldy = h->ldy; a.Ytm = h->Ytm; a.ldtm = h->ldy; a.max_T = m.max_T;
         a.B = B; a.Bpad = Bpad; a.stop_after = stop_after; a.t = t; a.d = d;
         run_row_chain(h, a, 0);
-    }
-}
-
-// Side-stream enqueue thread: for t in [t0,t1): wait until attn(t-1) has been RECORDED by the main
-// thread, make stream2 wait on it, enqueue cone(t), record its completion event.
-void worker_main(oph_handle* h) {
-    (void)hipSetDevice(h->device);
-    for (;;) {
-        int t0, t1;
-        {
-            std::unique_lock<std::mutex> lk(h->wmu);
-            h->wcv.wait(lk, [&] { return h->job_pending || h->quit; });
-            if (h->quit) return;
-            t0 = h->job_t0; t1 = h->job_t1; h->job_pending = false;
-        }
-        g_cur = h->scone;
-        for (int t = t0; t < t1; ++t) {
-            bool stop = false;
-            while (h->attn_posted.load(std::memory_order_acquire) < t - 1) {
-                if (h->limit.load(std::memory_order_acquire) < t) { stop = true; break; }
-                __builtin_ia32_pause();
-            }
-            if (stop || h->limit.load(std::memory_order_acquire) < t) break;
-            hipStreamWaitEvent(h->scone, h->ev_attn_v[t - 1], 0);
-            launch_cone(h, t);
-            hipEventRecord(h->ev_cone_v[t], h->scone);
-            h->cone_posted.store(t, std::memory_order_release);
-        }
-        {
-            std::lock_guard<std::mutex> lk(h->wmu);
-            h->job_done = true;
-        }
-        h->wcv_done.notify_all();
     }
 }
 
@@ -863,24 +808,7 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
             t_begin = t_end;      // skip the eager loop below
         }
     }
-    const bool threaded = h->use_threads && !h->profiling && t_begin < t_end;
-    if (threaded) {
-        if ((int)h->ev_attn_v.size() < m.max_T + 1) {
-            h->ev_attn_v.resize(m.max_T + 1); h->ev_cone_v.resize(m.max_T + 1);
-            for (auto& e : h->ev_attn_v) hipEventCreateWithFlags(&e, hipEventDisableTiming);
-            for (auto& e : h->ev_cone_v) hipEventCreateWithFlags(&e, hipEventDisableTiming);
-        }
-        if (!h->worker.joinable()) h->worker = std::thread(worker_main, h);
-        h->limit.store(INT_MAX);
-        h->cone_posted.store(t_begin >= 1 ? t_begin - 1 : 0);
-        if (t_begin >= 1) hipEventRecord(h->ev_attn_v[t_begin - 1], h->sdec);   // resuming: cone(t_begin) may start now
-        h->attn_posted.store(t_begin - 1, std::memory_order_release);
-        {
-            std::lock_guard<std::mutex> lk(h->wmu);
-            h->job_t0 = std::max(1, t_begin); h->job_t1 = t_end; h->job_pending = true; h->job_done = false;
-        }
-        h->wcv.notify_all();
-    } else if (t_begin >= 1 && t_begin < t_end) {      // resuming mid-utterance: cone(t_begin) has not been launched yet
+    if (t_begin >= 1 && t_begin < t_end) {      // resuming mid-utterance: cone(t_begin) has not been launched yet
         hipEventRecord(h->ev_attn, h->sdec);
         hipStreamWaitEvent(h->scone, h->ev_attn, 0);
         launch_cone(h, t_begin);
@@ -888,7 +816,7 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
     }
     int rc_loop = OPH_OK;
     for (int t = t_begin; t < t_end; ++t) {
-        decode_step(h, t, t_end, stop_mode, threaded);
+        decode_step(h, t, t_end, stop_mode);
         last = t + 1;
         // bounded look-ahead: poll the device-side stop flag every 8 steps (reference semantics keep
         // frames after the break step at zero because later steps early-out on the device)
@@ -897,11 +825,6 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
                 hipStreamSynchronize(h->sdec) != hipSuccess) { rc_loop = OPH_ERR_DEVICE; break; }
             if (ctl[1] != INT_MAX) break;
         }
-    }
-    if (threaded) {      // the worker must have stopped enqueuing before stream2 is joined
-        h->limit.store(last - 1, std::memory_order_release);
-        std::unique_lock<std::mutex> lk(h->wmu);
-        h->wcv_done.wait(lk, [&] { return h->job_done; });
     }
     g_cur = h->sdec;
     if (rc_loop != OPH_OK) { h->fail("device error while polling the stop flag"); return rc_loop; }
@@ -923,6 +846,7 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
 
 int run_encode(oph_handle* h) {
     const oph_dims& m = h->dm;
+    g_cur = h->stream;
     const int B = h->B;
     // embed_1 (modules.py:15-44) -> rows [B*max_N][e]
     h->pbegin(PC_MISC);
@@ -1027,7 +951,6 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
     g_cur = h->stream;
     h->ssrn_prec = getenv("OPH_SSRN_FP32") ? 0 : 1;
     h->use_graph = getenv("OPH_USE_GRAPH") != nullptr;
-    h->use_threads = getenv("OPH_USE_THREADS") != nullptr && !h->use_graph;   // measured slower (HIP serialises launches across threads)   // replay measured slower than eager launches
     build_networks(h);
     *out = h;
     return OPH_OK;
@@ -1036,11 +959,6 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
 int oph_destroy(oph_handle* h) {
     if (!h) return OPH_OK;
     hipSetDevice(h->device);
-    if (h->worker.joinable()) {
-        { std::lock_guard<std::mutex> lk(h->wmu); h->quit = true; }
-        h->wcv.notify_all();
-        h->worker.join();
-    }
     TRACE("destroy: sync streams");
     for (hipStream_t st : {h->stream, h->sdec, h->scone, h->sssrn}) if (st) hipStreamSynchronize(st);
     TRACE("destroy: graphs/events");
@@ -1049,8 +967,6 @@ int oph_destroy(oph_handle* h) {
         for (auto& e : pc.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (hipEvent_t e : {h->ev0, h->ev1, h->ev_attn, h->ev_cone, h->ev_in, h->ev_out, h->ev_dec_done, h->ev_ssrn_done[0], h->ev_ssrn_done[1]})
         if (e) hipEventDestroy(e);
-    for (auto e : h->ev_attn_v) hipEventDestroy(e);
-    for (auto e : h->ev_cone_v) hipEventDestroy(e);
     TRACE("destroy: free");
     for (void* p : h->allocs) hipFree(p);
     TRACE("destroy: streams");
@@ -1149,6 +1065,7 @@ int oph_decode_steps(oph_handle* h, int t_begin, int t_end, int stop_mode, int32
 int oph_run_ssrn_resident(oph_handle* h) {
     if (!h || !h->KV) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
+    g_cur = h->stream;
     return run_ssrn_on(h, h->Yout, h->ldy, h->B, h->dm.max_T, h->Z);
 }
 
@@ -1280,6 +1197,7 @@ int oph_ssrn(oph_handle* h, const float* Y, int B, int T, float* Z) {
     const oph_dims& m = h->dm;
     if (T > m.max_T) { h->fail("T=%d exceeds max_T=%d", T, m.max_T); return OPH_ERR_INVALID; }
     if ((rc = ensure_batched_capacity(h, B))) return rc;
+    g_cur = h->stream;
     const int ldy = round_up(m.n_mels, 32);
     float* dY = nullptr; float* dZ = nullptr;
     const size_t zn = (size_t)B * T * m.r * m.full_dim;

@@ -67,19 +67,6 @@ struct DecArgs {
     const int* stop_after; int t;
 };
 
-struct AttnStepArgs {
-    // query = gate(LN(H1), LN(H2), xres) of AudioEnc's last highway layer
-    const float* hraw; int ldh; const float *g1, *b1, *g2, *b2; const float* xres; int ldres;
-    const float* KV; int N; int d;  // [B][N][2d] : K cols [0,d), V cols [d,2d)
-    int win; int B; int Bpad; int max_T; int t;
-    const int* pcur; int* pnext;    // prev_max_attentions ping-pong
-    const int* ends; int* t_ends; int* n_ended; int* stop_after;
-    int stop_mode;
-    float* Qhist;                   // [max_T][Bpad][d]
-    float* Rrow; int ldr;           // [Bpad][2d]
-    float* align;                   // (B, N, max_T)
-};
-
 struct AttnRowsArgs {
     int mode;                       // 0: decoder history rows (position-major), 1: batched op (b,t) rows
     const float* Q; int ldq;
@@ -91,13 +78,6 @@ struct AttnRowsArgs {
     float* R; int ldr;
     float* align; long long* amax;  // mode 1 outputs (B,N,T) and (B,T)
     const int* stop_after; int t;
-};
-
-struct EmitArgs {
-    const float* hraw; int ldh; const float *g, *b; int C; int squash;
-    float* Yout; int ldy; int max_T;    // [B][max_T][ldy]
-    float* Ytm;  int ldtm; int Bpad;    // [max_T+1][Bpad][ldtm], row t+1 receives Y[t]
-    int B; const int* stop_after; int t;
 };
 
 // ---- row-parallel fused chain of k=1 layers (LayerNorm is row-local, so a run of k=1 convs needs no
@@ -130,9 +110,7 @@ void launch_conv_gemm_bf16x3(const GemmArgs& a, hipStream_t s);   // split-bf16 
 int  conv_gemm_tile_m(int M, int N);          // tile size chosen for a problem (64 or 128)
 void launch_epilogue(const EpiArgs& a, hipStream_t s);
 void launch_dec_layer(const DecArgs& a, int Npad16, hipStream_t s);
-void launch_attn_step(const AttnStepArgs& a, hipStream_t s);
 void launch_attn_rows(const AttnRowsArgs& a, hipStream_t s);
-void launch_emit_mel(const EmitArgs& a, hipStream_t s);
 void launch_embed(const int* ids, long long n, const float* table, int units, float* out, int ldo, hipStream_t s);
 void launch_pad_rows(const float* src, int lds_, float* dst, int ldd, long long rows, int C, hipStream_t s);
 void launch_fill_int(int* p, int v, int n, hipStream_t s);

@@ -7,8 +7,9 @@
 //   ln_rows<NV>           LayerNorm epilogues: conv(LN+act) and highway (2xLN+gate+mix)
 //   dec_layer16           fused M=16 decoder layer: previous layer's LN/gate as prologue,
 //                         then a 16 x K . K x 16 slice per workgroup, K split over 4 waves
-//   attn_step / attn_rows windowed monotonic attention (networks.py:286-325)
-//   emit_mel, embed_rows, pad_rows
+//   row_chain             row-parallel fused run of k=1 layers (+ attention row t, + mel emit)
+//   attn_rows             windowed monotonic attention rows (networks.py:286-325)
+//   embed_rows, pad_rows
 #include "oph_internal.h"
 
 #include <map>
@@ -193,11 +194,13 @@ int conv_gemm_tile_m(int M, int N) {
 
 template <int BM, int BN>
 static void launch_conv_gemm_t(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
+    static bool attr_set[64] = {false};          // function attributes are per device
     const size_t lds = (size_t)(2 * (BM + BN) * 36) * 4 + (size_t)3 * BM * 4;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_gemm_f32<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 63]) {
+        (void)hipFuncSetAttribute((const void*)conv_gemm_f32<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set[dev & 63] = true;
     }
     const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
     hipLaunchKernelGGL((conv_gemm_f32<BM, BN>), dim3(MT * NT, a.ksplit > 1 ? a.ksplit : 1), dim3(256), lds, s, a);
@@ -358,11 +361,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3(GemmArgs a) {
 
 template <int BM, int BN>
 static void launch_conv_gemm_bf16x3_t(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
+    static bool attr_set[64] = {false};
     const size_t lds = (size_t)(2 * 2 * (BM + BN) * 40) * 2 + (size_t)3 * BM * 4;
-    if (!attr_set) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 63]) {
         (void)hipFuncSetAttribute((const void*)conv_gemm_bf16x3<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+        attr_set[dev & 63] = true;
     }
     const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
     hipLaunchKernelGGL((conv_gemm_bf16x3<BM, BN>), dim3(MT * NT), dim3(256), lds, s, a);
@@ -710,8 +715,11 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void dec_layer16(DecArgs a) {
 template <int NV, int PRE>
 static void launch_dec_t(const DecArgs& a, dim3 grid, size_t lds, hipStream_t s) {
     auto set = [&](const void* f) {
-        static std::map<const void*, size_t> done;
-        if (done[f] < lds) { (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done[f] = lds; }
+        static std::map<std::pair<const void*, int>, size_t> done;      // per (function, device)
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        size_t& d = done[{f, dev}];
+        if (d < lds) { (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); d = lds; }
     };
     if (a.ntaps == 3) { set((const void*)dec_layer16<NV, PRE, 3>); hipLaunchKernelGGL((dec_layer16<NV, PRE, 3>), grid, dim3(64 * DEC_WAVES), lds, s, a); }
     else              { set((const void*)dec_layer16<NV, PRE, 1>); hipLaunchKernelGGL((dec_layer16<NV, PRE, 1>), grid, dim3(64 * DEC_WAVES), lds, s, a); }
@@ -793,95 +801,6 @@ __device__ __forceinline__ AttnOut attend_window(const f32x4 (&q)[ATT_NV], const
         }
     }
     return o;
-}
-
-// attn_step: grid = Bpad/16 blocks of 16 waves; wave = utterance.
-__global__ __launch_bounds__(1024) void attn_step(AttnStepArgs a) {
-    if (a.t > *a.stop_after) return;
-    const int lane = threadIdx.x & 63, b = blockIdx.x * 16 + (threadIdx.x >> 6);
-    if (b >= a.B) return;
-    const int d = a.d;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    // query = highway output of AudioEnc's last layer
-    f32x4 q[ATT_NV], u[ATT_NV];
-    const float* h = a.hraw + (size_t)b * a.ldh;
-    auto ln = [&](f32x4 (&z)[ATT_NV], const float* base, const float* gam, const float* bet) {
-        float s = 0.f;
-#pragma unroll
-        for (int v = 0; v < ATT_NV; ++v) {
-            const int c = (v * 64 + lane) * 4;
-            z[v] = c < d ? *(const f32x4*)(base + c) : zero4;
-            s += z[v][0] + z[v][1] + z[v][2] + z[v][3];
-        }
-        const float mean = wave_sum(s) / (float)d;
-        float qq = 0.f;
-#pragma unroll
-        for (int v = 0; v < ATT_NV; ++v) {
-            const int c = (v * 64 + lane) * 4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float dlt = c < d ? z[v][e] - mean : 0.f;
-                z[v][e] = dlt;
-                qq += dlt * dlt;
-            }
-        }
-        const float rstd = 1.0f / sqrtf(wave_sum(qq) / (float)d + LN_EPS);
-#pragma unroll
-        for (int v = 0; v < ATT_NV; ++v) {
-            const int c = (v * 64 + lane) * 4;
-            if (c < d) {
-                const f32x4 gv = *(const f32x4*)(gam + c), bv = *(const f32x4*)(bet + c);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) z[v][e] = z[v][e] * rstd * gv[e] + bv[e];
-            }
-        }
-    };
-    ln(q, h, a.g1, a.b1);
-    ln(u, h + d, a.g2, a.b2);
-    const float* xr = a.xres + (size_t)b * a.ldres;
-    float* qh = a.Qhist + ((size_t)a.t * a.Bpad + b) * d;
-    float* rr = a.Rrow + (size_t)b * a.ldr;
-#pragma unroll
-    for (int v = 0; v < ATT_NV; ++v) {
-        const int c = (v * 64 + lane) * 4;
-        if (c < d) {
-            const f32x4 xv = *(const f32x4*)(xr + c);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float gte = sigmoidf_(q[v][e]);
-                q[v][e] = gte * u[v][e] + (1.0f - gte) * xv[e];
-            }
-            *(f32x4*)(qh + c) = q[v];
-            *(f32x4*)(rr + d + c) = q[v];       // R' = concat(R, Q)  networks.py:317-319
-        }
-    }
-    const int p = a.pcur[b];
-    const float* KVb = a.KV + (size_t)b * a.N * 2 * d;
-    f32x4 ctx[ATT_NV];
-    const AttnOut o = attend_window(q, KVb, KVb + d, 2 * d, p, a.N, a.win, d, lane, ctx);
-#pragma unroll
-    for (int v = 0; v < ATT_NV; ++v) {
-        const int c = (v * 64 + lane) * 4;
-        if (c < d) *(f32x4*)(rr + c) = ctx[v];
-    }
-    if (lane == 0) {
-        float* al = a.align + (size_t)b * a.N * a.max_T + a.t;      // alignments[b, n, t]
-#pragma unroll
-        for (int i = 0; i < ATT_WMAX; ++i)
-            if (i < o.nwin) al[(size_t)(p + i) * a.max_T] = o.prob[i];
-        const int m = p + o.arg;                                    // max_attentions[b, t]
-        a.pnext[b] = m;
-        // synthesize.py:218-228: first step at which attention sits on/after the text end
-        if (a.t_ends[b] == a.max_T && m >= a.ends[b]) {
-            a.t_ends[b] = a.t;
-            const int old = atomicAdd(a.n_ended, 1);
-            if (old + 1 == a.B && a.stop_mode == 0) *a.stop_after = a.t;
-        }
-    }
-}
-
-void launch_attn_step(const AttnStepArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(attn_step, dim3(a.Bpad / 16), dim3(1024), 0, s, a);
 }
 
 // attn_rows: generic rows.  mode 0 = decoder history rows (position-major, current mask p);
@@ -1123,28 +1042,6 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain(RowChainArgs a) {
 
 void launch_row_chain(const RowChainArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(row_chain, dim3(a.B), dim3(64 * RC_WAVES), 0, s, a);
-}
-
-// emit_mel: Y[b, t, :] = sigmoid(LN(logits))  (networks.py:421-431); also feeds S[t+1] (architectures.py:191)
-__global__ __launch_bounds__(256) void emit_mel(EmitArgs a) {
-    if (stopped(a.stop_after, a.t)) return;
-    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= a.B) return;
-    f32x4 x[1];
-    const int c = lane * 4;
-    x[0] = c < a.C ? *(const f32x4*)(a.hraw + (size_t)b * a.ldh + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-    ln_vec<1>(x, a.C, lane, a.g, a.b);
-    float* yo = a.Yout + ((size_t)b * a.max_T + a.t) * a.ldy;
-    float* yt = a.Ytm + ((size_t)(a.t + 1) * a.Bpad + b) * a.ldtm;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float v = c + e < a.C ? (a.squash ? sigmoidf_(x[0][e]) : x[0][e]) : 0.f;
-        if (c + e < a.ldy) yo[c + e] = v;
-        if (c + e < a.ldtm) yt[c + e] = v;
-    }
-}
-void launch_emit_mel(const EmitArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(emit_mel, dim3((a.B + 3) / 4), dim3(256), 0, s, a);
 }
 
 // embed_rows: modules.py:15-44 (row 0 replaced by zeros at lookup time); pads to ldo with zeros
