@@ -115,30 +115,27 @@ def split_batch(synth_batch, end_indices):
 
 
 def make_mel_batch(hp, fnames, oracle=True):
-    if oracle:
-        mels = [os.path.join(hp.coarse_audio_dir, basename(fname) + ".npy") for fname in fnames]
-    else:
-        mels = fnames
-    mels = [np.load(melfile) for melfile in mels]
-    mel_batch = np.zeros((len(mels), hp.max_T, hp.n_mels), np.float32)
+    """Stack coarse mels into a zero-padded (n, max_T, n_mels) batch; lengths are in full-rate frames (x r).
+    oracle=True reads {hp.coarse_audio_dir}/{base}.npy for each name, otherwise `fnames` are .npy paths."""
+    paths = [os.path.join(hp.coarse_audio_dir, basename(f) + ".npy") for f in fnames] if oracle else list(fnames)
+    batch = np.zeros((len(paths), hp.max_T, hp.n_mels), np.float32)
     lengths = []
-    for (i, mel) in enumerate(mels):
-        length, n = mel.shape
-        mel_batch[i, :length, :] = mel
-        lengths.append(length * hp.r)
-    return mel_batch, lengths
+    for row, path in zip(batch, paths):
+        mel = np.load(path)
+        row[:mel.shape[0]] = mel
+        lengths.append(mel.shape[0] * hp.r)
+    return batch, lengths
 
 
 def list2batch(inlist, pad_length):
-    m, dim = inlist[0].shape
-    if pad_length == 0:
-        pad_length = max([a.shape[0] for a in inlist])
+    """Zero-pad a list of (len_i, dim) arrays to one (n, pad_length, dim) float32 batch (0 = longest)."""
+    dim = inlist[0].shape[1]
+    longest = max(a.shape[0] for a in inlist)
+    pad_length = pad_length or longest
+    assert longest <= pad_length and all(a.shape[1] == dim for a in inlist)
     batch = np.zeros((len(inlist), pad_length, dim), np.float32)
-    for (i, array) in enumerate(inlist):
-        length, n = array.shape
-        assert length <= pad_length
-        assert n == dim
-        batch[i, :length, :] = array
+    for row, a in zip(batch, inlist):
+        row[:a.shape[0]] = a
     return batch
 
 
