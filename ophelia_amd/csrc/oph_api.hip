@@ -910,7 +910,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
         int ncu = 0;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) ncu = prop.multiProcessorCount;
         const int words = (ncu + 31) / 32;
-        int ndec = ncu / 4, nconep = ncu * 3 / 8;           // 64 | 96 | 96 of 256 CUs (sweep in DESIGN.md)
+        int ndec = ncu / 4, nconep = ncu / 2;               // 64 | 128 | 64 of 256 CUs (sweep in DESIGN.md)
         if (const char* sp = getenv("OPH_CU_SPLIT")) { int a_ = 0, b_ = 0; if (sscanf(sp, "%d,%d", &a_, &b_) == 2 && a_ > 0 && b_ > 0 && a_ + b_ < ncu) { ndec = a_; nconep = b_; } }
         if (ncu >= 64 && words <= 16 && !getenv("OPH_NO_CU_MASK")) {
             for (int i = 0; i < ncu; ++i) {
