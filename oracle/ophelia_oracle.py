@@ -344,7 +344,7 @@ def _inc_hc(st, name, x, j, W, rate):
 
 
 def synth_codedtext2mel_incremental(hp, W, K, V, ends, speakers=None, stop=True, trace=None,
-                                    forced_prev_max=None, margins=None):
+                                    forced_prev_max=None, margins=None, max_steps=None, step_times=None):
     """Same contract and (up to fp reassociation) same outputs as synth_codedtext2mel.
     forced_prev_max: optional (steps,B) int array -- teacher-forced attention
     positions (separates numerics from argmax flips in parity tests).
@@ -360,7 +360,9 @@ def synth_codedtext2mel_incremental(hp, W, K, V, ends, speakers=None, stop=True,
     ends = np.asarray(ends)
     t_ends = np.ones(ends.shape, dtype=int) * T
     ae = "Text2Mel/AudioEnc"
-    for j in range(T):
+    import time as _time
+    for j in range(T if max_steps is None else min(T, max_steps)):
+        _t0 = _time.perf_counter()
         x = Y[:, j - 1] if j > 0 else np.zeros((B, hp.n_mels), F32)
         i = 1
         x = _inc_conv1d(st, "%s/C_%d" % (ae, i), x, j, W, relu); i += 1
@@ -388,6 +390,8 @@ def synth_codedtext2mel_incremental(hp, W, K, V, ends, speakers=None, stop=True,
         for b in range(B):
             if t_ends[b] == T and reached[b]:
                 t_ends[b] = j
+        if step_times is not None:
+            step_times.append(_time.perf_counter() - _t0)
         if stop and (t_ends < T).all():
             break
     return Y, t_ends.tolist(), alignments
