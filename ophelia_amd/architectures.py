@@ -10,6 +10,7 @@ import os
 import sys
 
 from .engine import Engine
+from . import tf_checkpoint
 from . import weights as WT
 
 
@@ -84,7 +85,11 @@ MODEL_TYPES = {"t2m": "Text2Mel", "ssrn": "SSRN"}
 
 
 def _load_scope(sess, path, scope):
-    W = WT.load_npz(path)
+    """path: a TF-1 checkpoint prefix (<path>.index + .data-*) or an .npz keyed by TF variable names."""
+    W = WT.load_npz(path) if path.endswith(".npz") else tf_checkpoint.read_checkpoint(path, scope=scope + "/")
+    missing = [n for n, _ in sess.inventory(scope) if n not in W]
+    if missing:
+        sys.exit("checkpoint %s lacks %d variables of scope %s (first: %s)" % (path, len(missing), scope, missing[0]))
     sess.assign({n: W[n] for n, _ in sess.inventory(scope)})
 
 
@@ -104,14 +109,15 @@ def latest_checkpoint(savepath):
 
 
 def restore_latest_model_parameters(sess, hp, model_type):
-    """synthesize.py:302-316.  Variables live in {hp.logdir}-{t2m|ssrn}/model_epoch_{E}.npz keyed by
-    the TF variable names (a TF-free tensor-bundle reader is the 'next' row f-1 of SURVEY.md 8f)."""
+    """synthesize.py:302-316.  Looks in {hp.logdir}-{t2m|ssrn}/ first for a TF-1 checkpoint (the `checkpoint`
+    state file names model_epoch_{E}; read TF-free by tf_checkpoint.py), then for model_epoch_{E}.npz keyed by
+    the TF variable names."""
     scope = MODEL_TYPES[model_type]
     savepath = hp.logdir + "-" + model_type
-    ckpt = latest_checkpoint(savepath)
+    ckpt = tf_checkpoint.latest_checkpoint(savepath) or latest_checkpoint(savepath)
     if ckpt is None:
         sys.exit("No %s at %s?" % (model_type, savepath))
-    latest_epoch = os.path.basename(ckpt)[:-4].replace("model_epoch_", "")
+    latest_epoch = ckpt.strip("/ ").split("/")[-1].replace("model_epoch_", "").replace(".npz", "")
     _load_scope(sess, ckpt, scope)
     print("Model of type %s restored from latest epoch %s" % (model_type, latest_epoch))
     return latest_epoch
@@ -121,7 +127,10 @@ def restore_archived_model_parameters(sess, hp, model_type, epoch_number):
     """synthesize.py:319-330."""
     scope = MODEL_TYPES[model_type]
     desired = hp.logdir + "-" + model_type + "/archive/model_epoch_" + str(epoch_number)
-    if not os.path.isfile(desired + ".npz"):
+    if os.path.isfile(desired + ".index"):
+        _load_scope(sess, desired, scope)
+    elif os.path.isfile(desired + ".npz"):
+        _load_scope(sess, desired + ".npz", scope)
+    else:
         sys.exit("No %s at %s?" % (model_type, desired))
-    _load_scope(sess, desired + ".npz", scope)
     print("Model of type %s restored from archived epoch %s" % (model_type, epoch_number))
