@@ -42,6 +42,26 @@ def test_synthesize_driver_outputs(tmp_path):
     assert len(os.listdir(outdir)) == 8
 
 
+def test_synthesize_from_tf_format_checkpoints(tmp_path):
+    """CLI-level restore path: latest t2m checkpoint + archived ssrn epoch, both in TF tensor-bundle format."""
+    from ophelia_amd import synthesize as S, tf_checkpoint as T
+    hp = _hp()
+    hp.logdir = str(tmp_path / "work" / "train")
+    hp.sampledir = str(tmp_path / "work" / "synth")
+    W = O.random_weights(hp, 41)
+    adam = {n + "/Adam": np.zeros_like(v) for n, v in W.items()}           # optimizer slots must be ignored
+    T.write_checkpoint(hp.logdir + "-t2m/model_epoch_3", {**{n: v for n, v in W.items() if n.startswith("Text2Mel")}, **adam})
+    T.write_checkpoint(hp.logdir + "-ssrn/archive/model_epoch_5", {n: v for n, v in W.items() if n.startswith("SSRN")})
+    outdir = S.synthesize(hp, num_sentences=2, ssrn_epoch=5)
+    assert outdir == os.path.join(hp.sampledir, "t2m3_ssrn5")
+    ref = S.synthesize(hp, num_sentences=2, topoutdir=str(tmp_path / "ref"), weights=W)
+    for f in sorted(os.listdir(ref)):
+        assert np.array_equal(np.load(os.path.join(ref, f)), np.load(os.path.join(outdir, f))), f
+    hp.logdir = str(tmp_path / "nowhere" / "train")
+    with pytest.raises(SystemExit, match="No t2m at"):
+        S.synthesize(hp, num_sentences=2)
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
