@@ -268,9 +268,11 @@ def _make_block(items, restart_interval=16):
     return bytes(out)
 
 
-def write_checkpoint(prefix, W, block_entries=64):
+def write_checkpoint(prefix, W, block_entries=64, data_crc=True):
     """Write {name: ndarray} as <prefix>.index + <prefix>.data-00000-of-00001 (uncompressed blocks) and
-    update <dir>/checkpoint.  Used by the tests and to export weights in the reference's format."""
+    update <dir>/checkpoint.  Used by the tests and to export weights in the reference's format.
+    data_crc=False skips the per-tensor CRC32C (pure-Python, ~4 MB/s): fine for this module's reader, but
+    TensorFlow verifies it, so keep the default when exporting for TensorFlow."""
     os.makedirs(os.path.dirname(prefix) or ".", exist_ok=True)
     names = sorted(W, key=lambda s: s.encode("utf-8"))
     items, offset = [], 0
@@ -281,7 +283,7 @@ def write_checkpoint(prefix, W, block_entries=64):
             shape = b"".join(_pb_bytes_field(2, _pb_varint_field(1, int(d))) for d in a.shape)
             entry = (_pb_varint_field(1, _DT_INV[a.dtype]) + _pb_bytes_field(2, shape) +
                      (_pb_varint_field(4, offset) if offset else b"") + _pb_varint_field(5, len(raw)) +
-                     _put_varint((6 << 3) | 5) + struct.pack("<I", mask_crc(crc32c(raw))))
+                     (_put_varint((6 << 3) | 5) + struct.pack("<I", mask_crc(crc32c(raw))) if data_crc else b""))
             items.append((n.encode("utf-8"), entry))
             fd.write(raw)
             offset += len(raw)

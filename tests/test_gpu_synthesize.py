@@ -50,8 +50,8 @@ def test_synthesize_from_tf_format_checkpoints(tmp_path):
     hp.sampledir = str(tmp_path / "work" / "synth")
     W = O.random_weights(hp, 41)
     adam = {n + "/Adam": np.zeros_like(v) for n, v in W.items()}           # optimizer slots must be ignored
-    T.write_checkpoint(hp.logdir + "-t2m/model_epoch_3", {**{n: v for n, v in W.items() if n.startswith("Text2Mel")}, **adam})
-    T.write_checkpoint(hp.logdir + "-ssrn/archive/model_epoch_5", {n: v for n, v in W.items() if n.startswith("SSRN")})
+    T.write_checkpoint(hp.logdir + "-t2m/model_epoch_3", {**{n: v for n, v in W.items() if n.startswith("Text2Mel")}, **adam}, data_crc=False)
+    T.write_checkpoint(hp.logdir + "-ssrn/archive/model_epoch_5", {n: v for n, v in W.items() if n.startswith("SSRN")}, data_crc=False)
     outdir = S.synthesize(hp, num_sentences=2, ssrn_epoch=5)
     assert outdir == os.path.join(hp.sampledir, "t2m3_ssrn5")
     ref = S.synthesize(hp, num_sentences=2, topoutdir=str(tmp_path / "ref"), weights=W)
