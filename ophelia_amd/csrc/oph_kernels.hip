@@ -873,12 +873,28 @@ constexpr int RC_XMAX = 1024;
 __global__ __launch_bounds__(64 * RC_WAVES) void row_chain(RowChainArgs a) {
     __shared__ __attribute__((aligned(16))) float xs[2][RC_XMAX];
     __shared__ __attribute__((aligned(16))) float part[RC_WAVES][256];
-    __shared__ __attribute__((aligned(16))) float ys[256];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b = blockIdx.x;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const int stop_v = a.stop_after ? *a.stop_after : 0x7fffffff;
     const bool live = a.t <= stop_v;
     int cur = 0;
+    // Stage weights do not depend on activations: all 16 rows of a wave's K-slice are requested one stage ahead
+    // (stage 0: before the prologue; stage l+1: right after stage l's FMAs), so their L2/MALL round trip hides
+    // behind the prologue or behind the previous stage's reduce + LayerNorm barriers instead of being paid twice
+    // per stage (micro-benchmark: a cold 256 KB block costs ~1.3 us per exposed round trip).
+    f32x4 wA[8], wB[8];
+    const int col = lane * 4;
+    const int wu = __builtin_amdgcn_readfirstlane(w);      // wave index as a scalar: row pointers live in SGPRs
+#define RC_FETCH_STAGE(LREF, BASE)   /* rows BASE..BASE+15 of this wave's K slice -> wA (8), wB (8) */   \
+    {                                                                                                 \
+        const int kr_ = (LREF).kc / RC_WAVES, ldn_ = (LREF).ldn;                                      \
+        const float* rowp_ = (LREF).W + (size_t)(wu * kr_ + (BASE)) * ldn_ + col;                     \
+        const bool colok_ = col < (LREF).N;                                                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                            \
+            wA[i_] = (colok_ && (BASE) + i_ < kr_) ? *(const f32x4*)(rowp_ + (size_t)i_ * ldn_) : zero4;        \
+            wB[i_] = (colok_ && (BASE) + 8 + i_ < kr_) ? *(const f32x4*)(rowp_ + (size_t)(8 + i_) * ldn_) : zero4; \
+        }                                                                                             \
+    }
     // ---------------- prologue -> xs[0][0 .. kc0)
     const int kc0 = a.L[0].kc;
     if (a.pro == ROW_COPY) {
@@ -966,42 +982,43 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain(RowChainArgs a) {
             }
         }
     }
+    RC_FETCH_STAGE(a.L[0], 0);      // (holding 16 rows across the prologue would spill at the 128-VGPR cap of 1024 threads)
     __syncthreads();
     // ---------------- stages
     for (int li = 0; li < a.nlayers; ++li) {
         const RowLayer& L = a.L[li];
-        const int kr = L.kc / RC_WAVES, k0 = w * kr, col = lane * 4;
+        const int kr = L.kc / RC_WAVES, k0 = w * kr;
+        // bias / gamma / beta are needed only after the barriers below: request them now so that their
+        // global round trips are not exposed between the barriers
+        f32x4 gv = zero4, bv = zero4, biasv = zero4;
+        if (w == 0 && col < L.N) { gv = *(const f32x4*)(L.g + col); bv = *(const f32x4*)(L.b + col); biasv = *(const f32x4*)(L.bias + col); }
         f32x4 acc = zero4;
-        if (col < L.N) {
-            const float* wp = L.W + (size_t)k0 * L.ldn + col;
-            for (int base = 0; base < kr; base += 8) {
-                f32x4 wv[8];
+        for (int base = 0; base < kr; base += 16) {
+            if (base > 0) RC_FETCH_STAGE(L, base);            // K slices longer than 16 rows (kc > 256): exposed fetch
 #pragma unroll
-                for (int i = 0; i < 8; ++i) wv[i] = base + i < kr ? *(const f32x4*)(wp + (size_t)(base + i) * L.ldn) : zero4;
+            for (int i = 0; i < 8; ++i) {
+                const float xa = base + i < kr ? xs[cur][k0 + base + i] : 0.f;
+                const float xb = base + 8 + i < kr ? xs[cur][k0 + base + 8 + i] : 0.f;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float xk = base + i < kr ? xs[cur][k0 + base + i] : 0.f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[e] += xk * wv[i][e];
-                }
+                for (int e = 0; e < 4; ++e) acc[e] += xa * wA[i][e] + xb * wB[i][e];
             }
-            *(f32x4*)(&part[w][col]) = acc;
         }
-        __syncthreads();
-        if (tid < L.N) {
-            float y = L.bias[tid];
-#pragma unroll
-            for (int ww = 0; ww < RC_WAVES; ++ww) y += part[ww][tid];
-            ys[tid] = y;
-        }
+        if (col < L.N) *(f32x4*)(&part[w][col]) = acc;
+        if (li + 1 < a.nlayers) RC_FETCH_STAGE(a.L[li + 1], 0);   // prefetch: lands during the barriers below
         __syncthreads();
         const int nxt = cur ^ 1;
         const bool last = li + 1 == a.nlayers;
         const int kc_next = last ? (a.xout ? a.ldout : L.N) : a.L[li + 1].kc;
         if (w == 0) {
+            // wave 0 reduces the 16 K-slice partials of its own 4 columns and goes straight into the LayerNorm
             f32x4 v = zero4;
+            if (col < L.N) {
+                v = biasv;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = col + e < L.N ? ys[col + e] : 0.f;
+                for (int ww = 0; ww < RC_WAVES; ++ww) v += *(const f32x4*)(&part[ww][col]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (col + e >= L.N) v[e] = 0.f;
+            }
             float s = v[0] + v[1] + v[2] + v[3];
             const float mean = wave_sum(s) / (float)L.N;
             float qq = 0.f;
@@ -1010,7 +1027,7 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain(RowChainArgs a) {
             const float rstd = 1.0f / sqrtf(wave_sum(qq) / (float)L.N + LN_EPS);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                v[e] = col + e < L.N ? apply_act(v[e] * rstd * L.g[col + e] + L.b[col + e], L.act) : 0.f;
+                v[e] = col + e < L.N ? apply_act(v[e] * rstd * gv[e] + bv[e], L.act) : 0.f;
             if (col < RC_XMAX && col < ((kc_next + 3) & ~3)) *(f32x4*)(&xs[nxt][col]) = v;
             for (int c = 256 + lane; c < kc_next; c += 64) xs[nxt][c] = 0.f;
             if (!last && a.L[li + 1].ccat > 0) {     // speaker embedding appended to the next layer's input
