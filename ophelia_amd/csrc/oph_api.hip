@@ -99,6 +99,7 @@ struct oph_handle {
     float* emb_text = nullptr;       // (vocab, e)
     float* emb_spk = nullptr;        // (nspeakers, spk_emb)   AudioDec/embed_2
     std::vector<void*> allocs;
+    size_t n_weight_allocs = 0;       // allocs[0 .. n_weight_allocs) are the packed weights (live as long as the handle)
     // batched workspaces
     int capB = 0;
     float *actA = nullptr, *actB = nullptr, *raw = nullptr;   // workspace of the API stream (TextEnc, host-buffer SSRN)
@@ -473,7 +474,17 @@ int idx_of(const std::vector<int>& v, int x) {
 int ensure_decode_state(oph_handle* h, int B) {
     const int Bpad = round_up(B, 16);
     if (h->Bpad == Bpad && h->KV) { h->B = B; return 0; }
-    if (h->KV) { h->fail("batch size changed from %d to %d rows: create a new handle", h->Bpad, Bpad); return OPH_ERR_STATE; }
+    if (h->KV) {
+        // a different number of 16-row tiles: release the per-batch state and the workspaces and rebuild them
+        for (hipStream_t st : {h->stream, h->sdec, h->scone, h->sssrn}) if (st) hipStreamSynchronize(st);
+        for (size_t i = h->n_weight_allocs; i < h->allocs.size(); ++i) hipFree(h->allocs[i]);
+        h->allocs.resize(h->n_weight_allocs);
+        h->ae_hist.clear(); h->ae_raw.clear(); h->ad_raw.clear(); h->ad_xrow.clear();
+        h->cone[0].clear(); h->cone[1].clear(); h->d_tab.clear(); h->d_need.clear(); h->d_res.clear(); h->Hset.clear();
+        for (auto& ge : h->dec_graph) if (ge) { hipGraphExecDestroy(ge); ge = nullptr; }
+        h->KV = nullptr; h->capB = 0; h->actA = h->actB = h->raw = h->actA2 = h->actB2 = h->raw2 = nullptr;
+        h->pipelined = false; h->buf = 0; h->ssrn_inflight[0] = h->ssrn_inflight[1] = false;
+    }
     const oph_dims& m = h->dm;
     const int d = m.d;
     h->B = B; h->Bpad = Bpad;
@@ -1020,6 +1031,7 @@ int oph_finalize_weights(oph_handle* h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     h->hostw.clear();
+    h->n_weight_allocs = h->allocs.size();
     h->finalized = true;
     return OPH_OK;
 }

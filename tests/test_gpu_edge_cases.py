@@ -97,6 +97,15 @@ def test_engine_reuse_across_batches_and_validation():
         K0, V0 = O.encode_text(hp, W, L)
         Y0, t0, al0 = O.synth_codedtext2mel_incremental(hp, W, K0, V0, ends, stop=False)
         assert np.abs(Y - Y0).max() < TOL and t_ends.tolist() == t0
+    # a batch with a different number of 16-row tiles on the same handle (state is rebuilt), then back again
+    for B, seed in ((20, 3), (4, 4)):
+        L = O.random_text(hp, B, seed, min_len=4, max_len=30)
+        ends = O.get_text_lengths(L)
+        K, V = eng.encode_text(L)
+        Y, t_ends, al, steps = eng.text2mel(K, V, ends, stop_mode=1)
+        K0, V0 = O.encode_text(hp, W, L)
+        Y0, t0, al0 = O.synth_codedtext2mel_incremental(hp, W, K0, V0, ends, stop=False)
+        assert np.abs(K - K0).max() < TOL and np.abs(Y - Y0).max() < TOL and t_ends.tolist() == t0
     with pytest.raises(_lib.OpheliaHipError, match="out of range"):
         eng.encode_text(np.full((2, 32), 999, np.int32))
     with pytest.raises(_lib.OpheliaHipError):
