@@ -116,6 +116,10 @@ int oph_fetch_kv(oph_handle* h, float* K, float* V);
 int oph_fetch_mel(oph_handle* h, float* Y, int32_t* t_ends, float* alignments);
 int oph_fetch_mag(oph_handle* h, float* Z);
 int oph_synchronize(oph_handle* h);
+/* Device address of the SSRN output of the last resident run: (B, r*max_T, full_dim) fp32, utterance b at
+ * *d_mag + b * *utt_stride floats.  Synchronises first; valid until the next run on this handle.  Lets the vocoder
+ * library (ophelia_vocoder.h) consume Z without the host round trip of synthesize.py:585-617. */
+int oph_device_mag(oph_handle* h, const float** d_mag, int64_t* utt_stride, int32_t* B);
 /* SSRN contraction arithmetic: 1 (default) = each fp32 operand split into hi+lo bf16, a.b ~ ah.bh+ah.bl+al.bh on the
  * bf16 MFMA with fp32 accumulation (~1e-5 relative); 0 = exact fp32 MFMA.  Text2Mel is always exact fp32 (its
  * attention argmax feeds back into the decode). */

@@ -50,6 +50,7 @@ SIGNATURES = {
     "oph_fetch_mel": (C.c_int, [C.c_void_p, c_f32p, c_i32p, c_f32p]),
     "oph_fetch_mag": (C.c_int, [C.c_void_p, c_f32p]),
     "oph_synchronize": (C.c_int, [C.c_void_p]),
+    "oph_device_mag": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i64p, c_i32p]),
     "oph_set_ssrn_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "oph_timer_start": (C.c_int, [C.c_void_p]),
     "oph_timer_stop": (C.c_int, [C.c_void_p, c_f32p]),
@@ -66,29 +67,62 @@ SIGNATURES = {
     "oph_op_last_error": (C.c_char_p, []),
 }
 
+
+
+class OphGLParams(C.Structure):
+    _fields_ = [("n_fft", C.c_int32), ("hop_length", C.c_int32), ("win_length", C.c_int32), ("n_iter", C.c_int32),
+                ("power", C.c_float), ("preemphasis", C.c_float), ("max_db", C.c_float), ("ref_db", C.c_float)]
+
+
+# every symbol declared in include/ophelia_vocoder.h
+VOCODER_LIBPATH = os.path.join(LIBDIR, "libophelia_vocoder.so")
+VOCODER_SOURCES = ["oph_vocoder.hip"]
+VOCODER_SIGNATURES = {
+    "oph_vocoder_abi_version": (C.c_int, []),
+    "oph_vocoder_create": (C.c_int, [C.POINTER(OphGLParams), C.c_int, C.POINTER(C.c_void_p)]),
+    "oph_vocoder_destroy": (C.c_int, [C.c_void_p]),
+    "oph_vocoder_last_error": (C.c_char_p, [C.c_void_p]),
+    "oph_spectrogram2wav": (C.c_int, [C.c_void_p, c_f32p, c_i32p, C.c_int, c_f32p]),
+    "oph_spectrogram2wav_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, c_i32p, C.c_int, c_f32p]),
+    "oph_vocoder_griffin_lim": (C.c_int, [C.c_void_p, c_f32p, c_i32p, C.c_int, C.c_int, c_f32p]),
+    "oph_vocoder_stft": (C.c_int, [C.c_void_p, c_f32p, C.c_int64, c_f32p]),
+    "oph_vocoder_istft": (C.c_int, [C.c_void_p, c_f32p, C.c_int, c_f32p]),
+    "oph_vocoder_deemphasis": (C.c_int, [C.c_void_p, c_f32p, C.c_int64, c_f32p]),
+    "oph_vocoder_last_device_ms": (C.c_int, [C.c_void_p, c_f32p]),
+}
+
 _lib = None
+_vlib = None
 
 
 class OpheliaHipError(RuntimeError):
     pass
 
 
-def build(verbose=False):
-    """Compile the HIP extension for gfx950 in-tree (cross-compiles without a GPU)."""
-    os.makedirs(LIBDIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "oph_internal.h"),
-                   os.path.join(os.path.dirname(HERE), "include", "ophelia_hip.h")]
-    if os.path.exists(LIBPATH) and all(os.path.getmtime(LIBPATH) >= os.path.getmtime(d) for d in deps):
-        return LIBPATH
+def _hipcc_shared(out, srcs, deps, extra, verbose):
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", "-Wno-unused-result"] + srcs + ["-o", LIBPATH]
+           "-Wno-unused-value", "-Wno-unused-result"] + srcs + extra + ["-o", out]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout)
     if res.returncode != 0:
-        raise OpheliaHipError("hipcc failed building libophelia_hip.so")
+        raise OpheliaHipError("hipcc failed building %s" % os.path.basename(out))
+    return out
+
+
+def build(verbose=False):
+    """Compile the HIP extensions for gfx950 in-tree (cross-compiles without a GPU)."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    _hipcc_shared(LIBPATH, srcs, srcs + [os.path.join(CSRC, "oph_internal.h"), os.path.join(inc, "ophelia_hip.h")],
+                  [], verbose)
+    vsrcs = [os.path.join(CSRC, s) for s in VOCODER_SOURCES]
+    _hipcc_shared(VOCODER_LIBPATH, vsrcs, vsrcs + [os.path.join(inc, "ophelia_vocoder.h")],
+                  ["-L/opt/rocm/lib", "-lhipfft", "-Wl,-rpath,/opt/rocm/lib"], verbose)
     return LIBPATH
 
 
@@ -109,6 +143,26 @@ def load():
     if lib.oph_abi_version() != 1:
         raise OpheliaHipError("ABI version mismatch")
     _lib = lib
+    return lib
+
+
+def load_vocoder():
+    """Load libophelia_vocoder.so (Griffin-Lim).  Raises if it is not built."""
+    global _vlib
+    if _vlib is not None:
+        return _vlib
+    if not os.path.exists(VOCODER_LIBPATH):
+        raise OpheliaHipError(
+            "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)" % VOCODER_LIBPATH)
+    lib = C.CDLL(VOCODER_LIBPATH)
+    for name, (res, args) in VOCODER_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.oph_vocoder_abi_version() != 1:
+        raise OpheliaHipError("vocoder ABI version mismatch")
+    _vlib = lib
     return lib
 
 

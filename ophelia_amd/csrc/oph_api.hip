@@ -1167,6 +1167,17 @@ int oph_fetch_mag(oph_handle* h, float* Z) {
     return OPH_OK;
 }
 
+int oph_device_mag(oph_handle* h, const float** d_mag, int64_t* utt_stride, int32_t* B) {
+    if (!h || !h->KV || !h->Z || !d_mag) { if (h) h->fail("no staged batch / null"); return OPH_ERR_STATE; }
+    if (h->sssrn) HIPCHK(h, hipStreamSynchronize(h->sssrn));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const oph_dims& m = h->dm;
+    *d_mag = h->Z;
+    if (utt_stride) *utt_stride = (int64_t)m.max_T * m.r * m.full_dim;
+    if (B) *B = h->B;
+    return OPH_OK;
+}
+
 // ---- host-buffer session calls ---------------------------------------------------------------
 int oph_encode_text(oph_handle* h, const int32_t* L, const int32_t* spk, int B, float* K, float* V) {
     int rc = check_ready(h, B);

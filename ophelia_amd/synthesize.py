@@ -8,11 +8,12 @@ make_mel_batch 270-285, list2batch 287-299, restore_* 302-330, synth_wave 433-44
            [-t2m_epoch e] [-ssrn_epoch e] [-max_N n] [-max_T t] [-tr transcript] [-ncores k]
 
 Same flags, same output directory naming ({sampledir|odir/cfg}/t2m{E}_ssrn{E}[_speaker-{id}]/),
-same trimming rules.  Scope differences: Griffin-Lim / WORLD vocoding, alignment
-plots and the CDP/Ain diagnostics are not part of the hot path -- the driver writes the trimmed
-magnitude spectrogram {base}.npy (what hp.store_synth_features stores, synthesize.py:436-437)
-and the trimmed mel {base}.mel.npy instead of a .wav.  Under torchrun (WORLD_SIZE>1) the
-utterances are sharded over the GPUs of the node (ophelia_amd.parallel).
+same trimming rules, same {base}.wav files (16-bit PCM) from Griffin-Lim -- which runs batched on the GPU
+(ophelia_amd.vocoder) instead of on `-ncores` CPU processes -- and the same per-utterance
+"File | CDP | Ain" report.  With hp.store_synth_features the trimmed magnitudes {base}.npy are stored as in the
+reference (synthesize.py:436-437), plus {base}.mel.npy and {base}.alignment.npy.  Not provided: the WORLD vocoder
+(external binaries) and the alignment PNGs (matplotlib).  Under torchrun (WORLD_SIZE>1) the utterances are sharded
+over the GPUs of the node (ophelia_amd.parallel).
 """
 from __future__ import print_function
 
@@ -25,8 +26,10 @@ import numpy as np
 
 from . import _lib
 from . import parallel
+from . import vocoder
 from .architectures import (SSRNGraph, Session, Text2MelGraph, restore_archived_model_parameters,
                             restore_latest_model_parameters)
+from .calculate_CDP_Ain_Aout import getAP, getCDP
 from .configuration import load_config
 from .data_load import load_data
 from .libutil import basename, safe_makedir
@@ -139,11 +142,38 @@ def list2batch(inlist, pad_length):
     return batch
 
 
-def synth_wave(hp, mag, outfile):
-    """Vocoding is outside the hot path: store the trimmed magnitudes the reference stores when
-    hp.store_synth_features is set (same file name: {base}.npy)."""
-    assert hp.vocoder in ["griffin_lim", "world"], "Other vocoders than griffin_lim/world not yet supported"
-    np.save(outfile.replace(".wav", ".npy"), mag)
+# utterances vocoded per Griffin-Lim launch are bounded by this many spectrogram frames (~30 KB of HBM per frame)
+GL_MAX_FRAMES_PER_CALL = 32768
+
+
+def synth_wave(hp, mag, outfile, wav=None):
+    """synthesize.py:433-440.  `wav` may carry the already (batch-)vocoded samples for this utterance."""
+    if hp.vocoder == "griffin_lim":
+        if wav is None:
+            wav = vocoder.spectrogram2wav(hp, mag, device=int(os.environ.get("LOCAL_RANK", "0")))
+        if hp.store_synth_features:          # To synthesize using WaveRNN save the mag spectrum created by SSRN
+            np.save(outfile.replace(".wav", ".npy"), mag)
+        vocoder.write_wav(outfile, wav, hp.sr)
+    elif hp.vocoder == "world":
+        raise NotImplementedError("the WORLD vocoder shells out to external binaries (synthesize.py:366-430); "
+                                  "only hp.vocoder == 'griffin_lim' is supported")
+
+
+def synth_waves(hp, mags, outfiles, device=0):
+    """The loop of synthesize.py:604-617 with the utterances vocoded together on the GPU instead of one process per
+    utterance (`-ncores`)."""
+    if hp.vocoder != "griffin_lim":
+        return [synth_wave(hp, m, f) for m, f in zip(mags, outfiles)]
+    voc = vocoder._vocoder_for(hp, device)
+    i = 0
+    while i < len(mags):
+        j, frames = i, 0
+        while j < len(mags) and (j == i or frames + len(mags[j]) <= GL_MAX_FRAMES_PER_CALL):
+            frames += len(mags[j])
+            j += 1
+        for m, f, w in zip(mags[i:j], outfiles[i:j], voc.spectrogram2wav_batch(mags[i:j])):
+            synth_wave(hp, m, f, wav=w)
+        i = j
 
 
 def synthesize(hp, speaker_id="", num_sentences=0, ncores=1, topoutdir="", t2m_epoch=-1, ssrn_epoch=-1,
@@ -211,12 +241,23 @@ def synthesize(hp, speaker_id="", num_sentences=0, ncores=1, topoutdir="", t2m_e
         if speaker_id:
             outdir += "_speaker-%s" % (speaker_id)
         safe_makedir(outdir)
-        print("Generating feature files, will save to following dir: %s" % (outdir))
-        for i, mag in enumerate(Z):
-            outfile = os.path.join(outdir, bases[i] + ".wav")
-            mag = mag[:lengths[i] * hp.r, :]                   # trim to generated length
-            synth_wave(hp, mag, outfile)
-            np.save(os.path.join(outdir, bases[i] + ".mel.npy"), Y[i, :lengths[i], :])
+        print("File |  CDP | Ain")
+        for i in range(len(Z)):
+            trimmed_alignment = alignments[i, :text_lengths[i], :lengths[i]]
+            CDP = getCDP(trimmed_alignment)
+            APin, APout = getAP(trimmed_alignment)
+            print("%s | %.2f | %.2f" % (bases[i], CDP, APin))
+            if hp.store_synth_features:
+                np.save(os.path.join(outdir, bases[i] + ".alignment.npy"), trimmed_alignment)
+
+        print("Generating wav files, will save to following dir: %s" % (outdir))
+        t = start_clock("Griffin-Lim generating...")
+        mags = [mag[:lengths[i] * hp.r, :] for i, mag in enumerate(Z)]          # trim to generated length
+        synth_waves(hp, mags, [os.path.join(outdir, b + ".wav") for b in bases], device=device)
+        stop_clock(t)
+        if hp.store_synth_features:
+            for i, b in enumerate(bases):
+                np.save(os.path.join(outdir, b + ".mel.npy"), Y[i, :lengths[i], :])
     return outdir
 
 
@@ -226,7 +267,7 @@ def main_work():
     a.add_argument("-speaker", default="", type=str)
     a.add_argument("-N", dest="num_sentences", default=0, type=int)
     a.add_argument("-babble", action="store_true")
-    a.add_argument("-ncores", type=int, default=1, help="Number of CPUs for Griffin-Lim stage (unused: vocoding is out of scope)")
+    a.add_argument("-ncores", type=int, default=1, help="Number of CPUs for Griffin-Lim stage (accepted and ignored: Griffin-Lim runs batched on the GPU)")
     a.add_argument("-odir", type=str, default="", help="Alternative place to put output samples")
     a.add_argument("-t2m_epoch", default=-1, type=int, help="Default: use latest (-1)")
     a.add_argument("-ssrn_epoch", default=-1, type=int, help="Default: use latest (-1)")

@@ -9,8 +9,8 @@ import pytest
 from conftest import ROOT
 
 
-def _declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "ophelia_hip.h")).read()
+def _declared_symbols(header="ophelia_hip.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(oph_[a-z0-9_]+)\s*\(", txt)))
 
@@ -25,6 +25,31 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), s
     assert set(syms) == set(_lib.SIGNATURES), set(syms) ^ set(_lib.SIGNATURES)
     assert lib.oph_abi_version() == 1
+
+
+def test_vocoder_library_exports_every_declared_symbol():
+    from ophelia_amd import _lib
+    _lib.build()
+    lib = C.CDLL(_lib.VOCODER_LIBPATH)
+    syms = _declared_symbols("ophelia_vocoder.h")
+    assert len(syms) >= 11
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert set(syms) == set(_lib.VOCODER_SIGNATURES), set(syms) ^ set(_lib.VOCODER_SIGNATURES)
+    assert lib.oph_vocoder_abi_version() == 1
+
+
+def test_vocoder_has_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from types import SimpleNamespace
+    from ophelia_amd import _lib
+    from ophelia_amd.vocoder import Vocoder
+    hp = SimpleNamespace(n_fft=2048, hop_length=275, win_length=1102, power=1.5, n_iter=50, preemphasis=0.97,
+                         max_db=100, ref_db=20, sr=22050)
+    with pytest.raises(_lib.OpheliaHipError, match="no usable HIP device"):
+        Vocoder(hp)
 
 
 def test_no_cpu_fallback_without_gpu():

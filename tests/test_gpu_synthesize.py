@@ -16,6 +16,7 @@ def _hp(max_T=24):
     from ophelia_amd.configuration import load_config
     hp = load_config(os.path.join(GOLDEN, "cfg_unit.cfg"))
     hp.max_T = max_T
+    hp.store_synth_features = True          # keep {base}.npy / .mel.npy / .alignment.npy next to the .wav
     return hp
 
 
@@ -31,6 +32,8 @@ def test_synthesize_driver_outputs(tmp_path):
     K, V = O.encode_text(hp, W, L)
     Y0, t_ends, _ = O.synth_codedtext2mel_incremental(hp, W, K, V, ends)
     Z0 = O.synth_mel2mag(hp, W, Y0)
+    import wave
+    from oracle import griffin_lim_oracle as GL
     names = ["LJ003-0043", "LJ050-0001", "LJ050-0002", "LJ050-0003"]
     for i, base in enumerate(names):
         mag = np.load(os.path.join(outdir, base + ".npy"))
@@ -39,7 +42,14 @@ def test_synthesize_driver_outputs(tmp_path):
         assert mel.shape == (t_ends[i], hp.n_mels)
         assert np.abs(mag - Z0[i, :t_ends[i] * hp.r]).max() < 1e-4
         assert np.abs(mel - Y0[i, :t_ends[i]]).max() < 1e-4
-    assert len(os.listdir(outdir)) == 8
+        with wave.open(os.path.join(outdir, base + ".wav"), "rb") as f:                     # synthesize.py:433-438
+            n = hp.hop_length * (t_ends[i] * hp.r - 1)
+            assert (f.getnchannels(), f.getsampwidth(), f.getframerate(), f.getnframes()) == (1, 2, hp.sr, n)
+            pcm = np.frombuffer(f.readframes(n), "<i2").astype(np.float64) / 32767.0
+        if i == 0:                                           # vocoder parity on the driver's own output (mag as stored)
+            ref = GL.spectrogram2wav(hp, mag)
+            assert np.abs(pcm - np.clip(ref, -1, 1)).max() <= 2e-3 * np.abs(ref).max() + 1.0 / 32767
+    assert len(os.listdir(outdir)) == 16
 
 
 def test_synthesize_from_tf_format_checkpoints(tmp_path):
@@ -56,7 +66,7 @@ def test_synthesize_from_tf_format_checkpoints(tmp_path):
     assert outdir == os.path.join(hp.sampledir, "t2m3_ssrn5")
     ref = S.synthesize(hp, num_sentences=2, topoutdir=str(tmp_path / "ref"), weights=W)
     for f in sorted(os.listdir(ref)):
-        assert np.array_equal(np.load(os.path.join(ref, f)), np.load(os.path.join(outdir, f))), f
+        assert open(os.path.join(ref, f), "rb").read() == open(os.path.join(outdir, f), "rb").read(), f
     hp.logdir = str(tmp_path / "nowhere" / "train")
     with pytest.raises(SystemExit, match="No t2m at"):
         S.synthesize(hp, num_sentences=2)
