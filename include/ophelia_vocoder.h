@@ -71,6 +71,11 @@ int oph_vocoder_stft(oph_vocoder* v, const float* y, int64_t len, float* D);
 int oph_vocoder_istft(oph_vocoder* v, const float* D, int n_frames, float* y);
 int oph_vocoder_deemphasis(oph_vocoder* v, const float* x, int64_t len, float* y);
 
+/* Implementation choice for griffin_lim / spectrogram2wav: 0 (default) = the fused in-LDS iteration kernel when
+ * n_fft == 2048 (every shipped config but one), else the generic path; 1 = always the generic path (hipFFT batched
+ * transforms + streaming kernels).  Both implement the same arithmetic; env OPH_VOCODER_BACKEND sets the initial value. */
+int oph_vocoder_set_backend(oph_vocoder* v, int backend);
+
 /* Device time (ms, HIP events on the vocoder's stream) of the last spectrogram2wav / griffin_lim call, excluding the
  * host<->device copies. */
 int oph_vocoder_last_device_ms(const oph_vocoder* v, float* ms);

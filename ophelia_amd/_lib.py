@@ -88,6 +88,7 @@ VOCODER_SIGNATURES = {
     "oph_vocoder_stft": (C.c_int, [C.c_void_p, c_f32p, C.c_int64, c_f32p]),
     "oph_vocoder_istft": (C.c_int, [C.c_void_p, c_f32p, C.c_int, c_f32p]),
     "oph_vocoder_deemphasis": (C.c_int, [C.c_void_p, c_f32p, C.c_int64, c_f32p]),
+    "oph_vocoder_set_backend": (C.c_int, [C.c_void_p, C.c_int]),
     "oph_vocoder_last_device_ms": (C.c_int, [C.c_void_p, c_f32p]),
 }
 

@@ -14,6 +14,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -45,6 +46,8 @@ enum { OPHV_OK = 0, OPHV_ERR_INVALID = -1, OPHV_ERR_STATE = -2, OPHV_ERR_DEVICE 
 
 struct Tables {            // per-batch tables in device memory
     int* frame_utt = nullptr;     // [G]   utterance of global frame g
+    int4* meta = nullptr;         // [G]   {frame index in its utterance, frames of the utterance, first global frame,
+                                  //        first sample of the utterance in y}: one 16-byte load per frame
     int* foff = nullptr;          // [B+1] first global frame of utterance b
     long long* yoff = nullptr;    // [B+1] first sample of utterance b in y / wav
     long long* src_off = nullptr; // [B]   float offset of utterance b's first row in the source spectrogram
@@ -69,6 +72,12 @@ struct oph_vocoder {
     Tables t;
     hipfftHandle plan_c2r = 0, plan_r2c = 0;
     long long planG = 0;
+    // fused path (n_fft == 2048): windowed inverse-transform segments, ping-pong, [G][wstride]; window-sum-square [Y]
+    int backend = 0;                 // 0 = auto (fused when n_fft == 2048), 1 = hipFFT path
+    int wstride = 0;
+    long long capGF = 0, capYF = 0;
+    float *wseg[2] = {nullptr, nullptr}, *wss = nullptr, *d_wsup = nullptr;
+    float2* d_tw = nullptr;          // W_2048^k, k < 1024
 };
 
 namespace {
@@ -95,7 +104,7 @@ __global__ __launch_bounds__(256) void gl_prepare(const float* __restrict__ src,
             s = m;
         }
         S[(long long)g * nbin + k] = s;
-        X[(long long)g * nbin + k] = make_float2(s, 0.f);
+        if (X) X[(long long)g * nbin + k] = make_float2(s, 0.f);
     }
 }
 
@@ -210,6 +219,226 @@ __global__ __launch_bounds__(64) void gl_deemphasis(const float* __restrict__ x,
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// fused Griffin-Lim iteration for n_fft = 2048: one workgroup owns one frame at a time and keeps it in LDS through
+//   gather(overlap-add of the neighbours' windowed segments, /wss, reflect pad, window) -> real FFT -> phase
+//   projection against S -> inverse real FFT -> window -> store this frame's windowed segment.
+// The only HBM traffic per frame and iteration is S (4.1 KB), the neighbour segments (L2/MALL hits, <= 5 x 4.4 KB)
+// and the 4.4 KB segment written.  The real transforms run as a 1024-point complex radix-4 Stockham FFT (5 passes,
+// one butterfly per thread, LDS ping-pong) with the even/odd split folded, together with the phase projection and the
+// inverse transform's split, into one in-place pass over bin pairs (k, 1024-k).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int FN = 2048, FH = 1024;
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+// LDS index swizzle of the two transform buffers: with it every ds_read_b64 / ds_write_b64 of the five radix-4 passes
+// is bank-conflict free (checked exhaustively against the CDNA4 lane-group / bank rules); a bijection inside each
+// block of 16 complex values, so the float view of a buffer stays pairwise contiguous.
+__device__ __forceinline__ int PX(int i) { return i ^ (((i >> 4) * 5) & 15); }
+
+// Twiddle table in LDS (float2 entries), one compact run per pass so that lanes read consecutive entries:
+//   pass Ns (4,16,64,256): entry (r-1)*Ns + k = W_2048^(k*r*512/Ns), r = 1..3          offsets 0, 12, 60, 252
+//   pair pass:             W_2048^k, k = 0..256                                        offset 1020
+constexpr int TW_PAIR = 1020, TW_TOTAL = 1280;
+__host__ __device__ constexpr int tw_off(int Ns) { return Ns == 4 ? 0 : Ns == 16 ? 12 : Ns == 64 ? 60 : 252; }
+
+template <bool INV, int Ns>
+__device__ __forceinline__ void fft_pass(const float2* __restrict__ in, float2* __restrict__ out, const float2* sT,
+                                         int tid) {
+    const int k = tid & (Ns - 1);
+    float2 v0 = in[PX(tid)], v1 = in[PX(tid + 256)], v2 = in[PX(tid + 512)], v3 = in[PX(tid + 768)];
+    if (Ns > 1) {
+        float2 t1 = sT[tw_off(Ns) + k], t2 = sT[tw_off(Ns) + Ns + k], t3 = sT[tw_off(Ns) + 2 * Ns + k];
+        if (INV) { t1.y = -t1.y; t2.y = -t2.y; t3.y = -t3.y; }
+        v1 = cmul(v1, t1); v2 = cmul(v2, t2); v3 = cmul(v3, t3);
+    }
+    const float2 a0 = cadd(v0, v2), a1 = csub(v0, v2), a2 = cadd(v1, v3), d = csub(v1, v3);
+    const float2 a3 = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);
+    const int j0 = ((tid - k) << 2) + k;
+    out[PX(j0)] = cadd(a0, a2);
+    out[PX(j0 + Ns)] = cadd(a1, a3);
+    out[PX(j0 + 2 * Ns)] = csub(a0, a2);
+    out[PX(j0 + 3 * Ns)] = csub(a1, a3);
+}
+
+__device__ __forceinline__ float2 project(float2 X, float s) {      // utils.py:104-105
+    const float a = fmaxf(1e-8f, sqrtf(X.x * X.x + X.y * X.y));
+    return make_float2(s * (X.x / a), s * (X.y / a));
+}
+
+// bins k and 1024-k (1 <= k <= 512): split the packed transform, project, re-pack for the inverse transform.
+// wk = W_2048^k.
+template <bool INIT>
+__device__ __forceinline__ void pair_pass(float2* Z, float2 wk, int k, float Sk, float Sp) {
+    float2 Pk, Pp;
+    if (!INIT) {
+        const float2 a = Z[PX(k)], b = cconj(Z[PX(FH - k)]);
+        const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
+        const float2 d = csub(a, b);
+        const float2 o = make_float2(0.5f * d.y, -0.5f * d.x);
+        const float2 wo = cmul(wk, o);
+        Pk = project(cadd(e, wo), Sk);
+        Pp = project(cconj(csub(e, wo)), Sp);
+    } else {
+        Pk = make_float2(Sk, 0.f);
+        Pp = make_float2(Sp, 0.f);
+    }
+    const float2 b2 = cconj(Pp);
+    const float2 e2 = cadd(Pk, b2);
+    const float2 t = cmul(cconj(wk), csub(Pk, b2));
+    const float2 o2 = make_float2(-t.y, t.x);
+    Z[PX(k)] = cadd(e2, o2);
+    if (k != FH / 2) Z[PX(FH - k)] = cconj(csub(e2, o2));
+}
+
+// overlap-add of the stored windowed segments at trimmed position n of an utterance (frames in ascending order),
+// normalised by the window-sum-square like librosa.istft.  32-bit index arithmetic: an utterance is < 2^31 samples.
+// Up to five overlapping frames (every shipped geometry) are loaded together; absent ones contribute +0.
+__device__ __forceinline__ float ola_at(const float* __restrict__ seg, const float* __restrict__ wss_b, int n, int F,
+                                        int hop, int lpad, int win, int wstride) {
+    const unsigned c = (unsigned)(n + FH - lpad);          // position relative to the start of frame 0's support
+    int fhi = (int)(c / (unsigned)hop);
+    int off = (int)(c - (unsigned)fhi * (unsigned)hop);    // offset inside frame fhi's segment (< hop <= win)
+    int flo = fhi;
+    while (flo > 0 && off + hop < win) { off += hop; --flo; }
+    if (fhi > F - 1) fhi = F - 1;
+    const int cnt = fhi - flo + 1;
+    const float* p = seg + (long long)flo * wstride + off;
+    const int step = wstride - hop;
+    const float ws = wss_b[n];
+    float acc = 0.f;
+    if (cnt <= 5) {
+        float v[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) v[i] = i < cnt ? p[(long long)i * step] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) acc += v[i];
+    } else {
+        for (int i = 0; i < cnt; ++i) acc += p[(long long)i * step];
+    }
+    if (ws > 1.17549435e-38f) acc /= ws;
+    return acc;
+}
+
+template <bool INIT>
+__global__ __launch_bounds__(256) void gl_fused(const float* __restrict__ S, const float* __restrict__ y,
+                                               float* __restrict__ seg_out, const int4* __restrict__ meta,
+                                               const float2* __restrict__ tw, const float* __restrict__ wsup, int G,
+                                               int hop, int lpad, int win, int wstride, int nbin) {
+    __shared__ float2 bufA[FH], bufB[FH], sT[TW_TOTAL];
+    extern __shared__ float sw[];                        // window support, win floats
+    const int tid = threadIdx.x;
+    for (int i = tid; i < TW_TOTAL; i += 256) sT[i] = tw[i];
+    for (int i = tid; i < win; i += 256) sw[i] = wsup[i];
+    float* Af = reinterpret_cast<float*>(bufA);
+    auto FX = [](int i) { return 2 * PX(i >> 1) + (i & 1); };      // float view of a swizzled complex buffer
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    const int chunk = (G + 7) / 8;
+    const int gend = min(G, (xcd + 1) * chunk);
+    int g = xcd * chunk + slot;
+    int4 md = g < gend ? meta[g] : make_int4(0, 2, 0, 0);
+    __syncthreads();
+    // W_2048^k for this thread's two bin pairs: k = tid+1 directly, k = tid+257 through W^k = -i conj(W^(512-k))
+    const float2 wk1 = sT[TW_PAIR + tid + 1];
+    const float2 wr = sT[TW_PAIR + 255 - tid];
+    const float2 wk2 = make_float2(-wr.y, -wr.x);
+    for (; g < gend; g += nslots) {
+        const int f = md.x, F = md.y, y0 = md.w;
+        if (g + nslots < gend) md = meta[g + nslots];    // next frame's descriptor travels during this frame
+        const float* Srow = S + (long long)g * nbin;
+        // requested now, consumed after the forward transform
+        const float s0 = Srow[0], sN = Srow[FH];
+        const float sk1 = Srow[tid + 1], sp1 = Srow[FH - 1 - tid];
+        const float sk2 = Srow[tid + 257], sp2 = Srow[FH - 257 - tid];
+        if (!INIT) {
+            // librosa.stft framing of the current signal: reflect padding + analysis window, zero outside the support
+            const int len = hop * (F - 1), period = 2 * (len - 1);
+            const float* yb = y + y0;
+            const int nbase = f * hop + lpad - FH;       // trimmed position of the first support sample
+            for (int i = tid; i < lpad; i += 256) Af[FX(i)] = 0.f;
+            for (int i = lpad + win + tid; i < FN; i += 256) Af[FX(i)] = 0.f;
+            if (nbase >= 0 && nbase + win <= len) {
+                for (int k = tid; k < win; k += 256) Af[FX(lpad + k)] = sw[k] * yb[nbase + k];
+            } else {
+                for (int k = tid; k < win; k += 256) {
+                    int n = nbase + k;
+                    if (n < 0 || n >= len) {                 // np.pad(mode='reflect'), repeated if needed
+                        if (len == 1) n = 0;
+                        else {
+                            n %= period;
+                            if (n < 0) n += period;
+                            if (n >= len) n = period - n;
+                        }
+                    }
+                    Af[FX(lpad + k)] = sw[k] * yb[n];
+                }
+            }
+            __syncthreads();
+            fft_pass<false, 1>(bufA, bufB, sT, tid);   __syncthreads();
+            fft_pass<false, 4>(bufB, bufA, sT, tid);   __syncthreads();
+            fft_pass<false, 16>(bufA, bufB, sT, tid);  __syncthreads();
+            fft_pass<false, 64>(bufB, bufA, sT, tid);  __syncthreads();
+            fft_pass<false, 256>(bufA, bufB, sT, tid); __syncthreads();
+        }
+        if (tid == 0) {
+            float P0 = s0, PN = sN;
+            if (!INIT) {
+                const float2 z = bufB[0];
+                const float x0 = z.x + z.y, xN = z.x - z.y;
+                P0 = s0 * (x0 / fmaxf(1e-8f, fabsf(x0)));
+                PN = sN * (xN / fmaxf(1e-8f, fabsf(xN)));
+            }
+            bufB[0] = make_float2(P0 + PN, P0 - PN);
+        }
+        pair_pass<INIT>(bufB, wk1, tid + 1, sk1, sp1);
+        pair_pass<INIT>(bufB, wk2, tid + 257, sk2, sp2);
+        __syncthreads();
+        fft_pass<true, 1>(bufB, bufA, sT, tid);   __syncthreads();
+        fft_pass<true, 4>(bufA, bufB, sT, tid);   __syncthreads();
+        fft_pass<true, 16>(bufB, bufA, sT, tid);  __syncthreads();
+        fft_pass<true, 64>(bufA, bufB, sT, tid);  __syncthreads();
+        fft_pass<true, 256>(bufB, bufA, sT, tid); __syncthreads();
+        float* out = seg_out + (long long)g * wstride;
+        for (int k = tid; k < win; k += 256) out[k] = sw[k] * (Af[FX(lpad + k)] * (1.0f / FN));
+        __syncthreads();
+    }
+}
+
+// window-sum-square at every kept sample (librosa.filters.window_sumsquare, float32, ascending frames)
+__global__ __launch_bounds__(256) void gl_wss(const float* __restrict__ w2, const int* __restrict__ foff,
+                                             const long long* __restrict__ yoff, float* __restrict__ wss, int n_fft,
+                                             int hop, int lpad, int win) {
+    const int b = blockIdx.y;
+    const int F = foff[b + 1] - foff[b];
+    const long long len = (long long)hop * (F - 1);
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= len) return;
+    const long long m = n + n_fft / 2;
+    long long flo = m - (lpad + win - 1);
+    flo = flo > 0 ? (flo + hop - 1) / hop : 0;
+    long long fhi = (m - lpad) / hop;
+    if (fhi > F - 1) fhi = F - 1;
+    float ws = 0.f;
+    for (long long f = flo; f <= fhi; ++f) ws += w2[m - f * hop];
+    wss[yoff[b] + n] = ws;
+}
+
+// final istft of the fused path: y[n] from the stored segments
+__global__ __launch_bounds__(256) void gl_ola_seg(const float* __restrict__ seg, const float* __restrict__ wss,
+                                                 const int* __restrict__ foff, const long long* __restrict__ yoff,
+                                                 float* __restrict__ y, int hop, int lpad, int win, int wstride) {
+    const int b = blockIdx.y;
+    const int F = foff[b + 1] - foff[b];
+    const long long len = (long long)hop * (F - 1);
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= len) return;
+    y[yoff[b] + n] = ola_at(seg + (long long)foff[b] * wstride, wss + yoff[b], (int)n, F, hop, lpad, win, wstride);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
@@ -228,6 +457,7 @@ struct Batch {
     long long G = 0, Y = 0;
     int maxF = 0;
     std::vector<int> foff, frame_utt;
+    std::vector<int4> meta;
     std::vector<long long> yoff;
 };
 
@@ -247,9 +477,14 @@ int plan_batch(oph_vocoder* v, const int32_t* n_frames, int B, Batch& bt) {
     }
     bt.G = bt.foff[B];
     bt.Y = bt.yoff[B];
+    if (bt.Y >= (1ll << 31)) { v->err = "batch too large: more than 2^31 samples"; return OPHV_ERR_INVALID; }
     bt.frame_utt.resize(bt.G);
+    bt.meta.resize(bt.G);
     for (int b = 0; b < B; ++b)
-        for (int g = bt.foff[b]; g < bt.foff[b + 1]; ++g) bt.frame_utt[g] = b;
+        for (int g = bt.foff[b]; g < bt.foff[b + 1]; ++g) {
+            bt.frame_utt[g] = b;
+            bt.meta[g] = make_int4(g - bt.foff[b], n_frames[b], bt.foff[b], (int)bt.yoff[b]);
+        }
     return OPHV_OK;
 }
 
@@ -264,6 +499,7 @@ int ensure_capacity(oph_vocoder* v, const Batch& bt) {
         if ((rc = dev_alloc(v, &v->tfr, G * n_fft, false))) return rc;
         if ((rc = dev_alloc(v, &v->wfr, G * n_fft, true))) return rc;
         if ((rc = dev_alloc(v, &v->t.frame_utt, G, true))) return rc;
+        if ((rc = dev_alloc(v, &v->t.meta, G, true))) return rc;
         v->capG = G;
     }
     if (bt.Y > v->capY) {
@@ -292,8 +528,26 @@ int ensure_capacity(oph_vocoder* v, const Batch& bt) {
     return OPHV_OK;
 }
 
+bool use_fused(const oph_vocoder* v) { return v->backend == 0 && v->p.n_fft == FN; }
+
+// buffers of the fused path: the windowed segments + the window-sum-square of every kept sample
+int ensure_capacity_fused(oph_vocoder* v, const Batch& bt) {
+    const long long G = (bt.G + 255) / 256 * 256;
+    int rc;
+    if (G > v->capGF) {
+        if ((rc = dev_alloc(v, &v->wseg[0], G * v->wstride, false))) return rc;
+        v->capGF = G;
+    }
+    if (bt.Y > v->capYF) {
+        if ((rc = dev_alloc(v, &v->wss, bt.Y, false))) return rc;
+        v->capYF = bt.Y;
+    }
+    return OPHV_OK;
+}
+
 int upload_tables(oph_vocoder* v, const Batch& bt, const std::vector<long long>& src_off) {
     VCHECK(hipMemcpyAsync(v->t.frame_utt, bt.frame_utt.data(), bt.G * sizeof(int), hipMemcpyHostToDevice, v->stream));
+    VCHECK(hipMemcpyAsync(v->t.meta, bt.meta.data(), bt.G * sizeof(int4), hipMemcpyHostToDevice, v->stream));
     VCHECK(hipMemcpyAsync(v->t.foff, bt.foff.data(), (bt.B + 1) * sizeof(int), hipMemcpyHostToDevice, v->stream));
     VCHECK(hipMemcpyAsync(v->t.yoff, bt.yoff.data(), (bt.B + 1) * sizeof(long long), hipMemcpyHostToDevice, v->stream));
     VCHECK(hipMemcpyAsync(v->t.src_off, src_off.data(), bt.B * sizeof(long long), hipMemcpyHostToDevice, v->stream));
@@ -318,7 +572,32 @@ int launch_stft(oph_vocoder* v, const Batch& bt) {
     return OPHV_OK;
 }
 
-// S/X prepared -> y (device).  utils.py:99-109
+// S prepared -> y (device), fused path: utils.py:99-109 with
+//   istft           = inverse half of gl_fused (windowed segment per frame) + gl_ola_seg (overlap-add, /wss, trim)
+//   stft + phase    = forward half of the next gl_fused launch, which goes straight on to the next inverse transform
+int run_griffin_lim_fused(oph_vocoder* v, const Batch& bt, int n_iter) {
+    const auto& p = v->p;
+    dim3 ygrid((unsigned)(((long long)p.hop_length * (bt.maxF - 1) + 255) / 256), bt.B);
+    hipLaunchKernelGGL(gl_wss, ygrid, dim3(256), 0, v->stream, v->d_w2, v->t.foff, v->t.yoff, v->wss, p.n_fft,
+                       p.hop_length, v->lpad, p.win_length);
+    long long want = (bt.G + 7) / 8 * 8;
+    const unsigned nblk = (unsigned)(want < 256 * 5 ? want : 256 * 5);       // persistent: 5 workgroups of LDS per CU
+    const size_t shm = (size_t)p.win_length * sizeof(float);
+    hipLaunchKernelGGL(gl_fused<true>, dim3(nblk), dim3(256), shm, v->stream, v->S, (const float*)nullptr, v->wseg[0],
+                       v->t.meta, v->d_tw, v->d_wsup, (int)bt.G, p.hop_length, v->lpad, p.win_length, v->wstride,
+                       v->nbin);
+    for (int it = 0; it <= n_iter; ++it) {
+        hipLaunchKernelGGL(gl_ola_seg, ygrid, dim3(256), 0, v->stream, v->wseg[0], v->wss, v->t.foff, v->t.yoff, v->y,
+                           p.hop_length, v->lpad, p.win_length, v->wstride);
+        if (it == n_iter) break;
+        hipLaunchKernelGGL(gl_fused<false>, dim3(nblk), dim3(256), shm, v->stream, v->S, v->y, v->wseg[0], v->t.meta,
+                           v->d_tw, v->d_wsup, (int)bt.G, p.hop_length, v->lpad, p.win_length, v->wstride, v->nbin);
+    }
+    VCHECK(hipGetLastError());
+    return OPHV_OK;
+}
+
+// S/X prepared -> y (device), generic path over hipFFT.  utils.py:99-109
 int run_griffin_lim(oph_vocoder* v, const Batch& bt, int n_iter) {
     int rc;
     const long long n = bt.G * v->nbin;
@@ -337,9 +616,11 @@ int run_pipeline(oph_vocoder* v, const float* d_src, const std::vector<long long
     int rc;
     if ((rc = upload_tables(v, bt, src_off))) return rc;
     VCHECK(hipEventRecord(v->ev0, v->stream));
+    const bool fused = use_fused(v);
     hipLaunchKernelGGL(gl_prepare, dim3((unsigned)bt.G), dim3(256), 0, v->stream, d_src, v->t.src_off, v->t.frame_utt,
-                       v->t.foff, v->S, v->X, v->nbin, v->p.max_db, v->p.ref_db, v->p.power, denorm);
-    if ((rc = run_griffin_lim(v, bt, n_iter))) return rc;
+                       v->t.foff, v->S, fused ? (float2*)nullptr : v->X, v->nbin, v->p.max_db, v->p.ref_db, v->p.power,
+                       denorm);
+    if ((rc = fused ? run_griffin_lim_fused(v, bt, n_iter) : run_griffin_lim(v, bt, n_iter))) return rc;
     const float* result = v->y;
     if (deemph) {
         hipLaunchKernelGGL(gl_deemphasis, dim3(bt.B), dim3(64), 0, v->stream, v->y, v->t.yoff, v->wav,
@@ -371,6 +652,7 @@ int from_host(oph_vocoder* v, const float* host_rows, const int32_t* n_frames, i
     int rc;
     if ((rc = plan_batch(v, n_frames, B, bt))) return rc;
     if ((rc = ensure_capacity(v, bt))) return rc;
+    if (use_fused(v) && (rc = ensure_capacity_fused(v, bt))) return rc;
     if ((rc = ensure_stage(v, bt.G * v->nbin))) return rc;
     VCHECK(hipMemcpyAsync(v->stage, host_rows, bt.G * v->nbin * sizeof(float), hipMemcpyHostToDevice, v->stream));
     std::vector<long long> src_off(B);
@@ -429,7 +711,31 @@ int oph_vocoder_create(const oph_gl_params* p, int device, oph_vocoder** out) {
         hipMemcpy(v->d_w, w.data(), p->n_fft * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(v->d_w2, w2.data(), p->n_fft * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         return fail("window upload failed");
+    v->wstride = (p->win_length + 3) / 4 * 4;
+    if (p->n_fft == FN) {
+        std::vector<float2> tw(TW_TOTAL, make_float2(0.f, 0.f));
+        auto root = [](long long e) {                       // W_2048^e evaluated in double
+            const double a = -2.0 * M_PI * (double)(e % FN) / FN;
+            return make_float2((float)std::cos(a), (float)std::sin(a));
+        };
+        for (int Ns : {4, 16, 64, 256})
+            for (int r = 1; r <= 3; ++r)
+                for (int k = 0; k < Ns; ++k) tw[tw_off(Ns) + (r - 1) * Ns + k] = root((long long)k * r * (512 / Ns));
+        for (int k = 0; k <= 256; ++k) tw[TW_PAIR + k] = root(k);
+        if (hipMalloc((void**)&v->d_tw, TW_TOTAL * sizeof(float2)) != hipSuccess ||
+            hipMalloc((void**)&v->d_wsup, p->win_length * sizeof(float)) != hipSuccess ||
+            hipMemcpy(v->d_tw, tw.data(), TW_TOTAL * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(v->d_wsup, w.data() + v->lpad, p->win_length * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            return fail("twiddle upload failed");
+    }
+    if (const char* e = std::getenv("OPH_VOCODER_BACKEND")) v->backend = std::atoi(e);
     *out = v;
+    return OPHV_OK;
+}
+
+int oph_vocoder_set_backend(oph_vocoder* v, int backend) {
+    if (!v || backend < 0 || backend > 1) return OPHV_ERR_INVALID;
+    v->backend = backend;
     return OPHV_OK;
 }
 
@@ -440,7 +746,7 @@ int oph_vocoder_destroy(oph_vocoder* v) {
     if (v->plan_c2r) hipfftDestroy(v->plan_c2r);
     if (v->plan_r2c) hipfftDestroy(v->plan_r2c);
     void* bufs[] = {v->d_w, v->d_w2, v->S, v->X, v->tfr, v->wfr, v->y, v->wav, v->stage, v->t.frame_utt, v->t.foff,
-                    v->t.yoff, v->t.src_off};
+                    v->t.yoff, v->t.src_off, v->t.meta, v->wseg[0], v->wseg[1], v->wss, v->d_wsup, v->d_tw};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (v->ev0) (void)hipEventDestroy(v->ev0);
@@ -465,6 +771,7 @@ int oph_spectrogram2wav_device(oph_vocoder* v, const float* d_mag, int64_t utt_s
     for (int b = 0; b < B; ++b)
         if ((int64_t)n_frames[b] * v->nbin > utt_stride) { v->err = "n_frames exceeds utt_stride"; return OPHV_ERR_INVALID; }
     if ((rc = ensure_capacity(v, bt))) return rc;
+    if (use_fused(v) && (rc = ensure_capacity_fused(v, bt))) return rc;
     std::vector<long long> src_off(B);
     for (int b = 0; b < B; ++b) src_off[b] = (long long)b * utt_stride;
     return run_pipeline(v, d_mag, src_off, bt, 1, v->p.n_iter, true, wav);

@@ -118,6 +118,10 @@ class Vocoder(object):
         self._chk(self.lib.oph_vocoder_deemphasis(self._h, _lib.fptr(x), len(x), _lib.fptr(y)))
         return y
 
+    def set_backend(self, backend):
+        """0 = fused in-LDS Griffin-Lim kernel when n_fft == 2048 (default), 1 = generic hipFFT path"""
+        self._chk(self.lib.oph_vocoder_set_backend(self._h, int(backend)))
+
     def last_device_ms(self):
         ms = C.c_float()
         self._chk(self.lib.oph_vocoder_last_device_ms(self._h, C.byref(ms)))

@@ -7,6 +7,7 @@ v = Vocoder(HP, 0)
 rng = np.random.default_rng(0)
 B, T = 16, 800
 mags = [rng.uniform(0, 1, (T, 1025)).astype(np.float32) for _ in range(B)]
-for i in range(3):
+for i in range(6):
+    v.set_backend(int(os.environ.get("VB", "0")) if i >= 3 else 1)
     t = time.perf_counter(); out = v.spectrogram2wav_batch(mags); dt = time.perf_counter() - t
     print("wall %.1f ms  device %.2f ms" % (dt * 1e3, v.last_device_ms()))

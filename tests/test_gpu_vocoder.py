@@ -85,14 +85,56 @@ def test_deemphasis(voc):
         assert np.abs(out - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), n
 
 
-@pytest.mark.parametrize("n_iter,tol", [(0, 3e-6), (3, 1e-4), (50, 2e-3)])
-def test_griffin_lim_ragged_batch(voc, gl, n_iter, tol):
-    specs = [gl.amplitude_from_mag(HP, _speechlike_mag(T, T)).T.copy() for T in (40, 7, 64, 2)]
+@pytest.fixture(params=[0, 1], ids=["fused", "hipfft"])
+def backend(request, voc):
+    voc.set_backend(request.param)
+    yield request.param
+    voc.set_backend(0)
+
+
+@pytest.mark.parametrize("n_iter,tol", [(0, 3e-6), (1, 2e-5), (3, 1e-4), (50, 2e-3)])
+def test_griffin_lim_ragged_batch(voc, gl, backend, n_iter, tol):
+    specs = [gl.amplitude_from_mag(HP, _speechlike_mag(T, T)).T.copy() for T in (40, 7, 64, 2, 3)]
     out = voc.griffin_lim_batch(specs, n_iter=n_iter)
     for S, y in zip(specs, out):
         ref = gl.griffin_lim(S.T, HP.n_fft, HP.hop_length, HP.win_length, n_iter)
         assert y.shape == ref.shape
         assert np.abs(y - ref).max() <= tol * np.abs(ref).max(), (S.shape, np.abs(y - ref).max(), np.abs(ref).max())
+
+
+def test_backends_agree(voc):
+    """fused in-LDS kernel vs hipFFT path: same arithmetic, different FFT factorisation"""
+    mags = [_speechlike_mag(T, 3 * T) for T in (90, 2, 31)]
+    voc.set_backend(1)
+    a = voc.spectrogram2wav_batch(mags)
+    voc.set_backend(0)
+    b = voc.spectrogram2wav_batch(mags)
+    for x, y in zip(a, b):
+        assert np.abs(x - y).max() <= 2e-3 * np.abs(x).max()
+
+
+@pytest.mark.parametrize("hop,win", [(200, 800), (256, 1024), (275, 1102), (512, 2048)])
+def test_other_stft_geometries(gl, hop, win):
+    """the 16 kHz configs (hop 200 / win 800) and nancy-style (256 / 1024) share n_fft = 2048"""
+    from ophelia_amd.vocoder import Vocoder
+    hp = SimpleNamespace(**dict(vars(HP), hop_length=hop, win_length=win, n_iter=4))
+    with Vocoder(hp, 0) as v:
+        mags = [_speechlike_mag(T, T + hop) for T in (25, 6)]
+        for backend in (0, 1):
+            v.set_backend(backend)
+            for m, w in zip(mags, v.spectrogram2wav_batch(mags)):
+                ref = gl.spectrogram2wav(hp, m)
+                assert w.shape == ref.shape and np.abs(w - ref).max() <= 2e-4 * np.abs(ref).max(), (backend, hop)
+
+
+def test_non_2048_fft_uses_generic_path(gl):
+    from ophelia_amd.vocoder import Vocoder
+    hp = SimpleNamespace(**dict(vars(HP), n_fft=1024, hop_length=256, win_length=1024, n_iter=3))
+    with Vocoder(hp, 0) as v:
+        m = _speechlike_mag(20, 9)[:, :513].copy()
+        w = v.spectrogram2wav(m)
+        ref = gl.spectrogram2wav(hp, m)
+        assert np.abs(w - ref).max() <= 2e-4 * np.abs(ref).max()
 
 
 def test_spectrogram2wav_matches_oracle(voc, gl):
