@@ -35,10 +35,10 @@ typedef struct oph_gl_params {
     int32_t hop_length;
     int32_t win_length;
     int32_t n_iter;
-    float power;
-    float preemphasis;
-    float max_db;
-    float ref_db;
+    double power;
+    double preemphasis;       /* double: the reference filters with the Python float 0.97, not its float32 rounding */
+    double max_db;
+    double ref_db;
 } oph_gl_params;
 
 typedef struct oph_vocoder oph_vocoder;

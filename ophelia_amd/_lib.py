@@ -71,7 +71,7 @@ SIGNATURES = {
 
 class OphGLParams(C.Structure):
     _fields_ = [("n_fft", C.c_int32), ("hop_length", C.c_int32), ("win_length", C.c_int32), ("n_iter", C.c_int32),
-                ("power", C.c_float), ("preemphasis", C.c_float), ("max_db", C.c_float), ("ref_db", C.c_float)]
+                ("power", C.c_double), ("preemphasis", C.c_double), ("max_db", C.c_double), ("ref_db", C.c_double)]
 
 
 # every symbol declared in include/ophelia_vocoder.h

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <hipfft/hipfft.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -175,12 +176,21 @@ __global__ __launch_bounds__(256) void gl_phase(const float* __restrict__ S, flo
     X[i] = make_float2(s * (e.x / a), s * (e.y / a));
 }
 
-// scipy.signal.lfilter([1],[1,-a]): y[n] = x[n] + a*y[n-1], float64 state.  One wave per utterance; each lane owns 16
-// consecutive samples of a 1024-sample chunk, the linear recurrence is combined across lanes with a log-step scan.
+// scipy.signal.lfilter([1],[1,-a]): y[n] = x[n] + a*y[n-1], float64 state.  One wave per (utterance, span of `span`
+// samples); each lane owns 16 consecutive samples of a 1024-sample chunk and the linear recurrence is combined across
+// lanes with a log-step scan.  A span does not wait for its predecessor: it re-runs the recurrence over the `warm`
+// samples before it from a zero state, whose missing history has decayed below a^warm <= 1e-17 of the signal, i.e.
+// under the float64 round-off of the sequential filter (warm >= len reproduces the sequential order exactly).
 __global__ __launch_bounds__(64) void gl_deemphasis(const float* __restrict__ x, const long long* __restrict__ yoff,
-                                                   float* __restrict__ out, double a) {
-    const int b = blockIdx.x;
+                                                   float* __restrict__ out, double a, int span, int warm) {
+    const int b = blockIdx.y;
     const long long off = yoff[b], len = yoff[b + 1] - yoff[b];
+    const long long first = (long long)blockIdx.x * span;            // first sample this wave stores
+    if (first >= len) return;
+    const long long last = min(len, first + span);
+    long long begin = first - warm;
+    if (begin < 0) begin = 0;
+    begin &= ~1023ll;                                                // chunks stay aligned for every span
     const int lane = threadIdx.x;
     double apow[17];
     apow[0] = 1.0;
@@ -189,13 +199,13 @@ __global__ __launch_bounds__(64) void gl_deemphasis(const float* __restrict__ x,
     const double A16 = apow[16];
     const double Alane = pow(A16, (double)lane);
     double carry = 0.0;
-    for (long long base = 0; base < len; base += 1024) {
+    for (long long base = begin; base < last; base += 1024) {
         const long long s = base + lane * 16;
         double v[16];
         double prev = 0.0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const double xv = (s + j < len) ? (double)x[off + s + j] : 0.0;
+            const double xv = (s + j < last) ? (double)x[off + s + j] : 0.0;
             prev = xv + a * prev;
             v[j] = prev;
         }
@@ -212,13 +222,12 @@ __global__ __launch_bounds__(64) void gl_deemphasis(const float* __restrict__ x,
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const double yv = v[j] + apow[j + 1] * cin;
-            if (s + j < len) out[off + s + j] = (float)yv;
+            if (s + j >= first && s + j < last) out[off + s + j] = (float)yv;
             if (j == 15) prev = yv;
         }
         carry = __shfl(prev, 63);
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // fused Griffin-Lim iteration for n_fft = 2048: one workgroup owns one frame at a time and keeps it in LDS through
@@ -528,6 +537,23 @@ int ensure_capacity(oph_vocoder* v, const Batch& bt) {
     return OPHV_OK;
 }
 
+// launch geometry of gl_deemphasis: spans of 8192 samples with a warm-up long enough for a^warm <= 1e-17; filters that
+// decay too slowly for that (a > ~0.9976) run each utterance as one sequential span
+void launch_deemphasis(oph_vocoder* v, const float* x, const long long* yoff, float* out, int B, long long max_len) {
+    const double a = std::fabs((double)v->p.preemphasis);
+    int span = 8192, warm = 0;
+    if (a > 0.0 && a < 1.0) {
+        const double need = std::ceil(-39.2 / std::log(a));
+        warm = need > 16384.0 ? -1 : (int)need;
+    } else if (a >= 1.0) {
+        warm = -1;
+    }
+    if (warm < 0 || max_len <= span) { span = (int)std::min<long long>(max_len, 0x7fffffff); warm = 0; }
+    if (span < 1) span = 1;
+    dim3 grid((unsigned)((max_len + span - 1) / span), B);
+    hipLaunchKernelGGL(gl_deemphasis, grid, dim3(64), 0, v->stream, x, yoff, out, (double)v->p.preemphasis, span, warm);
+}
+
 bool use_fused(const oph_vocoder* v) { return v->backend == 0 && v->p.n_fft == FN; }
 
 // buffers of the fused path: the windowed segments + the window-sum-square of every kept sample
@@ -618,13 +644,13 @@ int run_pipeline(oph_vocoder* v, const float* d_src, const std::vector<long long
     VCHECK(hipEventRecord(v->ev0, v->stream));
     const bool fused = use_fused(v);
     hipLaunchKernelGGL(gl_prepare, dim3((unsigned)bt.G), dim3(256), 0, v->stream, d_src, v->t.src_off, v->t.frame_utt,
-                       v->t.foff, v->S, fused ? (float2*)nullptr : v->X, v->nbin, v->p.max_db, v->p.ref_db, v->p.power,
+                       v->t.foff, v->S, fused ? (float2*)nullptr : v->X, v->nbin, (float)v->p.max_db, (float)v->p.ref_db,
+                       (float)v->p.power,
                        denorm);
     if ((rc = fused ? run_griffin_lim_fused(v, bt, n_iter) : run_griffin_lim(v, bt, n_iter))) return rc;
     const float* result = v->y;
     if (deemph) {
-        hipLaunchKernelGGL(gl_deemphasis, dim3(bt.B), dim3(64), 0, v->stream, v->y, v->t.yoff, v->wav,
-                           (double)v->p.preemphasis);
+        launch_deemphasis(v, v->y, v->t.yoff, v->wav, bt.B, (long long)v->p.hop_length * (bt.maxF - 1));
         result = v->wav;
     }
     VCHECK(hipEventRecord(v->ev1, v->stream));
@@ -830,7 +856,7 @@ int oph_vocoder_deemphasis(oph_vocoder* v, const float* x, int64_t len, float* y
     VCHECK(hipMalloc((void**)&doff, sizeof(off)));
     VCHECK(hipMemcpyAsync(dx, x, len * sizeof(float), hipMemcpyHostToDevice, v->stream));
     VCHECK(hipMemcpyAsync(doff, off, sizeof(off), hipMemcpyHostToDevice, v->stream));
-    hipLaunchKernelGGL(gl_deemphasis, dim3(1), dim3(64), 0, v->stream, dx, doff, dy, (double)v->p.preemphasis);
+    launch_deemphasis(v, dx, doff, dy, 1, (long long)len);
     VCHECK(hipMemcpyAsync(y, dy, len * sizeof(float), hipMemcpyDeviceToHost, v->stream));
     VCHECK(hipStreamSynchronize(v->stream));
     (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(doff);

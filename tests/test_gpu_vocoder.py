@@ -85,6 +85,18 @@ def test_deemphasis(voc):
         assert np.abs(out - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), n
 
 
+def test_deemphasis_is_bit_exact_across_spans_and_slow_filters():
+    """spans restart from a warm-up instead of the true state: still the float32 values of the sequential float64
+    filter; a slowly decaying filter (0.999) runs sequentially"""
+    from scipy import signal
+    from ophelia_amd.vocoder import Vocoder
+    x = _signal(70001, 3)
+    for a in (0.97, 0.5, 0.999, 0.0):
+        with Vocoder(SimpleNamespace(**dict(vars(HP), preemphasis=a)), 0) as v:
+            ref = signal.lfilter([1], [1, -a], x).astype(np.float32)
+            assert np.array_equal(v.deemphasis(x), ref), a
+
+
 @pytest.fixture(params=[0, 1], ids=["fused", "hipfft"])
 def backend(request, voc):
     voc.set_backend(request.param)
