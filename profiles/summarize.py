@@ -20,7 +20,7 @@ dst = os.path.join(ROOT, "profiles")
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "").strip()
+    return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
 
 
 def agg(path):
@@ -49,13 +49,17 @@ for k in sorted(dur):
     mm = {c: statistics.mean(v) for c, v in mfma[k].items()}
     rows.append([k, len(dur[k]), "%.3f" % (statistics.mean(dur[k]) / 1e3), "%.1f" % f, "%.1f" % w, "%.0f" % hbm,
                  "%.0f" % mm.get("SQ_VALU_MFMA_BUSY_CYCLES", 0), "%.0f" % mm.get("SQ_BUSY_CYCLES", 0),
-                 "%.0f" % mm.get("GRBM_GUI_ACTIVE", 0)])
+                 "%.0f" % mm.get("GRBM_GUI_ACTIVE", 0), "%.0f" % mm.get("SQ_LDS_BANK_CONFLICT", 0),
+                 "%.0f" % mm.get("SQ_LDS_IDX_ACTIVE", 0)])
 with open(os.path.join(dst, tag + "_pmc_summary.csv"), "w") as fo:
     wr = csv.writer(fo)
     wr.writerow(["kernel", "dispatches", "avg_duration_us", "FETCH_SIZE_KB_raw_mean", "WRITE_SIZE_KB_raw_mean",
-                 "hbm_bytes_per_launch(2*FETCH+WRITE)", "SQ_VALU_MFMA_BUSY_CYCLES_mean", "SQ_BUSY_CYCLES_mean", "GRBM_GUI_ACTIVE_mean"])
+                 "hbm_bytes_per_launch(2*FETCH+WRITE)", "SQ_VALU_MFMA_BUSY_CYCLES_mean", "SQ_BUSY_CYCLES_mean", "GRBM_GUI_ACTIVE_mean",
+                 "SQ_LDS_BANK_CONFLICT_mean", "SQ_LDS_IDX_ACTIVE_mean"])
     wr.writerows(rows)
-json.dump({"tag": tag, "command": "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile",
+cmd_file = os.path.join(src, "command.txt")
+command = open(cmd_file).read().strip() if os.path.exists(cmd_file) else "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile"
+json.dump({"tag": tag, "command": command,
            "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)",
            "kernels": traffic}, open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1)
 print("wrote", [f for f in os.listdir(dst) if f.startswith(tag)])
