@@ -56,6 +56,12 @@ typedef struct oph_dims {
 } oph_dims;
 
 #define OPH_FLAG_SPK_AUDIO_DECODER_INPUT 1  /* 'audio_decoder_input' in hp.multispeaker (networks.py:381-389) */
+#define OPH_FLAG_NORM_NONE 2               /* hp.norm is None (modules.py:62-74): no LayerNorm variables; the SSRN
+                                              transposed convs keep theirs (networks.py:483-486 passes no normtype) */
+#define OPH_FLAG_NO_MONOTONIC 4             /* hp.turn_off_monotonic_for_synthesis (networks.py:304-309): no attention window;
+                                              keys n >= text_length+1 are masked (hp.text_lengths, synthesize.py:505-507) */
+#define OPH_FLAG_SPK_TEXT_ENCODER_INPUT 8  /* 'text_encoder_input' in hp.multispeaker (networks.py:138-144)        */
+#define OPH_FLAG_SPK_TEXT_ENCODER_TOWARDS_END 16 /* 'text_encoder_towards_end' (networks.py:184-199)               */
 
 /* stop_mode of the decode loop */
 #define OPH_STOP_REFERENCE 0   /* synthesize.py:218-228: break after the step at which all utterances ended */

@@ -26,6 +26,10 @@ class OphDims(C.Structure):
 
 
 FLAG_SPK_AUDIO_DECODER_INPUT = 1
+FLAG_NORM_NONE = 2
+FLAG_NO_MONOTONIC = 4
+FLAG_SPK_TEXT_ENCODER_INPUT = 8
+FLAG_SPK_TEXT_ENCODER_TOWARDS_END = 16
 STOP_REFERENCE, STOP_NEVER = 0, 1
 
 # name -> (restype, argtypes); every symbol declared in include/ophelia_hip.h

@@ -47,6 +47,9 @@ struct Layer {
     bool causal = false;
     int act = ACT_NONE;
     int ccat = 0;                // speaker-embedding channels concatenated to the input (cin includes them)
+    bool ln = true;              // false: hp.norm None -> no gamma/beta variables, normalisation is the identity
+    std::string cat_scope;       // TextEnc layers with ccat: TF scope of the speaker lookup table concatenated to the input
+    float* cat_table = nullptr;
     // packed
     int kc = 0, N = 0, Nalloc = 0, ntaps = 1;
     int off[3] = {0, 0, 0};
@@ -98,6 +101,7 @@ struct oph_handle {
     std::vector<Layer> textenc, audioenc, audiodec, ssrn;
     float* emb_text = nullptr;       // (vocab, e)
     float* emb_spk = nullptr;        // (nspeakers, spk_emb)   AudioDec/embed_2
+    float *d_ones = nullptr, *d_zeros = nullptr;   // gamma / beta stand-ins of layers without LayerNorm (hp.norm None)
     std::vector<void*> allocs;
     size_t n_weight_allocs = 0;       // allocs[0 .. n_weight_allocs) are the packed weights (live as long as the handle)
     // batched workspaces
@@ -201,11 +205,23 @@ void build_networks(oph_handle* h) {
     {   // TextEnc  networks.py:121-212
         const char* n = "Text2Mel/TextEnc";
         int i = 2;                                    // embed_1 handled separately
-        add_conv(h->textenc, sc(n, "C", i++), m.e, 2 * d, false, ACT_RELU);
+        const int se = m.speaker_embedding_size;
+        if (m.flags & OPH_FLAG_SPK_TEXT_ENCODER_INPUT) {          // networks.py:138-144: embed_2, concat, C_3
+            const std::string es = sc(n, "embed", i++);
+            add_conv(h->textenc, sc(n, "C", i++), m.e + se, 2 * d, false, ACT_RELU, se);
+            h->textenc.back().cat_scope = es;
+        } else {
+            add_conv(h->textenc, sc(n, "C", i++), m.e, 2 * d, false, ACT_RELU);
+        }
         add_conv(h->textenc, sc(n, "C", i++), 2 * d, 2 * d, false, ACT_NONE);
         for (int o = 0; o < 2; ++o)
             for (int j = 0, r = 1; j < 4; ++j, r *= 3) add_hc(h->textenc, sc(n, "HC", i++), 2 * d, 3, r, false);
         for (int o = 0; o < 2; ++o) add_hc(h->textenc, sc(n, "HC", i++), 2 * d, 3, 1, false);
+        if (m.flags & OPH_FLAG_SPK_TEXT_ENCODER_TOWARDS_END) {    // networks.py:184-199: embed, concat, 1x1 conv back to 2d
+            const std::string es = sc(n, "embed", i++);
+            add_conv(h->textenc, sc(n, "C", i++), 2 * d + se, 2 * d, false, ACT_RELU, se);
+            h->textenc.back().cat_scope = es;
+        }
         for (int o = 0; o < 2; ++o) add_hc(h->textenc, sc(n, "HC", i++), 2 * d, 1, 1, false);
     }
     {   // AudioEnc  networks.py:214-284
@@ -253,22 +269,30 @@ void build_networks(oph_handle* h) {
         for (int o = 0; o < 2; ++o) add_conv(h->ssrn, sc(n, "C", i++), m.full_dim, m.full_dim, false, ACT_RELU);
         add_conv(h->ssrn, sc(n, "C", i++), m.full_dim, m.full_dim, false, ACT_SIGMOID);   // squash_output_ssrn
     }
+    if (m.flags & OPH_FLAG_NORM_NONE)
+        for (auto* net : {&h->textenc, &h->audioenc, &h->audiodec, &h->ssrn})
+            for (Layer& l : *net) l.ln = l.kind == K_CONVT;
     // inventory of TF variables, in graph-creation order
     auto inv = [&](const std::string& name, std::vector<int64_t> shp) { h->inventory.emplace_back(name, shp); };
     auto inv_layers = [&](const std::vector<Layer>& v) {
         for (const Layer& l : v) {
+            if (!l.cat_scope.empty()) inv(l.cat_scope + "/lookup_table", {m.nspeakers, m.speaker_embedding_size});
             if (l.kind == K_CONV) {
                 inv(l.scope + "/conv1d/kernel", {1, l.cin, l.cout});
                 inv(l.scope + "/conv1d/bias", {l.cout});
-                inv(l.scope + "/normalize/beta", {l.cout});
-                inv(l.scope + "/normalize/gamma", {l.cout});
+                if (l.ln) {
+                    inv(l.scope + "/normalize/beta", {l.cout});
+                    inv(l.scope + "/normalize/gamma", {l.cout});
+                }
             } else if (l.kind == K_HC) {
                 inv(l.scope + "/conv1d/kernel", {l.size, l.cin, 2 * l.cout});
                 inv(l.scope + "/conv1d/bias", {2 * l.cout});
-                inv(l.scope + "/H1/beta", {l.cout});
-                inv(l.scope + "/H1/gamma", {l.cout});
-                inv(l.scope + "/H2/beta", {l.cout});
-                inv(l.scope + "/H2/gamma", {l.cout});
+                if (l.ln) {
+                    inv(l.scope + "/H1/beta", {l.cout});
+                    inv(l.scope + "/H1/gamma", {l.cout});
+                    inv(l.scope + "/H2/beta", {l.cout});
+                    inv(l.scope + "/H2/gamma", {l.cout});
+                }
             } else {
                 inv(l.scope + "/conv2d_transpose/kernel", {1, 3, l.cout, l.cin});
                 inv(l.scope + "/conv2d_transpose/bias", {l.cout});
@@ -357,7 +381,14 @@ int pack_layer(oph_handle* h, Layer& l) {
         if (!l.Wkn) return -1;
     }
     l.bias = upload_padded(h, *getw(h, l.scope + "/conv1d/bias"), l.Nalloc);
-    if (l.kind == K_HC) {
+    if (!l.cat_scope.empty()) {
+        l.cat_table = upload(h, *getw(h, l.cat_scope + "/lookup_table"));
+        if (!l.cat_table) return -1;
+    }
+    if (!l.ln) {
+        l.g1 = l.g2 = h->d_ones;
+        l.b1 = l.b2 = h->d_zeros;
+    } else if (l.kind == K_HC) {
         l.g1 = upload_padded(h, *getw(h, l.scope + "/H1/gamma"), 256);
         l.b1 = upload_padded(h, *getw(h, l.scope + "/H1/beta"), 256);
         l.g2 = upload_padded(h, *getw(h, l.scope + "/H2/gamma"), 256);
@@ -417,7 +448,12 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
         g.stop_after = nullptr;
         EpiArgs e{};
         e.g1 = l.g1; e.b1 = l.b1; e.g2 = l.g2; e.b2 = l.b2; e.act = l.act; e.Y = y; e.ldy = ldy; e.ypad = ypad;
-        e.H = wsraw; e.stop_after = nullptr;
+        e.H = wsraw; e.stop_after = nullptr; e.nonorm = !l.ln;
+        if (!last && layers[li + 1].cat_table) {      // the next layer's input = [this output | speaker embedding]
+            const Layer& nx = layers[li + 1];
+            e.spk_table = nx.cat_table; e.spk_ids = h->d_spk; e.spk_dim = nx.ccat; e.spk_T = Tcur;
+            e.ldy = e.ypad = nx.kc;
+        }
         if (l.kind == K_CONVT) {
             // even rows: taps (x[t], x[t-1]); odd rows: tap x[t]; raw rows interleaved 2t / 2t+1
             g.N = l.N; g.ldh = 2 * l.Nalloc; g.M = M;
@@ -437,7 +473,7 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
             else e.mode = PRE_CONV;
             run_epi(h, e);
         }
-        x = y; ldx = ldy;
+        x = y; ldx = e.ldy;
         flip ^= 1;
     }
     if (out_ld) *out_ld = ldx;
@@ -604,6 +640,7 @@ void launch_cone(oph_handle* h, int t) {
     ar.mode = 0; ar.Q = h->Qhist; ar.ldq = d; ar.K = h->KV; ar.V = h->KV + d; ar.ldkv = 2 * d; ar.N = m.max_N; ar.d = d;
     ar.win = m.attention_win_size; ar.p = pcur; ar.B = B; ar.Bpad = Bpad; ar.nrows = n0 * Bpad; ar.off = h->d_off0; ar.j = t;
     ar.R = h->coneR; ar.ldr = 2 * d; ar.stop_after = stop_after; ar.t = t;
+    if (m.flags & OPH_FLAG_NO_MONOTONIC) ar.ends = h->d_ends;
     h->pbegin(PC_ATTN_ROWS);
     launch_attn_rows(ar, g_cur);
     h->pend(PC_ATTN_ROWS, (double)n0 * B * 3.0 * d * 4.0, (double)n0 * B * 4.0 * m.attention_win_size * d);
@@ -619,7 +656,7 @@ void launch_cone(oph_handle* h, int t) {
         run_gemm(h, g, l.cin);
         EpiArgs e{};
         e.nsplit = g.ksplit; e.split_stride = g.split_stride;
-        e.H = h->coneRaw; e.ldh = l.Nalloc; e.M = g.M; e.C = l.cout; e.mode = PRE_CONV; e.act = l.act; e.g1 = l.g1; e.b1 = l.b1;
+        e.H = h->coneRaw; e.ldh = l.Nalloc; e.M = g.M; e.C = l.cout; e.mode = PRE_CONV; e.act = l.act; e.g1 = l.g1; e.b1 = l.b1; e.nonorm = !l.ln;
         e.Bpad = Bpad; e.stop_after = stop_after; e.t = t;
         const bool spk_next = (k + 1 < pre) && h->audiodec[k + 1].ccat > 0;
         if (spk_next) {
@@ -647,6 +684,7 @@ void launch_cone(oph_handle* h, int t) {
         e.nsplit = g.ksplit; e.split_stride = g.split_stride;
         e.H = h->coneRaw; e.ldh = l.Nalloc; e.M = g.M; e.C = l.cout; e.mode = PRE_HC;
         e.g1 = l.g1; e.b1 = l.b1; e.g2 = l.g2; e.b2 = l.b2; e.Xres = cone[k]; e.ldres = l.kc; e.restab = h->d_res[k]; e.Bpad = Bpad;
+        e.nonorm = !l.ln;
         const Layer& nx = h->audiodec[pre + k + 1];
         e.Y = cone[k + 1]; e.ldy = nx.kc; e.ypad = nx.kc; e.stop_after = stop_after; e.t = t;
         run_epi(h, e);
@@ -660,6 +698,8 @@ RowLayer row_layer(const Layer& l) {
     return r;
 }
 void run_row_chain(oph_handle* h, RowChainArgs& a, int first_is_attn) {
+    a.nonorm = (h->dm.flags & OPH_FLAG_NORM_NONE) ? 1 : 0;      // Text2Mel has no transposed convs: all or nothing
+    a.nomono = (h->dm.flags & OPH_FLAG_NO_MONOTONIC) ? 1 : 0;
     double wbytes = 0, flops = 0;
     for (int i = 0; i < a.nlayers; ++i) { wbytes += (double)a.L[i].kc * a.L[i].N * 4.0; flops += 2.0 * a.B * a.L[i].kc * a.L[i].N; }
     h->pbegin(PC_ROWCHAIN);
@@ -669,6 +709,7 @@ void run_row_chain(oph_handle* h, RowChainArgs& a, int first_is_attn) {
 
 // dec_layer16 arguments of decoder layer `l` whose input rows x[t] are produced by `prev`'s raw output
 void fill_pre(DecArgs& a, const Layer* prev, const float* prev_raw, const float* prev_x) {
+    a.nonorm = !prev->ln;
     if (prev->kind == K_CONV) { a.pre = PRE_CONV; a.src = prev_raw; a.ldsrc = prev->Nalloc; a.g1 = prev->g1; a.b1 = prev->b1; a.act = prev->act; a.cin = prev->cout; }
     else { a.pre = PRE_HC; a.src = prev_raw; a.ldsrc = prev->Nalloc; a.g1 = prev->g1; a.b1 = prev->b1; a.g2 = prev->g2; a.b2 = prev->b2; a.xres = prev_x; a.ldres = prev->kc; a.cin = prev->cout; }
 }
@@ -860,11 +901,15 @@ int run_encode(oph_handle* h) {
     g_cur = h->stream;
     const int B = h->B;
     // embed_1 (modules.py:15-44) -> rows [B*max_N][e]
+    const Layer& first = h->textenc[0];
+    const int ld0 = first.kc;                     // round_up(e [+ speaker embedding], 32)
     h->pbegin(PC_MISC);
-    launch_embed(h->d_L, (long long)B * m.max_N, h->emb_text, m.e, h->actA, round_up(m.e, 32), h->stream);
+    launch_embed(h->d_L, (long long)B * m.max_N, h->emb_text, m.e, h->actA, ld0, h->stream);
     h->pend(PC_MISC, (double)B * m.max_N * m.e * 4.0, 0);
+    if (first.cat_table)                          // 'text_encoder_input': [embed(L) | embed(speaker)]  networks.py:138-144
+        launch_spk_append_rows(h->actA, ld0, (long long)B * m.max_N, m.max_N, m.e, first.cat_table, h->d_spk, first.ccat, h->stream);
     // last highway layer writes K|V rows straight into the resident KV buffer [B][N][2d]
-    run_batched(h, h->textenc, h->actA, round_up(m.e, 32), B, m.max_N, 0, 0, h->KV, 2 * m.d, 2 * m.d, nullptr, nullptr);
+    run_batched(h, h->textenc, h->actA, ld0, B, m.max_N, 0, 0, h->KV, 2 * m.d, 2 * m.d, nullptr, nullptr);
     HIPCHK(h, hipGetLastError());
     return OPH_OK;
 }
@@ -901,7 +946,8 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
         g_create_error = "dimensions outside the supported hot path (d<=256, c<=512, n_mels<=256, full_dim<=1280, win<=8)";
         return OPH_ERR_UNSUPPORTED;
     }
-    if ((m.flags & OPH_FLAG_SPK_AUDIO_DECODER_INPUT) && (m.nspeakers < 1 || m.speaker_embedding_size < 1 || m.speaker_embedding_size % 4)) {
+    if ((m.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_TOWARDS_END)) &&
+        (m.nspeakers < 1 || m.speaker_embedding_size < 1 || m.speaker_embedding_size % 4)) {
         g_create_error = "multispeaker flag set but nspeakers/speaker_embedding_size invalid";
         return OPH_ERR_INVALID;
     }
@@ -1023,6 +1069,12 @@ int oph_finalize_weights(oph_handle* h) {
     HIPCHK(h, hipSetDevice(h->device));
     for (const auto& it : h->inventory)
         if (!h->hostw.count(it.first)) { h->fail("missing variable %s", it.first.c_str()); return OPH_ERR_STATE; }
+    {
+        const int n = round_up(std::max({2 * h->dm.c, h->dm.full_dim, 2 * h->dm.d, 256}), 256);
+        h->d_ones = upload(h, std::vector<float>((size_t)n, 1.f));
+        h->d_zeros = upload(h, std::vector<float>((size_t)n, 0.f));
+        if (!h->d_ones || !h->d_zeros) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
+    }
     for (auto* net : {&h->textenc, &h->audioenc, &h->audiodec, &h->ssrn})
         for (Layer& l : *net)
             if (pack_layer(h, l) != 0) { h->fail("out of device memory packing %s", l.scope.c_str()); return OPH_ERR_DEVICE; }
@@ -1048,7 +1100,7 @@ int oph_stage_text(oph_handle* h, const int32_t* L, const int32_t* ends, const i
     int rc = check_ready(h, B);
     if (rc) return rc;
     if (!L || !ends) { h->fail("null argument"); return OPH_ERR_INVALID; }
-    const bool ms = h->dm.flags & OPH_FLAG_SPK_AUDIO_DECODER_INPUT;
+    const bool ms = h->dm.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_TOWARDS_END);
     if (ms && !spk) { h->fail("multispeaker model needs speaker ids"); return OPH_ERR_INVALID; }
     const oph_dims& m = h->dm;
     for (long long i = 0; i < (long long)B * m.max_N; ++i)

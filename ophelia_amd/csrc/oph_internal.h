@@ -48,6 +48,7 @@ struct EpiArgs {
     // optional speaker-embedding append (AudioDec 'audio_decoder_input', networks.py:381-387)
     const float* spk_table; const int* spk_ids; int spk_dim; int spk_T; // utterance of row m: spk_T>0 ? m / spk_T : m % Bpad
     const int* stop_after; int t;
+    int nonorm;                     // hp.norm None: the "LayerNorm" is the identity (mean 0, rstd 1; gamma/beta = 1/0 buffers)
 };
 
 // ---- fused M=16 decode layer (prologue = previous layer's LN/gate, then 16xK . KxN slice)
@@ -65,6 +66,7 @@ struct DecArgs {
     float* H; int ldh;              // raw output rows [Bpad][ldh]
     int B;
     const int* stop_after; int t;
+    int nonorm;                     // the PREVIOUS layer (prologue) has no LayerNorm
 };
 
 struct AttnRowsArgs {
@@ -72,6 +74,8 @@ struct AttnRowsArgs {
     const float* Q; int ldq;
     const float* K; const float* V; int ldkv; int N; int d; int win;
     const int* p;                   // per-utterance window start
+    const int* ends;                // non-null: hp.turn_off_monotonic_for_synthesis -- no window, the unmasked keys of
+                                    // utterance b are [0, min(N, ends[b]+1))  (networks.py:307-309, synthesize.py:505-507)
     int B; int Bpad; int nrows;
     const int* off; int j;          // mode 0: row i*Bpad+b reads Qhist[(j-off[i])*Bpad+b]
     int T;                          // mode 1
@@ -101,6 +105,8 @@ struct RowChainArgs {
     float* xout; int ldout;         // final activation rows (zero padded to ldout) or null
     int emit; float* Yout; int ldy; float* Ytm; int ldtm;    // emit: final = mel frame t -> Yout[b][t], Ytm[t+1][b]
     int B; const int* stop_after; int t;
+    int nonorm;                     // no LayerNorm anywhere in this chain (hp.norm None)
+    int nomono;                     // ROW_ATTN without the monotonic window: keys [0, min(N_keys, ends[b]+1))
 };
 
 // launchers (oph_kernels.hip)
@@ -114,5 +120,6 @@ void launch_attn_rows(const AttnRowsArgs& a, hipStream_t s);
 void launch_embed(const int* ids, long long n, const float* table, int units, float* out, int ldo, hipStream_t s);
 void launch_pad_rows(const float* src, int lds_, float* dst, int ldd, long long rows, int C, hipStream_t s);
 void launch_fill_int(int* p, int v, int n, hipStream_t s);
+void launch_spk_append_rows(float* out, int ldo, long long rows, int T, int col0, const float* table, const int* ids, int dim, hipStream_t s);
 
 }  // namespace oph

@@ -384,13 +384,13 @@ void launch_conv_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {     // dense ro
 //   hc   : g = sigmoid(LN1(h[:C])), u = LN2(h[C:]), y = g*u + (1-g)*x   (modules.py:194-203)
 // =====================================================================================
 template <int NV>
-__device__ __forceinline__ void ln_vec(f32x4 (&x)[NV], int C, int lane, const float* gam, const float* bet) {
+__device__ __forceinline__ void ln_vec(f32x4 (&x)[NV], int C, int lane, const float* gam, const float* bet, int nonorm) {
     float s = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
         for (int e = 0; e < 4; ++e) s += ((v * 64 + lane) * 4 + e < C) ? x[v][e] : 0.f;
-    const float mean = wave_sum(s) / (float)C;
+    const float mean = nonorm ? 0.f : wave_sum(s) / (float)C;
     float q = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v)
@@ -401,7 +401,7 @@ __device__ __forceinline__ void ln_vec(f32x4 (&x)[NV], int C, int lane, const fl
             q += dlt * dlt;
         }
     const float var = wave_sum(q) / (float)C;
-    const float rstd = 1.0f / sqrtf(var + LN_EPS);
+    const float rstd = nonorm ? 1.0f : 1.0f / sqrtf(var + LN_EPS);
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const int c = (v * 64 + lane) * 4;
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void ln_rows(EpiArgs a) {
         for (int sp = 1; sp < a.nsplit; ++sp)
             if (c < C) x[v] += *(const f32x4*)(h + sp * a.split_stride + c);
     }
-    ln_vec<NV>(x, C, lane, a.g1, a.b1);
+    ln_vec<NV>(x, C, lane, a.g1, a.b1, a.nonorm);
     if (a.mode == PRE_HC) {
         f32x4 u[NV];
 #pragma unroll
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void ln_rows(EpiArgs a) {
             for (int sp = 1; sp < a.nsplit; ++sp)
                 if (c < C) u[v] += *(const f32x4*)(h + sp * a.split_stride + C + c);
         }
-        ln_vec<NV>(u, C, lane, a.g2, a.b2);
+        ln_vec<NV>(u, C, lane, a.g2, a.b2, a.nonorm);
         size_t rrow = m;
         if (a.restab) rrow = (size_t)a.restab[m / a.Bpad] * a.Bpad + (m % a.Bpad);
         const float* xr = a.Xres + rrow * a.ldres;
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void dec_layer16(DecArgs a) {
             for (int rr = 0; rr < DEC_RPW; ++rr) s[rr] = wave_sum(s[rr]);
 #pragma unroll
             for (int rr = 0; rr < DEC_RPW; ++rr) {
-                const float mean = s[rr] * invc;
+                const float mean = a.nonorm ? 0.f : s[rr] * invc;
                 q[rr] = 0.f;
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void dec_layer16(DecArgs a) {
             for (int rr = 0; rr < DEC_RPW; ++rr) q[rr] = wave_sum(q[rr]);
 #pragma unroll
             for (int rr = 0; rr < DEC_RPW; ++rr) {
-                const float rstd = 1.0f / sqrtf(q[rr] * invc + LN_EPS);
+                const float rstd = a.nonorm ? 1.0f : 1.0f / sqrtf(q[rr] * invc + LN_EPS);
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
 #pragma unroll
@@ -803,6 +803,89 @@ __device__ __forceinline__ AttnOut attend_window(const f32x4 (&q)[ATT_NV], const
     return o;
 }
 
+// hp.turn_off_monotonic_for_synthesis (networks.py:307-309): no forcibly-incremental window; the keys past the text
+// (n >= text_length + 1) are masked with -2**32+1, i.e. contribute exactly 0.  One wavefront, up to 256 keys: key n's
+// logit / probability lives in lane n%64, slot n/64.  arg = first maximum, like tf.argmax.
+constexpr int ATT_FULL_SLOTS = 4;
+struct AttnFull { float prob[ATT_FULL_SLOTS]; int arg; };
+
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+
+__device__ __forceinline__ AttnFull attend_full(const f32x4 (&q)[ATT_NV], const float* Kb, const float* Vb, int ldkv,
+                                               int nkeys, int d, int lane, f32x4 (&ctx)[ATT_NV]) {
+    AttnFull o;
+    const float scale = 1.0f / sqrtf((float)d);
+    float sc[ATT_FULL_SLOTS];
+#pragma unroll
+    for (int s_ = 0; s_ < ATT_FULL_SLOTS; ++s_) sc[s_] = -INFINITY;
+    for (int n = 0; n < nkeys; ++n) {
+        const float* kr = Kb + (size_t)n * ldkv;
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < ATT_NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (c < d) {
+                const f32x4 kv = *(const f32x4*)(kr + c);
+                s += q[v][0] * kv[0] + q[v][1] * kv[1] + q[v][2] * kv[2] + q[v][3] * kv[3];
+            }
+        }
+        s = wave_sum(s) * scale;
+        if (lane == (n & 63)) {
+#pragma unroll
+            for (int s_ = 0; s_ < ATT_FULL_SLOTS; ++s_)
+                if (s_ == (n >> 6)) sc[s_] = s;
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int s_ = 0; s_ < ATT_FULL_SLOTS; ++s_) mx = fmaxf(mx, sc[s_]);
+    mx = wave_max_f(mx);
+    float den = 0.f;
+#pragma unroll
+    for (int s_ = 0; s_ < ATT_FULL_SLOTS; ++s_) {
+        o.prob[s_] = (s_ * 64 + lane < nkeys) ? expf(sc[s_] - mx) : 0.f;
+        den += o.prob[s_];
+    }
+    den = wave_sum(den);
+    float best = -1.f;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int s_ = 0; s_ < ATT_FULL_SLOTS; ++s_) {
+        o.prob[s_] = o.prob[s_] / den;
+        if (s_ * 64 + lane < nkeys && o.prob[s_] > best) { best = o.prob[s_]; bi = s_ * 64 + lane; }
+    }
+    const float gbest = wave_max_f(best);
+    o.arg = wave_min_i(best == gbest ? bi : 0x7fffffff);
+#pragma unroll
+    for (int v = 0; v < ATT_NV; ++v) ctx[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < nkeys; ++n) {
+        float pn = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < ATT_FULL_SLOTS; ++s_)
+            if (s_ == (n >> 6)) pn = __shfl(o.prob[s_], n & 63);
+        const float* vr = Vb + (size_t)n * ldkv;
+#pragma unroll
+        for (int v = 0; v < ATT_NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (c < d) {
+                const f32x4 vv = *(const f32x4*)(vr + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ctx[v][e] += pn * vv[e];
+            }
+        }
+    }
+    return o;
+}
+
 // attn_rows: generic rows.  mode 0 = decoder history rows (position-major, current mask p);
 // mode 1 = batched operator over (b,t) with alignments + argmax outputs.
 __global__ __launch_bounds__(256) void attn_rows(AttnRowsArgs a) {
@@ -833,8 +916,30 @@ __global__ __launch_bounds__(256) void attn_rows(AttnRowsArgs a) {
     const int p = a.p[b];
     const float* Kb = a.K + (size_t)b * a.N * a.ldkv;
     const float* Vb = a.V + (size_t)b * a.N * a.ldkv;
-    const AttnOut o = attend_window(q, Kb, Vb, a.ldkv, p, a.N, a.win, d, lane, ctx);
     float* rr = a.R + (size_t)rid * a.ldr;
+    if (a.ends) {                     // non-monotonic synthesis: every key of the text (+1) takes part
+        const int nkeys = min(a.N, a.ends[b] + 1);
+        const AttnFull of = attend_full(q, Kb, Vb, a.ldkv, nkeys, d, lane, ctx);
+#pragma unroll
+        for (int v = 0; v < ATT_NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (c < d) {
+                *(f32x4*)(rr + c) = ctx[v];
+                *(f32x4*)(rr + d + c) = q[v];
+            }
+        }
+        if (a.mode == 1) {
+            float* al = a.align + (size_t)b * a.N * a.T + tq;
+#pragma unroll
+            for (int s_ = 0; s_ < ATT_FULL_SLOTS; ++s_) {
+                const int n = s_ * 64 + lane;
+                if (n < a.N) al[(size_t)n * a.T] = n < nkeys ? of.prob[s_] : 0.f;
+            }
+            if (lane == 0) a.amax[rid] = of.arg;
+        }
+        return;
+    }
+    const AttnOut o = attend_window(q, Kb, Vb, a.ldkv, p, a.N, a.win, d, lane, ctx);
 #pragma unroll
     for (int v = 0; v < ATT_NV; ++v) {
         const int c = (v * 64 + lane) * 4;
@@ -870,6 +975,8 @@ void launch_attn_rows(const AttnRowsArgs& a, hipStream_t s) {
 constexpr int RC_WAVES = 16;
 constexpr int RC_XMAX = 1024;
 
+template <bool NOMONO, bool NONORM>   // option variants are separate instantiations: the default kernel's register
+                                      // allocation (at the 128-VGPR cap, no scratch) must stay untouched
 __global__ __launch_bounds__(64 * RC_WAVES) void row_chain(RowChainArgs a) {
     __shared__ __attribute__((aligned(16))) float xs[2][RC_XMAX];
     __shared__ __attribute__((aligned(16))) float part[RC_WAVES][256];
@@ -921,7 +1028,7 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain(RowChainArgs a) {
             float s = 0.f;
 #pragma unroll
             for (int v = 0; v < ATT_NV; ++v) s += z[v][0] + z[v][1] + z[v][2] + z[v][3];
-            const float mean = wave_sum(s) / (float)d;
+            const float mean = NONORM ? 0.f : wave_sum(s) / (float)d;
             float qq = 0.f;
 #pragma unroll
             for (int v = 0; v < ATT_NV; ++v)
@@ -931,7 +1038,7 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain(RowChainArgs a) {
                     z[v][e] = dlt;
                     qq += dlt * dlt;
                 }
-            const float rstd = 1.0f / sqrtf(wave_sum(qq) / (float)d + LN_EPS);
+            const float rstd = NONORM ? 1.0f : 1.0f / sqrtf(wave_sum(qq) / (float)d + LN_EPS);
 #pragma unroll
             for (int v = 0; v < ATT_NV; ++v)
 #pragma unroll
@@ -956,7 +1063,11 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain(RowChainArgs a) {
             // R' = concat(softmax(QK^T/sqrt(d)) V, Q) for row t under the current mask
             const float* KVb = a.KV + (size_t)b * a.N_keys * 2 * d;
             f32x4 ctx[ATT_NV];
-            const AttnOut o = attend_window(q, KVb, KVb + d, 2 * d, p, a.N_keys, a.win, d, lane, ctx);
+            AttnOut o;
+            AttnFull of;
+            const int nkeys = NOMONO ? min(a.N_keys, a.ends[b] + 1) : 0;
+            if (NOMONO) of = attend_full(q, KVb, KVb + d, 2 * d, nkeys, d, lane, ctx);
+            else o = attend_window(q, KVb, KVb + d, 2 * d, p, a.N_keys, a.win, d, lane, ctx);
             float* qh = a.Qhist + ((size_t)a.t * a.Bpad + b) * d;
 #pragma unroll
             for (int v = 0; v < ATT_NV; ++v) {
@@ -967,12 +1078,22 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain(RowChainArgs a) {
                     if (live) *(f32x4*)(qh + c) = q[v];
                 }
             }
-            if (lane == 0 && live) {
+            if (NOMONO && live) {
                 float* al = a.align + (size_t)b * a.N_keys * a.max_T + a.t;
 #pragma unroll
-                for (int i = 0; i < ATT_WMAX; ++i)
-                    if (i < o.nwin) al[(size_t)(p + i) * a.max_T] = o.prob[i];
-                const int m = p + o.arg;
+                for (int s_ = 0; s_ < ATT_FULL_SLOTS; ++s_) {
+                    const int n = s_ * 64 + lane;
+                    if (n < nkeys) al[(size_t)n * a.max_T] = of.prob[s_];
+                }
+            }
+            if (lane == 0 && live) {
+                float* al = a.align + (size_t)b * a.N_keys * a.max_T + a.t;
+                if (!NOMONO) {
+#pragma unroll
+                    for (int i = 0; i < ATT_WMAX; ++i)
+                        if (i < o.nwin) al[(size_t)(p + i) * a.max_T] = o.prob[i];
+                }
+                const int m = NOMONO ? of.arg : p + o.arg;
                 a.pnext[b] = m;
                 if (a.t_ends[b] == a.max_T && m >= a.ends[b]) {
                     a.t_ends[b] = a.t;
@@ -1020,11 +1141,11 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain(RowChainArgs a) {
                 for (int e = 0; e < 4; ++e) if (col + e >= L.N) v[e] = 0.f;
             }
             float s = v[0] + v[1] + v[2] + v[3];
-            const float mean = wave_sum(s) / (float)L.N;
+            const float mean = NONORM ? 0.f : wave_sum(s) / (float)L.N;
             float qq = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float dlt = col + e < L.N ? v[e] - mean : 0.f; v[e] = dlt; qq += dlt * dlt; }
-            const float rstd = 1.0f / sqrtf(wave_sum(qq) / (float)L.N + LN_EPS);
+            const float rstd = NONORM ? 1.0f : 1.0f / sqrtf(wave_sum(qq) / (float)L.N + LN_EPS);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 v[e] = col + e < L.N ? apply_act(v[e] * rstd * gv[e] + bv[e], L.act) : 0.f;
@@ -1058,7 +1179,12 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain(RowChainArgs a) {
 }
 
 void launch_row_chain(const RowChainArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(row_chain, dim3(a.B), dim3(64 * RC_WAVES), 0, s, a);
+    const bool nm = a.nomono && a.pro == ROW_ATTN;
+    const dim3 grid(a.B), block(64 * RC_WAVES);
+    if (!nm && !a.nonorm) hipLaunchKernelGGL((row_chain<false, false>), grid, block, 0, s, a);
+    else if (!nm) hipLaunchKernelGGL((row_chain<false, true>), grid, block, 0, s, a);
+    else if (!a.nonorm) hipLaunchKernelGGL((row_chain<true, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((row_chain<true, true>), grid, block, 0, s, a);
 }
 
 // embed_rows: modules.py:15-44 (row 0 replaced by zeros at lookup time); pads to ldo with zeros
@@ -1078,6 +1204,21 @@ __global__ void embed_rows(const int* ids, long long n, const float* table, int 
 void launch_embed(const int* ids, long long n, const float* table, int units, float* out, int ldo, hipStream_t s) {
     const long long tot = n * (ldo / 4);
     hipLaunchKernelGGL(embed_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ids, n, table, units, out, ldo);
+}
+
+// spk_append_rows: out[row][col0 : col0+dim) = table[ids[row / T]] (row 0 of the table reads as zeros, modules.py:38-40)
+// -- tf.tile(speaker_codes, [1, T]) -> embed -> concat on the channel axis (networks.py:139-144)
+__global__ void spk_append_rows_k(float* out, int ldo, long long rows, int T, int col0, const float* table, const int* ids, int dim) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * dim) return;
+    const long long row = i / dim;
+    const int c = (int)(i - row * dim);
+    const int id = ids[row / T];
+    out[row * ldo + col0 + c] = id == 0 ? 0.f : table[(size_t)id * dim + c];
+}
+void launch_spk_append_rows(float* out, int ldo, long long rows, int T, int col0, const float* table, const int* ids, int dim, hipStream_t s) {
+    const long long tot = rows * dim;
+    hipLaunchKernelGGL(spk_append_rows_k, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, out, ldo, rows, T, col0, table, ids, dim);
 }
 
 // pad_rows: dst[r][0:ldd) = src[r][0:C) then zeros

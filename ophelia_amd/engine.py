@@ -10,13 +10,19 @@ from . import _lib
 
 def dims_from_hp(hp, max_N=None, max_T=None):
     ms = list(getattr(hp, "multispeaker", []) or [])
-    unsupported = [p for p in ms if p != "audio_decoder_input"]
+    positions = {"audio_decoder_input": _lib.FLAG_SPK_AUDIO_DECODER_INPUT,
+                 "text_encoder_input": _lib.FLAG_SPK_TEXT_ENCODER_INPUT,
+                 "text_encoder_towards_end": _lib.FLAG_SPK_TEXT_ENCODER_TOWARDS_END}
+    unsupported = [p for p in ms if p not in positions]
     if unsupported:
-        raise NotImplementedError("multispeaker positions %s are outside the hot-path scope "
-                                  "(SURVEY.md 8f-4)" % unsupported)
-    for attr, want in (("norm", "layer"), ("text_encoder_type", "DCTTS_standard"),
+        raise NotImplementedError("multispeaker positions %s are not supported (supported: %s)"
+                                  % (unsupported, sorted(positions)))
+    norm = getattr(hp, "norm", "layer")
+    if norm not in ("layer", None):
+        raise NotImplementedError("hp.norm=%r is not supported ('layer' or None)" % (norm,))
+    for attr, want in (("text_encoder_type", "DCTTS_standard"),
                        ("history_type", "DCTTS_standard"), ("use_external_durations", False),
-                       ("concatenate_query", True), ("turn_off_monotonic_for_synthesis", False),
+                       ("concatenate_query", True),
                        ("squash_output_t2m", True), ("squash_output_ssrn", True)):
         if getattr(hp, attr, want) != want:
             raise NotImplementedError("hp.%s=%r is outside the hot-path scope" % (attr, getattr(hp, attr)))
@@ -29,7 +35,13 @@ def dims_from_hp(hp, max_N=None, max_T=None):
     d.attention_win_size = hp.attention_win_size
     d.nspeakers = getattr(hp, "nspeakers", 0) if ms else 0
     d.speaker_embedding_size = getattr(hp, "speaker_embedding_size", 0) if ms else 0
-    d.flags = _lib.FLAG_SPK_AUDIO_DECODER_INPUT if ms else 0
+    d.flags = (_lib.FLAG_NORM_NONE if norm is None else 0)
+    if getattr(hp, "turn_off_monotonic_for_synthesis", False):
+        if d.max_N > 256:
+            raise NotImplementedError("turn_off_monotonic_for_synthesis is supported up to max_N = 256")
+        d.flags |= _lib.FLAG_NO_MONOTONIC
+    for p in ms:
+        d.flags |= positions[p]
     return d
 
 
@@ -42,7 +54,8 @@ class Engine(object):
         rc = self.lib.oph_create(C.byref(self.dims), int(device), C.byref(self._h))
         if rc != 0:
             raise _lib.OpheliaHipError("oph_create failed (%d): %s" % (rc, self.lib.oph_last_error(None).decode()))
-        self.multispeaker = bool(self.dims.flags & _lib.FLAG_SPK_AUDIO_DECODER_INPUT)
+        self.multispeaker = bool(self.dims.flags & (_lib.FLAG_SPK_AUDIO_DECODER_INPUT | _lib.FLAG_SPK_TEXT_ENCODER_INPUT |
+                                                    _lib.FLAG_SPK_TEXT_ENCODER_TOWARDS_END))
         self.B = 0
 
     # -- plumbing

@@ -98,11 +98,19 @@ def _conv_taps(x, kernel, bias, rate, padding):
     return out.astype(F32)
 
 
+def _norm(h, W, prefix):
+    """modules.normalize with hp.norm in ('layer', None): with norm=None the graph creates no gamma/beta variables
+    (modules.py:62-74), so the weight dictionary itself says which one applies."""
+    if prefix + "/gamma" in W:
+        return normalize(h, W[prefix + "/gamma"], W[prefix + "/beta"])
+    return np.asarray(h, F32)
+
+
 def conv1d(x, W, scope, rate=1, padding="SAME", activation_fn=None):
-    """modules.py:91-146: [causal pad] -> conv -> LayerNorm -> activation.
+    """modules.py:91-146: [causal pad] -> conv -> LayerNorm (unless hp.norm is None) -> activation.
     Dropout is identity at synthesis (training=False)."""
     h = _conv_taps(x, W[scope + "/conv1d/kernel"], W[scope + "/conv1d/bias"], rate, padding)
-    h = normalize(h, W[scope + "/normalize/gamma"], W[scope + "/normalize/beta"])
+    h = _norm(h, W, scope + "/normalize")
     if activation_fn is not None:
         h = activation_fn(h)
     return h
@@ -113,8 +121,8 @@ def hc(x, W, scope, rate=1, padding="SAME"):
     each (scopes H1, H2) -> out = sigmoid(H1)*H2 + (1-sigmoid(H1))*x."""
     h = _conv_taps(x, W[scope + "/conv1d/kernel"], W[scope + "/conv1d/bias"], rate, padding)
     C = h.shape[-1] // 2
-    H1 = normalize(h[..., :C], W[scope + "/H1/gamma"], W[scope + "/H1/beta"])
-    H2 = normalize(h[..., C:], W[scope + "/H2/gamma"], W[scope + "/H2/beta"])
+    H1 = _norm(h[..., :C], W, scope + "/H1")
+    H2 = _norm(h[..., C:], W, scope + "/H2")
     g = sigmoid(H1)
     return (g * H2 + (F32(1) - g) * x).astype(F32)
 
@@ -139,16 +147,27 @@ def conv1d_transpose(x, W, scope):
     out[:, 0::2] = even.reshape(B, T, Cout)
     out[:, 1::2] = odd.reshape(B, T, Cout)
     out += b
-    return normalize(out, W[scope + "/normalize/gamma"], W[scope + "/normalize/beta"])
+    return _norm(out, W, scope + "/normalize")
 
 
 # --------------------------------------------------------------------------
 # networks  (networks.py)
 # --------------------------------------------------------------------------
-def text_enc(hp, L, W, scope="Text2Mel/TextEnc"):
-    """networks.py:121-212 (no multispeaker hooks: unused by the BASELINE configs)."""
+def _speaker_reps(speakers, T, table):
+    """tf.tile(speaker_codes, [1, T]) -> embed (zero_pad: speaker 0 -> zeros)  (networks.py:139-143)"""
+    B = len(speakers)
+    codes = np.tile(np.asarray(speakers).reshape(B, 1).astype(np.int64), (1, T))
+    return embed(codes, table)
+
+
+def text_enc(hp, L, W, scope="Text2Mel/TextEnc", speakers=None):
+    """networks.py:121-212 with the 'text_encoder_input' (138-144) and 'text_encoder_towards_end' (184-199) speaker
+    hooks; 'learn_channel_contributions' is not covered."""
     i = 1
     t = embed(L, W["%s/embed_%d/lookup_table" % (scope, i)]); i += 1
+    if "text_encoder_input" in hp.multispeaker:
+        reps = _speaker_reps(speakers, t.shape[1], W["%s/embed_%d/lookup_table" % (scope, i)]); i += 1
+        t = np.concatenate((t, reps), -1)
     t = conv1d(t, W, "%s/C_%d" % (scope, i), activation_fn=relu); i += 1
     t = conv1d(t, W, "%s/C_%d" % (scope, i)); i += 1
     for _ in range(2):
@@ -156,6 +175,10 @@ def text_enc(hp, L, W, scope="Text2Mel/TextEnc"):
             t = hc(t, W, "%s/HC_%d" % (scope, i), rate=3 ** j); i += 1
     for _ in range(2):
         t = hc(t, W, "%s/HC_%d" % (scope, i), rate=1); i += 1
+    if "text_encoder_towards_end" in hp.multispeaker:
+        reps = _speaker_reps(speakers, t.shape[1], W["%s/embed_%d/lookup_table" % (scope, i)]); i += 1
+        t = np.concatenate((t, reps), -1)
+        t = conv1d(t, W, "%s/C_%d" % (scope, i), activation_fn=relu); i += 1   # squash hidden+embedding back to 2d
     for _ in range(2):                       # size-1 highway convs, networks.py:200-208
         t = hc(t, W, "%s/HC_%d" % (scope, i), rate=1); i += 1
     d = t.shape[-1] // 2
@@ -191,6 +214,11 @@ def attention(hp, Q, K, V, prev_max_attentions):
     rev_len = hp.max_N - hp.attention_win_size - p   # sequence_mask(len)[:, ::-1]
     reverse_masks = (N - 1 - n) < rev_len            # [TF-sem] len<=0 -> all False
     masks = np.logical_or(key_masks, reverse_masks)  # (B,N)
+    if getattr(hp, "turn_off_monotonic_for_synthesis", False):
+        # networks.py:307-309: no forcibly-incremental window; only keys past the text are masked.
+        # hp.text_lengths = get_text_lengths(L) + 1 is set by the host (synthesize.py:505-507)
+        tl = np.asarray(hp.text_lengths).astype(np.int64).reshape(B, 1)
+        masks = (N - 1 - n) < (hp.max_N - tl)
     A = np.where(masks[:, None, :], MASK_VALUE, A).astype(F32)
     A = A - A.max(axis=-1, keepdims=True)
     E = np.exp(A, dtype=F32)
@@ -259,9 +287,9 @@ def text2mel_graph(hp, W, K, V, mels, prev_max_attentions, speakers=None):
     return Y, max_attentions, alignments
 
 
-def encode_text(hp, W, L):
+def encode_text(hp, W, L, speakers=None):
     """synthesize.py:232-240."""
-    return text_enc(hp, np.asarray(L), W)
+    return text_enc(hp, np.asarray(L), W, speakers=speakers)
 
 
 def get_text_lengths(L):
@@ -331,15 +359,15 @@ def _push(st, name, x, j):
 
 def _inc_conv1d(st, name, x, j, W, act=None):
     h = _hist_conv(_push(st, name, x, j), j, W[name + "/conv1d/kernel"], W[name + "/conv1d/bias"], 1)
-    h = normalize(h, W[name + "/normalize/gamma"], W[name + "/normalize/beta"])
+    h = _norm(h, W, name + "/normalize")
     return act(h) if act is not None else h
 
 
 def _inc_hc(st, name, x, j, W, rate):
     h = _hist_conv(_push(st, name, x, j), j, W[name + "/conv1d/kernel"], W[name + "/conv1d/bias"], rate)
     C = h.shape[-1] // 2
-    g = sigmoid(normalize(h[:, :C], W[name + "/H1/gamma"], W[name + "/H1/beta"]))
-    u = normalize(h[:, C:], W[name + "/H2/gamma"], W[name + "/H2/beta"])
+    g = sigmoid(_norm(h[:, :C], W, name + "/H1"))
+    u = _norm(h[:, C:], W, name + "/H2")
     return (g * u + (F32(1) - g) * x).astype(F32)
 
 
@@ -415,26 +443,37 @@ def variable_shapes(hp):
     """Ordered {tf_variable_name: shape} for the synth-mode graphs."""
     out = {}
 
+    ln = getattr(hp, "norm", "layer") == "layer"     # hp.norm None: no gamma/beta variables at all
+
     def conv(scope, cin, cout, size=1):
         out[scope + "/conv1d/kernel"] = (size, cin, cout)
         out[scope + "/conv1d/bias"] = (cout,)
-        out[scope + "/normalize/beta"] = (cout,)
-        out[scope + "/normalize/gamma"] = (cout,)
+        if ln:
+            out[scope + "/normalize/beta"] = (cout,)
+            out[scope + "/normalize/gamma"] = (cout,)
 
     def hcl(scope, c, size=3):
         out[scope + "/conv1d/kernel"] = (size, c, 2 * c)
         out[scope + "/conv1d/bias"] = (2 * c,)
         for h in ("H1", "H2"):
-            out["%s/%s/beta" % (scope, h)] = (c,)
-            out["%s/%s/gamma" % (scope, h)] = (c,)
+            if ln:
+                out["%s/%s/beta" % (scope, h)] = (c,)
+                out["%s/%s/gamma" % (scope, h)] = (c,)
 
     d, e, c = hp.d, hp.e, hp.c
     s = "Text2Mel/TextEnc"; i = 1
     out["%s/embed_%d/lookup_table" % (s, i)] = (len(hp.vocab), e); i += 1
-    conv("%s/C_%d" % (s, i), e, 2 * d); i += 1
+    e_in = e
+    if "text_encoder_input" in hp.multispeaker:
+        out["%s/embed_%d/lookup_table" % (s, i)] = (hp.nspeakers, hp.speaker_embedding_size); i += 1
+        e_in = e + hp.speaker_embedding_size
+    conv("%s/C_%d" % (s, i), e_in, 2 * d); i += 1
     conv("%s/C_%d" % (s, i), 2 * d, 2 * d); i += 1
     for _ in range(10):
         hcl("%s/HC_%d" % (s, i), 2 * d, 3); i += 1
+    if "text_encoder_towards_end" in hp.multispeaker:
+        out["%s/embed_%d/lookup_table" % (s, i)] = (hp.nspeakers, hp.speaker_embedding_size); i += 1
+        conv("%s/C_%d" % (s, i), 2 * d + hp.speaker_embedding_size, 2 * d); i += 1
     for _ in range(2):
         hcl("%s/HC_%d" % (s, i), 2 * d, 1); i += 1
     s = "Text2Mel/AudioEnc"; i = 1
@@ -461,6 +500,7 @@ def variable_shapes(hp):
         sc = "%s/D_%d" % (s, i); i += 1
         out[sc + "/conv2d_transpose/kernel"] = (1, 3, c, c)
         out[sc + "/conv2d_transpose/bias"] = (c,)
+        # networks.py:483-486 does not pass normtype: the transposed convs keep their LayerNorm even with hp.norm None
         out[sc + "/normalize/beta"] = (c,)
         out[sc + "/normalize/gamma"] = (c,)
         for _ in range(2):

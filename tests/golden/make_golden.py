@@ -77,6 +77,8 @@ def run_case(tag, cfg, B, max_N, max_T, wseed, tseed, min_len, max_len, stop, sp
     if hp.multispeaker:
         speakers = (np.ones((B, 1)) * speaker_ix)           # synthesize.py:499-501 (float64 (B,1))
     ends = np.array([np.where(L[i] == 0)[0][0] for i in range(B)])   # synthesize.py:242-247
+    if getattr(hp, "turn_off_monotonic_for_synthesis", False):
+        hp.text_lengths = ends + 1                                   # synthesize.py:505-507
 
     # --- host loop, restating synthesize.py:150-230 around the REFERENCE graph ---
     Y = np.zeros((B, hp.max_T, hp.n_mels), np.float32)
@@ -142,9 +144,15 @@ def frontend_case():
         out[tag + "_bases"] = np.array([os.path.basename(p)[:-4] for p in ds["fpaths"]])
         out[tag + "_text_lengths"] = np.array(ds["text_lengths"], np.int32)
         print(tag, "front-end:", ds["texts"].shape, ds["text_lengths"])
-    # config attribute snapshot (the drop-in config API): every simple-typed attribute
-    snap = {}
-    for cfg in ("lj_tutorial.cfg", "lj_test.cfg", "vctk_01.cfg"):
+    config_snapshot(("lj_tutorial.cfg", "lj_test.cfg", "vctk_01.cfg"), fresh=True)
+    np.savez_compressed(os.path.join(HERE, "frontend.npz"), **out)
+
+
+def config_snapshot(cfgs, fresh=False):
+    """config attribute snapshot (the drop-in config API): every simple-typed attribute"""
+    path = os.path.join(HERE, "config_snapshot.json")
+    snap = {} if fresh else json.load(open(path))
+    for cfg in cfgs:
         hp = ref_configuration.load_config(os.path.join(REF, "config", cfg))
         d = {}
         for k, v in sorted(hp.__dict__.items()):
@@ -152,12 +160,45 @@ def frontend_case():
                     and k not in ("transcript", "test_transcript", "waveforms", "logdir", "topworkdir"):
                 d[k] = v
         snap[cfg] = d
-    with open(os.path.join(HERE, "config_snapshot.json"), "w") as f:
+    with open(path, "w") as f:
         json.dump(snap, f, indent=1, sort_keys=True)
-    np.savez_compressed(os.path.join(HERE, "frontend.npz"), **out)
+
+
+# option variants of the shipped configs beyond C1-C5.  The reference's load_config re-executes
+# every config file in ONE module namespace (imp.load_source('config', ...)), so attributes a config does not set
+# survive from the previously loaded one: every case below therefore runs in its own interpreter, exactly like the
+# reference (one config per process).
+VARIANTS = {
+    # norm=None + turn_off_monotonic_for_synthesis (config/project/baseline.cfg)
+    "proj_nomono": dict(cfg="project/baseline.cfg", B=3, max_N=20, max_T=14, wseed=41, tseed=42, min_len=6, max_len=17,
+                        stop=True),
+    # ssw10/G1ABC_01.cfg: norm=None (+ whatever else that file really sets)
+    "g1abc_nonorm": dict(cfg="ssw10/G1ABC_01.cfg", B=2, max_N=14, max_T=18, wseed=43, tseed=44, min_len=3, max_len=7,
+                         stop=True),
+    # multispeaker ['text_encoder_input', 'audio_decoder_input'] (config/nancyplusnick_01..03.cfg)
+    "nn_spk_in": dict(cfg="nancyplusnick_01.cfg", B=2, max_N=16, max_T=12, wseed=45, tseed=46, min_len=8, max_len=15,
+                      stop=True, speaker_ix=1),
+    # multispeaker ['text_encoder_towards_end', 'audio_decoder_input'] (config/vctk_02.cfg)
+    "vctk02_spk_end": dict(cfg="vctk_02.cfg", B=2, max_N=16, max_T=12, wseed=47, tseed=48, min_len=8, max_len=15,
+                           stop=True, speaker_ix=5),
+}
+
+
+def variant_cases():
+    import subprocess
+    for tag in VARIANTS:
+        subprocess.check_call([sys.executable, "-B", os.path.abspath(__file__), "case", tag])
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "case":           # one variant case, in this (fresh) interpreter
+        v = dict(VARIANTS[sys.argv[2]])
+        config_snapshot((v["cfg"],))
+        run_case(sys.argv[2], v.pop("cfg"), **v)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "variants":
+        variant_cases()
+        sys.exit(0)
     frontend_case()
     # free-running, no early stop reached within max_T (long texts)
     run_case("lj_free", "lj_tutorial.cfg", B=2, max_N=24, max_T=16, wseed=11, tseed=12,

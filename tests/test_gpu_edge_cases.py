@@ -26,7 +26,9 @@ def _run(hp, W, L, spk=None, stop=True):
 def _check(hp, W, L, spk=None, stop=True):
     K, V, Y, t_ends, al, steps, Z = _run(hp, W, L, spk, stop)
     ends = O.get_text_lengths(L)
-    K0, V0 = O.encode_text(hp, W, L)
+    if getattr(hp, "turn_off_monotonic_for_synthesis", False):
+        hp.text_lengths = ends + 1                         # synthesize.py:505-507 (read by the oracle's attention)
+    K0, V0 = O.encode_text(hp, W, L, speakers=spk)
     trace = []
     Y0, t0, al0 = O.synth_codedtext2mel_incremental(hp, W, K0, V0, ends, speakers=spk, stop=stop, trace=trace)
     Z0 = O.synth_mel2mag(hp, W, Y0)
@@ -63,6 +65,27 @@ def test_c5_vctk_multispeaker_dims():
     # speaker id 0 is the padding speaker: its embedding row is zeroed at lookup (modules.py:38-40)
     spk[0, 0] = 0
     _check(hp, W, L, spk=spk, stop=False)
+
+
+def test_variant_project_baseline_full_width_attention():
+    """config/project/baseline.cfg: no LayerNorm, no monotonic window -- attention over every key of the text (+1);
+    max_N = 150 spreads the keys over three lane slots of the full-attention path"""
+    hp = hp_from_snapshot("project/baseline.cfg", max_T=24)
+    assert hp.norm is None and hp.turn_off_monotonic_for_synthesis and hp.max_N == 150
+    W = O.random_weights(hp, 61)
+    L = O.random_text(hp, 5, 62, min_len=3, max_len=149)
+    _check(hp, W, L, stop=False)
+
+
+def test_variant_text_encoder_speaker_embeddings_full_width():
+    """nancyplusnick_01.cfg ('text_encoder_input' + 'audio_decoder_input') and vctk_02.cfg ('text_encoder_towards_end'
+    + 'audio_decoder_input') at their own max_N; speaker 0 is the zeroed padding row"""
+    for cfg in ("nancyplusnick_01.cfg", "vctk_02.cfg"):
+        hp = hp_from_snapshot(cfg, max_T=20)
+        W = O.random_weights(hp, 63)
+        L = O.random_text(hp, 4, 64, min_len=10, max_len=hp.max_N - 1)
+        spk = np.array([[1], [0], [hp.nspeakers - 1], [2]], np.int32)
+        _check(hp, W, L, spk=spk, stop=False)
 
 
 def test_host_polled_early_stop_after_many_steps():

@@ -142,10 +142,27 @@ def test_cli_requires_speaker_for_multispeaker(tmp_path, monkeypatch):
 
 def test_out_of_scope_configs_fail_loudly():
     from ophelia_amd.engine import dims_from_hp
-    hp = hp_from_snapshot("lj_tutorial.cfg")
-    hp.multispeaker = ["text_encoder_input"]
+    for attr, val in (("multispeaker", ["learn_channel_contributions"]), ("multispeaker", ["ssrn_input"]),
+                      ("norm", "batch"), ("use_external_durations", True), ("text_encoder_type", "minimal_feedforward"),
+                      ("history_type", "fractional_position_in_phone"), ("squash_output_t2m", False)):
+        hp = hp_from_snapshot("lj_tutorial.cfg")
+        setattr(hp, attr, val)
+        with pytest.raises(NotImplementedError):
+            dims_from_hp(hp)
+
+
+def test_option_variants_map_to_abi_flags():
+    """hp.norm None, the non-monotonic synthesis switch and the speaker-embedding positions are carried as oph_dims.flags"""
+    from ophelia_amd import _lib
+    from ophelia_amd.engine import dims_from_hp
+    assert dims_from_hp(hp_from_snapshot("lj_tutorial.cfg")).flags == 0
+    d = dims_from_hp(hp_from_snapshot("project/baseline.cfg"))
+    assert d.flags == _lib.FLAG_NORM_NONE | _lib.FLAG_NO_MONOTONIC and d.nspeakers == 0
+    d = dims_from_hp(hp_from_snapshot("nancyplusnick_01.cfg"))
+    assert d.flags == _lib.FLAG_SPK_TEXT_ENCODER_INPUT | _lib.FLAG_SPK_AUDIO_DECODER_INPUT
+    assert d.nspeakers == hp_from_snapshot("nancyplusnick_01.cfg").nspeakers and d.speaker_embedding_size == 128
+    d = dims_from_hp(hp_from_snapshot("vctk_02.cfg"))
+    assert d.flags == _lib.FLAG_SPK_TEXT_ENCODER_TOWARDS_END | _lib.FLAG_SPK_AUDIO_DECODER_INPUT
+    hp = hp_from_snapshot("project/baseline.cfg", max_N=300)
     with pytest.raises(NotImplementedError):
-        dims_from_hp(hp)
-    hp = hp_from_snapshot("lj_tutorial.cfg"); hp.norm = None
-    with pytest.raises(NotImplementedError):
-        dims_from_hp(hp)
+        dims_from_hp(hp)                      # full-key attention keeps one key per lane slot: max_N <= 256

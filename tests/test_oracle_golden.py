@@ -6,7 +6,10 @@ import pytest
 from conftest import load_wiring_case
 from oracle import ophelia_oracle as O
 
-CASES = ["lj_free", "lj_stop", "vctk_spk"]
+CASES = ["lj_free", "lj_stop", "vctk_spk",
+         # option variants (make_golden.py variants): norm=None + non-monotonic, norm=None, speaker embedding at the
+         # text-encoder input / towards its end
+         "proj_nomono", "g1abc_nonorm", "nn_spk_in", "vctk02_spk_end"]
 TOL = 2e-5   # fp32 reassociation between numpy-BLAS (oracle) and torch (golden primitives)
 
 
@@ -33,7 +36,7 @@ def test_param_totals_lj_tutorial():
 def test_text_enc(tag):
     hp, meta, g = load_wiring_case(tag)
     W = O.random_weights(hp, meta["weight_seed"], scopes=("Text2Mel/TextEnc",))
-    K, V = O.encode_text(hp, W, g["L"])
+    K, V = O.encode_text(hp, W, g["L"], speakers=g.get("speakers"))
     assert np.abs(K - g["K"]).max() < TOL and np.abs(V - g["V"]).max() < TOL
 
 
