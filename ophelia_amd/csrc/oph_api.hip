@@ -50,6 +50,8 @@ struct Layer {
     bool ln = true;              // false: hp.norm None -> no gamma/beta variables, normalisation is the identity
     std::string cat_scope;       // TextEnc layers with ccat: TF scope of the speaker lookup table concatenated to the input
     float* cat_table = nullptr;
+    bool lcc = false;            // learned channel contributions: variable <scope>/lcc_embed/lookup_table (nspeakers, cout)
+    float* lcc_gate = nullptr;   // device table [nspeakers][cout] = sigmoid(lookup_table), row 0 = sigmoid(0) (embed zero_pad)
     // packed
     int kc = 0, N = 0, Nalloc = 0, ntaps = 1;
     int off[3] = {0, 0, 0};
@@ -272,6 +274,13 @@ void build_networks(oph_handle* h) {
     if (m.flags & OPH_FLAG_NORM_NONE)
         for (auto* net : {&h->textenc, &h->audioenc, &h->audiodec, &h->ssrn})
             for (Layer& l : *net) l.ln = l.kind == K_CONVT;
+    if (m.flags & OPH_FLAG_LCC) {
+        // the layers the reference passes lcc=/codes= to: all of TextEnc except the 'towards_end' squash conv
+        // (networks.py:191-198), all of AudioEnc, AudioDec after its input convs (networks.py:373-389 pass none); SSRN none
+        for (Layer& l : h->textenc) l.lcc = l.cat_scope.empty() || (m.flags & OPH_FLAG_SPK_TEXT_ENCODER_INPUT && &l == &h->textenc[0]);
+        for (Layer& l : h->audioenc) l.lcc = true;
+        for (size_t i = (size_t)h->dec_pre; i < h->audiodec.size(); ++i) h->audiodec[i].lcc = true;
+    }
     // inventory of TF variables, in graph-creation order
     auto inv = [&](const std::string& name, std::vector<int64_t> shp) { h->inventory.emplace_back(name, shp); };
     auto inv_layers = [&](const std::vector<Layer>& v) {
@@ -284,6 +293,7 @@ void build_networks(oph_handle* h) {
                     inv(l.scope + "/normalize/beta", {l.cout});
                     inv(l.scope + "/normalize/gamma", {l.cout});
                 }
+                if (l.lcc) inv(l.scope + "/lcc_embed/lookup_table", {m.nspeakers, l.cout});
             } else if (l.kind == K_HC) {
                 inv(l.scope + "/conv1d/kernel", {l.size, l.cin, 2 * l.cout});
                 inv(l.scope + "/conv1d/bias", {2 * l.cout});
@@ -293,6 +303,7 @@ void build_networks(oph_handle* h) {
                     inv(l.scope + "/H2/beta", {l.cout});
                     inv(l.scope + "/H2/gamma", {l.cout});
                 }
+                if (l.lcc) inv(l.scope + "/lcc_embed/lookup_table", {m.nspeakers, l.cout});
             } else {
                 inv(l.scope + "/conv2d_transpose/kernel", {1, 3, l.cout, l.cin});
                 inv(l.scope + "/conv2d_transpose/bias", {l.cout});
@@ -385,6 +396,13 @@ int pack_layer(oph_handle* h, Layer& l) {
         l.cat_table = upload(h, *getw(h, l.cat_scope + "/lookup_table"));
         if (!l.cat_table) return -1;
     }
+    if (l.lcc) {
+        const std::vector<float>& tb = *getw(h, l.scope + "/lcc_embed/lookup_table");    // (nspeakers, cout)
+        std::vector<float> gate(tb.size());
+        for (size_t i = 0; i < tb.size(); ++i) gate[i] = 1.0f / (1.0f + expf(-(i < (size_t)l.cout ? 0.0f : tb[i])));
+        l.lcc_gate = upload(h, gate);
+        if (!l.lcc_gate) return -1;
+    }
     if (!l.ln) {
         l.g1 = l.g2 = h->d_ones;
         l.b1 = l.b2 = h->d_zeros;
@@ -449,6 +467,7 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
         EpiArgs e{};
         e.g1 = l.g1; e.b1 = l.b1; e.g2 = l.g2; e.b2 = l.b2; e.act = l.act; e.Y = y; e.ldy = ldy; e.ypad = ypad;
         e.H = wsraw; e.stop_after = nullptr; e.nonorm = !l.ln;
+        e.lcc = l.lcc_gate; e.lcc_ids = h->d_spk; e.lcc_T = Tcur;
         if (!last && layers[li + 1].cat_table) {      // the next layer's input = [this output | speaker embedding]
             const Layer& nx = layers[li + 1];
             e.spk_table = nx.cat_table; e.spk_ids = h->d_spk; e.spk_dim = nx.ccat; e.spk_T = Tcur;
@@ -657,6 +676,7 @@ void launch_cone(oph_handle* h, int t) {
         EpiArgs e{};
         e.nsplit = g.ksplit; e.split_stride = g.split_stride;
         e.H = h->coneRaw; e.ldh = l.Nalloc; e.M = g.M; e.C = l.cout; e.mode = PRE_CONV; e.act = l.act; e.g1 = l.g1; e.b1 = l.b1; e.nonorm = !l.ln;
+        e.lcc = l.lcc_gate; e.lcc_ids = h->d_spk; e.lcc_T = 0; e.Bpad = Bpad;
         e.Bpad = Bpad; e.stop_after = stop_after; e.t = t;
         const bool spk_next = (k + 1 < pre) && h->audiodec[k + 1].ccat > 0;
         if (spk_next) {
@@ -685,6 +705,7 @@ void launch_cone(oph_handle* h, int t) {
         e.H = h->coneRaw; e.ldh = l.Nalloc; e.M = g.M; e.C = l.cout; e.mode = PRE_HC;
         e.g1 = l.g1; e.b1 = l.b1; e.g2 = l.g2; e.b2 = l.b2; e.Xres = cone[k]; e.ldres = l.kc; e.restab = h->d_res[k]; e.Bpad = Bpad;
         e.nonorm = !l.ln;
+        e.lcc = l.lcc_gate; e.lcc_ids = h->d_spk; e.lcc_T = 0;
         const Layer& nx = h->audiodec[pre + k + 1];
         e.Y = cone[k + 1]; e.ldy = nx.kc; e.ypad = nx.kc; e.stop_after = stop_after; e.t = t;
         run_epi(h, e);
@@ -694,12 +715,14 @@ void launch_cone(oph_handle* h, int t) {
 
 RowLayer row_layer(const Layer& l) {
     RowLayer r{};
-    r.W = l.Wkn; r.ldn = l.ldn; r.bias = l.bias; r.g = l.g1; r.b = l.b1; r.kc = l.kc; r.N = l.cout; r.act = l.act; r.ccat = l.ccat;
+    r.W = l.Wkn; r.ldn = l.ldn; r.bias = l.bias; r.g = l.g1; r.b = l.b1; r.kc = l.kc; r.N = l.cout; r.act = l.act; r.ccat = l.ccat; r.lcc = l.lcc_gate;
     return r;
 }
 void run_row_chain(oph_handle* h, RowChainArgs& a, int first_is_attn) {
     a.nonorm = (h->dm.flags & OPH_FLAG_NORM_NONE) ? 1 : 0;      // Text2Mel has no transposed convs: all or nothing
     a.nomono = (h->dm.flags & OPH_FLAG_NO_MONOTONIC) ? 1 : 0;
+    a.has_lcc = (h->dm.flags & OPH_FLAG_LCC) ? 1 : 0;
+    if (a.has_lcc) a.cat_ids = h->d_spk;
     double wbytes = 0, flops = 0;
     for (int i = 0; i < a.nlayers; ++i) { wbytes += (double)a.L[i].kc * a.L[i].N * 4.0; flops += 2.0 * a.B * a.L[i].kc * a.L[i].N; }
     h->pbegin(PC_ROWCHAIN);
@@ -710,6 +733,7 @@ void run_row_chain(oph_handle* h, RowChainArgs& a, int first_is_attn) {
 // dec_layer16 arguments of decoder layer `l` whose input rows x[t] are produced by `prev`'s raw output
 void fill_pre(DecArgs& a, const Layer* prev, const float* prev_raw, const float* prev_x) {
     a.nonorm = !prev->ln;
+    a.lcc = prev->lcc_gate;
     if (prev->kind == K_CONV) { a.pre = PRE_CONV; a.src = prev_raw; a.ldsrc = prev->Nalloc; a.g1 = prev->g1; a.b1 = prev->b1; a.act = prev->act; a.cin = prev->cout; }
     else { a.pre = PRE_HC; a.src = prev_raw; a.ldsrc = prev->Nalloc; a.g1 = prev->g1; a.b1 = prev->b1; a.g2 = prev->g2; a.b2 = prev->b2; a.xres = prev_x; a.ldres = prev->kc; a.cin = prev->cout; }
 }
@@ -751,7 +775,7 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode) {
         float* hist = h->ae_hist[li];
         DecArgs a{};
         if (li == nk1) { a.pre = PRE_COPY; a.src = hist + (size_t)t * Bpad * l.kc; a.ldsrc = l.kc; a.cin = l.cin; }
-        else { fill_pre(a, prev, prev_raw, prev_x); a.xstore = hist + (size_t)t * Bpad * l.kc; a.ldstore = l.kc; }
+        else { fill_pre(a, prev, prev_raw, prev_x); a.lcc_ids = h->d_spk; a.xstore = hist + (size_t)t * Bpad * l.kc; a.ldstore = l.kc; }
         a.ntaps = l.ntaps; a.kc = l.kc; a.ldtap = l.kc;
         const int o0 = -l.off[0], o1 = -l.off[1];
         a.tap0 = t - o0 >= 0 ? hist + (size_t)(t - o0) * Bpad * l.kc : nullptr;
@@ -769,6 +793,7 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode) {
         RowChainArgs a{};
         a.pro = ROW_ATTN; a.src = prev_raw; a.ldsrc = prev->Nalloc; a.cin = d;
         a.g1 = prev->g1; a.b1 = prev->b1; a.g2 = prev->g2; a.b2 = prev->b2; a.xres = prev_x; a.ldres = prev->kc;
+        a.lcc_pro = prev->lcc_gate;
         a.KV = h->KV; a.N_keys = m.max_N; a.d = d; a.win = m.attention_win_size; a.max_T = m.max_T;
         a.pcur = h->d_p + (t & 1) * Bpad; a.pnext = h->d_p + ((t + 1) & 1) * Bpad;
         a.ends = h->d_ends; a.t_ends = h->d_tends; a.n_ended = h->d_ctl; a.stop_flag = stop_after; a.stop_mode = stop_mode;
@@ -798,7 +823,7 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode) {
         const Layer& l = h->audiodec[li];
         DecArgs a{};
         if (k == 0) { a.pre = PRE_COPY; a.src = h->ad_xrow[li]; a.ldsrc = l.kc; a.cin = l.cin; }
-        else { fill_pre(a, prev, prev_raw, prev_x); a.xstore = h->ad_xrow[li]; a.ldstore = l.kc; }
+        else { fill_pre(a, prev, prev_raw, prev_x); a.lcc_ids = h->d_spk; a.xstore = h->ad_xrow[li]; a.ldstore = l.kc; }
         a.ntaps = l.ntaps; a.kc = l.kc; a.ldtap = l.kc;
         const int o0 = -l.off[0], o1 = -l.off[1];
         a.tap0 = t - o0 >= 0 ? cone[k] + (size_t)idx_of(h->Hset[k], o0) * Bpad * l.kc : nullptr;
@@ -814,6 +839,7 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode) {
         RowChainArgs a{};
         a.pro = ROW_HC; a.src = prev_raw; a.ldsrc = prev->Nalloc; a.cin = d;
         a.g1 = prev->g1; a.b1 = prev->b1; a.g2 = prev->g2; a.b2 = prev->b2; a.xres = prev_x; a.ldres = prev->kc;
+        a.lcc_pro = prev->lcc_gate;
         a.nlayers = (int)h->audiodec.size() - pre - nh;
         for (int i = 0; i < a.nlayers; ++i) a.L[i] = row_layer(h->audiodec[pre + nh + i]);
         a.L[a.nlayers - 1].act = ACT_SIGMOID;           // squash_output_t2m (networks.py:430-431)
@@ -946,7 +972,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
         g_create_error = "dimensions outside the supported hot path (d<=256, c<=512, n_mels<=256, full_dim<=1280, win<=8)";
         return OPH_ERR_UNSUPPORTED;
     }
-    if ((m.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_TOWARDS_END)) &&
+    if ((m.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_TOWARDS_END | OPH_FLAG_LCC)) &&
         (m.nspeakers < 1 || m.speaker_embedding_size < 1 || m.speaker_embedding_size % 4)) {
         g_create_error = "multispeaker flag set but nspeakers/speaker_embedding_size invalid";
         return OPH_ERR_INVALID;
@@ -1100,7 +1126,7 @@ int oph_stage_text(oph_handle* h, const int32_t* L, const int32_t* ends, const i
     int rc = check_ready(h, B);
     if (rc) return rc;
     if (!L || !ends) { h->fail("null argument"); return OPH_ERR_INVALID; }
-    const bool ms = h->dm.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_TOWARDS_END);
+    const bool ms = h->dm.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_TOWARDS_END | OPH_FLAG_LCC);
     if (ms && !spk) { h->fail("multispeaker model needs speaker ids"); return OPH_ERR_INVALID; }
     const oph_dims& m = h->dm;
     for (long long i = 0; i < (long long)B * m.max_N; ++i)
@@ -1247,7 +1273,7 @@ int oph_text2mel(oph_handle* h, const float* K, const float* V, const int32_t* e
     int rc = check_ready(h, B);
     if (rc) return rc;
     if (!K || !V || !ends) { h->fail("null argument"); return OPH_ERR_INVALID; }
-    const bool ms = h->dm.flags & OPH_FLAG_SPK_AUDIO_DECODER_INPUT;
+    const bool ms = h->dm.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_LCC);
     if (ms && !spk) { h->fail("multispeaker model needs speaker ids"); return OPH_ERR_INVALID; }
     if ((rc = ensure_decode_state(h, B))) return rc;
     const oph_dims& m = h->dm;

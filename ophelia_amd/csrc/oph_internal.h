@@ -49,6 +49,9 @@ struct EpiArgs {
     const float* spk_table; const int* spk_ids; int spk_dim; int spk_T; // utterance of row m: spk_T>0 ? m / spk_T : m % Bpad
     const int* stop_after; int t;
     int nonorm;                     // hp.norm None: the "LayerNorm" is the identity (mean 0, rstd 1; gamma/beta = 1/0 buffers)
+    // learned channel contributions (modules.py:78-88): per-speaker channel gate sigmoid(lcc_embed[spk]) stored as a
+    // table [nspeakers][C]; conv: y = gate * act(LN(h)) (a final squash sigmoid comes after the gate); hc: H2 *= gate
+    const float* lcc; const int* lcc_ids; int lcc_T;   // utterance of row m: lcc_T > 0 ? m / lcc_T : m % Bpad
 };
 
 // ---- fused M=16 decode layer (prologue = previous layer's LN/gate, then 16xK . KxN slice)
@@ -67,6 +70,7 @@ struct DecArgs {
     int B;
     const int* stop_after; int t;
     int nonorm;                     // the PREVIOUS layer (prologue) has no LayerNorm
+    const float* lcc; const int* lcc_ids;   // the PREVIOUS layer's LCC gate table [nspeakers][cin] (or null), speaker per row
 };
 
 struct AttnRowsArgs {
@@ -90,6 +94,7 @@ struct RowLayer {
     const float* W; int ldn;        // weights [kc][ldn], n contiguous (second packed copy of the k=1 layers)
     const float* bias; const float* g; const float* b;
     int kc; int N; int act; int ccat;   // ccat: speaker-embedding channels appended to this layer's INPUT
+    const float* lcc;               // LCC gate table [nspeakers][N] of this layer or null
 };
 enum RowPro { ROW_COPY = 0, ROW_HC = 1, ROW_ATTN = 2 };
 struct RowChainArgs {
@@ -107,6 +112,8 @@ struct RowChainArgs {
     int B; const int* stop_after; int t;
     int nonorm;                     // no LayerNorm anywhere in this chain (hp.norm None)
     int nomono;                     // ROW_ATTN without the monotonic window: keys [0, min(N_keys, ends[b]+1))
+    const float* lcc_pro;           // LCC gate table of the highway layer whose gate the prologue applies (or null)
+    int has_lcc;                    // any LCC table in this chain (selects the kernel instantiation); ids = cat_ids
 };
 
 // launchers (oph_kernels.hip)

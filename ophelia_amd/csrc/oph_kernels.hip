@@ -431,6 +431,8 @@ __global__ __launch_bounds__(256) void ln_rows(EpiArgs a) {
             if (c < C) x[v] += *(const f32x4*)(h + sp * a.split_stride + c);
     }
     ln_vec<NV>(x, C, lane, a.g1, a.b1, a.nonorm);
+    const float* lg = nullptr;             // this row's LCC gate vector
+    if (a.lcc) lg = a.lcc + (size_t)a.lcc_ids[a.lcc_T > 0 ? m / a.lcc_T : m % a.Bpad] * C;
     if (a.mode == PRE_HC) {
         f32x4 u[NV];
 #pragma unroll
@@ -441,6 +443,15 @@ __global__ __launch_bounds__(256) void ln_rows(EpiArgs a) {
                 if (c < C) u[v] += *(const f32x4*)(h + sp * a.split_stride + C + c);
         }
         ln_vec<NV>(u, C, lane, a.g2, a.b2, a.nonorm);
+        if (lg) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = (v * 64 + lane) * 4 + e;
+                    if (c < C) u[v][e] *= lg[c];
+                }
+        }
         size_t rrow = m;
         if (a.restab) rrow = (size_t)a.restab[m / a.Bpad] * a.Bpad + (m % a.Bpad);
         const float* xr = a.Xres + rrow * a.ldres;
@@ -456,6 +467,15 @@ __global__ __launch_bounds__(256) void ln_rows(EpiArgs a) {
                 }
             }
         }
+    } else if (lg) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = (v * 64 + lane) * 4 + e;
+                const float gt = c < C ? lg[c] : 0.f;
+                x[v][e] = a.act == ACT_SIGMOID ? sigmoidf_(gt * x[v][e]) : gt * apply_act(x[v][e], a.act);
+            }
     } else {
 #pragma unroll
         for (int v = 0; v < NV; ++v)
@@ -513,7 +533,7 @@ constexpr int DEC_PF = 48 / DEC_WAVES;    // 16-wide k-chunks prefetched per wav
 // gamma/beta, bias, the stop flag -- is requested up front in ONE batch (rows unrolled 4-wide
 // per wave), the LayerNorm reductions of the 4 rows are interleaved, and the stop flag only
 // predicates the final stores instead of gating the kernel.
-template <int NV, int PRE, int NTAPS>
+template <int NV, int PRE, int NTAPS, bool LCC>      // LCC: separate instantiation, the default critical-path kernel stays as it was
 __global__ __launch_bounds__(64 * DEC_WAVES) void dec_layer16(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Ktot = NTAPS * a.kc, ldxs = Ktot + 4;
@@ -619,6 +639,19 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void dec_layer16(DecArgs a) {
             }
         };
         ln4(x, g1v, b1v);
+        f32x4 lgv[DEC_RPW][NV];          // LCC gate of the previous layer for this wave's rows
+        if (LCC) {
+#pragma unroll
+            for (int rr = 0; rr < DEC_RPW; ++rr) {
+                const int grow = row0 + DEC_RPW * w + rr;
+                const float* lgp = a.lcc + (size_t)a.lcc_ids[grow < a.B ? grow : 0] * a.cin;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const int c = (v * 64 + lane) * 4;
+                    lgv[rr][v] = c < a.cin ? *(const f32x4*)(lgp + c) : zero4;
+                }
+            }
+        }
         if (PRE == PRE_HC) {
             ln4(u, g2v, b2v);
 #pragma unroll
@@ -628,7 +661,8 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void dec_layer16(DecArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float gte = sigmoidf_(x[rr][v][e]);
-                        x[rr][v][e] = gte * u[rr][v][e] + (1.0f - gte) * xr[rr][v][e];
+                        const float tr = LCC ? lgv[rr][v][e] * u[rr][v][e] : u[rr][v][e];
+                        x[rr][v][e] = gte * tr + (1.0f - gte) * xr[rr][v][e];
                     }
         } else {
 #pragma unroll
@@ -636,7 +670,10 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void dec_layer16(DecArgs a) {
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) x[rr][v][e] = apply_act(x[rr][v][e], a.act);
+                    for (int e = 0; e < 4; ++e) {
+                        const float av = apply_act(x[rr][v][e], a.act);
+                        x[rr][v][e] = LCC ? lgv[rr][v][e] * av : av;
+                    }
         }
     }
     // ---- 3. stage the 16 x Ktot operand in LDS: [taps (oldest first) | current]
@@ -721,8 +758,11 @@ static void launch_dec_t(const DecArgs& a, dim3 grid, size_t lds, hipStream_t s)
         size_t& d = done[{f, dev}];
         if (d < lds) { (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); d = lds; }
     };
-    if (a.ntaps == 3) { set((const void*)dec_layer16<NV, PRE, 3>); hipLaunchKernelGGL((dec_layer16<NV, PRE, 3>), grid, dim3(64 * DEC_WAVES), lds, s, a); }
-    else              { set((const void*)dec_layer16<NV, PRE, 1>); hipLaunchKernelGGL((dec_layer16<NV, PRE, 1>), grid, dim3(64 * DEC_WAVES), lds, s, a); }
+    const bool lcc = a.lcc != nullptr && PRE != PRE_COPY;
+    if (a.ntaps == 3 && !lcc)      { set((const void*)dec_layer16<NV, PRE, 3, false>); hipLaunchKernelGGL((dec_layer16<NV, PRE, 3, false>), grid, dim3(64 * DEC_WAVES), lds, s, a); }
+    else if (a.ntaps == 3)         { set((const void*)dec_layer16<NV, PRE, 3, true>);  hipLaunchKernelGGL((dec_layer16<NV, PRE, 3, true>), grid, dim3(64 * DEC_WAVES), lds, s, a); }
+    else if (!lcc)                 { set((const void*)dec_layer16<NV, PRE, 1, false>); hipLaunchKernelGGL((dec_layer16<NV, PRE, 1, false>), grid, dim3(64 * DEC_WAVES), lds, s, a); }
+    else                           { set((const void*)dec_layer16<NV, PRE, 1, true>);  hipLaunchKernelGGL((dec_layer16<NV, PRE, 1, true>), grid, dim3(64 * DEC_WAVES), lds, s, a); }
 }
 
 void launch_dec_layer(const DecArgs& a, int Npad16, hipStream_t s) {
@@ -975,7 +1015,7 @@ void launch_attn_rows(const AttnRowsArgs& a, hipStream_t s) {
 constexpr int RC_WAVES = 16;
 constexpr int RC_XMAX = 1024;
 
-template <bool NOMONO, bool NONORM>   // option variants are separate instantiations: the default kernel's register
+template <bool NOMONO, bool NONORM, bool LCC>   // option variants are separate instantiations: the default kernel's register
                                       // allocation (at the 128-VGPR cap, no scratch) must stay untouched
 __global__ __launch_bounds__(64 * RC_WAVES) void row_chain(RowChainArgs a) {
     __shared__ __attribute__((aligned(16))) float xs[2][RC_XMAX];
@@ -1046,6 +1086,18 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain(RowChainArgs a) {
         };
         ln(q, g1v, b1v);
         ln(u, g2v, b2v);
+        if (LCC && a.lcc_pro) {
+            const float* lgp = a.lcc_pro + (size_t)a.cat_ids[b] * d;
+#pragma unroll
+            for (int v = 0; v < ATT_NV; ++v) {
+                const int c = (v * 64 + lane) * 4;
+                if (c < d) {
+                    const f32x4 lgv = *(const f32x4*)(lgp + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) u[v][e] *= lgv[e];
+                }
+            }
+        }
 #pragma unroll
         for (int v = 0; v < ATT_NV; ++v)
 #pragma unroll
@@ -1146,9 +1198,20 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain(RowChainArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float dlt = col + e < L.N ? v[e] - mean : 0.f; v[e] = dlt; qq += dlt * dlt; }
             const float rstd = NONORM ? 1.0f : 1.0f / sqrtf(wave_sum(qq) / (float)L.N + LN_EPS);
+            if (LCC && L.lcc) {
+                // y = gate * act(LN(h)); the squash sigmoid of the last decoder layer (outside conv1d) comes after the gate
+                f32x4 lgv = zero4;
+                if (col < L.N) lgv = *(const f32x4*)(L.lcc + (size_t)a.cat_ids[b] * L.N + col);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                v[e] = col + e < L.N ? apply_act(v[e] * rstd * gv[e] + bv[e], L.act) : 0.f;
+                for (int e = 0; e < 4; ++e) {
+                    const float hn = v[e] * rstd * gv[e] + bv[e];
+                    v[e] = col + e < L.N ? (L.act == ACT_SIGMOID ? sigmoidf_(lgv[e] * hn) : lgv[e] * apply_act(hn, L.act)) : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = col + e < L.N ? apply_act(v[e] * rstd * gv[e] + bv[e], L.act) : 0.f;
+            }
             if (col < RC_XMAX && col < ((kc_next + 3) & ~3)) *(f32x4*)(&xs[nxt][col]) = v;
             for (int c = 256 + lane; c < kc_next; c += 64) xs[nxt][c] = 0.f;
             if (!last && a.L[li + 1].ccat > 0) {     // speaker embedding appended to the next layer's input
@@ -1181,10 +1244,19 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain(RowChainArgs a) {
 void launch_row_chain(const RowChainArgs& a, hipStream_t s) {
     const bool nm = a.nomono && a.pro == ROW_ATTN;
     const dim3 grid(a.B), block(64 * RC_WAVES);
-    if (!nm && !a.nonorm) hipLaunchKernelGGL((row_chain<false, false>), grid, block, 0, s, a);
-    else if (!nm) hipLaunchKernelGGL((row_chain<false, true>), grid, block, 0, s, a);
-    else if (!a.nonorm) hipLaunchKernelGGL((row_chain<true, false>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((row_chain<true, true>), grid, block, 0, s, a);
+#define RC_LAUNCH(NM, NN, LC) hipLaunchKernelGGL((row_chain<NM, NN, LC>), grid, block, 0, s, a)
+    const int sel = (nm ? 4 : 0) | (a.nonorm ? 2 : 0) | (a.has_lcc ? 1 : 0);
+    switch (sel) {
+        case 0: RC_LAUNCH(false, false, false); break;
+        case 1: RC_LAUNCH(false, false, true); break;
+        case 2: RC_LAUNCH(false, true, false); break;
+        case 3: RC_LAUNCH(false, true, true); break;
+        case 4: RC_LAUNCH(true, false, false); break;
+        case 5: RC_LAUNCH(true, false, true); break;
+        case 6: RC_LAUNCH(true, true, false); break;
+        default: RC_LAUNCH(true, true, true); break;
+    }
+#undef RC_LAUNCH
 }
 
 // embed_rows: modules.py:15-44 (row 0 replaced by zeros at lookup time); pads to ldo with zeros

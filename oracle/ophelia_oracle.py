@@ -106,23 +106,40 @@ def _norm(h, W, prefix):
     return np.asarray(h, F32)
 
 
-def conv1d(x, W, scope, rate=1, padding="SAME", activation_fn=None):
+def _lcc_gate(W, scope, speakers, like):
+    """modules.learn_channel_contributions (78-88): sigmoid(embed(codes)) broadcast over time; the table's row 0 reads as
+    zeros (embed zero_pad) -> gate 0.5.  Returns None when the layer has no LCC table or no speakers are given."""
+    key = scope + "/lcc_embed/lookup_table"
+    if key not in W or speakers is None:
+        return None
+    B = like.shape[0]
+    g = sigmoid(embed(np.asarray(speakers).reshape(B, 1).astype(np.int64), W[key]))      # (B,1,C)
+    return g if like.ndim == 3 else g[:, 0]
+
+
+def conv1d(x, W, scope, rate=1, padding="SAME", activation_fn=None, speakers=None):
     """modules.py:91-146: [causal pad] -> conv -> LayerNorm (unless hp.norm is None) -> activation.
     Dropout is identity at synthesis (training=False)."""
     h = _conv_taps(x, W[scope + "/conv1d/kernel"], W[scope + "/conv1d/bias"], rate, padding)
     h = _norm(h, W, scope + "/normalize")
     if activation_fn is not None:
         h = activation_fn(h)
+    g = _lcc_gate(W, scope, speakers, h)              # modules.py:143-144: after activation (and dropout)
+    if g is not None:
+        h = (g * h).astype(F32)
     return h
 
 
-def hc(x, W, scope, rate=1, padding="SAME"):
+def hc(x, W, scope, rate=1, padding="SAME", speakers=None):
     """modules.py:148-207 highway conv: conv to 2C -> split H1,H2 -> separate LN on
     each (scopes H1, H2) -> out = sigmoid(H1)*H2 + (1-sigmoid(H1))*x."""
     h = _conv_taps(x, W[scope + "/conv1d/kernel"], W[scope + "/conv1d/bias"], rate, padding)
     C = h.shape[-1] // 2
     H1 = _norm(h[..., :C], W, scope + "/H1")
     H2 = _norm(h[..., C:], W, scope + "/H2")
+    lg = _lcc_gate(W, scope, speakers, H2)            # modules.py:200-201: on the transformation branch only
+    if lg is not None:
+        H2 = (lg * H2).astype(F32)
     g = sigmoid(H1)
     return (g * H2 + (F32(1) - g) * x).astype(F32)
 
@@ -168,34 +185,34 @@ def text_enc(hp, L, W, scope="Text2Mel/TextEnc", speakers=None):
     if "text_encoder_input" in hp.multispeaker:
         reps = _speaker_reps(speakers, t.shape[1], W["%s/embed_%d/lookup_table" % (scope, i)]); i += 1
         t = np.concatenate((t, reps), -1)
-    t = conv1d(t, W, "%s/C_%d" % (scope, i), activation_fn=relu); i += 1
-    t = conv1d(t, W, "%s/C_%d" % (scope, i)); i += 1
+    t = conv1d(t, W, "%s/C_%d" % (scope, i), activation_fn=relu, speakers=speakers); i += 1
+    t = conv1d(t, W, "%s/C_%d" % (scope, i), speakers=speakers); i += 1
     for _ in range(2):
         for j in range(4):
-            t = hc(t, W, "%s/HC_%d" % (scope, i), rate=3 ** j); i += 1
+            t = hc(t, W, "%s/HC_%d" % (scope, i), rate=3 ** j, speakers=speakers); i += 1
     for _ in range(2):
-        t = hc(t, W, "%s/HC_%d" % (scope, i), rate=1); i += 1
+        t = hc(t, W, "%s/HC_%d" % (scope, i), rate=1, speakers=speakers); i += 1
     if "text_encoder_towards_end" in hp.multispeaker:
         reps = _speaker_reps(speakers, t.shape[1], W["%s/embed_%d/lookup_table" % (scope, i)]); i += 1
         t = np.concatenate((t, reps), -1)
         t = conv1d(t, W, "%s/C_%d" % (scope, i), activation_fn=relu); i += 1   # squash hidden+embedding back to 2d
     for _ in range(2):                       # size-1 highway convs, networks.py:200-208
-        t = hc(t, W, "%s/HC_%d" % (scope, i), rate=1); i += 1
+        t = hc(t, W, "%s/HC_%d" % (scope, i), rate=1, speakers=speakers); i += 1
     d = t.shape[-1] // 2
     return t[..., :d].copy(), t[..., d:].copy()
 
 
-def audio_enc(hp, S, W, scope="Text2Mel/AudioEnc"):
-    """networks.py:214-284."""
+def audio_enc(hp, S, W, scope="Text2Mel/AudioEnc", speakers=None):
+    """networks.py:214-284 (`speakers` only feeds the LCC gates; 'audio_encoder_input' is not covered)."""
     i = 1
-    t = conv1d(S, W, "%s/C_%d" % (scope, i), padding="CAUSAL", activation_fn=relu); i += 1
-    t = conv1d(t, W, "%s/C_%d" % (scope, i), padding="CAUSAL", activation_fn=relu); i += 1
-    t = conv1d(t, W, "%s/C_%d" % (scope, i), padding="CAUSAL"); i += 1
+    t = conv1d(S, W, "%s/C_%d" % (scope, i), padding="CAUSAL", activation_fn=relu, speakers=speakers); i += 1
+    t = conv1d(t, W, "%s/C_%d" % (scope, i), padding="CAUSAL", activation_fn=relu, speakers=speakers); i += 1
+    t = conv1d(t, W, "%s/C_%d" % (scope, i), padding="CAUSAL", speakers=speakers); i += 1
     for _ in range(2):
         for j in range(4):
-            t = hc(t, W, "%s/HC_%d" % (scope, i), rate=3 ** j, padding="CAUSAL"); i += 1
+            t = hc(t, W, "%s/HC_%d" % (scope, i), rate=3 ** j, padding="CAUSAL", speakers=speakers); i += 1
     for _ in range(2):
-        t = hc(t, W, "%s/HC_%d" % (scope, i), rate=3, padding="CAUSAL"); i += 1
+        t = hc(t, W, "%s/HC_%d" % (scope, i), rate=3, padding="CAUSAL", speakers=speakers); i += 1
     return t
 
 
@@ -243,12 +260,12 @@ def audio_dec(hp, R, W, speakers=None, scope="Text2Mel/AudioDec"):
         t = np.concatenate((t, reps), -1)
         t = conv1d(t, W, "%s/C_%d" % (scope, i)); i += 1     # default SAME, size 1
     for j in range(4):
-        t = hc(t, W, "%s/HC_%d" % (scope, i), rate=3 ** j, padding="CAUSAL"); i += 1
+        t = hc(t, W, "%s/HC_%d" % (scope, i), rate=3 ** j, padding="CAUSAL", speakers=speakers); i += 1
     for _ in range(2):
-        t = hc(t, W, "%s/HC_%d" % (scope, i), rate=1, padding="CAUSAL"); i += 1
+        t = hc(t, W, "%s/HC_%d" % (scope, i), rate=1, padding="CAUSAL", speakers=speakers); i += 1
     for _ in range(3):
-        t = conv1d(t, W, "%s/C_%d" % (scope, i), padding="CAUSAL", activation_fn=relu); i += 1
-    logits = conv1d(t, W, "%s/C_%d" % (scope, i), padding="CAUSAL"); i += 1
+        t = conv1d(t, W, "%s/C_%d" % (scope, i), padding="CAUSAL", activation_fn=relu, speakers=speakers); i += 1
+    logits = conv1d(t, W, "%s/C_%d" % (scope, i), padding="CAUSAL", speakers=speakers); i += 1
     Y = sigmoid(logits) if getattr(hp, "squash_output_t2m", True) else logits
     return logits, Y
 
@@ -281,7 +298,7 @@ def ssrn(hp, Y, W, scope="SSRN"):
 def text2mel_graph(hp, W, K, V, mels, prev_max_attentions, speakers=None):
     """architectures.py:188-239, mode 'synthesize', with K and V fed."""
     S = np.concatenate((np.zeros_like(mels[:, :1]), mels[:, :-1]), 1)   # :191
-    Q = audio_enc(hp, S, W)
+    Q = audio_enc(hp, S, W, speakers=speakers)
     R, alignments, max_attentions = attention(hp, Q, K, V, prev_max_attentions)
     _, Y = audio_dec(hp, R, W, speakers)
     return Y, max_attentions, alignments
@@ -357,17 +374,22 @@ def _push(st, name, x, j):
     return buf
 
 
-def _inc_conv1d(st, name, x, j, W, act=None):
+def _inc_conv1d(st, name, x, j, W, act=None, speakers=None):
     h = _hist_conv(_push(st, name, x, j), j, W[name + "/conv1d/kernel"], W[name + "/conv1d/bias"], 1)
     h = _norm(h, W, name + "/normalize")
-    return act(h) if act is not None else h
+    h = act(h) if act is not None else h
+    lg = _lcc_gate(W, name, speakers, h)
+    return h if lg is None else (lg * h).astype(F32)
 
 
-def _inc_hc(st, name, x, j, W, rate):
+def _inc_hc(st, name, x, j, W, rate, speakers=None):
     h = _hist_conv(_push(st, name, x, j), j, W[name + "/conv1d/kernel"], W[name + "/conv1d/bias"], rate)
     C = h.shape[-1] // 2
     g = sigmoid(_norm(h[:, :C], W, name + "/H1"))
     u = _norm(h[:, C:], W, name + "/H2")
+    lg = _lcc_gate(W, name, speakers, u)
+    if lg is not None:
+        u = (lg * u).astype(F32)
     return (g * u + (F32(1) - g) * x).astype(F32)
 
 
@@ -393,14 +415,14 @@ def synth_codedtext2mel_incremental(hp, W, K, V, ends, speakers=None, stop=True,
         _t0 = _time.perf_counter()
         x = Y[:, j - 1] if j > 0 else np.zeros((B, hp.n_mels), F32)
         i = 1
-        x = _inc_conv1d(st, "%s/C_%d" % (ae, i), x, j, W, relu); i += 1
-        x = _inc_conv1d(st, "%s/C_%d" % (ae, i), x, j, W, relu); i += 1
-        x = _inc_conv1d(st, "%s/C_%d" % (ae, i), x, j, W); i += 1
+        x = _inc_conv1d(st, "%s/C_%d" % (ae, i), x, j, W, relu, speakers); i += 1
+        x = _inc_conv1d(st, "%s/C_%d" % (ae, i), x, j, W, relu, speakers); i += 1
+        x = _inc_conv1d(st, "%s/C_%d" % (ae, i), x, j, W, None, speakers); i += 1
         for _ in range(2):
             for jj in range(4):
-                x = _inc_hc(st, "%s/HC_%d" % (ae, i), x, j, W, 3 ** jj); i += 1
+                x = _inc_hc(st, "%s/HC_%d" % (ae, i), x, j, W, 3 ** jj, speakers); i += 1
         for _ in range(2):
-            x = _inc_hc(st, "%s/HC_%d" % (ae, i), x, j, W, 3); i += 1
+            x = _inc_hc(st, "%s/HC_%d" % (ae, i), x, j, W, 3, speakers); i += 1
         Qh[:, j] = x
         lo = max(0, j - AUDIODEC_LOOKBACK)
         R, al, mx = attention(hp, Qh[:, lo:j + 1], K, V, prev_max)   # current mask, all rows
@@ -444,21 +466,26 @@ def variable_shapes(hp):
     out = {}
 
     ln = getattr(hp, "norm", "layer") == "layer"     # hp.norm None: no gamma/beta variables at all
+    lcc_on = "learn_channel_contributions" in hp.multispeaker
 
-    def conv(scope, cin, cout, size=1):
+    def conv(scope, cin, cout, size=1, lcc=True):
         out[scope + "/conv1d/kernel"] = (size, cin, cout)
         out[scope + "/conv1d/bias"] = (cout,)
         if ln:
             out[scope + "/normalize/beta"] = (cout,)
             out[scope + "/normalize/gamma"] = (cout,)
+        if lcc_on and lcc:
+            out[scope + "/lcc_embed/lookup_table"] = (hp.nspeakers, cout)
 
-    def hcl(scope, c, size=3):
+    def hcl(scope, c, size=3, lcc=True):
         out[scope + "/conv1d/kernel"] = (size, c, 2 * c)
         out[scope + "/conv1d/bias"] = (2 * c,)
         for h in ("H1", "H2"):
             if ln:
                 out["%s/%s/beta" % (scope, h)] = (c,)
                 out["%s/%s/gamma" % (scope, h)] = (c,)
+        if lcc_on and lcc:
+            out[scope + "/lcc_embed/lookup_table"] = (hp.nspeakers, c)
 
     d, e, c = hp.d, hp.e, hp.c
     s = "Text2Mel/TextEnc"; i = 1
@@ -473,7 +500,7 @@ def variable_shapes(hp):
         hcl("%s/HC_%d" % (s, i), 2 * d, 3); i += 1
     if "text_encoder_towards_end" in hp.multispeaker:
         out["%s/embed_%d/lookup_table" % (s, i)] = (hp.nspeakers, hp.speaker_embedding_size); i += 1
-        conv("%s/C_%d" % (s, i), 2 * d + hp.speaker_embedding_size, 2 * d); i += 1
+        conv("%s/C_%d" % (s, i), 2 * d + hp.speaker_embedding_size, 2 * d, lcc=False); i += 1
     for _ in range(2):
         hcl("%s/HC_%d" % (s, i), 2 * d, 1); i += 1
     s = "Text2Mel/AudioEnc"; i = 1
@@ -483,15 +510,16 @@ def variable_shapes(hp):
     for _ in range(10):
         hcl("%s/HC_%d" % (s, i), d, 3); i += 1
     s = "Text2Mel/AudioDec"; i = 1
-    conv("%s/C_%d" % (s, i), 2 * d, d); i += 1
+    conv("%s/C_%d" % (s, i), 2 * d, d, lcc=False); i += 1
     if "audio_decoder_input" in hp.multispeaker:
         out["%s/embed_%d/lookup_table" % (s, i)] = (hp.nspeakers, hp.speaker_embedding_size); i += 1
-        conv("%s/C_%d" % (s, i), d + hp.speaker_embedding_size, d); i += 1
+        conv("%s/C_%d" % (s, i), d + hp.speaker_embedding_size, d, lcc=False); i += 1
     for _ in range(6):
         hcl("%s/HC_%d" % (s, i), d, 3); i += 1
     for _ in range(3):
         conv("%s/C_%d" % (s, i), d, d); i += 1
     conv("%s/C_%d" % (s, i), d, hp.n_mels); i += 1
+    lcc_on = False                                   # SSRN passes no lcc / codes to its layers (networks.py:437-537)
     s = "SSRN"; i = 1
     conv("%s/C_%d" % (s, i), hp.n_mels, c); i += 1
     for _ in range(2):

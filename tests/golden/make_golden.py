@@ -181,6 +181,9 @@ VARIANTS = {
     # multispeaker ['text_encoder_towards_end', 'audio_decoder_input'] (config/vctk_02.cfg)
     "vctk02_spk_end": dict(cfg="vctk_02.cfg", B=2, max_N=16, max_T=12, wseed=47, tseed=48, min_len=8, max_len=15,
                            stop=True, speaker_ix=5),
+    # multispeaker ['learn_channel_contributions'] (config/vctk_03_lcc.cfg, nancyplusnick_04_lcc.cfg)
+    "vctk03_lcc": dict(cfg="vctk_03_lcc.cfg", B=3, max_N=16, max_T=12, wseed=49, tseed=50, min_len=8, max_len=15,
+                       stop=True, speaker_ix=3),
 }
 
 

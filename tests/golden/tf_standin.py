@@ -39,14 +39,34 @@ int64 = np.int64
 
 class Tensor(np.ndarray):
     class _Shape(object):
+        """TensorShape stand-in: NOT a tuple, so that '%s' % (t.shape) formats like it does in TF (modules.py:80)"""
         def __init__(self, s):
             self._s = list(s)
 
         def as_list(self):
             return list(self._s)
 
+        def __iter__(self):
+            return iter(self._s)
+
+        def __len__(self):
+            return len(self._s)
+
+        def __getitem__(self, i):
+            return self._s[i]
+
+        def __eq__(self, other):
+            return list(self._s) == list(other)
+
+        def __repr__(self):
+            return "(%s)" % ", ".join(str(v) for v in self._s)
+
+    @property
+    def shape(self):
+        return Tensor._Shape(np.ndarray.shape.__get__(self))
+
     def get_shape(self):
-        return Tensor._Shape(self.shape)
+        return Tensor._Shape(np.ndarray.shape.__get__(self))
 
 
 def _t(x):

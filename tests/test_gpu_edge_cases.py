@@ -80,7 +80,7 @@ def test_variant_project_baseline_full_width_attention():
 def test_variant_text_encoder_speaker_embeddings_full_width():
     """nancyplusnick_01.cfg ('text_encoder_input' + 'audio_decoder_input') and vctk_02.cfg ('text_encoder_towards_end'
     + 'audio_decoder_input') at their own max_N; speaker 0 is the zeroed padding row"""
-    for cfg in ("nancyplusnick_01.cfg", "vctk_02.cfg"):
+    for cfg in ("nancyplusnick_01.cfg", "vctk_02.cfg", "vctk_03_lcc.cfg"):     # the last: learned channel contributions
         hp = hp_from_snapshot(cfg, max_T=20)
         W = O.random_weights(hp, 63)
         L = O.random_text(hp, 4, 64, min_len=10, max_len=hp.max_N - 1)

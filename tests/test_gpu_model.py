@@ -22,7 +22,7 @@ def _engine(hp, W):
 @pytest.mark.parametrize("tag", ["lj_free", "lj_stop", "vctk_spk",
                                  # option variants of other shipped configs: hp.norm None, speaker
                                  # embedding at the text-encoder input / towards its end
-                                 "proj_nomono", "g1abc_nonorm", "nn_spk_in", "vctk02_spk_end"])
+                                 "proj_nomono", "g1abc_nonorm", "nn_spk_in", "vctk02_spk_end", "vctk03_lcc"])
 def test_golden_cases(tag):
     hp, meta, g = load_wiring_case(tag)
     W = O.random_weights(hp, meta["weight_seed"])
@@ -45,7 +45,7 @@ def test_golden_cases(tag):
     eng.close()
 
 
-@pytest.mark.parametrize("tag", ["vctk_spk", "g1abc_nonorm", "nn_spk_in", "vctk02_spk_end"])
+@pytest.mark.parametrize("tag", ["vctk_spk", "g1abc_nonorm", "nn_spk_in", "vctk02_spk_end", "vctk03_lcc"])
 def test_inventory_matches_reference_variables(tag):
     hp, meta, g = load_wiring_case(tag)
     from ophelia_amd.engine import Engine

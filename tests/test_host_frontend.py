@@ -142,7 +142,7 @@ def test_cli_requires_speaker_for_multispeaker(tmp_path, monkeypatch):
 
 def test_out_of_scope_configs_fail_loudly():
     from ophelia_amd.engine import dims_from_hp
-    for attr, val in (("multispeaker", ["learn_channel_contributions"]), ("multispeaker", ["ssrn_input"]),
+    for attr, val in (("multispeaker", ["speaker_dependent_phones"]), ("multispeaker", ["ssrn_input"]),
                       ("norm", "batch"), ("use_external_durations", True), ("text_encoder_type", "minimal_feedforward"),
                       ("history_type", "fractional_position_in_phone"), ("squash_output_t2m", False)):
         hp = hp_from_snapshot("lj_tutorial.cfg")

@@ -9,7 +9,8 @@ from oracle import ophelia_oracle as O
 CASES = ["lj_free", "lj_stop", "vctk_spk",
          # option variants (make_golden.py variants): norm=None + non-monotonic, norm=None, speaker embedding at the
          # text-encoder input / towards its end
-         "proj_nomono", "g1abc_nonorm", "nn_spk_in", "vctk02_spk_end"]
+         # ... and learned channel contributions (per-speaker sigmoid channel gates)
+         "proj_nomono", "g1abc_nonorm", "nn_spk_in", "vctk02_spk_end", "vctk03_lcc"]
 TOL = 2e-5   # fp32 reassociation between numpy-BLAS (oracle) and torch (golden primitives)
 
 
