@@ -515,10 +515,10 @@ void launch_epilogue(const EpiArgs& a, hipStream_t s) {
 
 // =====================================================================================
 // dec_layer16: one decoder layer for a tile of 16 utterances at ONE time step.
-//   grid = (Npad/16, Bpad/16), 256 threads.  Every workgroup redundantly runs the cheap
+//   grid = (Npad/16, Bpad/16), 16 waves.  Every workgroup redundantly runs the cheap
 //   prologue (the previous layer's LayerNorm / gate / highway mix for its 16 rows) into LDS,
 //   gathers the dilated taps x[t-2r], x[t-r] from the layer's history rows, then computes a
-//   16x16 output slice on v_mfma_f32_16x16x4_f32 with K split round-robin over the 4 waves;
+//   16x16 output slice on v_mfma_f32_16x16x4_f32 with K split round-robin over the 16 waves;
 //   weight fragments (Wt is [n][k], k contiguous) are fetched straight from L2 into
 //   registers and are issued BEFORE the prologue so their latency hides behind it.
 //   Output = raw conv rows (bias added); the consumer kernel applies this layer's LN.
