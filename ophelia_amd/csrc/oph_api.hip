@@ -8,6 +8,7 @@
 #include "../../include/ophelia_hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cstdarg>
 #include <cstdio>
@@ -893,6 +894,7 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
         hipEventRecord(h->ev_cone, h->scone);
     }
     int rc_loop = OPH_OK;
+    const auto tq0 = std::chrono::steady_clock::now();
     for (int t = t_begin; t < t_end; ++t) {
         decode_step(h, t, t_end, stop_mode);
         last = t + 1;
@@ -906,7 +908,13 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
     }
     g_cur = h->sdec;
     if (rc_loop != OPH_OK) { h->fail("device error while polling the stop flag"); return rc_loop; }
-    TRACE("decode loop enqueued, last=%d", last);
+    if (g_trace) {
+        const double enq_ms = (std::chrono::duration<double>(std::chrono::steady_clock::now() - tq0).count() * 1e3);
+        hipStreamSynchronize(h->sdec);
+        hipStreamSynchronize(h->scone);
+        const double all_ms = (std::chrono::duration<double>(std::chrono::steady_clock::now() - tq0).count() * 1e3);
+        TRACE("decode loop: host enqueue %.2f ms, device drained %.2f ms after the first launch (last=%d)", enq_ms, all_ms, last);
+    }
     // join: the API stream continues (SSRN, fetches) only after both decode streams drained
     hipEventRecord(h->ev_out, h->sdec);
     hipStreamWaitEvent(h->stream, h->ev_out, 0);
