@@ -23,6 +23,12 @@ using namespace oph;
 static thread_local std::string g_create_error;
 static thread_local hipStream_t g_cur = nullptr;    // stream the launch wrappers of THIS host thread target
 static thread_local int g_group_cls = -1;
+static double g_host_us[4] = {0, 0, 0, 0};     // OPH_TRACE: host time spent enqueuing {event ops, cone, critical launches, other}
+struct HostTimer {
+    int slot; std::chrono::steady_clock::time_point t0; bool on;
+    HostTimer(int s, bool enable) : slot(s), on(enable) { if (on) t0 = std::chrono::steady_clock::now(); }
+    ~HostTimer() { if (on) g_host_us[slot] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e6; }
+};
 static const bool g_trace = getenv("OPH_TRACE") != nullptr;
 #define TRACE(...) do { if (g_trace) { fprintf(stderr, "[oph] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 static thread_local std::string g_op_error;
@@ -95,6 +101,13 @@ struct oph_handle {
     bool use_graph = true;
     hipStream_t scone = nullptr;       // side stream in use: AudioDec history cone, overlapped with the AudioEnc chain
     hipEvent_t ev_attn = nullptr, ev_cone = nullptr;
+    // The two per-step cross-stream dependencies (cone(t+1) after row_chain B(t); AudioDec(t) after cone(t)) as stream
+    // write-value / wait-value operations on two device words instead of event record / wait pairs: an event operation
+    // interleaved with launches costs the host ~15 us and the device ~10 us on this runtime, a stream-value operation
+    // ~4 us / ~2 us (profiles/launch_rate_probe.hip).  Values grow monotonically: sig_base + step.
+    uint32_t* d_sig = nullptr;          // [0] attention of step t done (written on sdec), [16] cone of step t done (scone)
+    uint32_t sig_base = 0;
+    bool use_sigval = false;
     std::string err;
     bool finalized = false;
     // expected variables (TF names) and host copies
@@ -807,13 +820,32 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode) {
         run_row_chain(h, a, 1);
     }
     // cone(t) (launched during step t-1, or by decode_range for the first step) must have landed
-    if (t >= 1) hipStreamWaitEvent(h->sdec, h->ev_cone, 0);
+    const bool sv = h->use_sigval && !h->capturing;
+    {
+        HostTimer ht(0, g_trace);
+        if (t >= 1) {
+            if (sv) hipStreamWaitValue32(h->sdec, h->d_sig + 16, h->sig_base + (uint32_t)t, hipStreamWaitValueGte, 0xffffffffu);
+            else hipStreamWaitEvent(h->sdec, h->ev_cone, 0);
+        }
+    }
     // release cone(t+1) on the side stream: needs p_{t+1} and Q[t], both written by row_chain B of step t
     if (t + 1 < t_last) {
-        hipEventRecord(h->ev_attn, h->sdec);
-        hipStreamWaitEvent(h->scone, h->ev_attn, 0);
-        launch_cone(h, t + 1);
-        hipEventRecord(h->ev_cone, h->scone);
+        {
+            HostTimer ht(0, g_trace);
+            if (sv) {
+                hipStreamWriteValue32(h->sdec, h->d_sig, h->sig_base + (uint32_t)t + 1, 0);
+                hipStreamWaitValue32(h->scone, h->d_sig, h->sig_base + (uint32_t)t + 1, hipStreamWaitValueGte, 0xffffffffu);
+            } else {
+                hipEventRecord(h->ev_attn, h->sdec);
+                hipStreamWaitEvent(h->scone, h->ev_attn, 0);
+            }
+        }
+        { HostTimer ht(1, g_trace); launch_cone(h, t + 1); }
+        {
+            HostTimer ht(0, g_trace);
+            if (sv) hipStreamWriteValue32(h->scone, h->d_sig + 16, h->sig_base + (uint32_t)t + 1, 0);
+            else hipEventRecord(h->ev_cone, h->scone);
+        }
     }
     const std::vector<float*>& cone = h->cone[t & 1];
     // ---------------- AudioDec highway layers, row t (taps from the cone)
@@ -887,11 +919,28 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
             t_begin = t_end;      // skip the eager loop below
         }
     }
+    if (h->use_sigval) {
+        // a fresh value range for this loop: every value of an earlier loop is below sig_base + 1
+        if (h->sig_base > 0x7fff0000u) {       // wrap guard (once per ~10 million batches): start over from a quiet state
+            hipStreamSynchronize(h->sdec); hipStreamSynchronize(h->scone);
+            hipMemsetAsync(h->d_sig, 0, 32 * sizeof(uint32_t), h->stream);
+            hipStreamSynchronize(h->stream);
+            h->sig_base = 0;
+        }
+        h->sig_base += (uint32_t)m.max_T + 2;
+    }
     if (t_begin >= 1 && t_begin < t_end) {      // resuming mid-utterance: cone(t_begin) has not been launched yet
-        hipEventRecord(h->ev_attn, h->sdec);
-        hipStreamWaitEvent(h->scone, h->ev_attn, 0);
-        launch_cone(h, t_begin);
-        hipEventRecord(h->ev_cone, h->scone);
+        if (h->use_sigval) {
+            hipStreamWriteValue32(h->sdec, h->d_sig, h->sig_base + (uint32_t)t_begin, 0);
+            hipStreamWaitValue32(h->scone, h->d_sig, h->sig_base + (uint32_t)t_begin, hipStreamWaitValueGte, 0xffffffffu);
+            launch_cone(h, t_begin);
+            hipStreamWriteValue32(h->scone, h->d_sig + 16, h->sig_base + (uint32_t)t_begin, 0);
+        } else {
+            hipEventRecord(h->ev_attn, h->sdec);
+            hipStreamWaitEvent(h->scone, h->ev_attn, 0);
+            launch_cone(h, t_begin);
+            hipEventRecord(h->ev_cone, h->scone);
+        }
     }
     int rc_loop = OPH_OK;
     const auto tq0 = std::chrono::steady_clock::now();
@@ -913,7 +962,9 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
         hipStreamSynchronize(h->sdec);
         hipStreamSynchronize(h->scone);
         const double all_ms = (std::chrono::duration<double>(std::chrono::steady_clock::now() - tq0).count() * 1e3);
-        TRACE("decode loop: host enqueue %.2f ms, device drained %.2f ms after the first launch (last=%d)", enq_ms, all_ms, last);
+        TRACE("decode loop: host enqueue %.2f ms, device drained %.2f ms after the first launch (last=%d); of the enqueue: "
+              "event ops %.2f ms, cone launches %.2f ms", enq_ms, all_ms, last, g_host_us[0] * 1e-3, g_host_us[1] * 1e-3);
+        g_host_us[0] = g_host_us[1] = 0;
     }
     // join: the API stream continues (SSRN, fetches) only after both decode streams drained
     hipEventRecord(h->ev_out, h->sdec);
@@ -1040,6 +1091,15 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
         return OPH_ERR_DEVICE;
     }
     g_cur = h->stream;
+    {
+        int can = 0;
+        if (!getenv("OPH_NO_STREAM_VALUE") && hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) == hipSuccess && can) {
+            h->d_sig = h->dalloc<uint32_t>(32);
+            h->use_sigval = h->d_sig != nullptr && hipStreamWriteValue32(h->stream, h->d_sig, 0, 0) == hipSuccess &&
+                            hipStreamSynchronize(h->stream) == hipSuccess;
+        }
+        (void)hipGetLastError();
+    }
     h->ssrn_prec = getenv("OPH_SSRN_FP32") ? 0 : 1;
     h->use_graph = getenv("OPH_USE_GRAPH") != nullptr;
     build_networks(h);
