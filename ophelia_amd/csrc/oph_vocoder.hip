@@ -77,7 +77,7 @@ struct oph_vocoder {
     int backend = 0;                 // 0 = auto (fused when n_fft == 2048), 1 = hipFFT path
     int wstride = 0;
     long long capGF = 0, capYF = 0;
-    float *wseg[2] = {nullptr, nullptr}, *wss = nullptr, *d_wsup = nullptr;
+    float *wseg[2] = {nullptr, nullptr}, *wss = nullptr;
     float2* d_tw = nullptr;          // W_2048^k, k < 1024
 };
 
@@ -233,8 +233,8 @@ __global__ __launch_bounds__(64) void gl_deemphasis(const float* __restrict__ x,
 // fused Griffin-Lim iteration for n_fft = 2048: one workgroup owns one frame at a time and keeps it in LDS through
 //   gather(overlap-add of the neighbours' windowed segments, /wss, reflect pad, window) -> real FFT -> phase
 //   projection against S -> inverse real FFT -> window -> store this frame's windowed segment.
-// The only HBM traffic per frame and iteration is S (4.1 KB), the neighbour segments (L2/MALL hits, <= 5 x 4.4 KB)
-// and the 4.4 KB segment written.  The real transforms run as a 1024-point complex radix-4 Stockham FFT (5 passes,
+// The only HBM traffic per frame and iteration is S (4.1 KB), the signal under the window (4.4 KB) and the 4.4 KB
+// segment written.  Each thread owns eight consecutive samples of the frame (window values in registers).  The real transforms run as a 1024-point complex radix-4 Stockham FFT (5 passes,
 // one butterfly per thread, LDS ping-pong) with the even/odd split folded, together with the phase projection and the
 // inverse transform's split, into one in-place pass over bin pairs (k, 1024-k).
 // ---------------------------------------------------------------------------------------------------------------
@@ -255,23 +255,53 @@ __device__ __forceinline__ int PX(int i) { return i ^ (((i >> 4) * 5) & 15); }
 constexpr int TW_PAIR = 1020, TW_TOTAL = 1280;
 __host__ __device__ constexpr int tw_off(int Ns) { return Ns == 4 ? 0 : Ns == 16 ? 12 : Ns == 64 ? 60 : 252; }
 
-template <bool INV, int Ns>
+// Per-thread constants of the transform passes, computed once per workgroup lifetime and kept PACKED (two 16-bit LDS
+// slot numbers per register): the kernel is VALU-issue bound, and re-deriving the swizzled slots in every pass of every
+// frame was 40 % of its instructions.
+struct FusedConst {
+    int rd;                  // PX(tid); reads are at rd + 256 r in every pass
+    unsigned wr[5][2];       // pass p: slots PX(j0 + r Ns) for r = (0,1) and (2,3)
+    unsigned pk[2];          // pair pass: PX(k) | PX(1024-k) << 16 for k = tid+1 and k = tid+257
+    int own;                 // slot of logical element 4 tid; logical 4 tid + r lives at own ^ r
+};
+
+__device__ __forceinline__ void fused_const_init(FusedConst& fc, int tid) {
+    fc.rd = PX(tid);
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        const int Ns = 1 << (2 * p);
+        const int k = tid & (Ns - 1);
+        const int j0 = ((tid - k) << 2) + k;
+        fc.wr[p][0] = (unsigned)PX(j0) | ((unsigned)PX(j0 + Ns) << 16);
+        fc.wr[p][1] = (unsigned)PX(j0 + 2 * Ns) | ((unsigned)PX(j0 + 3 * Ns) << 16);
+    }
+    fc.pk[0] = (unsigned)PX(tid + 1) | ((unsigned)PX(FH - 1 - tid) << 16);
+    fc.pk[1] = (unsigned)PX(tid + 257) | ((unsigned)PX(FH - 257 - tid) << 16);
+    fc.own = PX(4 * tid);
+}
+
+// a * b, or a * conj(b)
+template <bool CONJ>
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {
+    return CONJ ? make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y)
+                : make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+template <bool INV, int P>      // pass P: Ns = 4^P
 __device__ __forceinline__ void fft_pass(const float2* __restrict__ in, float2* __restrict__ out, const float2* sT,
-                                         int tid) {
-    const int k = tid & (Ns - 1);
-    float2 v0 = in[PX(tid)], v1 = in[PX(tid + 256)], v2 = in[PX(tid + 512)], v3 = in[PX(tid + 768)];
-    if (Ns > 1) {
-        float2 t1 = sT[tw_off(Ns) + k], t2 = sT[tw_off(Ns) + Ns + k], t3 = sT[tw_off(Ns) + 2 * Ns + k];
-        if (INV) { t1.y = -t1.y; t2.y = -t2.y; t3.y = -t3.y; }
-        v1 = cmul(v1, t1); v2 = cmul(v2, t2); v3 = cmul(v3, t3);
+                                         const FusedConst& fc, int tid) {
+    constexpr int Ns = 1 << (2 * P);
+    float2 v0 = in[fc.rd], v1 = in[fc.rd + 256], v2 = in[fc.rd + 512], v3 = in[fc.rd + 768];
+    if (P > 0) {
+        const float2* tp = sT + tw_off(Ns) + (tid & (Ns - 1));
+        v1 = cmulc<INV>(v1, tp[0]); v2 = cmulc<INV>(v2, tp[Ns]); v3 = cmulc<INV>(v3, tp[2 * Ns]);
     }
     const float2 a0 = cadd(v0, v2), a1 = csub(v0, v2), a2 = cadd(v1, v3), d = csub(v1, v3);
     const float2 a3 = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);
-    const int j0 = ((tid - k) << 2) + k;
-    out[PX(j0)] = cadd(a0, a2);
-    out[PX(j0 + Ns)] = cadd(a1, a3);
-    out[PX(j0 + 2 * Ns)] = csub(a0, a2);
-    out[PX(j0 + 3 * Ns)] = csub(a1, a3);
+    out[fc.wr[P][0] & 0xffffu] = cadd(a0, a2);
+    out[fc.wr[P][0] >> 16] = cadd(a1, a3);
+    out[fc.wr[P][1] & 0xffffu] = csub(a0, a2);
+    out[fc.wr[P][1] >> 16] = csub(a1, a3);
 }
 
 __device__ __forceinline__ float2 project(float2 X, float s) {      // utils.py:104-105
@@ -282,10 +312,11 @@ __device__ __forceinline__ float2 project(float2 X, float s) {      // utils.py:
 // bins k and 1024-k (1 <= k <= 512): split the packed transform, project, re-pack for the inverse transform.
 // wk = W_2048^k.
 template <bool INIT>
-__device__ __forceinline__ void pair_pass(float2* Z, float2 wk, int k, float Sk, float Sp) {
+__device__ __forceinline__ void pair_pass(float2* Z, float2 wk, unsigned slots, bool self_paired, float Sk, float Sp) {
+    const int sk = (int)(slots & 0xffffu), sp = (int)(slots >> 16);     // slots of bin k and bin 1024-k
     float2 Pk, Pp;
     if (!INIT) {
-        const float2 a = Z[PX(k)], b = cconj(Z[PX(FH - k)]);
+        const float2 a = Z[sk], b = cconj(Z[sp]);
         const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
         const float2 d = csub(a, b);
         const float2 o = make_float2(0.5f * d.y, -0.5f * d.x);
@@ -300,8 +331,8 @@ __device__ __forceinline__ void pair_pass(float2* Z, float2 wk, int k, float Sk,
     const float2 e2 = cadd(Pk, b2);
     const float2 t = cmul(cconj(wk), csub(Pk, b2));
     const float2 o2 = make_float2(-t.y, t.x);
-    Z[PX(k)] = cadd(e2, o2);
-    if (k != FH / 2) Z[PX(FH - k)] = cconj(csub(e2, o2));
+    Z[sk] = cadd(e2, o2);
+    if (!self_paired) Z[sp] = cconj(csub(e2, o2));
 }
 
 // overlap-add of the stored windowed segments at trimmed position n of an utterance (frames in ascending order),
@@ -336,15 +367,20 @@ __device__ __forceinline__ float ola_at(const float* __restrict__ seg, const flo
 template <bool INIT>
 __global__ __launch_bounds__(256) void gl_fused(const float* __restrict__ S, const float* __restrict__ y,
                                                float* __restrict__ seg_out, const int4* __restrict__ meta,
-                                               const float2* __restrict__ tw, const float* __restrict__ wsup, int G,
+                                               const float2* __restrict__ tw, const float* __restrict__ wfull, int G,
                                                int hop, int lpad, int win, int wstride, int nbin) {
     __shared__ float2 bufA[FH], bufB[FH], sT[TW_TOTAL];
-    extern __shared__ float sw[];                        // window support, win floats
     const int tid = threadIdx.x;
     for (int i = tid; i < TW_TOTAL; i += 256) sT[i] = tw[i];
-    for (int i = tid; i < win; i += 256) sw[i] = wsup[i];
-    float* Af = reinterpret_cast<float*>(bufA);
-    auto FX = [](int i) { return 2 * PX(i >> 1) + (i & 1); };      // float view of a swizzled complex buffer
+    // this thread always owns samples 8 tid .. 8 tid + 7 of a frame: its eight window values (zero outside the window
+    // support) live in registers for both the analysis and the synthesis side
+    const int i0 = 8 * tid;
+    float wv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wv[e] = wfull[i0 + e];
+    const bool touch = i0 + 8 > lpad && i0 < lpad + win;
+    FusedConst fc;
+    fused_const_init(fc, tid);
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
     const int chunk = (G + 7) / 8;
     const int gend = min(G, (xcd + 1) * chunk);
@@ -365,33 +401,44 @@ __global__ __launch_bounds__(256) void gl_fused(const float* __restrict__ S, con
         const float sk2 = Srow[tid + 257], sp2 = Srow[FH - 257 - tid];
         if (!INIT) {
             // librosa.stft framing of the current signal: reflect padding + analysis window, zero outside the support
-            const int len = hop * (F - 1), period = 2 * (len - 1);
+            const int len = hop * (F - 1);
             const float* yb = y + y0;
-            const int nbase = f * hop + lpad - FH;       // trimmed position of the first support sample
-            for (int i = tid; i < lpad; i += 256) Af[FX(i)] = 0.f;
-            for (int i = lpad + win + tid; i < FN; i += 256) Af[FX(i)] = 0.f;
-            if (nbase >= 0 && nbase + win <= len) {
-                for (int k = tid; k < win; k += 256) Af[FX(lpad + k)] = sw[k] * yb[nbase + k];
-            } else {
-                for (int k = tid; k < win; k += 256) {
-                    int n = nbase + k;
-                    if (n < 0 || n >= len) {                 // np.pad(mode='reflect'), repeated if needed
-                        if (len == 1) n = 0;
-                        else {
-                            n %= period;
-                            if (n < 0) n += period;
-                            if (n >= len) n = period - n;
+            const int nb = f * hop + i0 - FH;            // trimmed position of this thread's first sample
+            float yv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) yv[e] = 0.f;
+            if (touch) {
+                if (nb >= 0 && nb + 8 <= len) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) yv[e] = yb[nb + e];
+                } else {
+                    const int period = 2 * (len - 1);
+#pragma unroll 1
+                    for (int e = 0; e < 8; ++e) {
+                        if (i0 + e < lpad || i0 + e >= lpad + win) continue;
+                        int n = nb + e;
+                        if (n < 0 || n >= len) {                 // np.pad(mode='reflect'), repeated if needed
+                            if (len == 1) n = 0;
+                            else {
+                                n %= period;
+                                if (n < 0) n += period;
+                                if (n >= len) n = period - n;
+                            }
                         }
+                        const float val = yb[n];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) if (q == e) yv[q] = val;
                     }
-                    Af[FX(lpad + k)] = sw[k] * yb[n];
                 }
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bufA[fc.own ^ r] = make_float2(wv[2 * r] * yv[2 * r], wv[2 * r + 1] * yv[2 * r + 1]);
             __syncthreads();
-            fft_pass<false, 1>(bufA, bufB, sT, tid);   __syncthreads();
-            fft_pass<false, 4>(bufB, bufA, sT, tid);   __syncthreads();
-            fft_pass<false, 16>(bufA, bufB, sT, tid);  __syncthreads();
-            fft_pass<false, 64>(bufB, bufA, sT, tid);  __syncthreads();
-            fft_pass<false, 256>(bufA, bufB, sT, tid); __syncthreads();
+            fft_pass<false, 0>(bufA, bufB, sT, fc, tid); __syncthreads();
+            fft_pass<false, 1>(bufB, bufA, sT, fc, tid); __syncthreads();
+            fft_pass<false, 2>(bufA, bufB, sT, fc, tid); __syncthreads();
+            fft_pass<false, 3>(bufB, bufA, sT, fc, tid); __syncthreads();
+            fft_pass<false, 4>(bufA, bufB, sT, fc, tid); __syncthreads();
         }
         if (tid == 0) {
             float P0 = s0, PN = sN;
@@ -403,16 +450,24 @@ __global__ __launch_bounds__(256) void gl_fused(const float* __restrict__ S, con
             }
             bufB[0] = make_float2(P0 + PN, P0 - PN);
         }
-        pair_pass<INIT>(bufB, wk1, tid + 1, sk1, sp1);
-        pair_pass<INIT>(bufB, wk2, tid + 257, sk2, sp2);
+        pair_pass<INIT>(bufB, wk1, fc.pk[0], false, sk1, sp1);
+        pair_pass<INIT>(bufB, wk2, fc.pk[1], tid == 255, sk2, sp2);      // tid 255: bin 512 pairs with itself
         __syncthreads();
-        fft_pass<true, 1>(bufB, bufA, sT, tid);   __syncthreads();
-        fft_pass<true, 4>(bufA, bufB, sT, tid);   __syncthreads();
-        fft_pass<true, 16>(bufB, bufA, sT, tid);  __syncthreads();
-        fft_pass<true, 64>(bufA, bufB, sT, tid);  __syncthreads();
-        fft_pass<true, 256>(bufB, bufA, sT, tid); __syncthreads();
-        float* out = seg_out + (long long)g * wstride;
-        for (int k = tid; k < win; k += 256) out[k] = sw[k] * (Af[FX(lpad + k)] * (1.0f / FN));
+        fft_pass<true, 0>(bufB, bufA, sT, fc, tid); __syncthreads();
+        fft_pass<true, 1>(bufA, bufB, sT, fc, tid); __syncthreads();
+        fft_pass<true, 2>(bufB, bufA, sT, fc, tid); __syncthreads();
+        fft_pass<true, 3>(bufA, bufB, sT, fc, tid); __syncthreads();
+        fft_pass<true, 4>(bufB, bufA, sT, fc, tid); __syncthreads();
+        if (touch) {
+            float* out = seg_out + (long long)g * wstride + (i0 - lpad);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float2 tv = bufA[fc.own ^ r];
+                const int ia = i0 + 2 * r, ib = ia + 1;
+                if (ia >= lpad && ia < lpad + win) out[2 * r] = wv[2 * r] * (tv.x * (1.0f / FN));
+                if (ib >= lpad && ib < lpad + win) out[2 * r + 1] = wv[2 * r + 1] * (tv.y * (1.0f / FN));
+            }
+        }
         __syncthreads();
     }
 }
@@ -561,7 +616,7 @@ int ensure_capacity_fused(oph_vocoder* v, const Batch& bt) {
     const long long G = (bt.G + 255) / 256 * 256;
     int rc;
     if (G > v->capGF) {
-        if ((rc = dev_alloc(v, &v->wseg[0], G * v->wstride, false))) return rc;
+        if ((rc = dev_alloc(v, &v->wseg[0], G * v->wstride, true))) return rc;
         v->capGF = G;
     }
     if (bt.Y > v->capYF) {
@@ -607,17 +662,19 @@ int run_griffin_lim_fused(oph_vocoder* v, const Batch& bt, int n_iter) {
     hipLaunchKernelGGL(gl_wss, ygrid, dim3(256), 0, v->stream, v->d_w2, v->t.foff, v->t.yoff, v->wss, p.n_fft,
                        p.hop_length, v->lpad, p.win_length);
     long long want = (bt.G + 7) / 8 * 8;
-    const unsigned nblk = (unsigned)(want < 256 * 5 ? want : 256 * 5);       // persistent: 5 workgroups of LDS per CU
-    const size_t shm = (size_t)p.win_length * sizeof(float);
-    hipLaunchKernelGGL(gl_fused<true>, dim3(nblk), dim3(256), shm, v->stream, v->S, (const float*)nullptr, v->wseg[0],
-                       v->t.meta, v->d_tw, v->d_wsup, (int)bt.G, p.hop_length, v->lpad, p.win_length, v->wstride,
+    // persistent workgroups: 4 per CU are resident (102 VGPRs); measured 16 x 800 frames: 2/CU 7.3 ms, 3: 6.3, 4: 6.0,
+    // 5: 6.8 (the fifth waits for a slot), 8: 6.0
+    static const int per_cu = getenv("OPH_VOC_WGS_PER_CU") ? std::max(1, atoi(getenv("OPH_VOC_WGS_PER_CU"))) : 4;
+    const unsigned nblk = (unsigned)(want < 256 * per_cu ? want : 256 * per_cu);
+    hipLaunchKernelGGL(gl_fused<true>, dim3(nblk), dim3(256), 0, v->stream, v->S, (const float*)nullptr, v->wseg[0],
+                       v->t.meta, v->d_tw, v->d_w, (int)bt.G, p.hop_length, v->lpad, p.win_length, v->wstride,
                        v->nbin);
     for (int it = 0; it <= n_iter; ++it) {
         hipLaunchKernelGGL(gl_ola_seg, ygrid, dim3(256), 0, v->stream, v->wseg[0], v->wss, v->t.foff, v->t.yoff, v->y,
                            p.hop_length, v->lpad, p.win_length, v->wstride);
         if (it == n_iter) break;
-        hipLaunchKernelGGL(gl_fused<false>, dim3(nblk), dim3(256), shm, v->stream, v->S, v->y, v->wseg[0], v->t.meta,
-                           v->d_tw, v->d_wsup, (int)bt.G, p.hop_length, v->lpad, p.win_length, v->wstride, v->nbin);
+        hipLaunchKernelGGL(gl_fused<false>, dim3(nblk), dim3(256), 0, v->stream, v->S, v->y, v->wseg[0], v->t.meta,
+                           v->d_tw, v->d_w, (int)bt.G, p.hop_length, v->lpad, p.win_length, v->wstride, v->nbin);
     }
     VCHECK(hipGetLastError());
     return OPHV_OK;
@@ -749,9 +806,7 @@ int oph_vocoder_create(const oph_gl_params* p, int device, oph_vocoder** out) {
                 for (int k = 0; k < Ns; ++k) tw[tw_off(Ns) + (r - 1) * Ns + k] = root((long long)k * r * (512 / Ns));
         for (int k = 0; k <= 256; ++k) tw[TW_PAIR + k] = root(k);
         if (hipMalloc((void**)&v->d_tw, TW_TOTAL * sizeof(float2)) != hipSuccess ||
-            hipMalloc((void**)&v->d_wsup, p->win_length * sizeof(float)) != hipSuccess ||
-            hipMemcpy(v->d_tw, tw.data(), TW_TOTAL * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(v->d_wsup, w.data() + v->lpad, p->win_length * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            hipMemcpy(v->d_tw, tw.data(), TW_TOTAL * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
             return fail("twiddle upload failed");
     }
     if (const char* e = std::getenv("OPH_VOCODER_BACKEND")) v->backend = std::atoi(e);
@@ -772,7 +827,7 @@ int oph_vocoder_destroy(oph_vocoder* v) {
     if (v->plan_c2r) hipfftDestroy(v->plan_c2r);
     if (v->plan_r2c) hipfftDestroy(v->plan_r2c);
     void* bufs[] = {v->d_w, v->d_w2, v->S, v->X, v->tfr, v->wfr, v->y, v->wav, v->stage, v->t.frame_utt, v->t.foff,
-                    v->t.yoff, v->t.src_off, v->t.meta, v->wseg[0], v->wseg[1], v->wss, v->d_wsup, v->d_tw};
+                    v->t.yoff, v->t.src_off, v->t.meta, v->wseg[0], v->wseg[1], v->wss, v->d_tw};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (v->ev0) (void)hipEventDestroy(v->ev0);
