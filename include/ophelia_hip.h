@@ -108,6 +108,16 @@ int oph_text2mel(oph_handle* h, const float* K, const float* V, const int32_t* e
                  const int32_t* spk, int B, int stop_mode,
                  float* Y, int32_t* t_ends, float* alignments, int32_t* steps_run);
 int oph_ssrn(oph_handle* h, const float* Y, int B, int T, float* Z);
+/* oph_text2mel_durations  replaces synth_codedtext2mel() when hp.use_external_durations is set (synthesize.py:168-169,
+ *     175-176, 211-216): the attention is the externally supplied selection matrix (networks.FixedAttention 327-358),
+ *     K is ignored by the graph and may be NULL.
+ *     durations (B,max_T,max_N) float32: rows are one-hot (weight exactly 1) or all zero, as data_load.py:243-251
+ *     builds them from the transcript's duration field.  t_ends[b] = number of selected frames of utterance b;
+ *     steps executed = n_steps if > 0, else min(max_T, max_b t_ends + 1)  (the reference's break rule; n_steps lets a
+ *     sharded batch use the maximum over ALL ranks).  Frames / alignment columns after the last step stay 0.       */
+int oph_text2mel_durations(oph_handle* h, const float* K, const float* V, const float* durations,
+                           const int32_t* spk, int B, int n_steps,
+                           float* Y, int32_t* t_ends, float* alignments, int32_t* steps_run);
 
 /* ---- device-resident pipeline (what bench.py times; no PCIe in the timed region)
  * oph_stage_text copies L / ends / spk into HBM.  oph_run_resident runs

@@ -46,6 +46,8 @@ SIGNATURES = {
     "oph_encode_text": (C.c_int, [C.c_void_p, c_i32p, c_i32p, C.c_int, c_f32p, c_f32p]),
     "oph_text2mel": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_i32p, c_i32p, C.c_int, C.c_int,
                                c_f32p, c_i32p, c_f32p, c_i32p]),
+    "oph_text2mel_durations": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_i32p, C.c_int, C.c_int,
+                                         c_f32p, c_i32p, c_f32p, c_i32p]),
     "oph_ssrn": (C.c_int, [C.c_void_p, c_f32p, C.c_int, C.c_int, c_f32p]),
     "oph_stage_text": (C.c_int, [C.c_void_p, c_i32p, c_i32p, c_i32p, C.c_int]),
     "oph_run_resident": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_i32p]),

@@ -105,6 +105,8 @@ struct oph_handle {
     // write-value / wait-value operations on two device words instead of event record / wait pairs: an event operation
     // interleaved with launches costs the host ~15 us and the device ~10 us on this runtime, a stream-value operation
     // ~4 us / ~2 us (profiles/launch_rate_probe.hip).  Values grow monotonically: sig_base + step.
+    int* d_ptab = nullptr;              // FixedAttention: key index per (t, b), time-major [max_T][Bpad], -1 = no key
+    bool fixed_att = false;             // the current decode uses d_ptab instead of the attention softmax
     uint32_t* d_sig = nullptr;          // [0] attention of step t done (written on sdec), [16] cone of step t done (scone)
     uint32_t sig_base = 0;
     bool use_sigval = false;
@@ -564,6 +566,7 @@ int ensure_decode_state(oph_handle* h, int B) {
     h->d_p = h->dalloc<int>(2 * Bpad);
     h->d_tends = h->dalloc<int>(Bpad);
     h->d_ctl = h->dalloc<int>(4);
+    h->d_ptab = h->dalloc<int>((size_t)m.max_T * Bpad);
     h->KV = h->dalloc<float>((size_t)Bpad * m.max_N * 2 * d);
     for (int i = 0; i < 2; ++i) h->Yout2[i] = h->dalloc<float>((size_t)Bpad * m.max_T * h->ldy);
     h->Yout = h->Yout2[0];
@@ -674,6 +677,7 @@ void launch_cone(oph_handle* h, int t) {
     ar.win = m.attention_win_size; ar.p = pcur; ar.B = B; ar.Bpad = Bpad; ar.nrows = n0 * Bpad; ar.off = h->d_off0; ar.j = t;
     ar.R = h->coneR; ar.ldr = 2 * d; ar.stop_after = stop_after; ar.t = t;
     if (m.flags & OPH_FLAG_NO_MONOTONIC) ar.ends = h->d_ends;
+    if (h->fixed_att) ar.ptab = h->d_ptab;
     h->pbegin(PC_ATTN_ROWS);
     launch_attn_rows(ar, g_cur);
     h->pend(PC_ATTN_ROWS, (double)n0 * B * 3.0 * d * 4.0, (double)n0 * B * 4.0 * m.attention_win_size * d);
@@ -736,6 +740,7 @@ void run_row_chain(oph_handle* h, RowChainArgs& a, int first_is_attn) {
     a.nonorm = (h->dm.flags & OPH_FLAG_NORM_NONE) ? 1 : 0;      // Text2Mel has no transposed convs: all or nothing
     a.nomono = (h->dm.flags & OPH_FLAG_NO_MONOTONIC) ? 1 : 0;
     a.has_lcc = (h->dm.flags & OPH_FLAG_LCC) ? 1 : 0;
+    if (h->fixed_att && a.pro == ROW_ATTN) a.ptab = h->d_ptab;
     if (a.has_lcc) a.cat_ids = h->d_spk;
     double wbytes = 0, flops = 0;
     for (int i = 0; i < a.nlayers; ++i) { wbytes += (double)a.L[i].kc * a.L[i].N * 4.0; flops += 2.0 * a.B * a.L[i].kc * a.L[i].N; }
@@ -895,7 +900,7 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
     // (~5 us per launch) is slower than the device (profiles/r01 trace: the critical stream idles
     // while the host enqueues the cone).  Capture all max_T steps once per (stop_mode, B) and replay.
     // After the stop step every node early-outs on the device, so outputs are identical.
-    const bool graphable = h->use_graph && !h->profiling && t_begin == 0 && t_end == m.max_T && stop_mode >= 0 && stop_mode <= 1;
+    const bool graphable = h->use_graph && !h->profiling && !h->fixed_att && t_begin == 0 && t_end == m.max_T && stop_mode >= 0 && stop_mode <= 1;
     if (graphable) {
         hipGraphExec_t& ge = h->dec_graph[stop_mode];
         if (ge && h->dec_graph_B[stop_mode] != h->B) { hipGraphExecDestroy(ge); ge = nullptr; }
@@ -1357,6 +1362,57 @@ int oph_text2mel(oph_handle* h, const float* K, const float* V, const int32_t* e
     reset_decode(h);
     if ((rc = decode_range(h, 0, m.max_T, stop_mode, steps_run))) return rc;
     return oph_fetch_mel(h, Y, t_ends, alignments);
+}
+
+int oph_text2mel_durations(oph_handle* h, const float* K, const float* V, const float* durations, const int32_t* spk,
+                           int B, int n_steps, float* Y, int32_t* t_ends, float* alignments, int32_t* steps_run) {
+    int rc = check_ready(h, B);
+    if (rc) return rc;
+    if (!V || !durations) { h->fail("null argument"); return OPH_ERR_INVALID; }
+    const bool ms = h->dm.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_LCC);
+    if (ms && !spk) { h->fail("multispeaker model needs speaker ids"); return OPH_ERR_INVALID; }
+    if ((rc = ensure_decode_state(h, B))) return rc;
+    const oph_dims& m = h->dm;
+    const int Bpad = h->Bpad;
+    // selection matrix -> key index per (t, b); only hard 0/1 rows (what data_load.py:243-251 produces) are supported
+    std::vector<int> ptab((size_t)m.max_T * Bpad, -1);
+    std::vector<int32_t> tends(B, 0);
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < m.max_T; ++t) {
+            const float* row = durations + ((size_t)b * m.max_T + t) * m.max_N;
+            int key = -1;
+            for (int n = 0; n < m.max_N; ++n) {
+                if (row[n] == 0.0f) continue;
+                if (row[n] != 1.0f || key >= 0) { h->fail("durations row (b=%d, t=%d) is not a 0/1 selection of at most one key", b, t); return OPH_ERR_UNSUPPORTED; }
+                key = n;
+            }
+            if (key >= 0) { ptab[(size_t)t * Bpad + b] = key; tends[b]++; }
+        }
+    int steps = n_steps;
+    if (steps <= 0) {
+        int mx = 0;
+        for (int b = 0; b < B; ++b) mx = std::max(mx, (int)tends[b]);
+        steps = std::min((int)m.max_T, mx + 1);          // synthesize.py:211-216: the step at which j >= max(t_ends) still runs
+    }
+    steps = std::min(steps, (int)m.max_T);
+    const size_t rows = (size_t)B * m.max_N, w = (size_t)m.d * 4;
+    if (K) HIPCHK(h, hipMemcpy2DAsync(h->KV, 2 * w, K, w, w, rows, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpy2DAsync(h->KV + m.d, 2 * w, V, w, w, rows, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_ptab, ptab.data(), ptab.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (ms) {
+        for (int b = 0; b < B; ++b) if (spk[b] < 0 || spk[b] >= m.nspeakers) { h->fail("speaker id out of range"); return OPH_ERR_INVALID; }
+        HIPCHK(h, hipMemcpyAsync(h->d_spk, spk, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    reset_decode(h);
+    h->fixed_att = true;
+    rc = decode_range(h, 0, steps, OPH_STOP_NEVER, nullptr);
+    h->fixed_att = false;
+    if (rc) return rc;
+    if ((rc = oph_fetch_mel(h, Y, nullptr, alignments))) return rc;
+    if (t_ends) std::copy(tends.begin(), tends.end(), t_ends);
+    if (steps_run) *steps_run = steps;
+    return OPH_OK;
 }
 
 int oph_ssrn(oph_handle* h, const float* Y, int B, int T, float* Z) {

@@ -78,6 +78,8 @@ struct AttnRowsArgs {
     const float* Q; int ldq;
     const float* K; const float* V; int ldkv; int N; int d; int win;
     const int* p;                   // per-utterance window start
+    const int* ptab;                // non-null (mode 0): FixedAttention -- the query at time t of utterance b selects key
+                                    // ptab[t*Bpad+b] with weight 1 (or nothing if < 0); networks.py:327-358
     const int* ends;                // non-null: hp.turn_off_monotonic_for_synthesis -- no window, the unmasked keys of
                                     // utterance b are [0, min(N, ends[b]+1))  (networks.py:307-309, synthesize.py:505-507)
     int B; int Bpad; int nrows;
@@ -112,6 +114,7 @@ struct RowChainArgs {
     int B; const int* stop_after; int t;
     int nonorm;                     // no LayerNorm anywhere in this chain (hp.norm None)
     int nomono;                     // ROW_ATTN without the monotonic window: keys [0, min(N_keys, ends[b]+1))
+    const int* ptab;                // ROW_ATTN with FixedAttention: key index per (t, b), time-major [max_T][Bpad], -1 = none
     const float* lcc_pro;           // LCC gate table of the highway layer whose gate the prologue applies (or null)
     int has_lcc;                    // any LCC table in this chain (selects the kernel instantiation); ids = cat_ids
 };

@@ -957,6 +957,19 @@ __global__ __launch_bounds__(256) void attn_rows(AttnRowsArgs a) {
     const float* Kb = a.K + (size_t)b * a.N * a.ldkv;
     const float* Vb = a.V + (size_t)b * a.N * a.ldkv;
     float* rr = a.R + (size_t)rid * a.ldr;
+    if (a.ptab) {                     // FixedAttention (external durations): R = [V[key of this query's time], Q]
+        const int tt = a.mode == 0 ? a.j - a.off[rid / a.Bpad] : tq;
+        const int pf = a.ptab[(size_t)tt * a.Bpad + b];
+#pragma unroll
+        for (int v = 0; v < ATT_NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (c < d) {
+                *(f32x4*)(rr + c) = pf >= 0 ? *(const f32x4*)(Vb + (size_t)pf * a.ldkv + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                *(f32x4*)(rr + d + c) = q[v];
+            }
+        }
+        return;
+    }
     if (a.ends) {                     // non-monotonic synthesis: every key of the text (+1) takes part
         const int nkeys = min(a.N, a.ends[b] + 1);
         const AttnFull of = attend_full(q, Kb, Vb, a.ldkv, nkeys, d, lane, ctx);
@@ -1015,7 +1028,8 @@ void launch_attn_rows(const AttnRowsArgs& a, hipStream_t s) {
 constexpr int RC_WAVES = 16;
 constexpr int RC_XMAX = 1024;
 
-template <bool NOMONO, bool NONORM, bool LCC>   // option variants are separate instantiations: the default kernel's register
+template <int ATT, bool NONORM, bool LCC>   // ATT: 0 monotonic window, 1 every key of the text, 2 fixed (external durations).
+                                            // Option variants are separate instantiations: the default kernel's register
                                       // allocation (at the 128-VGPR cap, no scratch) must stay untouched
 __global__ __launch_bounds__(64 * RC_WAVES) void row_chain(RowChainArgs a) {
     __shared__ __attribute__((aligned(16))) float xs[2][RC_XMAX];
@@ -1117,8 +1131,16 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain(RowChainArgs a) {
             f32x4 ctx[ATT_NV];
             AttnOut o;
             AttnFull of;
+            constexpr bool NOMONO = ATT == 1;
             const int nkeys = NOMONO ? min(a.N_keys, a.ends[b] + 1) : 0;
-            if (NOMONO) of = attend_full(q, KVb, KVb + d, 2 * d, nkeys, d, lane, ctx);
+            const int pf = ATT == 2 ? a.ptab[(size_t)a.t * a.Bpad + b] : 0;
+            if (ATT == 2) {
+#pragma unroll
+                for (int v = 0; v < ATT_NV; ++v) {
+                    const int c = (v * 64 + lane) * 4;
+                    ctx[v] = (pf >= 0 && c < d) ? *(const f32x4*)(KVb + d + (size_t)pf * 2 * d + c) : zero4;
+                }
+            } else if (NOMONO) of = attend_full(q, KVb, KVb + d, 2 * d, nkeys, d, lane, ctx);
             else o = attend_window(q, KVb, KVb + d, 2 * d, p, a.N_keys, a.win, d, lane, ctx);
             float* qh = a.Qhist + ((size_t)a.t * a.Bpad + b) * d;
 #pragma unroll
@@ -1138,7 +1160,13 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain(RowChainArgs a) {
                     if (n < nkeys) al[(size_t)n * a.max_T] = of.prob[s_];
                 }
             }
-            if (lane == 0 && live) {
+            if (ATT == 2) {
+                // the selection matrix itself is the alignment; utterance ends come from the durations (host side)
+                if (lane == 0 && live) {
+                    if (pf >= 0) a.align[(size_t)b * a.N_keys * a.max_T + (size_t)pf * a.max_T + a.t] = 1.0f;
+                    a.pnext[b] = pf >= 0 ? pf : 0;
+                }
+            } else if (lane == 0 && live) {
                 float* al = a.align + (size_t)b * a.N_keys * a.max_T + a.t;
                 if (!NOMONO) {
 #pragma unroll
@@ -1242,19 +1270,23 @@ __global__ __launch_bounds__(64 * RC_WAVES) void row_chain(RowChainArgs a) {
 }
 
 void launch_row_chain(const RowChainArgs& a, hipStream_t s) {
-    const bool nm = a.nomono && a.pro == ROW_ATTN;
+    const int att = a.pro != ROW_ATTN ? 0 : (a.ptab ? 2 : (a.nomono ? 1 : 0));
     const dim3 grid(a.B), block(64 * RC_WAVES);
-#define RC_LAUNCH(NM, NN, LC) hipLaunchKernelGGL((row_chain<NM, NN, LC>), grid, block, 0, s, a)
-    const int sel = (nm ? 4 : 0) | (a.nonorm ? 2 : 0) | (a.has_lcc ? 1 : 0);
+#define RC_LAUNCH(AT, NN, LC) hipLaunchKernelGGL((row_chain<AT, NN, LC>), grid, block, 0, s, a)
+    const int sel = att * 4 + (a.nonorm ? 2 : 0) + (a.has_lcc ? 1 : 0);
     switch (sel) {
-        case 0: RC_LAUNCH(false, false, false); break;
-        case 1: RC_LAUNCH(false, false, true); break;
-        case 2: RC_LAUNCH(false, true, false); break;
-        case 3: RC_LAUNCH(false, true, true); break;
-        case 4: RC_LAUNCH(true, false, false); break;
-        case 5: RC_LAUNCH(true, false, true); break;
-        case 6: RC_LAUNCH(true, true, false); break;
-        default: RC_LAUNCH(true, true, true); break;
+        case 0: RC_LAUNCH(0, false, false); break;
+        case 1: RC_LAUNCH(0, false, true); break;
+        case 2: RC_LAUNCH(0, true, false); break;
+        case 3: RC_LAUNCH(0, true, true); break;
+        case 4: RC_LAUNCH(1, false, false); break;
+        case 5: RC_LAUNCH(1, false, true); break;
+        case 6: RC_LAUNCH(1, true, false); break;
+        case 7: RC_LAUNCH(1, true, true); break;
+        case 8: RC_LAUNCH(2, false, false); break;
+        case 9: RC_LAUNCH(2, false, true); break;
+        case 10: RC_LAUNCH(2, true, false); break;
+        default: RC_LAUNCH(2, true, true); break;
     }
 #undef RC_LAUNCH
 }

@@ -53,8 +53,10 @@ def load_data(hp, mode="synthesis"):
     assert mode in ("train", "synthesis", "validation")
     if mode != "synthesis":
         raise NotImplementedError("only mode='synthesis' is on the hot path (training input pipeline is out of scope)")
-    if getattr(hp, "use_external_durations", False) or getattr(hp, "merlin_label_dir", ""):
-        raise NotImplementedError("external durations / Merlin labels are outside the hot-path scope")
+    if getattr(hp, "merlin_label_dir", ""):
+        raise NotImplementedError("Merlin labels are not supported")
+    use_durations = getattr(hp, "use_external_durations", False)
+    durations = []
     char2idx, _ = load_vocab(hp)
     with codecs.open(hp.test_transcript, "r", "utf-8") as f:
         lines = f.readlines()
@@ -84,10 +86,39 @@ def load_data(hp, mode="synthesis"):
             raise ValueError("unknown input_type %r" % hp.input_type)
         if len(ids) > hp.max_N:
             continue
+        if use_durations:            # 6th field: one duration (in un-reduced frames) per input symbol (data_load.py:181-193)
+            assert len(fields) >= 6, fields
+            dur = np.array([int(v) for v in re.split(r"\s+", fields[5].strip(" "))], np.int32)
+            assert len(dur) == len(ids), (len(dur), len(ids), fname)
+            durations.append(dur)
         texts.append(np.array(ids, np.int32))
         fpaths.append(os.path.join(hp.waveforms, fname + ".wav"))
         text_lengths.append(len(ids))
     L = np.zeros((len(texts), hp.max_N), np.int32)
     for i, t in enumerate(texts):
         L[i, :len(t)] = t
-    return {"texts": L, "fpaths": fpaths, "text_lengths": text_lengths, "audio_lengths": [], "label_lengths": []}
+    dataset = {"texts": L, "fpaths": fpaths, "text_lengths": text_lengths, "audio_lengths": [], "label_lengths": []}
+    if use_durations:                # (n, max_T, max_N) hard attention matrices, data_load.py:243-251
+        stacked = np.zeros((len(texts), hp.max_T, hp.max_N), np.int32)
+        for i, dur in enumerate(durations):
+            A = durations_to_hard_attention_matrix(dur)
+            A = end_pad_for_reduction_shape_sync(A, hp)[0::hp.r, :]
+            stacked[i, :A.shape[0], :A.shape[1]] = A
+        dataset["durations"] = stacked
+    return dataset
+
+
+def durations_to_hard_attention_matrix(durations):
+    """(nphones,) frame counts -> (nframes, nphones) 0/1 matrix whose row t selects the phone frame t belongs to
+    (utils.py:197-219; zero-duration phones get no row)."""
+    durations = np.asarray(durations)
+    owner = np.repeat(np.arange(len(durations)), durations)
+    A = np.zeros((len(owner), len(durations)), np.float32)
+    A[np.arange(len(owner)), owner] = 1.0
+    return A
+
+
+def end_pad_for_reduction_shape_sync(data, hp):
+    """zero rows appended so that the number of frames is a multiple of hp.r (utils.py:190-194)"""
+    short = (-data.shape[0]) % hp.r
+    return np.pad(data, [[0, short], [0, 0]], mode="constant")

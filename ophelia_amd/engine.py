@@ -22,7 +22,7 @@ def dims_from_hp(hp, max_N=None, max_T=None):
     if norm not in ("layer", None):
         raise NotImplementedError("hp.norm=%r is not supported ('layer' or None)" % (norm,))
     for attr, want in (("text_encoder_type", "DCTTS_standard"),
-                       ("history_type", "DCTTS_standard"), ("use_external_durations", False),
+                       ("history_type", "DCTTS_standard"), ("merlin_label_dir", ""),
                        ("concatenate_query", True),
                        ("squash_output_t2m", True), ("squash_output_ssrn", True)):
         if getattr(hp, attr, want) != want:
@@ -127,6 +127,29 @@ class Engine(object):
         s, sp = self._spk(speaker_data, B)
         self._chk(self.lib.oph_text2mel(self._h, _lib.fptr(K), _lib.fptr(V), _lib.iptr(ends), sp, B, int(stop_mode),
                                         _lib.fptr(Y), _lib.iptr(t_ends), _lib.fptr(al), C.byref(steps)))
+        return Y, t_ends, al, steps.value
+
+    def text2mel_durations(self, K, V, durations, speaker_data=None, n_steps=0):
+        """synth_codedtext2mel with hp.use_external_durations: `durations` (B, max_T, max_N) hard selection matrices
+        (data_load.py:243-251).  K may be None (FixedAttention never reads it).  n_steps > 0 overrides the
+        min(max_T, max(t_ends)+1) steps of the reference's break rule (sharded batches)."""
+        V = np.ascontiguousarray(V, dtype=np.float32)
+        B = V.shape[0]
+        assert V.shape == (B, self.dims.max_N, self.dims.d)
+        Kp = None
+        if K is not None:
+            K = np.ascontiguousarray(K, dtype=np.float32)
+            assert K.shape == V.shape
+            Kp = _lib.fptr(K)
+        D = np.ascontiguousarray(durations, dtype=np.float32)
+        assert D.shape == (B, self.dims.max_T, self.dims.max_N), D.shape
+        Y = np.empty((B, self.dims.max_T, self.dims.n_mels), np.float32)
+        t_ends = np.empty((B,), np.int32)
+        al = np.empty((B, self.dims.max_N, self.dims.max_T), np.float32)
+        steps = C.c_int32()
+        s, sp = self._spk(speaker_data, B)
+        self._chk(self.lib.oph_text2mel_durations(self._h, Kp, _lib.fptr(V), _lib.fptr(D), sp, B, int(n_steps),
+                                                  _lib.fptr(Y), _lib.iptr(t_ends), _lib.fptr(al), C.byref(steps)))
         return Y, t_ends, al, steps.value
 
     def ssrn(self, Y):

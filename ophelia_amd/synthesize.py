@@ -47,9 +47,8 @@ def stop_clock(clock, width=40):
 
 
 def _check_scope(hp):
-    if getattr(hp, "use_external_durations", False) or getattr(hp, "merlin_label_dir", "") \
-            or "position_in_phone" in getattr(hp, "history_type", ""):
-        raise NotImplementedError("external durations / Merlin labels / position-in-phone history are outside the hot path")
+    if getattr(hp, "merlin_label_dir", "") or "position_in_phone" in getattr(hp, "history_type", ""):
+        raise NotImplementedError("Merlin labels / position-in-phone history are not supported")
 
 
 def get_text_lengths(L):
@@ -74,6 +73,16 @@ def synth_codedtext2mel(hp, K, V, ends, g, sess, speaker_data=None, duration_dat
     _check_scope(hp)
     eng = sess.ensure_ready()
     dist_on = parallel._dist() is not None
+    if getattr(hp, "use_external_durations", False):
+        # FixedAttention: the utterance lengths are known up front (synthesize.py:168-169); the loop runs until the
+        # longest utterance of the WHOLE batch is through (211-216) -- across all shards when the batch is sharded
+        assert duration_data is not None, "hp.use_external_durations: duration_data (B, max_T, max_N) required"
+        n_steps = 0
+        if dist_on:
+            longest = int(np.asarray(duration_data).sum(axis=(1, 2)).max()) if len(duration_data) else 0
+            n_steps = min(hp.max_T, parallel.global_max_int(longest, device=sess.device) + 1)
+        Y, t_ends, alignments, _ = eng.text2mel_durations(K, V, duration_data, speaker_data, n_steps=n_steps)
+        return (Y, [int(t) for t in t_ends], alignments)
     if not dist_on:
         Y, t_ends, alignments, _ = eng.text2mel(K, V, ends, speaker_data, _lib.STOP_REFERENCE)
         return (Y, [int(t) for t in t_ends], alignments)
@@ -99,7 +108,8 @@ def synth_text2mel(hp, L, g, sess, speaker_data=None, duration_data=None, labels
     """The reference keeps this slower variant (K/V recomputed every step) for validation; results are
     identical to encode_text + synth_codedtext2mel, which is what runs here.  Returns (Y, t_ends)."""
     K, V = encode_text(hp, L, g, sess, speaker_data=speaker_data, labels=labels)
-    Y, t_ends, _ = synth_codedtext2mel(hp, K, V, get_text_lengths(L), g, sess, speaker_data=speaker_data)
+    Y, t_ends, _ = synth_codedtext2mel(hp, K, V, get_text_lengths(L), g, sess, speaker_data=speaker_data,
+                                       duration_data=duration_data)
     return (Y, t_ends)
 
 
@@ -195,8 +205,15 @@ def synthesize(hp, speaker_id="", num_sentences=0, ncores=1, topoutdir="", t2m_e
         L = L[:num_sentences, :]
         fpaths = fpaths[:num_sentences]
     bases = [basename(fpath) for fpath in fpaths]
+    duration_data = None
+    if getattr(hp, "use_external_durations", False):          # synthesize.py:451-455
+        duration_data = dataset["durations"]
+        if num_sentences > 0:
+            duration_data = duration_data[:num_sentences, :, :]
     lo, hi = parallel.shard_range(len(L), rank, world)       # contiguous utterance shard of this GPU
     L, bases = L[lo:hi], bases[lo:hi]
+    if duration_data is not None:
+        duration_data = duration_data[lo:hi]
 
     if speaker_id:
         speaker2ix = dict(zip(hp.speaker_list, range(len(hp.speaker_list))))
@@ -226,7 +243,8 @@ def synthesize(hp, speaker_id="", num_sentences=0, ncores=1, topoutdir="", t2m_e
         t = start_clock("Text2Mel generating...")
         text_lengths = get_text_lengths(L)
         K, V = encode_text(hp, L, g1, sess, speaker_data=speaker_data)
-        Y, lengths, alignments = synth_codedtext2mel(hp, K, V, text_lengths, g1, sess, speaker_data=speaker_data)
+        Y, lengths, alignments = synth_codedtext2mel(hp, K, V, text_lengths, g1, sess, speaker_data=speaker_data,
+                                                     duration_data=duration_data)
         stop_clock(t)
 
         t = start_clock("Mel2Mag generating...")

@@ -248,6 +248,18 @@ def attention(hp, Q, K, V, prev_max_attentions):
     return R, alignments, max_attentions
 
 
+def fixed_attention(hp, D, Q, V):
+    """networks.FixedAttention (327-358): an externally supplied (B,T,N) selection matrix replaces softmax(QK^T);
+    K is never used.  Returns R (B,T,2d), alignments (B,N,T), max_attentions (B,T)."""
+    D = np.asarray(D, F32)
+    Q = np.asarray(Q, F32); V = np.asarray(V, F32)
+    max_attentions = D.argmax(-1)
+    R = np.einsum("btn,bnd->btd", D, V).astype(F32)
+    if getattr(hp, "concatenate_query", True):
+        R = np.concatenate((R, Q), -1)
+    return R, np.transpose(D, (0, 2, 1)), max_attentions
+
+
 def audio_dec(hp, R, W, speakers=None, scope="Text2Mel/AudioDec"):
     """networks.py:360-435.  `speakers` (B,1) int only when
     'audio_decoder_input' in hp.multispeaker (vctk_01.cfg)."""
@@ -295,11 +307,14 @@ def ssrn(hp, Y, W, scope="SSRN"):
 # --------------------------------------------------------------------------
 # graph + host loop  (architectures.py, synthesize.py)
 # --------------------------------------------------------------------------
-def text2mel_graph(hp, W, K, V, mels, prev_max_attentions, speakers=None):
+def text2mel_graph(hp, W, K, V, mels, prev_max_attentions, speakers=None, durations=None):
     """architectures.py:188-239, mode 'synthesize', with K and V fed."""
     S = np.concatenate((np.zeros_like(mels[:, :1]), mels[:, :-1]), 1)   # :191
     Q = audio_enc(hp, S, W, speakers=speakers)
-    R, alignments, max_attentions = attention(hp, Q, K, V, prev_max_attentions)
+    if getattr(hp, "use_external_durations", False):                    # :222-223
+        R, alignments, max_attentions = fixed_attention(hp, durations, Q, V)
+    else:
+        R, alignments, max_attentions = attention(hp, Q, K, V, prev_max_attentions)
     _, Y = audio_dec(hp, R, W, speakers)
     return Y, max_attentions, alignments
 
@@ -314,7 +329,7 @@ def get_text_lengths(L):
     return np.array([np.where(L[i, :] == 0)[0][0] for i in range(len(L))])
 
 
-def synth_codedtext2mel(hp, W, K, V, ends, speakers=None, stop=True, trace=None):
+def synth_codedtext2mel(hp, W, K, V, ends, speakers=None, stop=True, trace=None, durations=None):
     """synthesize.py:150-230, faithful: the whole (B,max_T) graph is recomputed at
     every step and only column j is kept.  stop=False runs all max_T steps
     (the fixed-length timed configuration)."""
@@ -325,13 +340,20 @@ def synth_codedtext2mel(hp, W, K, V, ends, speakers=None, stop=True, trace=None)
     ends = np.asarray(ends)
     endcounts = np.zeros(ends.shape, dtype=int)
     t_ends = np.ones(ends.shape, dtype=int) * hp.max_T
+    fixed = getattr(hp, "use_external_durations", False)
+    if fixed:
+        t_ends = np.asarray(durations).sum(axis=(1, 2)).astype(int)      # synthesize.py:168-169
     for j in range(hp.max_T):
-        _Y, _max, _al = text2mel_graph(hp, W, K, V, Y, prev_max, speakers)
+        _Y, _max, _al = text2mel_graph(hp, W, K, V, Y, prev_max, speakers, durations)
         Y[:, j, :] = _Y[:, j, :]
         alignments[:, :, j] = _al[:, :, j]
         prev_max = _max[:, j].astype(np.int32)
         if trace is not None:
             trace.append(prev_max.copy())
+        if fixed:                                   # synthesize.py:211-216: stop once the longest utterance is through
+            if j >= t_ends.max():
+                break
+            continue
         reached_end = (_max[:, j] >= ends)
         endcounts += reached_end
         for i in range(B):
@@ -394,7 +416,7 @@ def _inc_hc(st, name, x, j, W, rate, speakers=None):
 
 
 def synth_codedtext2mel_incremental(hp, W, K, V, ends, speakers=None, stop=True, trace=None,
-                                    forced_prev_max=None, margins=None, max_steps=None, step_times=None):
+                                    forced_prev_max=None, margins=None, max_steps=None, step_times=None, durations=None):
     """Same contract and (up to fp reassociation) same outputs as synth_codedtext2mel.
     forced_prev_max: optional (steps,B) int array -- teacher-forced attention
     positions (separates numerics from argmax flips in parity tests).
@@ -409,6 +431,9 @@ def synth_codedtext2mel_incremental(hp, W, K, V, ends, speakers=None, stop=True,
     prev_max = np.zeros((B,), np.int32)
     ends = np.asarray(ends)
     t_ends = np.ones(ends.shape, dtype=int) * T
+    fixed = getattr(hp, "use_external_durations", False)
+    if fixed:
+        t_ends = np.asarray(durations).sum(axis=(1, 2)).astype(int)
     ae = "Text2Mel/AudioEnc"
     import time as _time
     for j in range(T if max_steps is None else min(T, max_steps)):
@@ -425,7 +450,10 @@ def synth_codedtext2mel_incremental(hp, W, K, V, ends, speakers=None, stop=True,
             x = _inc_hc(st, "%s/HC_%d" % (ae, i), x, j, W, 3, speakers); i += 1
         Qh[:, j] = x
         lo = max(0, j - AUDIODEC_LOOKBACK)
-        R, al, mx = attention(hp, Qh[:, lo:j + 1], K, V, prev_max)   # current mask, all rows
+        if fixed:
+            R, al, mx = fixed_attention(hp, np.asarray(durations)[:, lo:j + 1], Qh[:, lo:j + 1], V)
+        else:
+            R, al, mx = attention(hp, Qh[:, lo:j + 1], K, V, prev_max)   # current mask, all rows
         alignments[:, :, j] = al[:, :, -1]
         m = mx[:, -1].astype(np.int32)
         if margins is not None:
@@ -436,6 +464,12 @@ def synth_codedtext2mel_incremental(hp, W, K, V, ends, speakers=None, stop=True,
         prev_max = m if forced_prev_max is None else np.asarray(forced_prev_max[j], np.int32)
         if trace is not None:
             trace.append(m.copy())
+        if fixed:
+            if step_times is not None:
+                step_times.append(_time.perf_counter() - _t0)
+            if j >= t_ends.max():
+                break
+            continue
         reached = m >= ends
         for b in range(B):
             if t_ends[b] == T and reached[b]:

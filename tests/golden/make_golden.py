@@ -44,10 +44,12 @@ with contextlib.redirect_stdout(io.StringIO()):
     import data_load as ref_data_load        # reference
 
 
-def build_t2m(hp, L, mels, prev_max, speakers=None):
+def build_t2m(hp, L, mels, prev_max, speakers=None, durations=None):
     q = [L]
     if hp.multispeaker:
         q.append(speakers)
+    if hp.use_external_durations:                  # placeholder order of architectures.py:70-81
+        q.append(durations)
     q += [mels, prev_max]
     tf.PLACEHOLDER_QUEUE[:] = q
     with contextlib.redirect_stdout(io.StringIO()):
@@ -60,6 +62,8 @@ def build_ssrn(hp, mels, B, speakers=None):
     q = [np.zeros((B, hp.max_N), np.int32)]
     if hp.multispeaker:
         q.append(speakers)
+    if hp.use_external_durations:
+        q.append(np.zeros((B, hp.max_T, hp.max_N), np.float32))
     q += [mels, np.zeros((B,), np.int32)]
     tf.PLACEHOLDER_QUEUE[:] = q
     with contextlib.redirect_stdout(io.StringIO()):
@@ -79,6 +83,24 @@ def run_case(tag, cfg, B, max_N, max_T, wseed, tseed, min_len, max_len, stop, sp
     ends = np.array([np.where(L[i] == 0)[0][0] for i in range(B)])   # synthesize.py:242-247
     if getattr(hp, "turn_off_monotonic_for_synthesis", False):
         hp.text_lengths = ends + 1                                   # synthesize.py:505-507
+    durations = None
+    if hp.use_external_durations:
+        # per-symbol durations in fine frames -> hard attention matrix, padded and subsampled by r, exactly as the
+        # reference's load_data does (data_load.py:243-251) with the reference's own helpers
+        rng = np.random.default_rng(tseed + 1000)
+        durations = np.zeros((B, hp.max_T, hp.max_N), np.int32)
+        dur_lists = []
+        for i in range(B):
+            n = int(ends[i])
+            budget = hp.max_T * hp.r - rng.integers(0, 3 * hp.r)
+            d = rng.integers(0, 2 * budget // n + 1, size=n)
+            while d.sum() > budget:
+                d[rng.integers(0, n)] //= 2
+            d = d.astype(np.int32)
+            dm = ref_data_load.durations_to_hard_attention_matrix(d)
+            dm = ref_data_load.end_pad_for_reduction_shape_sync(dm, hp)[0::hp.r, :]
+            durations[i, :dm.shape[0], :dm.shape[1]] = dm
+            dur_lists.append(d)
 
     # --- host loop, restating synthesize.py:150-230 around the REFERENCE graph ---
     Y = np.zeros((B, hp.max_T, hp.n_mels), np.float32)
@@ -89,8 +111,10 @@ def run_case(tag, cfg, B, max_N, max_T, wseed, tseed, min_len, max_len, stop, sp
     trace = []
     K = V = Q0 = None
     steps = 0
+    if hp.use_external_durations:
+        t_ends = durations.sum(axis=(1, 2))                             # synthesize.py:168-169
     for j in range(hp.max_T):
-        g = build_t2m(hp, L, Y, prev_max, speakers)
+        g = build_t2m(hp, L, Y, prev_max, speakers, None if durations is None else durations.astype(np.float32))
         if K is None:
             K, V = np.asarray(g.K).copy(), np.asarray(g.V).copy()
             Q0 = np.asarray(g.Q).copy()
@@ -100,6 +124,10 @@ def run_case(tag, cfg, B, max_N, max_T, wseed, tseed, min_len, max_len, stop, sp
         prev_max = _max[:, j].astype(np.int32)
         trace.append(prev_max.copy())
         steps += 1
+        if hp.use_external_durations:                                   # synthesize.py:211-216
+            if j >= t_ends.max():
+                break
+            continue
         reached_end = (_max[:, j] >= ends)
         endcounts += reached_end
         for i in range(B):
@@ -119,6 +147,9 @@ def run_case(tag, cfg, B, max_N, max_T, wseed, tseed, min_len, max_len, stop, sp
                steps_run=np.int32(steps), Z=Z)
     if speakers is not None:
         out["speakers"] = speakers.astype(np.int32)
+    if durations is not None:
+        out["durations"] = durations
+        out["duration_lists"] = np.concatenate(dur_lists)
     np.savez_compressed(os.path.join(HERE, "wiring_%s.npz" % tag), **out)
     meta = dict(tag=tag, cfg=cfg, B=B, max_N=max_N, max_T=max_T, weight_seed=wseed, text_seed=tseed,
                 min_len=min_len, max_len=max_len, stop=bool(stop), speaker_ix=speaker_ix,
@@ -181,10 +212,25 @@ VARIANTS = {
     # multispeaker ['text_encoder_towards_end', 'audio_decoder_input'] (config/vctk_02.cfg)
     "vctk02_spk_end": dict(cfg="vctk_02.cfg", B=2, max_N=16, max_T=12, wseed=47, tseed=48, min_len=8, max_len=15,
                            stop=True, speaker_ix=5),
+    # use_external_durations: FixedAttention (config/ssw10/G1AB_03.cfg, project/fa_as_attention.cfg)
+    "g1ab_extdur": dict(cfg="ssw10/G1AB_03.cfg", B=3, max_N=14, max_T=16, wseed=51, tseed=52, min_len=4, max_len=11,
+                        stop=True),
     # multispeaker ['learn_channel_contributions'] (config/vctk_03_lcc.cfg, nancyplusnick_04_lcc.cfg)
     "vctk03_lcc": dict(cfg="vctk_03_lcc.cfg", B=3, max_N=16, max_T=12, wseed=49, tseed=50, min_len=8, max_len=15,
                        stop=True, speaker_ix=3),
 }
+
+
+def durations_frontend_case(cfg):
+    """reference load_data(mode='synthesis') with hp.use_external_durations on a transcript carrying the 6th field"""
+    hp = ref_configuration.load_config(os.path.join(REF, "config", cfg))
+    hp.test_transcript = os.path.join(HERE, "test_transcript_durations.csv")
+    with contextlib.redirect_stderr(io.StringIO()), contextlib.redirect_stdout(io.StringIO()):
+        ds = ref_data_load.load_data(hp, mode="synthesis")
+    np.savez_compressed(os.path.join(HERE, "frontend_durations.npz"), L=ds["texts"], durations=ds["durations"],
+                        bases=np.array([os.path.basename(p)[:-4] for p in ds["fpaths"]]),
+                        text_lengths=np.array(ds["text_lengths"], np.int32))
+    print("durations front-end:", ds["texts"].shape, ds["durations"].shape, ds["durations"].sum(axis=(1, 2)))
 
 
 def variant_cases():
@@ -197,6 +243,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "case":           # one variant case, in this (fresh) interpreter
         v = dict(VARIANTS[sys.argv[2]])
         config_snapshot((v["cfg"],))
+        if sys.argv[2] == "g1ab_extdur":
+            durations_frontend_case(v["cfg"])
         run_case(sys.argv[2], v.pop("cfg"), **v)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "variants":

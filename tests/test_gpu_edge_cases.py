@@ -88,6 +88,37 @@ def test_variant_text_encoder_speaker_embeddings_full_width():
         _check(hp, W, L, spk=spk, stop=False)
 
 
+def test_variant_external_durations_full_width():
+    """ssw10/G1AB_03.cfg at its own max_N = 173: ragged durations, zero-duration symbols, utterances of different
+    length (the loop runs until the longest one is through), against the incremental oracle"""
+    from ophelia_amd.data_load import durations_to_hard_attention_matrix, end_pad_for_reduction_shape_sync
+    from ophelia_amd.engine import Engine
+    hp = hp_from_snapshot("ssw10/G1AB_03.cfg", max_T=40)
+    W = O.random_weights(hp, 65)
+    B = 5
+    L = O.random_text(hp, B, 66, min_len=3, max_len=hp.max_N - 1)
+    ends = O.get_text_lengths(L)
+    rng = np.random.default_rng(67)
+    D = np.zeros((B, hp.max_T, hp.max_N), np.int32)
+    for b in range(B):
+        budget = int(rng.integers(8, hp.max_T + 1)) * hp.r - int(rng.integers(0, hp.r))
+        dur = np.zeros(ends[b], np.int64)
+        for _ in range(budget):
+            dur[rng.integers(0, ends[b])] += 1
+        A = end_pad_for_reduction_shape_sync(durations_to_hard_attention_matrix(dur), hp)[0::hp.r]
+        D[b, :len(A), :A.shape[1]] = A
+    eng = Engine(hp, device=0)
+    eng.load_weights(W)
+    K, V = eng.encode_text(L)
+    Y, t_ends, al, steps = eng.text2mel_durations(K, V, D)
+    eng.close()
+    K0, V0 = O.encode_text(hp, W, L)
+    Y0, t0, al0 = O.synth_codedtext2mel_incremental(hp, W, K0, V0, ends, durations=D)
+    assert t_ends.tolist() == t0 == D.sum(axis=(1, 2)).tolist()
+    assert steps == min(hp.max_T, max(t0) + 1)
+    assert np.abs(Y - Y0).max() < TOL and np.array_equal(al, al0)
+
+
 def test_host_polled_early_stop_after_many_steps():
     """short texts -> every utterance ends; the break step is past the first 8-step poll boundary"""
     hp = hp_from_snapshot("lj_tutorial.cfg", max_N=64, max_T=60)

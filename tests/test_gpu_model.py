@@ -45,6 +45,27 @@ def test_golden_cases(tag):
     eng.close()
 
 
+def test_golden_external_durations():
+    """ssw10/G1AB_03.cfg: FixedAttention (networks.py:327-358) driven by hard duration matrices"""
+    hp, meta, g = load_wiring_case("g1ab_extdur")
+    W = O.random_weights(hp, meta["weight_seed"])
+    eng = _engine(hp, W)
+    K, V = eng.encode_text(g["L"])
+    assert np.abs(K - g["K"]).max() < TOL and np.abs(V - g["V"]).max() < TOL
+    for Kin in (g["K"], None):                       # K is never read by the fixed attention
+        Y, t_ends, al, steps = eng.text2mel_durations(Kin, g["V"], g["durations"])
+        assert steps == int(g["steps_run"]) and t_ends.tolist() == g["t_ends"].tolist()
+        assert np.abs(Y - g["Y"]).max() < TOL
+        assert np.array_equal(al, g["alignments"])   # the selection matrix itself, exactly
+        assert not Y[:, steps:].any()
+    # a soft (non 0/1) row is refused, not approximated
+    from ophelia_amd._lib import OpheliaHipError
+    bad = g["durations"].astype(np.float32); bad[0, 0, :2] = 0.5
+    with pytest.raises(OpheliaHipError, match="selection"):
+        eng.text2mel_durations(None, g["V"], bad)
+    eng.close()
+
+
 @pytest.mark.parametrize("tag", ["vctk_spk", "g1abc_nonorm", "nn_spk_in", "vctk02_spk_end", "vctk03_lcc"])
 def test_inventory_matches_reference_variables(tag):
     hp, meta, g = load_wiring_case(tag)

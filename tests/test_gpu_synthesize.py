@@ -52,6 +52,30 @@ def test_synthesize_driver_outputs(tmp_path):
     assert len(os.listdir(outdir)) == 16
 
 
+def test_synthesize_driver_with_external_durations(tmp_path):
+    """hp.use_external_durations: durations come from the transcript's 6th field, utterance lengths from their sums"""
+    import wave
+    from ophelia_amd import synthesize as S
+    from ophelia_amd.data_load import load_data
+    hp = _hp()
+    hp.use_external_durations = True
+    hp.test_transcript = os.path.join(GOLDEN, "test_transcript_durations.csv")
+    W = O.random_weights(hp, 44)
+    outdir = S.synthesize(hp, topoutdir=str(tmp_path / "out"), weights=W)
+    ds = load_data(hp, mode="synthesis")
+    L, D = ds["texts"], ds["durations"]
+    K, V = O.encode_text(hp, W, L)
+    Y0, t0, _ = O.synth_codedtext2mel_incremental(hp, W, K, V, O.get_text_lengths(L), durations=D)
+    assert t0 == [12, 11, 9]                                  # ceil(sum of the durations / r)
+    for i, base in enumerate(["DUR-0001", "DUR-0002", "DUR-0003"]):
+        mel = np.load(os.path.join(outdir, base + ".mel.npy"))
+        assert mel.shape == (t0[i], hp.n_mels) and np.abs(mel - Y0[i, :t0[i]]).max() < 1e-4
+        al = np.load(os.path.join(outdir, base + ".alignment.npy"))
+        assert np.array_equal(al, D[i, :t0[i], :ds["text_lengths"][i]].T)
+        with wave.open(os.path.join(outdir, base + ".wav"), "rb") as f:
+            assert f.getnframes() == hp.hop_length * (t0[i] * hp.r - 1)
+
+
 def test_synthesize_from_tf_format_checkpoints(tmp_path):
     """CLI-level restore path: latest t2m checkpoint + archived ssrn epoch, both in TF tensor-bundle format."""
     from ophelia_amd import synthesize as S, tf_checkpoint as T

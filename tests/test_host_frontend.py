@@ -140,10 +140,25 @@ def test_cli_requires_speaker_for_multispeaker(tmp_path, monkeypatch):
         S.main_work()
 
 
+def test_external_durations_front_end_matches_reference():
+    """6th transcript field -> (n, max_T, max_N) hard attention matrices: golden from the reference's own load_data"""
+    from ophelia_amd.data_load import load_data, durations_to_hard_attention_matrix
+    g = np.load(os.path.join(GOLDEN, "frontend_durations.npz"))
+    hp = hp_from_snapshot("ssw10/G1AB_03.cfg")
+    hp.test_transcript, hp.waveforms = os.path.join(GOLDEN, "test_transcript_durations.csv"), "w"
+    assert hp.use_external_durations
+    ds = load_data(hp, mode="synthesis")
+    assert np.array_equal(ds["texts"], g["L"]) and ds["text_lengths"] == g["text_lengths"].tolist()
+    assert ds["durations"].dtype == np.int32 and np.array_equal(ds["durations"], g["durations"])
+    # docstring example of the reference (utils.py:202-207)
+    A = durations_to_hard_attention_matrix(np.array([3, 0, 1, 2]))
+    assert np.array_equal(A.T, [[1, 1, 1, 0, 0, 0], [0, 0, 0, 0, 0, 0], [0, 0, 0, 1, 0, 0], [0, 0, 0, 0, 1, 1]])
+
+
 def test_out_of_scope_configs_fail_loudly():
     from ophelia_amd.engine import dims_from_hp
     for attr, val in (("multispeaker", ["speaker_dependent_phones"]), ("multispeaker", ["ssrn_input"]),
-                      ("norm", "batch"), ("use_external_durations", True), ("text_encoder_type", "minimal_feedforward"),
+                      ("norm", "batch"), ("merlin_label_dir", "/some/labels"), ("text_encoder_type", "minimal_feedforward"),
                       ("history_type", "fractional_position_in_phone"), ("squash_output_t2m", False)):
         hp = hp_from_snapshot("lj_tutorial.cfg")
         setattr(hp, attr, val)

@@ -10,7 +10,8 @@ CASES = ["lj_free", "lj_stop", "vctk_spk",
          # option variants (make_golden.py variants): norm=None + non-monotonic, norm=None, speaker embedding at the
          # text-encoder input / towards its end
          # ... and learned channel contributions (per-speaker sigmoid channel gates)
-         "proj_nomono", "g1abc_nonorm", "nn_spk_in", "vctk02_spk_end", "vctk03_lcc"]
+         # ... and external durations (FixedAttention)
+         "proj_nomono", "g1abc_nonorm", "nn_spk_in", "vctk02_spk_end", "vctk03_lcc", "g1ab_extdur"]
 TOL = 2e-5   # fp32 reassociation between numpy-BLAS (oracle) and torch (golden primitives)
 
 
@@ -49,7 +50,7 @@ def test_decode_loop(tag, algo):
     fn = O.synth_codedtext2mel if algo == "faithful" else O.synth_codedtext2mel_incremental
     trace = []
     Y, t_ends, al = fn(hp, W, g["K"], g["V"], g["ends"], speakers=g.get("speakers"),
-                       stop=meta["stop"], trace=trace)
+                       stop=meta["stop"], trace=trace, durations=g.get("durations"))
     assert np.array_equal(np.array(trace), g["max_attentions_trace"])
     assert t_ends == g["t_ends"].tolist()
     assert len(trace) == int(g["steps_run"])
