@@ -66,7 +66,7 @@ struct oph_vocoder {
     std::string err;
     float *d_w = nullptr, *d_w2 = nullptr;          // padded window and its square, [n_fft]
     // capacity-managed buffers
-    long long capG = 0, capY = 0, capStage = 0;
+    long long capG = 0, capGg = 0, capY = 0, capStage = 0;    // capGg: frames the generic backend's buffers hold
     int capB = 0;
     float *S = nullptr, *tfr = nullptr, *wfr = nullptr, *y = nullptr, *wav = nullptr, *stage = nullptr;
     float2* X = nullptr;
@@ -559,9 +559,6 @@ int ensure_capacity(oph_vocoder* v, const Batch& bt) {
     if (G > v->capG) {
         int rc;
         if ((rc = dev_alloc(v, &v->S, G * v->nbin, false))) return rc;
-        if ((rc = dev_alloc(v, &v->X, G * v->nbin, true))) return rc;
-        if ((rc = dev_alloc(v, &v->tfr, G * n_fft, false))) return rc;
-        if ((rc = dev_alloc(v, &v->wfr, G * n_fft, true))) return rc;
         if ((rc = dev_alloc(v, &v->t.frame_utt, G, true))) return rc;
         if ((rc = dev_alloc(v, &v->t.meta, G, true))) return rc;
         v->capG = G;
@@ -579,12 +576,38 @@ int ensure_capacity(oph_vocoder* v, const Batch& bt) {
         if ((rc = dev_alloc(v, &v->t.src_off, bt.B, false))) return rc;
         v->capB = bt.B;
     }
+    (void)n_fft;
+    return OPHV_OK;
+}
+
+// Buffers and hipFFT plans of the generic backend, created only when that backend actually runs: the default fused
+// path never touches hipFFT (rocFFT compiles its kernels at plan creation, which can fail for reasons outside this
+// library -- seen once as HIPFFT_PARSE_ERROR late in a long-lived process -- so a failed creation is retried once
+// after the device has drained).
+int ensure_generic(oph_vocoder* v) {
+    const int n_fft = v->p.n_fft;
+    if (v->capGg < v->capG) {
+        int rc;
+        if ((rc = dev_alloc(v, &v->X, v->capG * v->nbin, true))) return rc;
+        if ((rc = dev_alloc(v, &v->tfr, v->capG * n_fft, false))) return rc;
+        if ((rc = dev_alloc(v, &v->wfr, v->capG * n_fft, true))) return rc;
+        v->capGg = v->capG;
+    }
     if (v->planG != v->capG) {
         if (v->plan_c2r) hipfftDestroy(v->plan_c2r);
         if (v->plan_r2c) hipfftDestroy(v->plan_r2c);
         v->plan_c2r = v->plan_r2c = 0;
-        FCHECK(hipfftPlan1d(&v->plan_c2r, n_fft, HIPFFT_C2R, (int)v->capG));
-        FCHECK(hipfftPlan1d(&v->plan_r2c, n_fft, HIPFFT_R2C, (int)v->capG));
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const hipfftResult a = hipfftPlan1d(&v->plan_c2r, n_fft, HIPFFT_C2R, (int)v->capG);
+            const hipfftResult b = a == HIPFFT_SUCCESS ? hipfftPlan1d(&v->plan_r2c, n_fft, HIPFFT_R2C, (int)v->capG) : a;
+            if (a == HIPFFT_SUCCESS && b == HIPFFT_SUCCESS) break;
+            if (v->plan_c2r) hipfftDestroy(v->plan_c2r);
+            if (v->plan_r2c) hipfftDestroy(v->plan_r2c);
+            v->plan_c2r = v->plan_r2c = 0;
+            if (attempt == 1) { v->err = "hipfftPlan1d failed: hipfft error " + std::to_string((int)(a != HIPFFT_SUCCESS ? a : b)); return OPHV_ERR_DEVICE; }
+            (void)hipDeviceSynchronize();
+            (void)hipGetLastError();
+        }
         FCHECK(hipfftSetStream(v->plan_c2r, v->stream));
         FCHECK(hipfftSetStream(v->plan_r2c, v->stream));
         v->planG = v->capG;
@@ -683,6 +706,7 @@ int run_griffin_lim_fused(oph_vocoder* v, const Batch& bt, int n_iter) {
 // S/X prepared -> y (device), generic path over hipFFT.  utils.py:99-109
 int run_griffin_lim(oph_vocoder* v, const Batch& bt, int n_iter) {
     int rc;
+    if ((rc = ensure_generic(v))) return rc;
     const long long n = bt.G * v->nbin;
     for (int it = 0; it < n_iter; ++it) {
         if ((rc = launch_istft(v, bt))) return rc;
@@ -700,6 +724,7 @@ int run_pipeline(oph_vocoder* v, const float* d_src, const std::vector<long long
     if ((rc = upload_tables(v, bt, src_off))) return rc;
     VCHECK(hipEventRecord(v->ev0, v->stream));
     const bool fused = use_fused(v);
+    if (!fused && (rc = ensure_generic(v))) return rc;
     hipLaunchKernelGGL(gl_prepare, dim3((unsigned)bt.G), dim3(256), 0, v->stream, d_src, v->t.src_off, v->t.frame_utt,
                        v->t.foff, v->S, fused ? (float2*)nullptr : v->X, v->nbin, (float)v->p.max_db, (float)v->p.ref_db,
                        (float)v->p.power,
@@ -874,6 +899,7 @@ int oph_vocoder_stft(oph_vocoder* v, const float* y, int64_t len, float* D) {
     int rc;
     if ((rc = plan_batch(v, &F, 1, bt))) return rc;
     if ((rc = ensure_capacity(v, bt))) return rc;
+    if ((rc = ensure_generic(v))) return rc;
     if ((rc = upload_tables(v, bt, std::vector<long long>(1, 0)))) return rc;
     VCHECK(hipMemcpyAsync(v->y, y, len * sizeof(float), hipMemcpyHostToDevice, v->stream));
     if ((rc = launch_stft(v, bt))) return rc;
@@ -891,6 +917,7 @@ int oph_vocoder_istft(oph_vocoder* v, const float* D, int n_frames, float* y) {
     int rc;
     if ((rc = plan_batch(v, &F, 1, bt))) return rc;
     if ((rc = ensure_capacity(v, bt))) return rc;
+    if ((rc = ensure_generic(v))) return rc;
     if ((rc = upload_tables(v, bt, std::vector<long long>(1, 0)))) return rc;
     VCHECK(hipMemcpyAsync(v->X, D, (size_t)F * v->nbin * sizeof(float2), hipMemcpyHostToDevice, v->stream));
     if ((rc = launch_istft(v, bt))) return rc;
