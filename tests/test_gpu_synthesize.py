@@ -159,3 +159,68 @@ def test_sharded_decode_reproduces_global_stop():
     assert np.abs(Y0[:3, steps[0]:steps[1]]).max() > 0
     assert np.abs(Y - Y0).max() < 1e-4
     assert not Y[:, steps[1]:].any()
+
+
+def _dur_case(hp):
+    """6 short texts with hard duration matrices: the first three (shard 0) are much shorter than the last three"""
+    from ophelia_amd.data_load import durations_to_hard_attention_matrix, end_pad_for_reduction_shape_sync
+    L = _short_texts(hp)
+    rng = np.random.default_rng(9)
+    D = np.zeros((len(L), hp.max_T, hp.max_N), np.int32)
+    for b in range(len(L)):
+        n = int(np.count_nonzero(L[b]))
+        frames = (6 + b) * hp.r if b < 3 else (24 + 3 * b) * hp.r
+        dur = np.zeros(n, np.int64)
+        for _ in range(frames):
+            dur[rng.integers(0, n)] += 1
+        A = end_pad_for_reduction_shape_sync(durations_to_hard_attention_matrix(dur), hp)[0::hp.r]
+        D[b, :len(A), :n] = A
+    return L, D
+
+
+def _shard_worker_durations(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ophelia_amd import parallel, synthesize as S
+        from ophelia_amd.architectures import Session, Text2MelGraph
+        hp = _hp(max_T=40)
+        hp.use_external_durations = True
+        L, D = _dur_case(hp)
+        lo, hi = parallel.shard_range(len(L), rank, world)
+        W = O.random_weights(hp, 43) if rank == 0 else None
+        with Session(hp, device=0) as sess:
+            W = parallel.broadcast_weights(W, sess.inventory(), src=0)
+            sess.assign(W)
+            g = Text2MelGraph(hp, mode="synthesize")
+            K, V = S.encode_text(hp, L[lo:hi], g, sess)
+            Y, t_ends, al = S.synth_codedtext2mel(hp, K, V, S.get_text_lengths(L[lo:hi]), g, sess, duration_data=D[lo:hi])
+        q.put((rank, Y, t_ends))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_external_durations_run_to_the_global_longest():
+    """with external durations every shard must run until the longest utterance of the WHOLE batch is through
+    (synthesize.py:211-216), so the short shard keeps generating frames past its own utterances' ends"""
+    import torch.multiprocessing as mp
+    hp = _hp(max_T=40)
+    hp.use_external_durations = True
+    L, D = _dur_case(hp)
+    W = O.random_weights(hp, 43)
+    K, V = O.encode_text(hp, W, L)
+    Y0, t0, _ = O.synth_codedtext2mel_incremental(hp, W, K, V, O.get_text_lengths(L), durations=D)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker_durations, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda r: r[0])
+    for p in procs: p.join(timeout=60)
+    Y = np.concatenate([r[1] for r in res]); t_ends = res[0][2] + res[1][2]
+    assert t_ends == t0 == D.sum(axis=(1, 2)).tolist()
+    steps = min(hp.max_T, max(t0) + 1)
+    assert max(t0[:3]) + 1 < steps                       # shard 0 alone would have stopped earlier
+    assert np.abs(Y0[:3, max(t0[:3]) + 1:steps]).max() > 0
+    assert np.abs(Y - Y0).max() < 1e-4 and not Y[:, steps:].any()
