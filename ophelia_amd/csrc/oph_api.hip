@@ -1098,7 +1098,10 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
     g_cur = h->stream;
     {
         int can = 0;
-        if (!getenv("OPH_NO_STREAM_VALUE") && hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) == hipSuccess && can) {
+        // opt-in (OPH_STREAM_VALUE=1): under rocprofv3 --pmc, which serialises dispatches across queues, a wait-value packet
+        // never sees the value the other queue would write and the run deadlocks; events are understood by the profiler
+        const char* sv = getenv("OPH_STREAM_VALUE");
+        if (sv && atoi(sv) != 0 && hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) == hipSuccess && can) {
             h->d_sig = h->dalloc<uint32_t>(32);
             h->use_sigval = h->d_sig != nullptr && hipStreamWriteValue32(h->stream, h->d_sig, 0, 0) == hipSuccess &&
                             hipStreamSynchronize(h->stream) == hipSuccess;
