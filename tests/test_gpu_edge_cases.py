@@ -119,6 +119,18 @@ def test_variant_external_durations_full_width():
     assert np.abs(Y - Y0).max() < TOL and np.array_equal(al, al0)
 
 
+def test_reduction_factor_8_ssrn_has_three_upsampling_stages():
+    """hp.r = 8 (networks.py:474-479): SSRN takes three stride-2 transposed convs, Z has 8 frames per mel frame"""
+    hp = hp_from_snapshot("lj_tutorial.cfg", max_N=30, max_T=12)
+    hp.r = 8
+    W = O.random_weights(hp, 71)
+    assert "SSRN/D_10/conv2d_transpose/kernel" in W          # C_1, HC_2-3, D_4, HC_5-6, D_7, HC_8-9, D_10
+    L = O.random_text(hp, 3, 72, min_len=5, max_len=25)
+    K, V, Y, t_ends, al, steps, Z = _run(hp, W, L, stop=False)
+    assert Z.shape == (3, hp.max_T * 8, hp.full_dim)
+    _check(hp, W, L, stop=False)
+
+
 def test_host_polled_early_stop_after_many_steps():
     """short texts -> every utterance ends; the break step is past the first 8-step poll boundary"""
     hp = hp_from_snapshot("lj_tutorial.cfg", max_N=64, max_T=60)
