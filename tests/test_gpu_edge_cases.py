@@ -131,6 +131,16 @@ def test_reduction_factor_8_ssrn_has_three_upsampling_stages():
     _check(hp, W, L, stop=False)
 
 
+@pytest.mark.parametrize("e,d,c", [(64, 128, 256), (128, 192, 320), (32, 64, 128)])
+def test_other_model_widths(e, d, c):
+    """narrower models than the shipped e=128 / d=256 / c=512 (the kernels pad K to 32 and N to 16)"""
+    hp = hp_from_snapshot("lj_tutorial.cfg", max_N=24, max_T=14)
+    hp.e, hp.d, hp.c = e, d, c
+    W = O.random_weights(hp, 73)
+    L = O.random_text(hp, 4, 74, min_len=4, max_len=20)
+    _check(hp, W, L, stop=False)
+
+
 def test_host_polled_early_stop_after_many_steps():
     """short texts -> every utterance ends; the break step is past the first 8-step poll boundary"""
     hp = hp_from_snapshot("lj_tutorial.cfg", max_N=64, max_T=60)
