@@ -11,8 +11,8 @@ Same flags, same output directory naming ({sampledir|odir/cfg}/t2m{E}_ssrn{E}[_s
 same trimming rules, same {base}.wav files (16-bit PCM) from Griffin-Lim -- which runs batched on the GPU
 (ophelia_amd.vocoder) instead of on `-ncores` CPU processes -- and the same per-utterance
 "File | CDP | Ain" report.  With hp.store_synth_features the trimmed magnitudes {base}.npy are stored as in the
-reference (synthesize.py:436-437), plus {base}.mel.npy and {base}.alignment.npy.  Not provided: the WORLD vocoder
-(external binaries) and the alignment PNGs (matplotlib).  Under torchrun (WORLD_SIZE>1) the utterances are sharded
+reference (synthesize.py:436-437), plus {base}.mel.npy and {base}.alignment.npy; {base}.png attention plots are
+written when matplotlib is importable.  Not provided: the WORLD vocoder (external binaries).  Under torchrun (WORLD_SIZE>1) the utterances are sharded
 over the GPUs of the node (ophelia_amd.parallel).
 """
 from __future__ import print_function
@@ -33,6 +33,13 @@ from .calculate_CDP_Ain_Aout import getAP, getCDP
 from .configuration import load_config
 from .data_load import load_data
 from .libutil import basename, safe_makedir
+from .utils import plot_alignment
+
+try:
+    import matplotlib  # noqa: F401
+    _HAVE_MATPLOTLIB = True
+except ImportError:             # the plots are a convenience output: without matplotlib they are skipped, not faked
+    _HAVE_MATPLOTLIB = False
 
 
 def start_clock(comment):
@@ -259,9 +266,13 @@ def synthesize(hp, speaker_id="", num_sentences=0, ncores=1, topoutdir="", t2m_e
         if speaker_id:
             outdir += "_speaker-%s" % (speaker_id)
         safe_makedir(outdir)
+        print("Plot attention, will save to following dir: %s" % (outdir))
         print("File |  CDP | Ain")
         for i in range(len(Z)):
             trimmed_alignment = alignments[i, :text_lengths[i], :lengths[i]]
+            if _HAVE_MATPLOTLIB:                               # synthesize.py:594-595
+                plot_alignment(hp, trimmed_alignment, utt_idx=lo + i + 1, t2m_epoch=t2m_epoch, dir=outdir,
+                               outfile=os.path.join(outdir, bases[i]))
             CDP = getCDP(trimmed_alignment)
             APin, APout = getAP(trimmed_alignment)
             print("%s | %.2f | %.2f" % (bases[i], CDP, APin))
