@@ -62,6 +62,7 @@ typedef struct oph_dims {
                                               keys n >= text_length+1 are masked (hp.text_lengths, synthesize.py:505-507) */
 #define OPH_FLAG_SPK_TEXT_ENCODER_INPUT 8  /* 'text_encoder_input' in hp.multispeaker (networks.py:138-144)        */
 #define OPH_FLAG_SPK_TEXT_ENCODER_TOWARDS_END 16 /* 'text_encoder_towards_end' (networks.py:184-199)               */
+#define OPH_FLAG_SPK_AUDIO_ENCODER_INPUT 64 /* 'audio_encoder_input' in hp.multispeaker (networks.py:237-245)         */
 #define OPH_FLAG_LCC 32                    /* 'learn_channel_contributions' (modules.py:78-88): per-speaker sigmoid
                                               channel gates on every Text2Mel layer that the reference passes lcc= to */
 

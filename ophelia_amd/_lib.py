@@ -31,6 +31,7 @@ FLAG_NO_MONOTONIC = 4
 FLAG_SPK_TEXT_ENCODER_INPUT = 8
 FLAG_SPK_TEXT_ENCODER_TOWARDS_END = 16
 FLAG_LCC = 32
+FLAG_SPK_AUDIO_ENCODER_INPUT = 64
 STOP_REFERENCE, STOP_NEVER = 0, 1
 
 # name -> (restype, argtypes); every symbol declared in include/ophelia_hip.h

@@ -246,6 +246,11 @@ void build_networks(oph_handle* h) {
         const char* n = "Text2Mel/AudioEnc";
         int i = 1;
         add_conv(h->audioenc, sc(n, "C", i++), m.n_mels, d, true, ACT_RELU);
+        if (m.flags & OPH_FLAG_SPK_AUDIO_ENCODER_INPUT) {         // networks.py:237-245: embed, concat, 1x1 conv (no act)
+            const std::string es = sc(n, "embed", i++);
+            add_conv(h->audioenc, sc(n, "C", i++), d + m.speaker_embedding_size, d, false, ACT_NONE, m.speaker_embedding_size);
+            h->audioenc.back().cat_scope = es;
+        }
         add_conv(h->audioenc, sc(n, "C", i++), d, d, true, ACT_RELU);
         add_conv(h->audioenc, sc(n, "C", i++), d, d, true, ACT_NONE);
         for (int o = 0; o < 2; ++o)
@@ -294,7 +299,7 @@ void build_networks(oph_handle* h) {
         // the layers the reference passes lcc=/codes= to: all of TextEnc except the 'towards_end' squash conv
         // (networks.py:191-198), all of AudioEnc, AudioDec after its input convs (networks.py:373-389 pass none); SSRN none
         for (Layer& l : h->textenc) l.lcc = l.cat_scope.empty() || (m.flags & OPH_FLAG_SPK_TEXT_ENCODER_INPUT && &l == &h->textenc[0]);
-        for (Layer& l : h->audioenc) l.lcc = true;
+        for (Layer& l : h->audioenc) l.lcc = l.cat_scope.empty();      // the 'audio_encoder_input' conv gets none (networks.py:244-245)
         for (size_t i = (size_t)h->dec_pre; i < h->audiodec.size(); ++i) h->audiodec[i].lcc = true;
     }
     // inventory of TF variables, in graph-creation order
@@ -779,7 +784,10 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode) {
         RowChainArgs a{};
         a.pro = ROW_COPY; a.src = h->Ytm + (size_t)t * Bpad * h->ldy; a.ldsrc = h->ldy; a.cin = m.n_mels;
         a.nlayers = (int)nk1;
-        for (size_t i = 0; i < nk1; ++i) a.L[i] = row_layer(h->audioenc[i]);
+        for (size_t i = 0; i < nk1; ++i) {
+            a.L[i] = row_layer(h->audioenc[i]);
+            if (h->audioenc[i].cat_table) { a.cat_table = h->audioenc[i].cat_table; a.cat_ids = h->d_spk; }   // 'audio_encoder_input'
+        }
         a.xout = h->ae_hist[nk1] + (size_t)t * Bpad * hc0.kc; a.ldout = hc0.kc;
         a.B = B; a.Bpad = Bpad; a.stop_after = stop_after; a.t = t; a.d = d;
         run_row_chain(h, a, 0);
@@ -1036,7 +1044,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
         g_create_error = "dimensions outside the supported hot path (d<=256, c<=512, n_mels<=256, full_dim<=1280, win<=8)";
         return OPH_ERR_UNSUPPORTED;
     }
-    if ((m.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_TOWARDS_END | OPH_FLAG_LCC)) &&
+    if ((m.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_TOWARDS_END | OPH_FLAG_LCC | OPH_FLAG_SPK_AUDIO_ENCODER_INPUT)) &&
         (m.nspeakers < 1 || m.speaker_embedding_size < 1 || m.speaker_embedding_size % 4)) {
         g_create_error = "multispeaker flag set but nspeakers/speaker_embedding_size invalid";
         return OPH_ERR_INVALID;
@@ -1202,7 +1210,7 @@ int oph_stage_text(oph_handle* h, const int32_t* L, const int32_t* ends, const i
     int rc = check_ready(h, B);
     if (rc) return rc;
     if (!L || !ends) { h->fail("null argument"); return OPH_ERR_INVALID; }
-    const bool ms = h->dm.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_TOWARDS_END | OPH_FLAG_LCC);
+    const bool ms = h->dm.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_TOWARDS_END | OPH_FLAG_LCC | OPH_FLAG_SPK_AUDIO_ENCODER_INPUT);
     if (ms && !spk) { h->fail("multispeaker model needs speaker ids"); return OPH_ERR_INVALID; }
     const oph_dims& m = h->dm;
     for (long long i = 0; i < (long long)B * m.max_N; ++i)
@@ -1349,7 +1357,7 @@ int oph_text2mel(oph_handle* h, const float* K, const float* V, const int32_t* e
     int rc = check_ready(h, B);
     if (rc) return rc;
     if (!K || !V || !ends) { h->fail("null argument"); return OPH_ERR_INVALID; }
-    const bool ms = h->dm.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_LCC);
+    const bool ms = h->dm.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_LCC | OPH_FLAG_SPK_AUDIO_ENCODER_INPUT);
     if (ms && !spk) { h->fail("multispeaker model needs speaker ids"); return OPH_ERR_INVALID; }
     if ((rc = ensure_decode_state(h, B))) return rc;
     const oph_dims& m = h->dm;
@@ -1372,7 +1380,7 @@ int oph_text2mel_durations(oph_handle* h, const float* K, const float* V, const 
     int rc = check_ready(h, B);
     if (rc) return rc;
     if (!V || !durations) { h->fail("null argument"); return OPH_ERR_INVALID; }
-    const bool ms = h->dm.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_LCC);
+    const bool ms = h->dm.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_LCC | OPH_FLAG_SPK_AUDIO_ENCODER_INPUT);
     if (ms && !spk) { h->fail("multispeaker model needs speaker ids"); return OPH_ERR_INVALID; }
     if ((rc = ensure_decode_state(h, B))) return rc;
     const oph_dims& m = h->dm;

@@ -13,7 +13,8 @@ def dims_from_hp(hp, max_N=None, max_T=None):
     positions = {"audio_decoder_input": _lib.FLAG_SPK_AUDIO_DECODER_INPUT,
                  "text_encoder_input": _lib.FLAG_SPK_TEXT_ENCODER_INPUT,
                  "text_encoder_towards_end": _lib.FLAG_SPK_TEXT_ENCODER_TOWARDS_END,
-                 "learn_channel_contributions": _lib.FLAG_LCC}
+                 "learn_channel_contributions": _lib.FLAG_LCC,
+                 "audio_encoder_input": _lib.FLAG_SPK_AUDIO_ENCODER_INPUT}
     unsupported = [p for p in ms if p not in positions]
     if unsupported:
         raise NotImplementedError("multispeaker positions %s are not supported (supported: %s)"
@@ -56,7 +57,8 @@ class Engine(object):
         if rc != 0:
             raise _lib.OpheliaHipError("oph_create failed (%d): %s" % (rc, self.lib.oph_last_error(None).decode()))
         self.multispeaker = bool(self.dims.flags & (_lib.FLAG_SPK_AUDIO_DECODER_INPUT | _lib.FLAG_SPK_TEXT_ENCODER_INPUT |
-                                                    _lib.FLAG_SPK_TEXT_ENCODER_TOWARDS_END | _lib.FLAG_LCC))
+                                                    _lib.FLAG_SPK_TEXT_ENCODER_TOWARDS_END | _lib.FLAG_LCC |
+                                                    _lib.FLAG_SPK_AUDIO_ENCODER_INPUT))
         self.B = 0
 
     # -- plumbing

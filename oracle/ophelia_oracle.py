@@ -203,9 +203,12 @@ def text_enc(hp, L, W, scope="Text2Mel/TextEnc", speakers=None):
 
 
 def audio_enc(hp, S, W, scope="Text2Mel/AudioEnc", speakers=None):
-    """networks.py:214-284 (`speakers` only feeds the LCC gates; 'audio_encoder_input' is not covered)."""
+    """networks.py:214-284 incl. the 'audio_encoder_input' speaker hook (237-245) and the LCC gates."""
     i = 1
     t = conv1d(S, W, "%s/C_%d" % (scope, i), padding="CAUSAL", activation_fn=relu, speakers=speakers); i += 1
+    if "audio_encoder_input" in hp.multispeaker:          # networks.py:237-245: embed, concat, 1x1 conv (no LCC, no act)
+        reps = _speaker_reps(speakers, t.shape[1], W["%s/embed_%d/lookup_table" % (scope, i)]); i += 1
+        t = conv1d(np.concatenate((t, reps), -1), W, "%s/C_%d" % (scope, i)); i += 1
     t = conv1d(t, W, "%s/C_%d" % (scope, i), padding="CAUSAL", activation_fn=relu, speakers=speakers); i += 1
     t = conv1d(t, W, "%s/C_%d" % (scope, i), padding="CAUSAL", speakers=speakers); i += 1
     for _ in range(2):
@@ -441,6 +444,10 @@ def synth_codedtext2mel_incremental(hp, W, K, V, ends, speakers=None, stop=True,
         x = Y[:, j - 1] if j > 0 else np.zeros((B, hp.n_mels), F32)
         i = 1
         x = _inc_conv1d(st, "%s/C_%d" % (ae, i), x, j, W, relu, speakers); i += 1
+        if "audio_encoder_input" in hp.multispeaker:
+            tab = W["%s/embed_%d/lookup_table" % (ae, i)]; i += 1
+            reps = embed(np.asarray(speakers).reshape(B).astype(np.int64), tab)
+            x = _inc_conv1d(st, "%s/C_%d" % (ae, i), np.concatenate((x, reps), -1), j, W); i += 1
         x = _inc_conv1d(st, "%s/C_%d" % (ae, i), x, j, W, relu, speakers); i += 1
         x = _inc_conv1d(st, "%s/C_%d" % (ae, i), x, j, W, None, speakers); i += 1
         for _ in range(2):
@@ -539,6 +546,9 @@ def variable_shapes(hp):
         hcl("%s/HC_%d" % (s, i), 2 * d, 1); i += 1
     s = "Text2Mel/AudioEnc"; i = 1
     conv("%s/C_%d" % (s, i), hp.n_mels, d); i += 1
+    if "audio_encoder_input" in hp.multispeaker:
+        out["%s/embed_%d/lookup_table" % (s, i)] = (hp.nspeakers, hp.speaker_embedding_size); i += 1
+        conv("%s/C_%d" % (s, i), d + hp.speaker_embedding_size, d, lcc=False); i += 1
     conv("%s/C_%d" % (s, i), d, d); i += 1
     conv("%s/C_%d" % (s, i), d, d); i += 1
     for _ in range(10):

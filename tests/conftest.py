@@ -33,7 +33,7 @@ def hp_from_snapshot(cfg, **over):
 def load_wiring_case(tag):
     meta = json.load(open(os.path.join(GOLDEN, "wiring_%s.json" % tag)))
     g = dict(np.load(os.path.join(GOLDEN, "wiring_%s.npz" % tag)))
-    hp = hp_from_snapshot(meta["cfg"], max_N=meta["max_N"], max_T=meta["max_T"])
+    hp = hp_from_snapshot(meta["cfg"], max_N=meta["max_N"], max_T=meta["max_T"], **meta.get("override", {}))
     if getattr(hp, "turn_off_monotonic_for_synthesis", False):
         hp.text_lengths = g["ends"] + 1                  # what the host sets before building the graph (synthesize.py:505-507)
     return hp, meta, g

@@ -71,9 +71,11 @@ def build_ssrn(hp, mels, B, speakers=None):
     return g
 
 
-def run_case(tag, cfg, B, max_N, max_T, wseed, tseed, min_len, max_len, stop, speaker_ix=None):
+def run_case(tag, cfg, B, max_N, max_T, wseed, tseed, min_len, max_len, stop, speaker_ix=None, override=None):
     hp = ref_configuration.load_config(os.path.join(REF, "config", cfg))
     hp.max_N, hp.max_T = max_N, max_T
+    for k, v in (override or {}).items():           # synthetic variants no shipped config uses (recorded in the json)
+        setattr(hp, k, v)
     W = O.random_weights(hp, wseed)
     tf.VARS.clear(); tf.VARS.update(W); tf.REQUESTED[:] = []
     L = O.random_text(hp, B, tseed, min_len=min_len, max_len=max_len)
@@ -152,7 +154,7 @@ def run_case(tag, cfg, B, max_N, max_T, wseed, tseed, min_len, max_len, stop, sp
         out["duration_lists"] = np.concatenate(dur_lists)
     np.savez_compressed(os.path.join(HERE, "wiring_%s.npz" % tag), **out)
     meta = dict(tag=tag, cfg=cfg, B=B, max_N=max_N, max_T=max_T, weight_seed=wseed, text_seed=tseed,
-                min_len=min_len, max_len=max_len, stop=bool(stop), speaker_ix=speaker_ix,
+                min_len=min_len, max_len=max_len, stop=bool(stop), speaker_ix=speaker_ix, override=override or {},
                 variables=[[n, list(W[n].shape)] for n in t2m_names + ssrn_names],
                 n_params_t2m=int(sum(W[n].size for n in t2m_names)),
                 n_params_ssrn=int(sum(W[n].size for n in ssrn_names)))
@@ -215,6 +217,9 @@ VARIANTS = {
     # use_external_durations: FixedAttention (config/ssw10/G1AB_03.cfg, project/fa_as_attention.cfg)
     "g1ab_extdur": dict(cfg="ssw10/G1AB_03.cfg", B=3, max_N=14, max_T=16, wseed=51, tseed=52, min_len=4, max_len=11,
                         stop=True),
+    # 'audio_encoder_input' (networks.py:237-245): no shipped config uses it -- vctk_01.cfg with multispeaker overridden
+    "vctk_spk_audioenc": dict(cfg="vctk_01.cfg", B=2, max_N=14, max_T=12, wseed=53, tseed=54, min_len=6, max_len=13,
+                              stop=True, speaker_ix=9, override={"multispeaker": ["audio_encoder_input", "audio_decoder_input"]}),
     # multispeaker ['learn_channel_contributions'] (config/vctk_03_lcc.cfg, nancyplusnick_04_lcc.cfg)
     "vctk03_lcc": dict(cfg="vctk_03_lcc.cfg", B=3, max_N=16, max_T=12, wseed=49, tseed=50, min_len=8, max_len=15,
                        stop=True, speaker_ix=3),

@@ -22,7 +22,8 @@ def _engine(hp, W):
 @pytest.mark.parametrize("tag", ["lj_free", "lj_stop", "vctk_spk",
                                  # option variants of other shipped configs: hp.norm None, speaker
                                  # embedding at the text-encoder input / towards its end
-                                 "proj_nomono", "g1abc_nonorm", "nn_spk_in", "vctk02_spk_end", "vctk03_lcc"])
+                                 "proj_nomono", "g1abc_nonorm", "nn_spk_in", "vctk02_spk_end", "vctk03_lcc",
+                                 "vctk_spk_audioenc"])
 def test_golden_cases(tag):
     hp, meta, g = load_wiring_case(tag)
     W = O.random_weights(hp, meta["weight_seed"])
@@ -66,7 +67,7 @@ def test_golden_external_durations():
     eng.close()
 
 
-@pytest.mark.parametrize("tag", ["vctk_spk", "g1abc_nonorm", "nn_spk_in", "vctk02_spk_end", "vctk03_lcc"])
+@pytest.mark.parametrize("tag", ["vctk_spk", "g1abc_nonorm", "nn_spk_in", "vctk02_spk_end", "vctk03_lcc", "vctk_spk_audioenc"])
 def test_inventory_matches_reference_variables(tag):
     hp, meta, g = load_wiring_case(tag)
     from ophelia_amd.engine import Engine

@@ -157,7 +157,8 @@ def test_external_durations_front_end_matches_reference():
 
 def test_out_of_scope_configs_fail_loudly():
     from ophelia_amd.engine import dims_from_hp
-    for attr, val in (("multispeaker", ["speaker_dependent_phones"]), ("multispeaker", ["ssrn_input"]),
+    for attr, val in (("multispeaker", ["speaker_dependent_phones"]), ("multispeaker", ["ssrn_input"]),   # (the reference's
+                      # own synth_mel2mag never feeds speakers to the SSRN graph, synthesize.py:250-260)
                       ("norm", "batch"), ("merlin_label_dir", "/some/labels"), ("text_encoder_type", "minimal_feedforward"),
                       ("history_type", "fractional_position_in_phone"), ("squash_output_t2m", False)):
         hp = hp_from_snapshot("lj_tutorial.cfg")

@@ -11,7 +11,9 @@ CASES = ["lj_free", "lj_stop", "vctk_spk",
          # text-encoder input / towards its end
          # ... and learned channel contributions (per-speaker sigmoid channel gates)
          # ... and external durations (FixedAttention)
-         "proj_nomono", "g1abc_nonorm", "nn_spk_in", "vctk02_spk_end", "vctk03_lcc", "g1ab_extdur"]
+         "proj_nomono", "g1abc_nonorm", "nn_spk_in", "vctk02_spk_end", "vctk03_lcc", "g1ab_extdur",
+         # ... and the speaker embedding at the audio-encoder input (synthetic variant of vctk_01.cfg)
+         "vctk_spk_audioenc"]
 TOL = 2e-5   # fp32 reassociation between numpy-BLAS (oracle) and torch (golden primitives)
 
 
