@@ -159,6 +159,18 @@ def test_spectrogram2wav_matches_oracle(voc, gl):
         assert np.abs(w - ref).max() <= 2e-3 * np.abs(ref).max()
 
 
+def test_full_size_batch_backends_agree(voc):
+    """the bench workload (16 utterances x 800 frames, 50 iterations): fused kernel vs hipFFT path, every utterance"""
+    mags = [_speechlike_mag(800, 1000 + b) for b in range(16)]
+    voc.set_backend(1)
+    a = voc.spectrogram2wav_batch(mags)
+    voc.set_backend(0)
+    b = voc.spectrogram2wav_batch(mags)
+    for x, y in zip(a, b):
+        assert x.shape == y.shape == (HP.hop_length * 799,)
+        assert np.isfinite(y).all() and np.abs(x - y).max() <= 2e-3 * np.abs(x).max()
+
+
 def test_batch_equals_single(voc):
     mags = [_speechlike_mag(T, 7 * T) for T in (33, 12, 50)]
     together = voc.spectrogram2wav_batch(mags)
