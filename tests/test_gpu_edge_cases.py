@@ -34,7 +34,10 @@ def _check(hp, W, L, spk=None, stop=True):
     Z0 = O.synth_mel2mag(hp, W, Y0)
     assert steps == len(trace) and t_ends.tolist() == t0
     assert np.abs(K - K0).max() < TOL and np.abs(V - V0).max() < TOL
-    assert np.abs(Y - Y0).max() < TOL and np.abs(al - al0).max() < TOL and np.abs(Z - Z0).max() < TOL
+    assert np.abs(Y - Y0).max() < TOL and np.abs(al - al0).max() < TOL
+    # SSRN runs its default split-bf16 contractions here: 3e-5 with LayerNorm, ~1e-4 without (nothing re-normalises the
+    # activations); the bar is 1e-3, asserted at a quarter of it like in test_gpu_model
+    assert np.abs(Z - Z0).max() < 1e-3 / 4
     assert not Y[:, steps:].any() and not al[:, :, steps:].any()
     return steps, t0
 
@@ -187,3 +190,31 @@ def test_engine_reuse_across_batches_and_validation():
     with pytest.raises(_lib.OpheliaHipError):
         eng.ssrn(np.zeros((2, hp.max_T + 5, hp.n_mels), np.float32))
     eng.close()
+
+
+def test_random_flag_combinations():
+    """option variants are independent switches in the reference; combinations no shipped config uses (e.g. LCC without
+    LayerNorm and without the monotonic window, all three speaker positions at once, r = 8 with a narrow model) must
+    behave like the oracle too"""
+    rng = np.random.default_rng(4242)
+    positions = ["text_encoder_input", "text_encoder_towards_end", "audio_encoder_input", "audio_decoder_input",
+                 "learn_channel_contributions"]
+    for case in range(14):
+        hp = hp_from_snapshot("lj_tutorial.cfg", max_N=int(rng.integers(8, 40)), max_T=int(rng.integers(6, 20)))
+        hp.e, hp.d, hp.c = int(rng.choice([32, 64, 128])), int(rng.choice([64, 128, 256])), int(rng.choice([128, 256]))
+        hp.r = int(rng.choice([4, 8]))
+        hp.norm = [None, "layer"][int(rng.integers(0, 2))]
+        hp.turn_off_monotonic_for_synthesis = bool(rng.integers(0, 2))
+        hp.attention_win_size = int(rng.integers(1, 6))
+        hp.multispeaker = [p for p in positions if rng.random() < 0.4]
+        hp.nspeakers, hp.speaker_embedding_size = int(rng.integers(2, 9)), int(rng.choice([16, 64, 128]))
+        B = int(rng.integers(1, 6))
+        W = O.random_weights(hp, 100 + case)
+        L = O.random_text(hp, B, 200 + case, min_len=2, max_len=hp.max_N - 1)
+        spk = rng.integers(0, hp.nspeakers, size=(B, 1)).astype(np.int32) if hp.multispeaker else None
+        try:
+            _check(hp, W, L, spk=spk, stop=bool(rng.integers(0, 2)))
+        except AssertionError as e:
+            raise AssertionError("case %d: %r" % (case, {k: getattr(hp, k) for k in (
+                "max_N", "max_T", "e", "d", "c", "r", "norm", "turn_off_monotonic_for_synthesis", "attention_win_size",
+                "multispeaker", "nspeakers", "speaker_embedding_size")})) from e
