@@ -222,3 +222,23 @@ def test_from_engine_resident_mag(voc):
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
     eng.close()
+
+
+def test_random_stft_geometries(gl):
+    """hop / window lengths no shipped config uses (odd values, window = n_fft, hop = window, tiny hops are refused
+    only when more than the supported overlap would be needed by the generic gather -- none here), ragged batches"""
+    from ophelia_amd.vocoder import Vocoder
+    rng = np.random.default_rng(77)
+    for case in range(8):
+        win = int(rng.integers(300, 2049))
+        hop = int(rng.integers(max(64, win // 5 + 1), win + 1))
+        hp = SimpleNamespace(**dict(vars(HP), hop_length=hop, win_length=win, n_iter=int(rng.integers(0, 4)),
+                                    power=float(rng.choice([1.0, 1.2, 1.5])), preemphasis=float(rng.choice([0.0, 0.9, 0.97]))))
+        mags = [_speechlike_mag(int(T), case * 10 + int(T)) for T in rng.integers(2, 40, size=3)]
+        with Vocoder(hp, 0) as v:
+            for backend in (0, 1):
+                v.set_backend(backend)
+                for m, w in zip(mags, v.spectrogram2wav_batch(mags)):
+                    ref = gl.spectrogram2wav(hp, m)
+                    assert w.shape == ref.shape, (case, hop, win)
+                    assert np.abs(w - ref).max() <= 3e-4 * max(np.abs(ref).max(), 1e-6), (case, backend, hop, win, hp.n_iter)
