@@ -752,7 +752,9 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void dec_layer16(DecArgs a) {
 template <int NV, int PRE>
 static void launch_dec_t(const DecArgs& a, dim3 grid, size_t lds, hipStream_t s) {
     auto set = [&](const void* f) {
-        static std::map<std::pair<const void*, int>, size_t> done;      // per (function, device)
+        // per (function, device); thread_local: handles are confined to one host thread each, different threads may
+        // run different handles at the same time, and setting the attribute twice is harmless
+        static thread_local std::map<std::pair<const void*, int>, size_t> done;
         int dev = 0;
         (void)hipGetDevice(&dev);
         size_t& d = done[{f, dev}];
