@@ -56,8 +56,9 @@ typedef struct oph_dims {
 } oph_dims;
 
 #define OPH_FLAG_SPK_AUDIO_DECODER_INPUT 1  /* 'audio_decoder_input' in hp.multispeaker (networks.py:381-389) */
-#define OPH_FLAG_NORM_NONE 2               /* hp.norm is None (modules.py:62-74): no LayerNorm variables; the SSRN
-                                              transposed convs keep theirs (networks.py:483-486 passes no normtype) */
+#define OPH_FLAG_NORM_NONE 2               /* hp.norm is None (modules.py:62-74): Text2Mel has no LayerNorm variables.  SSRN is
+                                              unaffected: synthesize() builds SSRNGraph under hp.norm = 'layer'
+                                              (synthesize.py:513-534), its gamma / beta variables are always expected */
 #define OPH_FLAG_NO_MONOTONIC 4             /* hp.turn_off_monotonic_for_synthesis (networks.py:304-309): no attention window;
                                               keys n >= text_length+1 are masked (hp.text_lengths, synthesize.py:505-507) */
 #define OPH_FLAG_SPK_TEXT_ENCODER_INPUT 8  /* 'text_encoder_input' in hp.multispeaker (networks.py:138-144)        */
@@ -109,6 +110,17 @@ int oph_text2mel(oph_handle* h, const float* K, const float* V, const int32_t* e
                  const int32_t* spk, int B, int stop_mode,
                  float* Y, int32_t* t_ends, float* alignments, int32_t* steps_run);
 int oph_ssrn(oph_handle* h, const float* Y, int B, int T, float* Z);
+/* oph_text2mel_graph  replaces ONE sess.run([g.Y, g.max_attentions, g.alignments], feed) of the reference's loop
+ *     (synthesize.py:172,181-183) and serves as the fetch surface for the graph tensors of architectures.py:188-239:
+ *     K,V (B,max_N,d), mels (B,max_T,n_mels) = the frames generated so far, prev_max (B) = the fed
+ *     prev_max_attentions, ends (B) = text lengths (only read with OPH_FLAG_NO_MONOTONIC, else may be NULL),
+ *     spk (B) or NULL  ->  any of (NULL = not wanted)  Q (B,max_T,d), R (B,max_T,2d), Y_logits / Y (B,max_T,n_mels),
+ *     alignments (B,max_N,max_T), max_attentions (B,max_T) int32.  All max_T positions are evaluated under the ONE
+ *     mask of prev_max, as the reference graph does (networks.py:311): O(max_T) per call, for validation and
+ *     feed/fetch-style callers -- the decode loop proper is oph_text2mel.  External durations are not offered here. */
+int oph_text2mel_graph(oph_handle* h, const float* K, const float* V, const float* mels, const int32_t* prev_max,
+                       const int32_t* ends, const int32_t* spk, int B,
+                       float* Q, float* R, float* Y_logits, float* Y, float* alignments, int32_t* max_attentions);
 /* oph_text2mel_durations  replaces synth_codedtext2mel() when hp.use_external_durations is set (synthesize.py:168-169,
  *     175-176, 211-216): the attention is the externally supplied selection matrix (networks.FixedAttention 327-358),
  *     K is ignored by the graph and may be NULL.

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libophelia_hip.so")
-SOURCES = ["oph_kernels.hip", "oph_api.hip"]
+SOURCES = ["oph_kernels.hip", "oph_decrun.hip", "oph_api.hip"]
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
@@ -50,6 +50,8 @@ SIGNATURES = {
     "oph_text2mel_durations": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_i32p, C.c_int, C.c_int,
                                          c_f32p, c_i32p, c_f32p, c_i32p]),
     "oph_ssrn": (C.c_int, [C.c_void_p, c_f32p, C.c_int, C.c_int, c_f32p]),
+    "oph_text2mel_graph": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, C.c_int,
+                                     c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p]),
     "oph_stage_text": (C.c_int, [C.c_void_p, c_i32p, c_i32p, c_i32p, C.c_int]),
     "oph_run_resident": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_i32p]),
     "oph_decode_steps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_i32p]),
@@ -112,13 +114,19 @@ def _hipcc_shared(out, srcs, deps, extra, verbose):
     if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # several ranks may find the library stale at the same time: each builds into its own temporary file and renames
+    # it into place (atomic on one filesystem), so a reader never maps a half-written library
+    tmp = "%s.%d.tmp" % (out, os.getpid())
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", "-Wno-unused-result"] + srcs + extra + ["-o", out]
+           "-Wno-unused-value", "-Wno-unused-result"] + srcs + extra + ["-o", tmp]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout)
     if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise OpheliaHipError("hipcc failed building %s" % os.path.basename(out))
+    os.replace(tmp, out)
     return out
 
 
@@ -127,7 +135,7 @@ def build(verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     inc = os.path.join(os.path.dirname(HERE), "include")
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    _hipcc_shared(LIBPATH, srcs, srcs + [os.path.join(CSRC, "oph_internal.h"), os.path.join(inc, "ophelia_hip.h")],
+    _hipcc_shared(LIBPATH, srcs, srcs + [os.path.join(CSRC, "oph_internal.h"), os.path.join(CSRC, "oph_device.h"), os.path.join(inc, "ophelia_hip.h")],
                   [], verbose)
     vsrcs = [os.path.join(CSRC, s) for s in VOCODER_SOURCES]
     _hipcc_shared(VOCODER_LIBPATH, vsrcs, vsrcs + [os.path.join(inc, "ophelia_vocoder.h")],

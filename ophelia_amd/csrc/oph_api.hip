@@ -77,7 +77,7 @@ struct ProfClass {
     double ms = 0;
 };
 constexpr int CONE_KSPLIT = 4;   // split-K of the latency-bound decoder-cone GEMMs (partials summed by ln_rows)
-enum { PC_GEMM = 0, PC_GEMM64, PC_GEMM_BF16, PC_LN, PC_DEC, PC_ROWCHAIN, PC_ATTN_ROWS, PC_MISC, PC_COUNT };   // PC_GEMM = the <128,128> instance
+enum { PC_GEMM = 0, PC_GEMM64, PC_GEMM_BF16, PC_LN, PC_DEC, PC_ROWCHAIN, PC_ATTN_ROWS, PC_MISC, PC_DECRUN, PC_DECLOOP, PC_COUNT };   // PC_GEMM = the <128,128> instance
 
 }  // namespace
 
@@ -110,6 +110,17 @@ struct oph_handle {
     uint32_t* d_sig = nullptr;          // [0] attention of step t done (written on sdec), [16] cone of step t done (scone)
     uint32_t sig_base = 0;
     bool use_sigval = false;
+    bool can_sigval = false;            // stream value operations work on this device
+    // persistent runs of decoder layers (oph_decrun.hip): two launches per step instead of nineteen
+    bool use_run = false;               // this configuration takes the dec_run path
+    unsigned long long* d_gbuf = nullptr;   // hand-off granules [RUN_MAX_LAYERS][Bpad][RUN_GCOLS]
+    uint32_t run_epoch = 0;             // advanced by RUN_MAX_LAYERS per launch: a tag value is never reused
+    long long* d_stamps = nullptr;      // OPH_RUN_STAMPS diagnostics: [2 launches][32 slices][LOOP_MAX_LAYERS][8]
+    // whole-decode persistent launch (dec_loop): static layer descriptions in device memory, progress words in pinned host memory
+    bool use_loop = false;
+    LoopLayer* d_loop_layers = nullptr;
+    int loop_nlayers = 0, loop_attn = 0, loop_slices = 0, loop_kmax = 0;
+    volatile int* host_prog = nullptr;  // [0] last step whose attention is done  [1] stop step or INT_MAX
     std::string err;
     bool finalized = false;
     // expected variables (TF names) and host copies
@@ -292,9 +303,12 @@ void build_networks(oph_handle* h) {
         for (int o = 0; o < 2; ++o) add_conv(h->ssrn, sc(n, "C", i++), m.full_dim, m.full_dim, false, ACT_RELU);
         add_conv(h->ssrn, sc(n, "C", i++), m.full_dim, m.full_dim, false, ACT_SIGMOID);   // squash_output_ssrn
     }
+    // hp.norm None concerns Text2Mel only: synthesize() sets hp.norm = 'layer' while it builds SSRNGraph and restores None
+    // afterwards (synthesize.py:513-534), so the SSRN of such a config is normalised like any other and its checkpoint
+    // holds the SSRN gamma / beta variables
     if (m.flags & OPH_FLAG_NORM_NONE)
-        for (auto* net : {&h->textenc, &h->audioenc, &h->audiodec, &h->ssrn})
-            for (Layer& l : *net) l.ln = l.kind == K_CONVT;
+        for (auto* net : {&h->textenc, &h->audioenc, &h->audiodec})
+            for (Layer& l : *net) l.ln = false;
     if (m.flags & OPH_FLAG_LCC) {
         // the layers the reference passes lcc=/codes= to: all of TextEnc except the 'towards_end' squash conv
         // (networks.py:191-198), all of AudioEnc, AudioDec after its input convs (networks.py:373-389 pass none); SSRN none
@@ -489,9 +503,10 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
         e.g1 = l.g1; e.b1 = l.b1; e.g2 = l.g2; e.b2 = l.b2; e.act = l.act; e.Y = y; e.ldy = ldy; e.ypad = ypad;
         e.H = wsraw; e.stop_after = nullptr; e.nonorm = !l.ln;
         e.lcc = l.lcc_gate; e.lcc_ids = h->d_spk; e.lcc_T = Tcur;
-        if (!last && layers[li + 1].cat_table) {      // the next layer's input = [this output | speaker embedding]
+        if (!last && layers[li + 1].ccat > 0) {       // the next layer's input = [this output | speaker embedding]
             const Layer& nx = layers[li + 1];
-            e.spk_table = nx.cat_table; e.spk_ids = h->d_spk; e.spk_dim = nx.ccat; e.spk_T = Tcur;
+            e.spk_table = nx.cat_table ? nx.cat_table : h->emb_spk;      // AudioDec 'audio_decoder_input': embed_2
+            e.spk_ids = h->d_spk; e.spk_dim = nx.ccat; e.spk_T = Tcur;
             e.ldy = e.ypad = nx.kc;
         }
         if (l.kind == K_CONVT) {
@@ -559,6 +574,7 @@ int ensure_decode_state(oph_handle* h, int B) {
         h->cone[0].clear(); h->cone[1].clear(); h->d_tab.clear(); h->d_need.clear(); h->d_res.clear(); h->Hset.clear();
         for (auto& ge : h->dec_graph) if (ge) { hipGraphExecDestroy(ge); ge = nullptr; }
         h->KV = nullptr; h->capB = 0; h->actA = h->actB = h->raw = h->actA2 = h->actB2 = h->raw2 = nullptr;
+        h->d_loop_layers = nullptr;
         h->pipelined = false; h->buf = 0; h->ssrn_inflight[0] = h->ssrn_inflight[1] = false;
     }
     const oph_dims& m = h->dm;
@@ -572,6 +588,9 @@ int ensure_decode_state(oph_handle* h, int B) {
     h->d_tends = h->dalloc<int>(Bpad);
     h->d_ctl = h->dalloc<int>(4);
     h->d_ptab = h->dalloc<int>((size_t)m.max_T * Bpad);
+    h->d_gbuf = h->dalloc<unsigned long long>((size_t)LOOP_MAX_LAYERS * Bpad * RUN_GCOLS);
+    h->run_epoch = 0;
+    if (getenv("OPH_RUN_STAMPS")) h->d_stamps = h->dalloc<long long>((size_t)2 * 32 * LOOP_MAX_LAYERS * 8);
     h->KV = h->dalloc<float>((size_t)Bpad * m.max_N * 2 * d);
     for (int i = 0; i < 2; ++i) h->Yout2[i] = h->dalloc<float>((size_t)Bpad * m.max_T * h->ldy);
     h->Yout = h->Yout2[0];
@@ -770,12 +789,250 @@ void fill_pre(DecArgs& a, const Layer* prev, const float* prev_raw, const float*
 //   dec_layer16  : AudioDec highway layers (taps from the cone of this step)
 //   row_chain C  : gate -> AudioDec C_8..C_11 -> LN -> sigmoid -> Y[:, t] (and S[t+1])
 // Side stream: cone(t+1), released by the event recorded right after row_chain B of step t.
+// ---------------------------------------------------------------- persistent runs (oph_decrun.hip)
+// Prologue description of the layer that consumes `prev`'s raw output.
+RunLayer run_layer(const Layer& l, const Layer* prev) {
+    RunLayer r{};
+    if (!prev) r.pre = RUN_COPY;
+    else if (prev->kind == K_CONV) { r.pre = RUN_CONV; r.act = prev->act; }
+    else r.pre = RUN_HC;
+    if (prev) { r.cin = prev->cout; r.nonorm = !prev->ln; r.g1 = prev->g1; r.b1 = prev->b1; r.g2 = prev->g2; r.b2 = prev->b2; }
+    r.ccat = l.ccat; r.cat_table = l.cat_table;
+    r.ntaps = l.ntaps; r.kc = l.kc; r.N = l.N; r.Wt = l.Wt; r.ldw = l.ntaps * l.kc; r.bias = l.bias;
+    return r;
+}
+void run_args_common(oph_handle* h, RunArgs& a, int t, int stop_mode) {
+    const oph_dims& m = h->dm;
+    a.B = h->B; a.Bpad = h->Bpad; a.t = t; a.stop_after = h->d_ctl + 1;
+    const bool ms = m.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_SPK_AUDIO_ENCODER_INPUT);
+    a.spk_ids = ms ? h->d_spk : nullptr;
+    a.gbuf = h->d_gbuf; a.err = h->d_ctl + 2;
+    a.KV = h->KV; a.N_keys = m.max_N; a.win = m.attention_win_size; a.max_T = m.max_T;
+    a.pcur = h->d_p + (t & 1) * h->Bpad; a.pnext = h->d_p + ((t + 1) & 1) * h->Bpad;
+    a.ends = h->d_ends; a.t_ends = h->d_tends; a.n_ended = h->d_ctl; a.stop_flag = h->d_ctl + 1; a.stop_mode = stop_mode;
+    a.Qhist = h->Qhist; a.align = h->align;
+    a.Yout = h->Yout; a.ldy = h->ldy; a.Ytm = h->Ytm; a.ldtm = h->ldy;
+}
+void run_launch(oph_handle* h, RunArgs& a) {
+    int slices = 1, kmax = 32;
+    double bytes = 0, flops = 0;
+    for (int i = 0; i < a.nlayers; ++i) {
+        const RunLayer& L = a.L[i];
+        slices = std::max(slices, round_up(L.N, 16) / 16);
+        kmax = std::max(kmax, L.ntaps * L.kc);
+        const double K = (double)L.ntaps * L.kc;
+        bytes += ((double)L.N * K + (double)a.B * (K + L.N)) * 4.0;
+        flops += 2.0 * a.B * L.N * K;
+    }
+    a.epoch0 = h->run_epoch;
+    h->run_epoch += RUN_MAX_LAYERS;
+    h->pbegin(PC_DECRUN);
+    static const int rows_per_group = getenv("OPH_RUN_ROWS") ? atoi(getenv("OPH_RUN_ROWS")) : 4;
+    launch_dec_run(a, slices, rows_per_group, kmax, g_cur);
+    h->pend(PC_DECRUN, bytes, flops);
+}
+// First launch of step t: S[t] -> AudioEnc (k=1 head, highway layers with cached dilated taps) -> attention row t
+// (+ alignments, prev_max, end detection) -> AudioDec input convs.  Leaves the raw rows of the last input conv.
+void run_encoder_half(oph_handle* h, int t, int stop_mode) {
+    const oph_dims& m = h->dm;
+    const int Bpad = h->Bpad, pre = h->dec_pre;
+    RunArgs a{};
+    run_args_common(h, a, t, stop_mode);
+    int n = 0;
+    for (size_t li = 0; li < h->audioenc.size(); ++li) {
+        const Layer& l = h->audioenc[li];
+        RunLayer r = run_layer(l, li ? &h->audioenc[li - 1] : nullptr);
+        if (li == 0) { r.src = h->Ytm + (size_t)t * Bpad * h->ldy; r.ldsrc = h->ldy; r.cin = m.n_mels; }
+        if (l.kind == K_HC) {
+            float* hist = h->ae_hist[li];
+            const int o0 = -l.off[0], o1 = -l.off[1];
+            r.tap0 = t - o0 >= 0 ? hist + (size_t)(t - o0) * Bpad * l.kc : nullptr;
+            r.tap1 = t - o1 >= 0 ? hist + (size_t)(t - o1) * Bpad * l.kc : nullptr;
+            r.ldtap = l.kc;
+            r.xstore = hist + (size_t)t * Bpad * l.kc; r.ldstore = l.kc;
+        }
+        a.L[n++] = r;
+    }
+    for (int k = 0; k < pre; ++k) {
+        const Layer& l = h->audiodec[k];
+        RunLayer r = run_layer(l, k ? &h->audiodec[k - 1] : &h->audioenc.back());
+        if (k == 0) r.pre = RUN_ATTN;
+        if (l.ccat > 0) r.cat_table = h->emb_spk;      // 'audio_decoder_input' (networks.py:381-389)
+        if (k + 1 == pre) { r.out = h->ad_raw[k]; r.ldout = l.Nalloc; }
+        a.L[n++] = r;
+    }
+    a.nlayers = n;
+    if (h->d_stamps && t == m.max_T / 2) a.stamps = h->d_stamps;
+    run_launch(h, a);
+}
+// Second launch of step t: AudioDec highway layers (older taps from the cone of this step) -> k=1 tail -> mel frame t.
+void run_decoder_half(oph_handle* h, int t, int stop_mode) {
+    const int Bpad = h->Bpad, pre = h->dec_pre, nh = h->n_hc_dec;
+    const std::vector<float*>& cone = h->cone[t & 1];
+    RunArgs a{};
+    run_args_common(h, a, t, stop_mode);
+    int n = 0;
+    for (size_t li = pre; li < h->audiodec.size(); ++li) {
+        const Layer& l = h->audiodec[li];
+        RunLayer r = run_layer(l, &h->audiodec[li - 1]);
+        if ((int)li == pre) { r.src = h->ad_raw[pre - 1]; r.ldsrc = h->audiodec[pre - 1].Nalloc; }
+        const int k = (int)li - pre;
+        if (k < nh) {
+            const int o0 = -l.off[0], o1 = -l.off[1];
+            r.tap0 = t - o0 >= 0 ? cone[k] + (size_t)idx_of(h->Hset[k], o0) * Bpad * l.kc : nullptr;
+            r.tap1 = t - o1 >= 0 ? cone[k] + (size_t)idx_of(h->Hset[k], o1) * Bpad * l.kc : nullptr;
+            r.ldtap = l.kc;
+        }
+        a.L[n++] = r;
+    }
+    RunLayer e = run_layer(h->audiodec.back(), &h->audiodec.back());     // prologue only: LN + squash sigmoid of the last conv
+    e.act = ACT_SIGMOID;                                                 // squash_output_t2m (networks.py:430-431)
+    e.N = 0; e.ccat = 0; e.cat_table = nullptr;
+    a.L[n++] = e;
+    a.nlayers = n;
+    if (h->d_stamps && t == h->dm.max_T / 2) a.stamps = h->d_stamps + (size_t)32 * RUN_MAX_LAYERS * 8;
+    run_launch(h, a);
+}
+// whether this handle's configuration can take the persistent-run path
+bool run_supported(const oph_handle* h) {
+    const oph_dims& m = h->dm;
+    if (getenv("OPH_NO_DECRUN")) return false;
+    if (m.flags & (OPH_FLAG_LCC | OPH_FLAG_NO_MONOTONIC)) return false;       // variants served by the per-layer kernels
+    if ((int)h->audioenc.size() + h->dec_pre > RUN_MAX_LAYERS || (int)h->audiodec.size() - h->dec_pre + 1 > RUN_MAX_LAYERS) return false;
+    for (const auto* net : {&h->audioenc, &h->audiodec})
+        for (const Layer& l : *net) {
+            if (l.ntaps * l.kc > 768 || l.N > RUN_GCOLS || (l.ntaps == 3 && l.kc > 256) || l.cout > 256) return false;
+        }
+    return true;
+}
+
+// ---------------------------------------------------------------- whole-decode launch (dec_loop)
+// Static layer table of a decode: AudioEnc (layer 0 consumes the previous step's last AudioDec layer) -> attention +
+// AudioDec input convs -> AudioDec highway layers (taps from the cone ping-pong buffers) -> k=1 tail.
+int build_loop_layers(oph_handle* h) {
+    const oph_dims& m = h->dm;
+    const int pre = h->dec_pre, nh = h->n_hc_dec;
+    std::vector<LoopLayer> v;
+    auto from = [&](const Layer& l, const Layer* prev) {
+        const RunLayer r = run_layer(l, prev);
+        LoopLayer q{};
+        q.pre = r.pre; q.act = r.act; q.cin = r.cin; q.nonorm = r.nonorm; q.g1 = r.g1; q.b1 = r.b1; q.g2 = r.g2; q.b2 = r.b2;
+        q.cat_table = r.cat_table; q.ccat = r.ccat; q.ntaps = r.ntaps; q.kc = r.kc; q.N = r.N; q.Wt = r.Wt; q.ldw = r.ldw; q.bias = r.bias;
+        return q;
+    };
+    for (size_t li = 0; li < h->audioenc.size(); ++li) {
+        const Layer& l = h->audioenc[li];
+        LoopLayer q = from(l, li ? &h->audioenc[li - 1] : &h->audiodec.back());
+        if (li == 0) q.act = ACT_SIGMOID;                 // squash_output_t2m (networks.py:430-431): x = mel frame t-1
+        if (l.kind == K_HC) { q.tapkind = 1; q.hist = h->ae_hist[li]; q.off0 = -l.off[0]; q.off1 = -l.off[1]; }
+        v.push_back(q);
+    }
+    h->loop_attn = (int)v.size();
+    for (size_t li = 0; li < h->audiodec.size(); ++li) {
+        const Layer& l = h->audiodec[li];
+        LoopLayer q = from(l, li ? &h->audiodec[li - 1] : &h->audioenc.back());
+        if (li == 0) q.pre = RUN_ATTN;
+        if (l.ccat > 0) q.cat_table = h->emb_spk;
+        const int k = (int)li - pre;
+        if (k >= 0 && k < nh) {
+            q.tapkind = 2; q.off0 = -l.off[0]; q.off1 = -l.off[1];
+            q.idx0 = idx_of(h->Hset[k], q.off0); q.idx1 = idx_of(h->Hset[k], q.off1);
+            q.cone0 = h->cone[0][k]; q.cone1 = h->cone[1][k];
+            if (q.idx0 < 0 || q.idx1 < 0) { h->fail("internal: cone tap not in the position set"); return OPH_ERR_STATE; }
+        }
+        v.push_back(q);
+    }
+    if ((int)v.size() > LOOP_MAX_LAYERS) { h->fail("internal: too many decoder layers for the loop kernel"); return OPH_ERR_STATE; }
+    h->loop_nlayers = (int)v.size();
+    h->loop_slices = 1; h->loop_kmax = 32;
+    for (const LoopLayer& q : v) { h->loop_slices = std::max(h->loop_slices, round_up(q.N, 16) / 16); h->loop_kmax = std::max(h->loop_kmax, q.ntaps * q.kc); }
+    h->d_loop_layers = h->dalloc<LoopLayer>(v.size());
+    if (!h->d_loop_layers) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
+    if (hipMemcpy(h->d_loop_layers, v.data(), v.size() * sizeof(LoopLayer), hipMemcpyHostToDevice) != hipSuccess) { h->fail("descriptor upload failed"); return OPH_ERR_DEVICE; }
+    (void)m;
+    return OPH_OK;
+}
+
+// The decode loop as ONE launch on the critical stream + the per-step cones on the side stream, chained by two device
+// words (stream wait-value / write-value on the side stream, in-kernel atomics on the other end).  t_end steps from 0.
+int decode_loop(oph_handle* h, int t_end, int stop_mode) {
+    const oph_dims& m = h->dm;
+    if (!h->d_loop_layers) { const int rc = build_loop_layers(h); if (rc) return rc; }
+    static const int rows_per_group = getenv("OPH_RUN_ROWS") ? atoi(getenv("OPH_RUN_ROWS")) : 4;
+    static const int lookahead = getenv("OPH_LOOP_LOOKAHEAD") ? atoi(getenv("OPH_LOOP_LOOKAHEAD")) : 8;
+    h->host_prog[0] = -1; h->host_prog[1] = INT_MAX;
+    if ((uint64_t)h->run_epoch + (uint64_t)(m.max_T + 1) * LOOP_MAX_LAYERS > 0xF0000000ull) {     // tag wrap guard
+        for (hipStream_t st : {h->sdec, h->scone}) hipStreamSynchronize(st);
+        hipMemsetAsync(h->d_gbuf, 0, (size_t)LOOP_MAX_LAYERS * h->Bpad * RUN_GCOLS * 8, h->sdec);
+        hipStreamSynchronize(h->sdec);
+        h->run_epoch = 0;
+    }
+    LoopArgs a{};
+    a.nlayers = h->loop_nlayers; a.B = h->B; a.Bpad = h->Bpad; a.t_end = t_end; a.stop_mode = stop_mode; a.attn_layer = h->loop_attn;
+    a.L = h->d_loop_layers; a.ctl = h->d_ctl;
+    const bool ms = m.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_SPK_AUDIO_ENCODER_INPUT);
+    a.spk_ids = ms ? h->d_spk : nullptr;
+    a.gbuf = h->d_gbuf; a.epoch0 = h->run_epoch;
+    h->run_epoch += (uint32_t)(m.max_T + 1) * LOOP_MAX_LAYERS;
+    a.stamps = h->d_stamps; a.stamp_t = m.max_T / 2;
+    a.KV = h->KV; a.N_keys = m.max_N; a.win = m.attention_win_size; a.max_T = m.max_T;
+    a.p = h->d_p; a.ends = h->d_ends; a.t_ends = h->d_tends;
+    a.Qhist = h->Qhist; a.align = h->align; a.Yout = h->Yout; a.ldy = h->ldy; a.Ytm = h->Ytm;
+    a.sig = h->d_sig; a.sig_base = h->sig_base;
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, (void*)h->host_prog, 0) != hipSuccess) { h->fail("pinned progress words are not mapped"); return OPH_ERR_DEVICE; }
+    a.host_progress = (volatile int*)dp;
+    hipStreamWaitEvent(h->scone, h->ev_in, 0);
+    g_cur = h->sdec;
+    double bytes = 0, flops = 0;
+    {
+        const size_t nl = (size_t)h->audioenc.size() + h->audiodec.size();
+        size_t i = 0;
+        for (const auto* net : {&h->audioenc, &h->audiodec})
+            for (const Layer& l : *net) { const double K = (double)l.ntaps * l.cin; bytes += ((double)l.N * K + (double)h->B * (K + l.N)) * 4.0; flops += 2.0 * h->B * l.N * K; ++i; }
+        (void)nl; (void)i;
+    }
+    h->pbegin(PC_DECLOOP);
+    launch_dec_loop(a, h->loop_slices, rows_per_group, h->loop_kmax, h->sdec);
+    h->pend(PC_DECLOOP, bytes * t_end, flops * t_end);
+    // side stream: cone(t) after the attention of step t-1, then the word the loop kernel polls before AudioDec(t)
+    g_cur = h->scone;
+    const auto t_host0 = std::chrono::steady_clock::now();
+    for (int t = 1; t < t_end; ++t) {
+        // bounded run-ahead, so that an early stop leaves at most `lookahead` queued cones (they early-out on the device)
+        auto t_wait0 = std::chrono::steady_clock::now();
+        while (h->host_prog[0] < t - 1 - lookahead && h->host_prog[1] == INT_MAX) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait0).count() > 10.0) {
+                h->fail("decode loop kernel made no progress for 10 s (step %d)", h->host_prog[0]);
+                return OPH_ERR_DEVICE;
+            }
+        }
+        const int stopped_at = h->host_prog[1];
+        if (stopped_at != INT_MAX && t > stopped_at + 1) break;       // step stop+1 still runs (stores off) and polls its cone
+        hipStreamWaitValue32(h->scone, h->d_sig, h->sig_base + (uint32_t)t, hipStreamWaitValueGte, 0xffffffffu);
+        launch_cone(h, t);
+        hipStreamWriteValue32(h->scone, h->d_sig + 16, h->sig_base + (uint32_t)t, 0);
+    }
+    if (g_trace) {
+        const double enq = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_host0).count() * 1e3;
+        hipStreamSynchronize(h->sdec); hipStreamSynchronize(h->scone);
+        const double all = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_host0).count() * 1e3;
+        TRACE("decode loop (one launch): side-stream enqueue %.2f ms, drained %.2f ms after the launch", enq, all);
+    }
+    g_cur = h->sdec;
+    return OPH_OK;
+}
+
 void decode_step(oph_handle* h, int t, int t_last, int stop_mode) {
     const oph_dims& m = h->dm;
     const int d = m.d, Bpad = h->Bpad, B = h->B;
     int* stop_after = h->d_ctl + 1;
     g_cur = h->sdec;
+    const bool run = h->use_run && !h->fixed_att;
     const int pre = h->dec_pre, nh = h->n_hc_dec;
+    if (run) {
+        run_encoder_half(h, t, stop_mode);
+    } else {
     // ---------------- row_chain A: AudioEnc k=1 head
     size_t nk1 = 0;
     while (nk1 < h->audioenc.size() && h->audioenc[nk1].kind == K_CONV) ++nk1;
@@ -832,6 +1089,7 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode) {
         a.B = B; a.stop_after = stop_after; a.t = t;
         run_row_chain(h, a, 1);
     }
+    }   // !run
     // cone(t) (launched during step t-1, or by decode_range for the first step) must have landed
     const bool sv = h->use_sigval && !h->capturing;
     {
@@ -853,16 +1111,18 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode) {
                 hipStreamWaitEvent(h->scone, h->ev_attn, 0);
             }
         }
-        { HostTimer ht(1, g_trace); launch_cone(h, t + 1); }
+        static const bool skip_cone = getenv("OPH_SKIP_CONE") != nullptr;      // timing experiments only: results are wrong
+        if (!skip_cone) { HostTimer ht(1, g_trace); launch_cone(h, t + 1); }
         {
             HostTimer ht(0, g_trace);
             if (sv) hipStreamWriteValue32(h->scone, h->d_sig + 16, h->sig_base + (uint32_t)t + 1, 0);
             else hipEventRecord(h->ev_cone, h->scone);
         }
     }
+    if (run) { run_decoder_half(h, t, stop_mode); return; }
     const std::vector<float*>& cone = h->cone[t & 1];
     // ---------------- AudioDec highway layers, row t (taps from the cone)
-    prev = nullptr; prev_raw = nullptr; prev_x = nullptr;
+    const Layer* prev = nullptr; const float* prev_raw = nullptr; const float* prev_x = nullptr;
     h->gbegin(PC_DEC);
     for (int k = 0; k < nh; ++k) {
         const size_t li = pre + k;
@@ -908,7 +1168,8 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
     // (~5 us per launch) is slower than the device (profiles/r01 trace: the critical stream idles
     // while the host enqueues the cone).  Capture all max_T steps once per (stop_mode, B) and replay.
     // After the stop step every node early-outs on the device, so outputs are identical.
-    const bool graphable = h->use_graph && !h->profiling && !h->fixed_att && t_begin == 0 && t_end == m.max_T && stop_mode >= 0 && stop_mode <= 1;
+    // (the persistent-run path stamps a fresh epoch into every launch: a replayed graph would reuse old ones)
+    const bool graphable = h->use_graph && !h->use_run && !h->profiling && !h->fixed_att && t_begin == 0 && t_end == m.max_T && stop_mode >= 0 && stop_mode <= 1;
     if (graphable) {
         hipGraphExec_t& ge = h->dec_graph[stop_mode];
         if (ge && h->dec_graph_B[stop_mode] != h->B) { hipGraphExecDestroy(ge); ge = nullptr; }
@@ -932,7 +1193,14 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
             t_begin = t_end;      // skip the eager loop below
         }
     }
-    if (h->use_sigval) {
+    if (h->use_run && h->run_epoch > 0xF0000000u) {      // tag wrap guard (once per ~10^5 batches): start over from zeroed granules
+        for (hipStream_t st : {h->sdec, h->scone}) hipStreamSynchronize(st);
+        hipMemsetAsync(h->d_gbuf, 0, (size_t)LOOP_MAX_LAYERS * h->Bpad * RUN_GCOLS * 8, h->sdec);
+        hipStreamSynchronize(h->sdec);
+        h->run_epoch = 0;
+    }
+    const bool loop_mode = h->use_loop && !h->fixed_att && !h->capturing && t_begin == 0 && t_end >= 1;
+    if (h->use_sigval || loop_mode) {
         // a fresh value range for this loop: every value of an earlier loop is below sig_base + 1
         if (h->sig_base > 0x7fff0000u) {       // wrap guard (once per ~10 million batches): start over from a quiet state
             hipStreamSynchronize(h->sdec); hipStreamSynchronize(h->scone);
@@ -957,6 +1225,11 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
     }
     int rc_loop = OPH_OK;
     const auto tq0 = std::chrono::steady_clock::now();
+    if (loop_mode) {
+        if ((rc_loop = decode_loop(h, t_end, stop_mode)) != OPH_OK) return rc_loop;
+        last = t_end;
+        t_begin = t_end;          // skip the per-step loop below
+    }
     for (int t = t_begin; t < t_end; ++t) {
         decode_step(h, t, t_end, stop_mode);
         last = t + 1;
@@ -978,6 +1251,24 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
         TRACE("decode loop: host enqueue %.2f ms, device drained %.2f ms after the first launch (last=%d); of the enqueue: "
               "event ops %.2f ms, cone launches %.2f ms", enq_ms, all_ms, last, g_host_us[0] * 1e-3, g_host_us[1] * 1e-3);
         g_host_us[0] = g_host_us[1] = 0;
+        if (h->d_stamps) {      // phase durations of the stamped launch(es) of step max_T/2, averaged over the column slices (us)
+            const int nruns = loop_mode ? 1 : 2, stride = loop_mode ? LOOP_MAX_LAYERS : RUN_MAX_LAYERS;
+            std::vector<long long> st((size_t)2 * 32 * LOOP_MAX_LAYERS * 8);
+            hipMemcpy(st.data(), h->d_stamps, st.size() * 8, hipMemcpyDeviceToHost);
+            for (int run = 0; run < nruns; ++run)
+                for (int l = 0; l < stride; ++l) {
+                    double d[5] = {0, 0, 0, 0, 0}, passes = 0, start = 0; int n = 0;
+                    const long long t00 = st[((size_t)run * 32 + 0) * stride * 8 + 0];
+                    for (int g = 0; g < 32; ++g) {
+                        const long long* s_ = &st[(((size_t)run * 32 + g) * stride + l) * 8];
+                        if (s_[0] == 0 || s_[5] == 0) continue;
+                        for (int k = 0; k < 5; ++k) d[k] += (double)(s_[k + 1] - s_[k]) * 0.01;
+                        passes += (double)s_[6]; start += (double)(s_[0] - t00) * 0.01; ++n;
+                    }
+                    if (n) TRACE("run %d layer %2d (%2d slices): start %+7.2f  sweep %.2f (%.1f passes)  prologue+stage %.2f  barrier %.2f  fma+prefetch %.2f  reduce+publish %.2f",
+                                 run, l, n, start / n, d[0] / n, passes / n, d[1] / n, d[2] / n, d[3] / n, d[4] / n);
+                }
+        }
     }
     // join: the API stream continues (SSRN, fetches) only after both decode streams drained
     hipEventRecord(h->ev_out, h->sdec);
@@ -985,9 +1276,10 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
     hipEventRecord(h->ev_out, h->scone);
     hipStreamWaitEvent(h->stream, h->ev_out, 0);
     g_cur = h->stream;
-    if (steps_run || stop_mode == OPH_STOP_REFERENCE) {
+    if (steps_run || stop_mode == OPH_STOP_REFERENCE || h->use_run) {
         HIPCHK(h, hipMemcpyAsync(ctl, h->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (ctl[2] != 0) { h->fail(ctl[2] == 2 ? "decoder loop: the side stream's cone never signalled (time-out)" : "decoder run: a workgroup hand-off timed out (workgroups of one run were not co-resident)"); return OPH_ERR_DEVICE; }
     }
     if (steps_run) *steps_run = ctl[1] != INT_MAX ? ctl[1] + 1 : last;
     HIPCHK(h, hipGetLastError());
@@ -1053,7 +1345,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
     oph_handle* h = new oph_handle();
     h->dm = m;
     h->device = device;
-    static const char* names[PC_COUNT] = {"conv_gemm_f32<128,128>", "conv_gemm_f32<64,64>", "conv_gemm_bf16x3", "ln_rows", "dec_layer16", "row_chain", "attn_rows", "misc"};
+    static const char* names[PC_COUNT] = {"conv_gemm_f32<128,128>", "conv_gemm_f32<64,64>", "conv_gemm_bf16x3", "ln_rows", "dec_layer16", "row_chain", "attn_rows", "misc", "dec_run", "dec_loop"};
     for (int i = 0; i < PC_COUNT; ++i) h->prof[i].name = names[i];
     // CU partition for the decode loop (MI355X: 256 CUs, mask bit i -> XCD i%8): the ~25 dependent
     // tiny launches of a step get a private slice of 8 CUs in every XCD so the concurrently running
@@ -1106,14 +1398,20 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
     g_cur = h->stream;
     {
         int can = 0;
-        // opt-in (OPH_STREAM_VALUE=1): under rocprofv3 --pmc, which serialises dispatches across queues, a wait-value packet
-        // never sees the value the other queue would write and the run deadlocks; events are understood by the profiler
+        // Stream write/wait-value operations on two device words.  The whole-decode launch (dec_loop) needs them for its
+        // side stream.  For the per-step launch path they are opt-in (OPH_STREAM_VALUE=1): under rocprofv3 --pmc, which
+        // serialises dispatches across queues, a wait-value packet never sees the value the other queue would write and
+        // the run deadlocks; events are understood by the profiler.
         const char* sv = getenv("OPH_STREAM_VALUE");
-        if (sv && atoi(sv) != 0 && hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) == hipSuccess && can) {
+        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) == hipSuccess && can) {
             h->d_sig = h->dalloc<uint32_t>(32);
-            h->use_sigval = h->d_sig != nullptr && hipStreamWriteValue32(h->stream, h->d_sig, 0, 0) == hipSuccess &&
+            h->can_sigval = h->d_sig != nullptr && hipStreamWriteValue32(h->stream, h->d_sig, 0, 0) == hipSuccess &&
                             hipStreamSynchronize(h->stream) == hipSuccess;
+            h->use_sigval = h->can_sigval && sv && atoi(sv) != 0;
         }
+        (void)hipGetLastError();
+        void* hp_ = nullptr;
+        if (hipHostMalloc(&hp_, 64, hipHostMallocMapped) == hipSuccess) { h->host_prog = (volatile int*)hp_; h->host_prog[0] = -1; h->host_prog[1] = INT_MAX; }
         (void)hipGetLastError();
     }
     h->ssrn_prec = getenv("OPH_SSRN_FP32") ? 0 : 1;
@@ -1136,6 +1434,7 @@ int oph_destroy(oph_handle* h) {
         if (e) hipEventDestroy(e);
     TRACE("destroy: free");
     for (void* p : h->allocs) hipFree(p);
+    if (h->host_prog) hipHostFree((void*)h->host_prog);
     TRACE("destroy: streams");
     for (hipStream_t st : {h->scone, h->sssrn, h->sdec, h->stream}) if (st) { TRACE("  destroy stream %p", (void*)st); hipStreamDestroy(st); }
     TRACE("destroy: done");
@@ -1194,6 +1493,11 @@ int oph_finalize_weights(oph_handle* h) {
     HIPCHK(h, hipGetLastError());
     h->hostw.clear();
     h->n_weight_allocs = h->allocs.size();
+    h->use_run = run_supported(h);
+    // OPH_DECODE = loop (default where possible) | runs (two launches per step) | layers (one launch per layer, round 1)
+    const char* mode = getenv("OPH_DECODE");
+    if (mode && !strcmp(mode, "layers")) h->use_run = false;
+    h->use_loop = h->use_run && h->can_sigval && h->host_prog && !(mode && !strcmp(mode, "runs")) && !getenv("OPH_NO_DECLOOP");
     h->finalized = true;
     return OPH_OK;
 }
@@ -1423,6 +1727,72 @@ int oph_text2mel_durations(oph_handle* h, const float* K, const float* V, const 
     if ((rc = oph_fetch_mel(h, Y, nullptr, alignments))) return rc;
     if (t_ends) std::copy(tends.begin(), tends.end(), t_ends);
     if (steps_run) *steps_run = steps;
+    return OPH_OK;
+}
+
+// One evaluation of the synthesis graph at fixed feeds -- what ONE sess.run of the reference's loop computes
+// (synthesize.py:181-183 with the feed dict of :172): S = shift(mels) -> AudioEnc over all max_T positions ->
+// Attention of every position under the ONE mask prev_max (networks.py:300-319) -> AudioDec -> logits / sigmoid.
+// O(max_T) work per call: the debug / fetch surface of architectures.py:188-239 (g.Q, g.R, g.Y_logits, ...), not the
+// decode loop (oph_text2mel).  Batched kernels: conv_gemm_f32 + ln_rows per layer, attn_rows.
+int oph_text2mel_graph(oph_handle* h, const float* K, const float* V, const float* mels, const int32_t* prev_max,
+                       const int32_t* ends, const int32_t* spk, int B,
+                       float* Q, float* R, float* Y_logits, float* Y, float* alignments, int32_t* max_attentions) {
+    int rc = check_ready(h, B);
+    if (rc) return rc;
+    if (!K || !V || !mels || !prev_max) { h->fail("null argument"); return OPH_ERR_INVALID; }
+    const oph_dims& m = h->dm;
+    const bool ms = m.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_LCC | OPH_FLAG_SPK_AUDIO_ENCODER_INPUT);
+    if (ms && !spk) { h->fail("multispeaker model needs speaker ids"); return OPH_ERR_INVALID; }
+    if ((m.flags & OPH_FLAG_NO_MONOTONIC) && !ends) { h->fail("turn_off_monotonic_for_synthesis needs the text lengths"); return OPH_ERR_INVALID; }
+    for (int b = 0; b < B; ++b) if (prev_max[b] < 0 || prev_max[b] >= m.max_N) { h->fail("prev_max_attentions out of range"); return OPH_ERR_INVALID; }
+    if ((rc = ensure_decode_state(h, B))) return rc;
+    g_cur = h->stream;
+    const int T = m.max_T, d = m.d, ldy = h->ldy;
+    const size_t rows = (size_t)B * m.max_N, w = (size_t)d * 4;
+    HIPCHK(h, hipMemcpy2DAsync(h->KV, 2 * w, K, w, w, rows, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpy2DAsync(h->KV + d, 2 * w, V, w, w, rows, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_p, prev_max, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    if (ends) HIPCHK(h, hipMemcpyAsync(h->d_ends, ends, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    if (ms) {
+        for (int b = 0; b < B; ++b) if (spk[b] < 0 || spk[b] >= m.nspeakers) { h->fail("speaker id out of range"); return OPH_ERR_INVALID; }
+        HIPCHK(h, hipMemcpyAsync(h->d_spk, spk, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    // S = concat(zeros, mels[:, :-1])  (architectures.py:191), rows padded to the first layer's K
+    std::vector<float> S((size_t)B * T * ldy, 0.f);
+    for (int b = 0; b < B; ++b)
+        for (int t = 1; t < T; ++t)
+            std::copy(mels + ((size_t)b * T + t - 1) * m.n_mels, mels + ((size_t)b * T + t) * m.n_mels, S.begin() + ((size_t)b * T + t) * ldy);
+    HIPCHK(h, hipMemcpyAsync(h->actA, S.data(), S.size() * 4, hipMemcpyHostToDevice, h->stream));
+    int ldq = 0;
+    float* dQ = run_batched(h, h->audioenc, h->actA, ldy, B, T, 0, 0, nullptr, 0, 0, &ldq, nullptr);
+    // attention over all positions, one mask per utterance; R' rows go to the workspace the encoder did not end in
+    float* dR = dQ == h->actA ? h->actB : h->actA;
+    long long* d_amax = nullptr;
+    HIPCHK(h, hipMalloc((void**)&d_amax, (size_t)B * T * 8));
+    HIPCHK(h, hipMemsetAsync(h->align, 0, (size_t)h->Bpad * m.max_N * T * 4, h->stream));
+    AttnRowsArgs a{};
+    a.mode = 1; a.Q = dQ; a.ldq = ldq; a.K = h->KV; a.V = h->KV + d; a.ldkv = 2 * d; a.N = m.max_N; a.d = d; a.win = m.attention_win_size;
+    a.p = h->d_p; a.B = B; a.Bpad = h->Bpad; a.nrows = B * T; a.T = T; a.R = dR; a.ldr = 2 * d; a.align = h->align; a.amax = d_amax;
+    if (m.flags & OPH_FLAG_NO_MONOTONIC) a.ends = h->d_ends;
+    launch_attn_rows(a, h->stream);
+    std::vector<float> hQ, hR;
+    if (Q) HIPCHK(h, hipMemcpy2DAsync(Q, w, dQ, (size_t)ldq * 4, w, (size_t)B * T, hipMemcpyDeviceToHost, h->stream));
+    if (R) HIPCHK(h, hipMemcpyAsync(R, dR, (size_t)B * T * 2 * d * 4, hipMemcpyDeviceToHost, h->stream));
+    if (alignments) HIPCHK(h, hipMemcpyAsync(alignments, h->align, (size_t)B * m.max_N * T * 4, hipMemcpyDeviceToHost, h->stream));
+    std::vector<long long> amax((size_t)B * T);
+    HIPCHK(h, hipMemcpyAsync(amax.data(), d_amax, amax.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));     // Q may live in the buffer the decoder overwrites next
+    int ldl = 0;
+    float* dL = run_batched(h, h->audiodec, dR, 2 * d, B, T, 0, 0, nullptr, 0, 0, &ldl, nullptr);
+    std::vector<float> logits((size_t)B * T * m.n_mels);
+    HIPCHK(h, hipMemcpy2DAsync(logits.data(), (size_t)m.n_mels * 4, dL, (size_t)ldl * 4, (size_t)m.n_mels * 4, (size_t)B * T, hipMemcpyDeviceToHost, h->stream));
+    hipError_t e = hipStreamSynchronize(h->stream);
+    hipFree(d_amax);
+    if (e != hipSuccess || (e = hipGetLastError()) != hipSuccess) { h->fail("graph evaluation failed: %s", hipGetErrorString(e)); return OPH_ERR_DEVICE; }
+    if (max_attentions) for (size_t i = 0; i < amax.size(); ++i) max_attentions[i] = (int32_t)amax[i];
+    if (Y_logits) std::copy(logits.begin(), logits.end(), Y_logits);
+    if (Y) for (size_t i = 0; i < logits.size(); ++i) Y[i] = 1.0f / (1.0f + expf(-logits[i]));     // squash_output_t2m (networks.py:430-431)
     return OPH_OK;
 }
 

@@ -1,0 +1,671 @@
+// dec_run: a RUN of decoder layers of one time step in ONE launch (gfx950).
+//
+// The decode step of synth_codedtext2mel (synthesize.py:181-209) is a chain of ~25 dependent layers over the batch's
+// rows (AudioEnc networks.py:214-284 -> Attention 286-325 -> AudioDec 360-435), each needing all channels of the
+// previous one.  As one launch per layer the chain costs ~5-7 us per layer of launch boundary + cold loads (profiles/r01).
+// Here the workgroups stay resident over the whole run.  Workgroup (g, rg) owns output columns [16g, 16g+16) of every
+// layer for the R rows (utterances) of row group rg: one wave per row runs the cheap row-local prologue (LayerNorm /
+// gate / activation / attention), then the R x 16 slice is contracted with VALU FMAs (fp32 FMA and the fp32-input MFMA
+// run at the same rate on gfx950, and without the MFMA's 16-row tile a workgroup can be R = 4 rows thin: 128 small
+// workgroups, one wave per SIMD, instead of 32 fat ones whose 16 waves queue on 4 SIMDs -- profiles/r02 stamps).
+// The raw slices travel between workgroups as 8-byte {epoch, value} granules written and polled with relaxed
+// agent-scope atomics (cdna_hip_programming.md Guideline 16, recipe R2: the data is its own flag, so no fence and no
+// separate flag round trip).  Rows are independent: a row group only ever waits for its own 32 column slices.
+// Weights, LayerNorm parameters and the dilated-tap rows of layer l+1 do not depend on activations and are requested
+// while layer l's partial sums are still being reduced.
+//
+// Arithmetic: fp32 throughout; every dot product is an fmaf chain over 4-wide k groups, K split round-robin over the
+// R waves and the 4 k-quarters of a 16-wide chunk, partials summed in a fixed order.
+#include "oph_internal.h"
+#include "oph_device.h"
+
+#include <map>
+
+namespace oph {
+
+typedef unsigned long long u64;
+constexpr int RUN_KMAX = 768;                     // largest contraction length of a layer (3 taps x 256)
+constexpr long long RUN_TIMEOUT_TICKS = 200000000LL;   // 2 s of the 100 MHz constant clock: a hand-off that takes
+                                                       // longer means a workgroup of the run never became resident
+
+static __device__ __forceinline__ u64 granule_load(const u64* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __device__ __forceinline__ void granule_store(u64* p, unsigned epoch, float v) {
+    __hip_atomic_store(p, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One wave re-reads its row's granules until every tag carries this layer's epoch.  Lane l owns columns c..c+3 (and
+// c2..c2+3 of the second half when `two`).  Bounded: on a time-out (or when another wave already failed) the error word
+// is set and the run continues with whatever was read, so the launch always terminates.
+static __device__ __forceinline__ int sweep_row(const u64* row, int c, bool cok, int c2, bool two, unsigned epoch, int lane,
+                                                int* err, f32x4& av, f32x4& uv) {
+    long long t0 = 0;
+    const u64 want = (u64)epoch << 32;
+    for (int it = 0;; ++it) {
+        u64 ga[4], gu[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ga[e] = cok ? granule_load(row + c + e) : want;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gu[e] = (cok && two) ? granule_load(row + c2 + e) : want;
+        bool ok = true;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ok = ok && (unsigned)(ga[e] >> 32) == epoch && (unsigned)(gu[e] >> 32) == epoch;
+        bool give_up = false;
+        if (!__all(ok) && it >= 64 && (it & 63) == 0) {
+            const long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            give_up = now - t0 > RUN_TIMEOUT_TICKS || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            if (give_up && lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (__all(ok) || give_up) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                av[e] = __uint_as_float((unsigned)ga[e]);
+                uv[e] = __uint_as_float((unsigned)gu[e]);
+            }
+            return it + 1;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+template <int R>       // rows (= waves) per workgroup
+__global__ __launch_bounds__(64 * R) void dec_run(RunArgs a) {
+    constexpr int PF = (RUN_KMAX / 16 + R - 1) / R;     // 16-wide k-chunks per wave
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* part = smem;                          // [R waves][4 k-quarters][16 columns][R rows] partial sums
+    float* xs = smem + R * 4 * 16 * R;           // [R][ldxs] this layer's R x Ktot operand: [taps (oldest first) | current]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave index as a scalar: row pointers live in SGPRs
+    const int g = blockIdx.x, n0 = g * 16, row0 = blockIdx.y * R, grow = row0 + w;    // wave w <-> row w of the group
+    const int r16 = lane & 15, kq = lane >> 4, c = lane * 4;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int stop_v = a.stop_after ? *a.stop_after : 0x7fffffff;
+    const bool live = a.t <= stop_v;
+    const int spk = a.spk_ids ? a.spk_ids[grow < a.B ? grow : 0] : 0;
+
+    f32x4 xprev = zero4;                         // the previous layer's input row = highway residual of this prologue
+    f32x4 bfrag[PF], tp0 = zero4, tp1 = zero4;
+    float bias_v = 0.f;
+    // everything of a layer that does not depend on activations: weight fragments (Wt is [n][k], k contiguous; L2 ->
+    // registers), dilated-tap rows, bias
+    auto fetch_layer = [&](const RunLayer& L) {
+        const int nch = (L.ntaps * L.kc) >> 4;
+        const bool cols = n0 < L.N;
+        const float* wrow = L.Wt + (size_t)(n0 + r16) * L.ldw + kq * 4;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int ch = w + R * i;
+            bfrag[i] = (cols && ch < nch) ? *(const f32x4*)(wrow + ch * 16) : zero4;
+        }
+        bias_v = cols ? L.bias[n0 + (tid & 15)] : 0.f;
+        if (L.ntaps == 3) {
+            tp0 = (L.tap0 && c < L.kc) ? *(const f32x4*)(L.tap0 + (size_t)grow * L.ldtap + c) : zero4;
+            tp1 = (L.tap1 && c < L.kc) ? *(const f32x4*)(L.tap1 + (size_t)grow * L.ldtap + c) : zero4;
+        }
+    };
+    fetch_layer(a.L[0]);
+    // diagnostics: wave 0 of every column slice stamps the phases of every layer
+    long long* const stp = (a.stamps && w == 0 && blockIdx.y == 0) ? a.stamps + (size_t)g * RUN_MAX_LAYERS * 8 : nullptr;
+#define RUN_STAMP(K) do { if (stp && lane == 0) stp[l * 8 + (K)] = wall_clock64(); } while (0)
+
+    for (int l = 0; l < a.nlayers; ++l) {
+        const RunLayer& L = a.L[l];
+        const int cin = L.cin;
+        const bool cok = c < cin;
+        const bool two = L.pre >= RUN_HC;
+        const bool cols = n0 < L.N;
+        if (L.N == 0 && g != 0) break;           // the mel frame is written by column slice 0 alone
+
+        // ---- 1. requests that do not depend on the hand-off: LayerNorm parameters, attention window start
+        f32x4 g1v = zero4, b1v = zero4, g2v = zero4, b2v = zero4;
+        if (L.pre != RUN_COPY && cok) {
+            g1v = *(const f32x4*)(L.g1 + c); b1v = *(const f32x4*)(L.b1 + c);
+            if (two) { g2v = *(const f32x4*)(L.g2 + c); b2v = *(const f32x4*)(L.b2 + c); }
+        }
+        const int p = L.pre == RUN_ATTN ? __builtin_amdgcn_readfirstlane(a.pcur[grow]) : 0;
+
+        // ---- 2. this wave's raw row of the producing layer
+        RUN_STAMP(0);
+        int passes = 0;
+        f32x4 av = zero4, uv = zero4;
+        if (L.src) {
+            const float* sp = L.src + (size_t)grow * L.ldsrc;
+            if (cok) {
+                av = *(const f32x4*)(sp + c);
+                if (two) uv = *(const f32x4*)(sp + cin + c);
+            }
+        } else {
+            const u64* row = a.gbuf + ((size_t)(l - 1) * a.Bpad + grow) * RUN_GCOLS;
+            passes = sweep_row(row, c, cok, cin + c, two, a.epoch0 + (unsigned)l, lane, a.err, av, uv);
+        }
+        RUN_STAMP(1);
+        if (stp && lane == 0) stp[l * 8 + 6] = passes;
+
+        // ---- 3. prologue math (one row per wave).  [TF-sem] layer_norm: mean, biased variance, eps 1e-12 (modules.py:65)
+        f32x4 x = av;
+        if (L.pre != RUN_COPY) {
+            const float invc = __builtin_amdgcn_rcpf((float)cin);
+            float s1 = av[0] + av[1] + av[2] + av[3], s2 = uv[0] + uv[1] + uv[2] + uv[3];
+            s1 = wave_sum(s1);
+            if (two) s2 = wave_sum(s2);
+            const float m1 = L.nonorm ? 0.f : s1 * invc, m2 = L.nonorm ? 0.f : s2 * invc;
+            float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d1 = cok ? av[e] - m1 : 0.f, d2 = cok ? uv[e] - m2 : 0.f;
+                av[e] = d1; uv[e] = d2;
+                q1 += d1 * d1; q2 += d2 * d2;
+            }
+            q1 = wave_sum(q1);
+            if (two) q2 = wave_sum(q2);
+            const float r1 = L.nonorm ? 1.0f : fast_rsqrt(q1 * invc + LN_EPS);
+            const float r2 = L.nonorm ? 1.0f : fast_rsqrt(q2 * invc + LN_EPS);
+            if (two) {          // highway: g = sigmoid(LN1(H1)), y = g*LN2(H2) + (1-g)*x   (modules.py:194-203)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float h1 = av[e] * r1 * g1v[e] + b1v[e], h2 = uv[e] * r2 * g2v[e] + b2v[e];
+                    const float gte = fast_sigmoid(h1);
+                    x[e] = cok ? gte * h2 + (1.0f - gte) * xprev[e] : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = cok ? fast_act(av[e] * r1 * g1v[e] + b1v[e], L.act) : 0.f;
+            }
+        }
+        xprev = x;
+
+        if (L.N == 0) {
+            // mel frame t -> Y[b][t] and the next step's decoder input S[t+1] (synthesize.py:204-209)
+            if (live && grow < a.B && c < a.ldy) {
+                *(f32x4*)(a.Yout + ((size_t)grow * a.max_T + a.t) * a.ldy + c) = x;
+                if (c < a.ldtm) *(f32x4*)(a.Ytm + ((size_t)(a.t + 1) * a.Bpad + grow) * a.ldtm + c) = x;
+            }
+            break;
+        }
+
+        // ---- 4. stage the operand row: [tap x[t-2r] | tap x[t-r] | current]
+        const int Ktot = L.ntaps * L.kc, ldxs = Ktot + 4, cur = (L.ntaps - 1) * L.kc;
+        float* xrow = xs + w * ldxs;
+        if (L.pre == RUN_ATTN) {
+            // R' = concat(softmax(Q K^T / sqrt(d)) V, Q) for row t under the current mask (networks.py:300-319)
+            const int d = cin;
+            const float* KVb = a.KV + (size_t)grow * a.N_keys * 2 * d;
+            // Same arithmetic as attend_window (oph_device.h) -- only the window [p, p+win) is unmasked -- but with run-time
+            // loops and the window's logits / probabilities kept one per LANE (lane i <-> key p+i) instead of in
+            // unrolled arrays: this kernel sits at the 128-VGPR cap of a 1024-thread workgroup.
+            const int nwin = min(a.win, a.N_keys - p);
+            const float scale = fast_rsqrt((float)d);        // tf.rsqrt(tf.to_float(hp.d))  networks.py:300
+            float scl = -INFINITY;
+            for (int i = 0; i < nwin; ++i) {
+                const f32x4 kv = cok ? *(const f32x4*)(KVb + (size_t)(p + i) * 2 * d + c) : zero4;
+                const float sdot = wave_sum(x[0] * kv[0] + x[1] * kv[1] + x[2] * kv[2] + x[3] * kv[3]) * scale;
+                if (lane == i) scl = sdot;
+            }
+            float mx = -INFINITY;
+            for (int i = 0; i < nwin; ++i) mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, scl), i)));
+            float prl = lane < nwin ? __builtin_amdgcn_exp2f(1.4426950408889634f * (scl - mx)) : 0.f;
+            float den = 0.f;
+            for (int i = 0; i < ATT_WMAX; ++i) den += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, prl), i));
+            prl = prl * __builtin_amdgcn_rcpf(den);
+            int arg = 0;
+            float best = -1.f;
+            f32x4 ctx = zero4;
+            for (int i = 0; i < nwin; ++i) {
+                const float pi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, prl), i));
+                if (pi > best) { best = pi; arg = i; }       // first maximum, like tf.argmax
+                const f32x4 vv = cok ? *(const f32x4*)(KVb + d + (size_t)(p + i) * 2 * d + c) : zero4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ctx[e] += pi * vv[e];
+            }
+            if (cok) {
+                *(f32x4*)(xrow + c) = ctx;
+                *(f32x4*)(xrow + d + c) = x;
+            }
+            for (int c2 = 2 * d + lane; c2 < L.kc; c2 += 64) xrow[c2] = 0.f;
+            if (g == 0 && live && grow < a.B) {
+                if (cok) *(f32x4*)(a.Qhist + ((size_t)a.t * a.Bpad + grow) * d + c) = x;
+                if (lane < nwin) a.align[(size_t)grow * a.N_keys * a.max_T + (size_t)(p + lane) * a.max_T + a.t] = prl;
+                if (lane == 0) {
+                    const int m = p + arg;
+                    a.pnext[grow] = m;
+                    if (a.t_ends[grow] == a.max_T && m >= a.ends[grow]) {      // synthesize.py:218-228
+                        a.t_ends[grow] = a.t;
+                        const int old = atomicAdd(a.n_ended, 1);
+                        if (old + 1 == a.B && a.stop_mode == 0) *a.stop_flag = a.t;
+                    }
+                }
+            }
+        } else {
+            if (c < L.kc) *(f32x4*)(xrow + cur + c) = x;
+            for (int c2 = 256 + c; c2 < L.kc; c2 += 256) *(f32x4*)(xrow + cur + c2) = zero4;
+            if (L.ccat > 0)     // speaker embedding appended to the input (row 0 of the table reads as zeros, modules.py:38-40)
+                for (int j = lane; j < L.ccat; j += 64)
+                    xrow[cur + cin + j] = spk == 0 ? 0.f : L.cat_table[(size_t)spk * L.ccat + j];
+            if (L.ntaps == 3 && c < L.kc) {
+                *(f32x4*)(xrow + c) = tp0;
+                *(f32x4*)(xrow + L.kc + c) = tp1;
+            }
+            if (g == 0 && L.xstore && live && c < L.kc) *(f32x4*)(L.xstore + (size_t)grow * L.ldstore + c) = x;
+        }
+        RUN_STAMP(2);
+        __syncthreads();
+        RUN_STAMP(3);
+
+        // ---- 5. R x 16 slice: lane (j = lane&15, kq = lane>>4) accumulates column n0+j over k-quarter kq of this wave's chunks
+        if (cols) {
+            // 16 independent fmaf chains per lane (R rows x 4 k-lanes of a chunk), chunks in groups of 256 k (one tap);
+            // a chunk index past the layer's K is clamped to a valid address: its weights are zero
+            constexpr int GC = 16 / R;           // chunks per wave in a 256-k group
+            float acc[R][4];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[r][e] = 0.f;
+            const float* xa = xs + kq * 4;
+            const int nch = Ktot >> 4;
+#pragma unroll
+            for (int grp = 0; grp < PF / GC; ++grp) {
+                if (grp * 16 < nch) {
+#pragma unroll
+                    for (int ii = 0; ii < GC; ++ii) {
+                        const int i = grp * GC + ii;
+                        const int ch = min(w + R * i, nch - 1);
+                        f32x4 xf[R];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) xf[r] = *(const f32x4*)(xa + r * ldxs + ch * 16);   // same address in 16 lanes: LDS broadcast
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[r][e] = fmaf(xf[r][e], bfrag[i][e], acc[r][e]);
+                    }
+                }
+            }
+            float* pw = part + ((w * 4 + kq) * 16 + r16) * R;
+#pragma unroll
+            for (int r = 0; r < R; ++r) pw[r] = (acc[r][0] + acc[r][1]) + (acc[r][2] + acc[r][3]);
+        }
+        const float bias_cur = bias_v;
+        if (l + 1 < a.nlayers && a.L[l + 1].N > 0) fetch_layer(a.L[l + 1]);     // lands during the reduction and the hand-off
+        RUN_STAMP(4);
+        __syncthreads();
+        if (cols && tid < 16 * R) {
+            const int row = tid >> 4, col = tid & 15;
+            float v = bias_cur;
+#pragma unroll
+            for (int wk = 0; wk < 4 * R; ++wk) v += part[(wk * 16 + col) * R + row];
+            if (L.out) {
+                if (live) L.out[(size_t)(row0 + row) * L.ldout + n0 + col] = v;
+            } else {
+                granule_store(a.gbuf + ((size_t)l * a.Bpad + row0 + row) * RUN_GCOLS + n0 + col, a.epoch0 + (unsigned)l + 1u, v);
+            }
+        }
+        RUN_STAMP(5);
+    }
+#undef RUN_STAMP
+}
+
+// =====================================================================================
+// dec_loop: the WHOLE decode loop of a batch in one launch (all steps x all layers), same layer anatomy as dec_run.
+// =====================================================================================
+// 16-byte row pieces that ANOTHER workgroup wrote earlier in this launch (tap history) or that a side-stream kernel
+// wrote while this launch was running (cone rows): moved as two 8-byte agent-scope relaxed atomics (sc1: past the CU's
+// L1, coherent across the XCDs' L2s, write-through), never as plain accesses -- a launch-long kernel gets no cache
+// maintenance at step boundaries.
+static __device__ __forceinline__ f32x4 ld_coherent(const float* p) {
+    const u64 lo = __hip_atomic_load((const u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64 hi = __hip_atomic_load((const u64*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    f32x4 v;
+    v[0] = __uint_as_float((unsigned)lo); v[1] = __uint_as_float((unsigned)(lo >> 32));
+    v[2] = __uint_as_float((unsigned)hi); v[3] = __uint_as_float((unsigned)(hi >> 32));
+    return v;
+}
+static __device__ __forceinline__ void st_coherent(float* p, const f32x4& v) {
+    __hip_atomic_store((u64*)p, (u64)__float_as_uint(v[0]) | ((u64)__float_as_uint(v[1]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((u64*)p + 1, (u64)__float_as_uint(v[2]) | ((u64)__float_as_uint(v[3]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+typedef const __attribute__((address_space(4))) LoopLayer* LoopLayerConstPtr;     // descriptors are read with scalar loads
+
+template <int R>
+__global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
+    constexpr int PF = (RUN_KMAX / 16 + R - 1) / R, GC = 16 / R;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* part = smem;                          // [R waves][4 k-quarters][16 columns][R rows]
+    float* xs = smem + R * 4 * 16 * R;           // [R][ldxs]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.x, n0 = g * 16, row0 = blockIdx.y * R, grow = row0 + w;
+    const int r16 = lane & 15, kq = lane >> 4, c = lane * 4;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int NL = a.nlayers, Bpad = a.Bpad;
+    LoopLayerConstPtr Ls = (LoopLayerConstPtr)a.L;
+    const int spk = a.spk_ids ? a.spk_ids[grow < a.B ? grow : 0] : 0;
+    const int my_end = __builtin_amdgcn_readfirstlane(a.ends[grow]);
+    int my_tend = a.max_T;                       // t_ends[grow] (reset to max_T before the launch); only column slice 0 records it
+    int p = 0;                                   // prev_max of this wave's utterance: every workgroup attends for its own rows
+    int* const stop_word = a.ctl + 1;
+    int* const err = a.ctl + 2;
+
+    f32x4 xprev = zero4;
+    f32x4 bfrag[PF], tp0 = zero4, tp1 = zero4;
+    float bias_v = 0.f;
+    auto fetch_layer = [&](int l, int t) {       // weights, bias and the two older taps of layer l at step t
+        const int ntaps = Ls[l].ntaps, kc = Ls[l].kc;
+        const int nch = (ntaps * kc) >> 4;
+        const bool cols = n0 < Ls[l].N;
+        const float* wrow = Ls[l].Wt + (size_t)(n0 + r16) * Ls[l].ldw + kq * 4;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int ch = w + R * i;
+            bfrag[i] = (cols && ch < nch) ? *(const f32x4*)(wrow + ch * 16) : zero4;
+        }
+        bias_v = cols ? Ls[l].bias[n0 + (tid & 15)] : 0.f;
+        const int kind = Ls[l].tapkind;
+        tp0 = zero4; tp1 = zero4;
+        if (kind != 0 && c < kc) {
+            const int o0 = Ls[l].off0, o1 = Ls[l].off1;
+            if (kind == 1) {
+                const float* hb = Ls[l].hist;
+                if (t - o0 >= 0) tp0 = ld_coherent(hb + ((size_t)(t - o0) * Bpad + grow) * kc + c);
+                if (t - o1 >= 0) tp1 = ld_coherent(hb + ((size_t)(t - o1) * Bpad + grow) * kc + c);
+            } else {
+                const float* cb = (t & 1) ? Ls[l].cone1 : Ls[l].cone0;
+                if (t - o0 >= 0) tp0 = ld_coherent(cb + ((size_t)Ls[l].idx0 * Bpad + grow) * kc + c);
+                if (t - o1 >= 0) tp1 = ld_coherent(cb + ((size_t)Ls[l].idx1 * Bpad + grow) * kc + c);
+            }
+        }
+    };
+    fetch_layer(0, 0);
+
+    int t = 0;
+    for (; t < a.t_end; ++t) {
+        // Early stop (synthesize.py:225-228): the step that sets the flag is >= 1 full step (tens of us) in the past when
+        // it is acted on here, so every workgroup takes the same decision; step stop+1 still runs, with its stores off.
+        if (__hip_atomic_load(stop_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= t - 2) break;
+        long long* const stp = (a.stamps && t == a.stamp_t && w == 0 && blockIdx.y == 0) ? a.stamps + (size_t)g * LOOP_MAX_LAYERS * 8 : nullptr;
+#define LOOP_STAMP(K) do { if (stp && lane == 0) stp[l * 8 + (K)] = wall_clock64(); } while (0)
+        for (int l = 0; l < NL; ++l) {
+            const bool first = l == 0, no_input = first && t == 0;      // S[0] = 0 (architectures.py:191)
+            const int pre = Ls[l].pre, cin = Ls[l].cin, nonorm = Ls[l].nonorm, kc = Ls[l].kc, ntaps = Ls[l].ntaps;
+            const bool cok = c < cin, two = pre >= RUN_HC, cols = n0 < Ls[l].N;
+            const bool is_attn = l == a.attn_layer;
+
+            // ---- 1. requests that do not depend on the hand-off
+            f32x4 g1v = zero4, b1v = zero4, g2v = zero4, b2v = zero4;
+            if (pre != RUN_COPY && cok) {
+                g1v = *(const f32x4*)(Ls[l].g1 + c); b1v = *(const f32x4*)(Ls[l].b1 + c);
+                if (two) { g2v = *(const f32x4*)(Ls[l].g2 + c); b2v = *(const f32x4*)(Ls[l].b2 + c); }
+            }
+            int stop_v = 0x7fffffff;
+            if (g == 0) stop_v = __hip_atomic_load(stop_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned sigc = 0;
+            if (is_attn && t >= 1) sigc = __hip_atomic_load(a.sig + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+
+            // ---- 2. this wave's raw row of the producing layer (layer 0: the last layer of the previous step)
+            LOOP_STAMP(0);
+            int passes = 0;
+            f32x4 av = zero4, uv = zero4;
+            if (!no_input) {
+                const int slot = first ? NL - 1 : l - 1;
+                const unsigned ep = a.epoch0 + (unsigned)((first ? t - 1 : t) * LOOP_MAX_LAYERS + slot + 1);
+                passes = sweep_row(a.gbuf + ((size_t)slot * Bpad + grow) * RUN_GCOLS, c, cok, cin + c, two, ep, lane, err, av, uv);
+            }
+            LOOP_STAMP(1);
+            if (stp && lane == 0) stp[l * 8 + 6] = passes;
+
+            // ---- 3. prologue math (one row per wave)
+            f32x4 x = av;
+            if (pre != RUN_COPY) {
+                const float invc = __builtin_amdgcn_rcpf((float)cin);
+                float s1 = av[0] + av[1] + av[2] + av[3], s2 = uv[0] + uv[1] + uv[2] + uv[3];
+                s1 = wave_sum(s1);
+                if (two) s2 = wave_sum(s2);
+                const float m1 = nonorm ? 0.f : s1 * invc, m2 = nonorm ? 0.f : s2 * invc;
+                float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d1 = cok ? av[e] - m1 : 0.f, d2 = cok ? uv[e] - m2 : 0.f;
+                    av[e] = d1; uv[e] = d2;
+                    q1 += d1 * d1; q2 += d2 * d2;
+                }
+                q1 = wave_sum(q1);
+                if (two) q2 = wave_sum(q2);
+                const float r1 = nonorm ? 1.0f : fast_rsqrt(q1 * invc + LN_EPS);
+                const float r2 = nonorm ? 1.0f : fast_rsqrt(q2 * invc + LN_EPS);
+                if (two) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float h1 = av[e] * r1 * g1v[e] + b1v[e], h2 = uv[e] * r2 * g2v[e] + b2v[e];
+                        const float gte = fast_sigmoid(h1);
+                        x[e] = cok ? gte * h2 + (1.0f - gte) * xprev[e] : 0.f;
+                    }
+                } else {
+                    const int act = Ls[l].act;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = cok ? fast_act(av[e] * r1 * g1v[e] + b1v[e], act) : 0.f;
+                }
+            }
+            if (no_input) x = zero4;
+            xprev = x;
+            if (first && t >= 1) {
+                // x is mel frame t-1 -> Y[b][t-1] and the decoder input S[t] (synthesize.py:204-209)
+                if (g == 0 && grow < a.B && t - 1 <= stop_v && c < a.ldy) {
+                    *(f32x4*)(a.Yout + ((size_t)grow * a.max_T + (t - 1)) * a.ldy + c) = x;
+                    *(f32x4*)(a.Ytm + ((size_t)t * Bpad + grow) * a.ldy + c) = x;
+                }
+            }
+            if (is_attn && t >= 1) {
+                // the cone of this step (side stream) must have landed before its rows are requested as taps
+                long long t0 = 0;
+                for (int it = 0; (int)(sigc - (a.sig_base + (unsigned)t)) < 0; ++it) {
+                    __builtin_amdgcn_s_sleep(2);
+                    sigc = __hip_atomic_load(a.sig + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if ((it & 63) == 63) {
+                        const long long now = wall_clock64();
+                        if (t0 == 0) t0 = now;
+                        if (now - t0 > RUN_TIMEOUT_TICKS || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                            if (lane == 0) __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                }
+            }
+
+            // ---- 4. stage the operand row: [tap x[t-2r] | tap x[t-r] | current]
+            const int Ktot = ntaps * kc, ldxs = Ktot + 4, cur = (ntaps - 1) * kc;
+            float* xrow = xs + w * ldxs;
+            const bool live = t <= stop_v;
+            if (pre == RUN_ATTN) {
+                // R' = concat(softmax(Q K^T / sqrt(d)) V, Q) for row t under the current mask (networks.py:300-319); see dec_run
+                const int d = cin;
+                const float* KVb = a.KV + (size_t)grow * a.N_keys * 2 * d;
+                const int nwin = min(a.win, a.N_keys - p);
+                const float scale = fast_rsqrt((float)d);
+                float scl = -INFINITY;
+                for (int i = 0; i < nwin; ++i) {
+                    const f32x4 kv = cok ? *(const f32x4*)(KVb + (size_t)(p + i) * 2 * d + c) : zero4;
+                    const float sdot = wave_sum(x[0] * kv[0] + x[1] * kv[1] + x[2] * kv[2] + x[3] * kv[3]) * scale;
+                    if (lane == i) scl = sdot;
+                }
+                float mx = -INFINITY;
+                for (int i = 0; i < nwin; ++i) mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, scl), i)));
+                float prl = lane < nwin ? __builtin_amdgcn_exp2f(1.4426950408889634f * (scl - mx)) : 0.f;
+                float den = 0.f;
+                for (int i = 0; i < ATT_WMAX; ++i) den += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, prl), i));
+                prl = prl * __builtin_amdgcn_rcpf(den);
+                int arg = 0;
+                float best = -1.f;
+                f32x4 ctx = zero4;
+                for (int i = 0; i < nwin; ++i) {
+                    const float pi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, prl), i));
+                    if (pi > best) { best = pi; arg = i; }       // first maximum, like tf.argmax
+                    const f32x4 vv = cok ? *(const f32x4*)(KVb + d + (size_t)(p + i) * 2 * d + c) : zero4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ctx[e] += pi * vv[e];
+                }
+                if (cok) {
+                    *(f32x4*)(xrow + c) = ctx;
+                    *(f32x4*)(xrow + d + c) = x;
+                }
+                for (int c2 = 2 * d + lane; c2 < kc; c2 += 64) xrow[c2] = 0.f;
+                const int m = p + arg;
+                if (g == 0 && live && grow < a.B) {
+                    if (cok) st_coherent(a.Qhist + ((size_t)t * Bpad + grow) * d + c, x);          // read by the cone kernels
+                    if (lane < nwin) a.align[(size_t)grow * a.N_keys * a.max_T + (size_t)(p + lane) * a.max_T + t] = prl;
+                    if (lane == 0) {
+                        __hip_atomic_store(a.p + ((t + 1) & 1) * Bpad + grow, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (my_tend == a.max_T && m >= my_end) {       // synthesize.py:218-228
+                            my_tend = t;
+                            a.t_ends[grow] = t;
+                            const int old = atomicAdd(a.ctl, 1);
+                            if (old + 1 == a.B && a.stop_mode == 0) {
+                                __hip_atomic_store(stop_word, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store((int*)a.host_progress + 1, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            }
+                        }
+                    }
+                } else if (my_tend == a.max_T && m >= my_end) my_tend = t;
+                p = m;
+            } else {
+                if (c < kc) *(f32x4*)(xrow + cur + c) = x;
+                for (int c2 = 256 + c; c2 < kc; c2 += 256) *(f32x4*)(xrow + cur + c2) = zero4;
+                const int ccat = Ls[l].ccat;
+                if (ccat > 0) {
+                    const float* tab = Ls[l].cat_table;
+                    for (int j = lane; j < ccat; j += 64) xrow[cur + cin + j] = spk == 0 ? 0.f : tab[(size_t)spk * ccat + j];
+                }
+                if (ntaps == 3 && c < kc) {
+                    *(f32x4*)(xrow + c) = tp0;
+                    *(f32x4*)(xrow + kc + c) = tp1;
+                }
+                if (Ls[l].tapkind == 1 && g == 0 && live && c < kc) st_coherent(Ls[l].hist + ((size_t)t * Bpad + grow) * kc + c, x);
+            }
+            LOOP_STAMP(2);
+            __syncthreads();
+            LOOP_STAMP(3);
+
+            // ---- 5. R x 16 slice (see dec_run); the LDS reads of a 256-k group are all issued before its FMAs
+            if (cols) {
+                float acc[R][4];
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[r][e] = 0.f;
+                const float* xa = xs + kq * 4;
+                const int nch = Ktot >> 4;
+#pragma unroll
+                for (int grp = 0; grp < PF / GC; ++grp) {
+                    if (grp * 16 < nch) {
+                        f32x4 xf[GC][R];
+#pragma unroll
+                        for (int ii = 0; ii < GC; ++ii) {
+                            const int ch = min(w + R * (grp * GC + ii), nch - 1);
+#pragma unroll
+                            for (int r = 0; r < R; ++r) xf[ii][r] = *(const f32x4*)(xa + r * ldxs + ch * 16);
+                        }
+#pragma unroll
+                        for (int ii = 0; ii < GC; ++ii)
+#pragma unroll
+                            for (int r = 0; r < R; ++r)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[r][e] = fmaf(xf[ii][r][e], bfrag[grp * GC + ii][e], acc[r][e]);
+                    }
+                }
+                float* pw = part + ((w * 4 + kq) * 16 + r16) * R;
+#pragma unroll
+                for (int r = 0; r < R; ++r) pw[r] = (acc[r][0] + acc[r][1]) + (acc[r][2] + acc[r][3]);
+            }
+            const float bias_cur = bias_v;
+            if (l + 1 < NL) fetch_layer(l + 1, t);
+            else if (t + 1 < a.t_end) fetch_layer(0, t + 1);
+            LOOP_STAMP(4);
+            __syncthreads();
+            if (cols && tid < 16 * R) {
+                const int row = tid >> 4, col = tid & 15;
+                float v = bias_cur;
+#pragma unroll
+                for (int wk = 0; wk < 4 * R; ++wk) v += part[(wk * 16 + col) * R + row];
+                granule_store(a.gbuf + ((size_t)l * Bpad + row0 + row) * RUN_GCOLS + n0 + col,
+                              a.epoch0 + (unsigned)(t * LOOP_MAX_LAYERS + l + 1), v);
+            }
+            LOOP_STAMP(5);
+            if (is_attn && g == 0) {
+                // release the cone of step t+1 on the side stream: Q[t] and prev_max are written through; once every
+                // row group has arrived, one lane raises the word the stream's wait-value operation polls
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    const int old = atomicAdd(a.ctl + 3, 1);
+                    if (old + 1 == (Bpad / R) * (t + 1)) {
+                        __hip_atomic_fetch_max(a.sig, a.sig_base + (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store((int*)a.host_progress, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+            }
+        }
+#undef LOOP_STAMP
+    }
+    // ---- the last executed step's mel frame (its consumer, layer 0 of the next step, does not run)
+    const int t_last = t - 1;
+    if (g == 0 && t_last >= 0) {
+        const int stop_v = __hip_atomic_load(stop_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t_last <= stop_v) {
+            const int cin = Ls[0].cin;
+            const bool cok = c < cin;
+            f32x4 g1v = zero4, b1v = zero4, av = zero4, uv = zero4;
+            if (cok) { g1v = *(const f32x4*)(Ls[0].g1 + c); b1v = *(const f32x4*)(Ls[0].b1 + c); }
+            sweep_row(a.gbuf + ((size_t)(NL - 1) * Bpad + grow) * RUN_GCOLS, c, cok, cin + c, false,
+                      a.epoch0 + (unsigned)(t_last * LOOP_MAX_LAYERS + NL), lane, err, av, uv);
+            const float invc = __builtin_amdgcn_rcpf((float)cin);
+            const float m1 = Ls[0].nonorm ? 0.f : wave_sum(av[0] + av[1] + av[2] + av[3]) * invc;
+            float q1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d1 = cok ? av[e] - m1 : 0.f; av[e] = d1; q1 += d1 * d1; }
+            const float r1 = Ls[0].nonorm ? 1.0f : fast_rsqrt(wave_sum(q1) * invc + LN_EPS);
+            f32x4 x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = cok ? fast_sigmoid(av[e] * r1 * g1v[e] + b1v[e]) : 0.f;
+            if (grow < a.B && c < a.ldy) {
+                *(f32x4*)(a.Yout + ((size_t)grow * a.max_T + t_last) * a.ldy + c) = x;
+                *(f32x4*)(a.Ytm + ((size_t)(t_last + 1) * Bpad + grow) * a.ldy + c) = x;
+            }
+        }
+    }
+    // whatever happened, the side stream's remaining wait-value operations must not wait for steps that never ran
+    if (g == 0 && blockIdx.y == 0 && tid == 0)
+        __hip_atomic_fetch_max(a.sig, a.sig_base + (unsigned)a.max_T + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <int R>
+static void launch_dec_loop_t(const LoopArgs& a, int col_slices, int kmax, hipStream_t s) {
+    static thread_local std::map<int, size_t> done;
+    const size_t lds_bytes = (size_t)(R * 4 * 16 * R + R * (kmax + 4)) * 4;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t& d = done[dev];
+    if (d < lds_bytes) { (void)hipFuncSetAttribute((const void*)dec_loop<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); d = lds_bytes; }
+    hipLaunchKernelGGL(dec_loop<R>, dim3(col_slices, a.Bpad / R), dim3(64 * R), lds_bytes, s, a);
+}
+void launch_dec_loop(const LoopArgs& a, int col_slices, int rows_per_group, int kmax, hipStream_t s) {
+    if (rows_per_group == 8) launch_dec_loop_t<8>(a, col_slices, kmax, s);
+    else launch_dec_loop_t<4>(a, col_slices, kmax, s);
+}
+
+template <int R>
+static void launch_dec_run_t(const RunArgs& a, int col_slices, int kmax, hipStream_t s) {
+    // per (device); thread_local: a handle is confined to one host thread, different threads may drive different devices
+    static thread_local std::map<int, size_t> done;
+    const size_t lds_bytes = (size_t)(R * 4 * 16 * R + R * (kmax + 4)) * 4;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t& d = done[dev];
+    if (d < lds_bytes) { (void)hipFuncSetAttribute((const void*)dec_run<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); d = lds_bytes; }
+    hipLaunchKernelGGL(dec_run<R>, dim3(col_slices, a.Bpad / R), dim3(64 * R), lds_bytes, s, a);
+}
+void launch_dec_run(const RunArgs& a, int col_slices, int rows_per_group, int kmax, hipStream_t s) {
+    if (rows_per_group == 8) launch_dec_run_t<8>(a, col_slices, kmax, s);
+    else launch_dec_run_t<4>(a, col_slices, kmax, s);
+}
+
+}  // namespace oph

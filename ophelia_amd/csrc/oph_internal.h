@@ -119,6 +119,83 @@ struct RowChainArgs {
     int has_lcc;                    // any LCC table in this chain (selects the kernel instantiation); ids = cat_ids
 };
 
+// ---- persistent run of decoder layers in ONE launch (oph_decrun.hip): grid = (N/16 column slices, Bpad/R row groups),
+// R waves.  Every workgroup runs each layer's prologue (the producing layer's LayerNorm / gate / attention for its R
+// rows, one row per wave) and an R x 16 output slice; between layers the raw outputs travel through 8-byte
+// {epoch, value} granules (agent-scope relaxed atomics: the data is its own flag), so a layer boundary costs one
+// L2/fabric hand-off instead of a kernel boundary.
+enum RunPre { RUN_COPY = 0, RUN_CONV = 1, RUN_HC = 2, RUN_ATTN = 3 };
+constexpr int RUN_MAX_LAYERS = 16;
+constexpr int RUN_GCOLS = 512;          // granule columns per row (raw width of a highway layer, 2d <= 512)
+struct RunLayer {
+    int pre;                            // how this layer's input row x[t] is produced (RunPre)
+    int act;                            // RUN_CONV: activation of the producing conv layer
+    int cin;                            // channels the prologue produces (<= 256); RUN_ATTN yields [ctx | q] = 2*cin
+    int nonorm;                         // the producing layer has no LayerNorm (hp.norm None)
+    const float *g1, *b1, *g2, *b2;     // the producing layer's gamma / beta (hc: H1 -> g1,b1 ; H2 -> g2,b2)
+    const float* src; int ldsrc;        // plain rows: RUN_COPY input, or the raw rows an EARLIER launch left; null = granules
+                                        // of the previous layer of this run
+    const float* cat_table; int ccat;   // speaker embedding appended to x (ids: RunArgs::spk_ids)
+    int ntaps, kc, N;                   // this layer's conv; N == 0: none (the prologue result is the mel frame)
+    const float* tap0; const float* tap1; int ldtap;   // older taps x[t-2r], x[t-r]: rows [Bpad][ldtap], null = zeros
+    const float* Wt; int ldw; const float* bias;
+    float* xstore; int ldstore;         // x[t] rows stored by column slice 0 (tap history of later steps), or null
+    float* out; int ldout;              // last layer of the launch: plain raw rows [Bpad][ldout]; else null (granules)
+};
+struct RunArgs {
+    int nlayers; int B; int Bpad; int t;
+    const int* stop_after;
+    const int* spk_ids;
+    unsigned long long* gbuf;           // granules [RUN_MAX_LAYERS][Bpad][RUN_GCOLS]
+    unsigned epoch0;                    // tag of layer l's output = epoch0 + l + 1 (never reused: the host advances it per launch)
+    int* err;                           // set when a hand-off timed out (the launch still terminates)
+    long long* stamps;                  // diagnostics (OPH_RUN_STAMPS): [slice][layer][8] 100 MHz clock stamps of wave 0, or null
+    // RUN_ATTN layer: attention at row t + bookkeeping (networks.py:286-325, synthesize.py:204-228)
+    const float* KV; int N_keys; int win; int max_T;
+    const int* pcur; int* pnext; const int* ends; int* t_ends; int* n_ended; int* stop_flag; int stop_mode;
+    float* Qhist; float* align;
+    // mel frame t (the N == 0 pseudo-layer)
+    float* Yout; int ldy; float* Ytm; int ldtm;
+    RunLayer L[RUN_MAX_LAYERS];
+};
+void launch_dec_run(const RunArgs& a, int col_slices, int rows_per_group, int kmax, hipStream_t s);   // rows_per_group 4 or 8
+
+// ---- the WHOLE decode loop in one launch (oph_decrun.hip, dec_loop): the same workgroups run every layer of every
+// step; the layer descriptions are static for a decode and live in device memory.  Layer 0's prologue consumes the
+// LAST layer of the previous step (LayerNorm + squash sigmoid = the mel frame, synthesize.py:204-209), so a step
+// boundary is one more granule hand-off.  The AudioDec history cone of step t runs on a side stream as before; the two
+// dependencies are device words: sig[0] (attention of step t done, written here, awaited by hipStreamWaitValue32 on the
+// side stream) and sig[16] (cone of step t done, written by hipStreamWriteValue32 there, polled here).
+constexpr int LOOP_MAX_LAYERS = 32;
+struct LoopLayer {
+    int pre; int act; int cin; int nonorm;          // as RunLayer (layer 0: RUN_CONV + sigmoid of the previous step's last layer)
+    const float *g1, *b1, *g2, *b2;
+    const float* cat_table; int ccat;
+    int ntaps, kc, N;
+    const float* Wt; int ldw; const float* bias;
+    int tapkind;                        // 0 none; 1 history: hist[t - off][Bpad][kc]; 2 cone: cone[t & 1][idx][Bpad][kc]
+    int off0, off1, idx0, idx1;         // time offsets (off0 > off1 > 0) of the two older taps, their row-block indices in a cone buffer
+    float* hist;                        // tapkind 1: this layer's input history, x[t] is stored here by column slice 0
+    const float* cone0; const float* cone1;
+};
+struct LoopArgs {
+    int nlayers; int B; int Bpad; int t_end; int stop_mode;
+    int attn_layer;                     // index of the RUN_ATTN layer
+    const LoopLayer* L;                 // device memory, [nlayers]
+    int* ctl;                           // [0] n_ended  [1] stop_after  [2] error  [3] attention arrivals
+    const int* spk_ids;
+    unsigned long long* gbuf;           // granules [LOOP_MAX_LAYERS][Bpad][RUN_GCOLS]
+    unsigned epoch0;                    // tag of (step t, layer l) = epoch0 + t * LOOP_MAX_LAYERS + l + 1
+    long long* stamps; int stamp_t;
+    const float* KV; int N_keys; int win; int max_T;
+    int* p;                             // prev_max double buffer [2][Bpad] (read by the cone kernels)
+    const int* ends; int* t_ends;
+    float* Qhist; float* align; float* Yout; int ldy; float* Ytm;
+    unsigned* sig; unsigned sig_base;
+    volatile int* host_progress;        // pinned host words: [0] last step whose attention is done, [1] stop step (or INT_MAX)
+};
+void launch_dec_loop(const LoopArgs& a, int col_slices, int rows_per_group, int kmax, hipStream_t s);
+
 // launchers (oph_kernels.hip)
 void launch_row_chain(const RowChainArgs& a, hipStream_t s);
 void launch_conv_gemm(const GemmArgs& a, hipStream_t s);

@@ -564,6 +564,9 @@ def variable_shapes(hp):
         conv("%s/C_%d" % (s, i), d, d); i += 1
     conv("%s/C_%d" % (s, i), d, hp.n_mels); i += 1
     lcc_on = False                                   # SSRN passes no lcc / codes to its layers (networks.py:437-537)
+    # synthesize() switches hp.norm to 'layer' before it builds SSRNGraph and back afterwards (synthesize.py:513-534):
+    # at synthesis the SSRN graph ALWAYS has its LayerNorm variables, whatever hp.norm says for Text2Mel
+    ln = True
     s = "SSRN"; i = 1
     conv("%s/C_%d" % (s, i), hp.n_mels, c); i += 1
     for _ in range(2):
@@ -572,7 +575,7 @@ def variable_shapes(hp):
         sc = "%s/D_%d" % (s, i); i += 1
         out[sc + "/conv2d_transpose/kernel"] = (1, 3, c, c)
         out[sc + "/conv2d_transpose/bias"] = (c,)
-        # networks.py:483-486 does not pass normtype: the transposed convs keep their LayerNorm even with hp.norm None
+        # (networks.py:483-486 does not even pass normtype to the transposed convs)
         out[sc + "/normalize/beta"] = (c,)
         out[sc + "/normalize/gamma"] = (c,)
         for _ in range(2):

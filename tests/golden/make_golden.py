@@ -3,18 +3,22 @@
 Generates the committed golden fixtures under tests/golden/ by executing the
 REFERENCE's own code (read from /root/reference at run time, build container only):
 
-  * wiring goldens: reference architectures.Text2MelGraph / SSRNGraph (mode
-    'synthesize') -> networks.py -> modules.py, executed over the eager stand-in
-    tests/golden/tf_standin.py (torch CPU primitives), driven by a re-statement of
-    the host loop synthesize.py:150-230 (synthesize.py itself is Python-2-only
-    syntax and cannot be imported).  Reduced max_N / max_T, FULL channel widths.
+  * wiring + host-loop goldens: the reference's own synthesize.synthesize() -- encode_text,
+    synth_codedtext2mel (the max_T-step loop with its early stop / t_ends rules),
+    synth_mel2mag (py2 integer-division chunking), get_text_lengths, the per-utterance
+    trimming, the output directory / file naming and the CDP / Ain report of
+    calculate_CDP_Ain_Aout.getCDP / getAP -- driving the reference's
+    architectures.Text2MelGraph / SSRNGraph -> networks.py -> modules.py over the eager
+    stand-in tests/golden/tf_standin.py (torch CPU primitives).  tests/golden/ref_host.py
+    loads the Python-2 sources in memory (lib2to3 + a py2-division pass) and supplies
+    the fake tf.Session.  Reduced max_N / max_T, FULL channel widths.
   * front-end goldens: reference configuration.load_config + data_load.load_data
     (mode='synthesis') on the transcript fixture tests/golden/test_transcript.csv.
 
 Only small outputs + seeds are stored; weights are regenerated from the seed by
 oracle.ophelia_oracle.random_weights on both sides.
 
-Usage (from the repo root, in the build container):
+Usage (from the repo root, in the build container) -- ONE command regenerates every fixture:
     python -B tests/golden/make_golden.py
 """
 import io
@@ -44,56 +48,31 @@ with contextlib.redirect_stdout(io.StringIO()):
     import data_load as ref_data_load        # reference
 
 
-def build_t2m(hp, L, mels, prev_max, speakers=None, durations=None):
-    q = [L]
-    if hp.multispeaker:
-        q.append(speakers)
-    if hp.use_external_durations:                  # placeholder order of architectures.py:70-81
-        q.append(durations)
-    q += [mels, prev_max]
-    tf.PLACEHOLDER_QUEUE[:] = q
-    with contextlib.redirect_stdout(io.StringIO()):
-        g = ref_arch.Text2MelGraph(hp, mode='synthesize')
-    assert not tf.PLACEHOLDER_QUEUE
-    return g
-
-
-def build_ssrn(hp, mels, B, speakers=None):
-    q = [np.zeros((B, hp.max_N), np.int32)]
-    if hp.multispeaker:
-        q.append(speakers)
-    if hp.use_external_durations:
-        q.append(np.zeros((B, hp.max_T, hp.max_N), np.float32))
-    q += [mels, np.zeros((B,), np.int32)]
-    tf.PLACEHOLDER_QUEUE[:] = q
-    with contextlib.redirect_stdout(io.StringIO()):
-        g = ref_arch.SSRNGraph(hp, mode='synthesize')
-    return g
+import ref_host
+HOST = ref_host.ReferenceHost(tf, ref_arch)
 
 
 def run_case(tag, cfg, B, max_N, max_T, wseed, tseed, min_len, max_len, stop, speaker_ix=None, override=None):
     hp = ref_configuration.load_config(os.path.join(REF, "config", cfg))
     hp.max_N, hp.max_T = max_N, max_T
+    hp.vocoder = "griffin_lim"
     for k, v in (override or {}).items():           # synthetic variants no shipped config uses (recorded in the json)
         setattr(hp, k, v)
+    # synthesize() builds SSRNGraph under hp.norm = 'layer' whatever the config says (synthesize.py:513-534): the
+    # variable inventory (and the seeded weights) must be those of that graph
     W = O.random_weights(hp, wseed)
     tf.VARS.clear(); tf.VARS.update(W); tf.REQUESTED[:] = []
     L = O.random_text(hp, B, tseed, min_len=min_len, max_len=max_len)
-    speakers = None
-    if hp.multispeaker:
-        speakers = (np.ones((B, 1)) * speaker_ix)           # synthesize.py:499-501 (float64 (B,1))
-    ends = np.array([np.where(L[i] == 0)[0][0] for i in range(B)])   # synthesize.py:242-247
-    if getattr(hp, "turn_off_monotonic_for_synthesis", False):
-        hp.text_lengths = ends + 1                                   # synthesize.py:505-507
+    ends0 = np.array([np.where(L[i] == 0)[0][0] for i in range(B)])
     durations = None
+    dur_lists = []
     if hp.use_external_durations:
         # per-symbol durations in fine frames -> hard attention matrix, padded and subsampled by r, exactly as the
         # reference's load_data does (data_load.py:243-251) with the reference's own helpers
         rng = np.random.default_rng(tseed + 1000)
         durations = np.zeros((B, hp.max_T, hp.max_N), np.int32)
-        dur_lists = []
         for i in range(B):
-            n = int(ends[i])
+            n = int(ends0[i])
             budget = hp.max_T * hp.r - rng.integers(0, 3 * hp.r)
             d = rng.integers(0, 2 * budget // n + 1, size=n)
             while d.sum() > budget:
@@ -104,64 +83,49 @@ def run_case(tag, cfg, B, max_N, max_T, wseed, tseed, min_len, max_len, stop, sp
             durations[i, :dm.shape[0], :dm.shape[1]] = dm
             dur_lists.append(d)
 
-    # --- host loop, restating synthesize.py:150-230 around the REFERENCE graph ---
-    Y = np.zeros((B, hp.max_T, hp.n_mels), np.float32)
-    alignments = np.zeros((B, hp.max_N, hp.max_T), np.float32)
-    prev_max = np.zeros((B,), np.int32)
-    endcounts = np.zeros(ends.shape, dtype=int)
-    t_ends = np.ones(ends.shape, dtype=int) * hp.max_T
-    trace = []
-    K = V = Q0 = None
-    steps = 0
-    if hp.use_external_durations:
-        t_ends = durations.sum(axis=(1, 2))                             # synthesize.py:168-169
-    for j in range(hp.max_T):
-        g = build_t2m(hp, L, Y, prev_max, speakers, None if durations is None else durations.astype(np.float32))
-        if K is None:
-            K, V = np.asarray(g.K).copy(), np.asarray(g.V).copy()
-            Q0 = np.asarray(g.Q).copy()
-        _Y, _max, _al = np.asarray(g.Y), np.asarray(g.max_attentions), np.asarray(g.alignments)
-        Y[:, j, :] = _Y[:, j, :]
-        alignments[:, :, j] = _al[:, :, j]
-        prev_max = _max[:, j].astype(np.int32)
-        trace.append(prev_max.copy())
-        steps += 1
-        if hp.use_external_durations:                                   # synthesize.py:211-216
-            if j >= t_ends.max():
-                break
-            continue
-        reached_end = (_max[:, j] >= ends)
-        endcounts += reached_end
-        for i in range(B):
-            if t_ends[i] == hp.max_T and endcounts[i] >= 1:
-                t_ends[i] = j
-        if stop and (t_ends < hp.max_T).all():
-            break
-    t2m_names = list(tf.REQUESTED)
-    tf.REQUESTED[:] = []
-    g2 = build_ssrn(hp, Y, B, speakers)
-    Z = np.asarray(g2.Z).copy()
-    ssrn_names = list(tf.REQUESTED)
+    # --- the REFERENCE's synthesize() (synthesize.py:449-617) around the REFERENCE graphs ---
+    bases = ["utt_%s_%03d" % (tag, i) for i in range(B)]
+    speaker_id = hp.speaker_list[speaker_ix] if hp.multispeaker else ""
+    if hp.multispeaker:                               # synthesize.py:496-501
+        assert dict(zip(hp.speaker_list, range(len(hp.speaker_list))))[speaker_id] == speaker_ix
+    rec = HOST.synthesize(hp, L, bases, speaker_id=speaker_id, durations=durations)
+    K, V = rec["encode_text"]
+    Y, lengths, alignments = rec["synth_codedtext2mel"]
+    Z = np.nan_to_num(rec["synth_mel2mag"])            # synthesize.py:578-579
+    ends = np.asarray(rec["get_text_lengths"])
+    assert np.array_equal(ends, ends0)
+    steps = rec["decode_runs"]
+    trace = rec["trace"]
+    t2m_names, ssrn_names = rec["t2m_names"], rec["ssrn_names"]
+    assert len(rec["waves"]) == B and [w[0] for w in rec["waves"]] == [os.path.join(rec["outdirs"][0], b + ".wav") for b in bases]
+    for i, (_, mag) in enumerate(rec["waves"]):       # per-utterance trimming mag[:lengths[i]*r] (synthesize.py:608)
+        assert np.array_equal(mag, Z[i, :lengths[i] * hp.r, :])
 
-    # attention-logit margin of the golden run: informational (parity through argmax)
-    out = dict(L=L, ends=ends, K=K, V=V, Q_step0=Q0, Y=Y, alignments=alignments,
-               max_attentions_trace=np.array(trace, np.int32), t_ends=np.array(t_ends, np.int32),
-               steps_run=np.int32(steps), Z=Z)
-    if speakers is not None:
-        out["speakers"] = speakers.astype(np.int32)
+    out = dict(L=L, ends=ends, K=K, V=V, Q_step0=rec["Q_step0"], Y=Y, alignments=alignments,
+               max_attentions_trace=np.array(trace, np.int32), t_ends=np.array(lengths, np.int32),
+               steps_run=np.int32(steps), Z=Z,
+               cdp=np.array(rec["cdp"], np.float64), ain=np.array([a[0] for a in rec["ap"]], np.float64),
+               aout=np.array([a[1] for a in rec["ap"]], np.float64),
+               wav_rows=np.array([w[1].shape[0] for w in rec["waves"]], np.int32))
+    if hp.multispeaker:
+        out["speakers"] = np.asarray(rec["speakers"]).astype(np.int32)
     if durations is not None:
         out["durations"] = durations
         out["duration_lists"] = np.concatenate(dur_lists)
     np.savez_compressed(os.path.join(HERE, "wiring_%s.npz" % tag), **out)
+    report = [l for l in rec["stdout"].splitlines() if " | " in l]
     meta = dict(tag=tag, cfg=cfg, B=B, max_N=max_N, max_T=max_T, weight_seed=wseed, text_seed=tseed,
                 min_len=min_len, max_len=max_len, stop=bool(stop), speaker_ix=speaker_ix, override=override or {},
+                speaker_id=speaker_id, bases=bases, outdir=rec["outdirs"][0], wav_files=[w[0] for w in rec["waves"]],
+                plot_files=[p[0] for p in rec["plots"]], plot_shapes=[list(p[1]) for p in rec["plots"]],
+                report_lines=report, ssrn_batches=rec["ssrn_batches"], reference_report_crashes=bool(rec["report_crashes"]),
                 variables=[[n, list(W[n].shape)] for n in t2m_names + ssrn_names],
                 n_params_t2m=int(sum(W[n].size for n in t2m_names)),
                 n_params_ssrn=int(sum(W[n].size for n in ssrn_names)))
     with open(os.path.join(HERE, "wiring_%s.json" % tag), "w") as f:
         json.dump(meta, f, indent=1)
-    print(tag, "steps", steps, "t_ends", t_ends.tolist(), "trace[-1]", trace[-1].tolist(),
-          "nvars", len(meta["variables"]), "params", meta["n_params_t2m"], meta["n_params_ssrn"])
+    print(tag, "steps", steps, "t_ends", list(lengths), "trace[-1]", trace[-1].tolist(),
+          "nvars", len(meta["variables"]), "params", meta["n_params_t2m"], meta["n_params_ssrn"], "outdir", meta["outdir"])
 
 
 def frontend_case():
@@ -244,6 +208,31 @@ def variant_cases():
         subprocess.check_call([sys.executable, "-B", os.path.abspath(__file__), "case", tag])
 
 
+def chunking_case():
+    """synth_mel2mag's batch splitting (synthesize.py:250-260) as the reference computes it under Python 2:
+    for n utterances and a batch size, the list of chunk lengths handed to sess.run."""
+    res = {}
+
+    class G(object):
+        Z, mels = "Z", "mels"
+
+    class S(object):
+        def __init__(self):
+            self.sizes = []
+
+        def run(self, fetch, feed):
+            self.sizes.append(len(feed["mels"]))
+            return np.zeros((len(feed["mels"]), 1, 1), np.float32)
+    for n in (1, 2, 3, 5, 7, 8, 16, 127, 128, 129, 255, 256, 257, 300):
+        for bs in (128, 32, 2, 1, 0, -1):
+            s_ = S()
+            HOST.mod.synth_mel2mag(None, np.zeros((n, 1, 1), np.float32), G, s_, batchsize=bs)
+            res["%d,%d" % (n, bs)] = s_.sizes
+    with open(os.path.join(HERE, "mel2mag_chunks.json"), "w") as f:
+        json.dump(res, f, sort_keys=True)
+    print("synth_mel2mag chunking:", len(res), "cases")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "case":           # one variant case, in this (fresh) interpreter
         v = dict(VARIANTS[sys.argv[2]])
@@ -252,10 +241,8 @@ if __name__ == "__main__":
             durations_frontend_case(v["cfg"])
         run_case(sys.argv[2], v.pop("cfg"), **v)
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "variants":
-        variant_cases()
-        sys.exit(0)
     frontend_case()
+    chunking_case()
     # free-running, no early stop reached within max_T (long texts)
     run_case("lj_free", "lj_tutorial.cfg", B=2, max_N=24, max_T=16, wseed=11, tseed=12,
              min_len=18, max_len=23, stop=True)
@@ -265,3 +252,4 @@ if __name__ == "__main__":
     # multispeaker (audio_decoder_input) wiring: vctk_01.cfg
     run_case("vctk_spk", "vctk_01.cfg", B=2, max_N=16, max_T=12, wseed=31, tseed=32,
              min_len=8, max_len=15, stop=True, speaker_ix=7)
+    variant_cases()          # each in its own interpreter (see VARIANTS); they add their configs to the snapshot
