@@ -14,6 +14,20 @@ from . import tf_checkpoint
 from . import weights as WT
 
 
+class Tensor(object):
+    """A named graph tensor handle: what the reference's code holds as `g.K`, `g.mels`, ... and passes to
+    sess.run as a fetch or as a feed-dict key (identity-hashed, like a tf.Tensor)."""
+
+    def __init__(self, graph, name, shape):
+        self.graph, self.name, self.shape = graph, name, shape
+
+    def get_shape(self):
+        return self.shape
+
+    def __repr__(self):
+        return "<%s/%s %s>" % (self.graph.scope, self.name, self.shape)
+
+
 class Graph(object):
     def __init__(self, hp, mode="train", reuse=None):
         assert mode in ["train", "synthesize", "generate_attention"]
@@ -21,24 +35,46 @@ class Graph(object):
             raise NotImplementedError("only mode='synthesize' is on the hot path")
         self.mode, self.training, self.reuse, self.hp = mode, False, reuse, hp
         self.scope = None
-        self.session = None          # bound by Session.bind()
+        self.add_data(reuse=reuse)
+
+    def add_data(self, reuse=None):
+        """The synthesis placeholders of architectures.py:69-81 (both graphs declare all of them)."""
+        hp = self.hp
+        self.L = Tensor(self, "L", (None, hp.max_N))
+        if hp.multispeaker:
+            self.speakers = Tensor(self, "speakers", (None, None))
+        if getattr(hp, "use_external_durations", False):
+            self.durations = Tensor(self, "durations", (None, None, None))
+        self.mels = Tensor(self, "mels", (None, hp.max_T, hp.n_mels))
+        self.prev_max_attentions = Tensor(self, "prev_max_attentions", (None,))
 
 
 class Text2MelGraph(Graph):
-    """Exposes the tensors the reference fetches/feeds: K, V, Y, alignments, max_attentions."""
-    scope = "Text2Mel"
+    """The tensors the reference feeds and fetches (architectures.py:188-239): K, V from TextEnc; Q from AudioEnc;
+    R, alignments, max_attentions from Attention; Y_logits, Y from AudioDec.  Evaluated by Session.run."""
 
     def __init__(self, hp, mode="train", reuse=None):
         Graph.__init__(self, hp, mode, reuse)
         self.scope = "Text2Mel"
+        d = hp.d
+        self.K = Tensor(self, "K", (None, hp.max_N, d))
+        self.V = Tensor(self, "V", (None, hp.max_N, d))
+        self.Q = Tensor(self, "Q", (None, hp.max_T, d))
+        self.R = Tensor(self, "R", (None, hp.max_T, 2 * d))
+        self.alignments = Tensor(self, "alignments", (None, hp.max_N, hp.max_T))
+        self.max_attentions = Tensor(self, "max_attentions", (None, hp.max_T))
+        self.Y_logits = Tensor(self, "Y_logits", (None, hp.max_T, hp.n_mels))
+        self.Y = Tensor(self, "Y", (None, hp.max_T, hp.n_mels))
 
 
 class SSRNGraph(Graph):
-    scope = "SSRN"
+    """architectures.py:133-142: Z_logits, Z = SSRN(mels)."""
 
     def __init__(self, hp, mode="train", reuse=None):
         Graph.__init__(self, hp, mode, reuse)
         self.scope = "SSRN"
+        self.Z_logits = Tensor(self, "Z_logits", (None, hp.max_T * hp.r, hp.full_dim))
+        self.Z = Tensor(self, "Z", (None, hp.max_T * hp.r, hp.full_dim))
 
 
 class Session(object):
@@ -72,6 +108,59 @@ class Session(object):
     def initialize_random(self, seed=0):
         """Counterpart of tf.global_variables_initializer() (synthesize.py:537)."""
         self.assign(WT.random_weights(self.inventory(), seed))
+
+    def run(self, fetches, feed_dict=None):
+        """sess.run for the three fetch sets of the synthesis path (synthesize.py:182-183, 237-239, 257) and, as a
+        debug fetch, every other tensor the graphs declare:
+          [g.K, g.V]                                <- {g.L [, g.speakers]}
+          [g.Y, g.max_attentions, g.alignments, g.Q, g.R, g.Y_logits]
+                                                    <- {g.K, g.V, g.mels, g.prev_max_attentions [, g.speakers]}
+          g.Z / g.Z_logits                          <- {g.mels}
+        One call evaluates the whole graph at the fed values (the Text2Mel graph over all max_T positions), exactly
+        what the reference session does; the fast path of the loop is synth_codedtext2mel."""
+        import numpy as np
+        single = not isinstance(fetches, (list, tuple))
+        fl = [fetches] if single else list(fetches)
+        feed = dict(feed_dict or {})
+        g = fl[0].graph
+        for t in list(fl) + list(feed):
+            if not isinstance(t, Tensor) or t.graph is not g:
+                raise ValueError("fetches and feeds must be tensors of one graph: %r" % (t,))
+        fed = {t.name: v for t, v in feed.items()}
+        eng = self.ensure_ready()
+        hp = self.hp
+        if isinstance(g, SSRNGraph):
+            if "mels" not in fed:
+                raise ValueError("SSRN graph: feed g.mels")
+            Z = eng.ssrn(fed["mels"])
+            vals = {"Z": Z}
+            if any(t.name == "Z_logits" for t in fl):
+                with np.errstate(divide="ignore"):
+                    vals["Z_logits"] = (np.log(Z) - np.log1p(-Z)).astype(np.float32)      # inverse of the squash sigmoid
+        elif "L" in fed and all(t.name in ("K", "V") for t in fl):
+            K, V = eng.encode_text(fed["L"], fed.get("speakers"))
+            self._last_L = np.asarray(fed["L"])
+            vals = {"K": K, "V": V}
+        else:
+            if "K" in fed and "V" in fed:
+                K, V = fed["K"], fed["V"]
+            elif "L" in fed:
+                K, V = eng.encode_text(fed["L"], fed.get("speakers"))
+                self._last_L = np.asarray(fed["L"])
+            else:
+                raise ValueError("Text2Mel graph: feed g.L, or g.K and g.V")
+            if getattr(hp, "use_external_durations", False):
+                raise NotImplementedError("graph evaluation with external durations: use synth_codedtext2mel")
+            B = len(K)
+            mels = fed.get("mels", np.zeros((B, hp.max_T, hp.n_mels), np.float32))
+            prev = fed.get("prev_max_attentions", np.zeros((B,), np.int32))
+            ends = None
+            if getattr(hp, "turn_off_monotonic_for_synthesis", False):
+                ends = np.asarray(hp.text_lengths) - 1                       # hp.text_lengths = text lengths + 1 (synthesize.py:505-507)
+            vals = eng.text2mel_graph(K, V, mels, prev, ends=ends, speaker_data=fed.get("speakers"))
+            vals["K"], vals["V"] = np.asarray(K), np.asarray(V)
+        out = [vals[t.name] for t in fl]
+        return out[0] if single else out
 
     def ensure_ready(self):
         if not self._ready:

@@ -115,12 +115,15 @@ struct oph_handle {
     bool use_run = false;               // this configuration takes the dec_run path
     unsigned long long* d_gbuf = nullptr;   // hand-off granules [RUN_MAX_LAYERS][Bpad][RUN_GCOLS]
     uint32_t run_epoch = 0;             // advanced by RUN_MAX_LAYERS per launch: a tag value is never reused
+    long long* d_sigdbg = nullptr;      // OPH_RUN_STAMPS diagnostics: [max_T][8] stamps of the cross-stream signals
     long long* d_stamps = nullptr;      // OPH_RUN_STAMPS diagnostics: [2 launches][32 slices][LOOP_MAX_LAYERS][8]
     // whole-decode persistent launch (dec_loop): static layer descriptions in device memory, progress words in pinned host memory
     bool use_loop = false;
     LoopLayer* d_loop_layers = nullptr;
     int loop_nlayers = 0, loop_attn = 0, loop_slices = 0, loop_kmax = 0;
     volatile int* host_prog = nullptr;  // [0] last step whose attention is done  [1] stop step or INT_MAX
+    int ndec_cus = 0;                   // CUs the critical stream may use (its CU mask, or the whole chip)
+    int loop_capacity = -1;             // workgroups of dec_loop that can be resident at once (-1: not yet asked)
     std::string err;
     bool finalized = false;
     // expected variables (TF names) and host copies
@@ -590,7 +593,10 @@ int ensure_decode_state(oph_handle* h, int B) {
     h->d_ptab = h->dalloc<int>((size_t)m.max_T * Bpad);
     h->d_gbuf = h->dalloc<unsigned long long>((size_t)LOOP_MAX_LAYERS * Bpad * RUN_GCOLS);
     h->run_epoch = 0;
-    if (getenv("OPH_RUN_STAMPS")) h->d_stamps = h->dalloc<long long>((size_t)2 * 32 * LOOP_MAX_LAYERS * 8);
+    if (getenv("OPH_RUN_STAMPS")) {
+        h->d_stamps = h->dalloc<long long>((size_t)2 * 32 * LOOP_MAX_LAYERS * 8);
+        h->d_sigdbg = h->dalloc<long long>((size_t)m.max_T * 8);
+    }
     h->KV = h->dalloc<float>((size_t)Bpad * m.max_N * 2 * d);
     for (int i = 0; i < 2; ++i) h->Yout2[i] = h->dalloc<float>((size_t)Bpad * m.max_T * h->ldy);
     h->Yout = h->Yout2[0];
@@ -958,7 +964,6 @@ int build_loop_layers(oph_handle* h) {
 int decode_loop(oph_handle* h, int t_end, int stop_mode) {
     const oph_dims& m = h->dm;
     if (!h->d_loop_layers) { const int rc = build_loop_layers(h); if (rc) return rc; }
-    static const int rows_per_group = getenv("OPH_RUN_ROWS") ? atoi(getenv("OPH_RUN_ROWS")) : 4;
     static const int lookahead = getenv("OPH_LOOP_LOOKAHEAD") ? atoi(getenv("OPH_LOOP_LOOKAHEAD")) : 8;
     h->host_prog[0] = -1; h->host_prog[1] = INT_MAX;
     if ((uint64_t)h->run_epoch + (uint64_t)(m.max_T + 1) * LOOP_MAX_LAYERS > 0xF0000000ull) {     // tag wrap guard
@@ -982,6 +987,9 @@ int decode_loop(oph_handle* h, int t_end, int stop_mode) {
     void* dp = nullptr;
     if (hipHostGetDevicePointer(&dp, (void*)h->host_prog, 0) != hipSuccess) { h->fail("pinned progress words are not mapped"); return OPH_ERR_DEVICE; }
     a.host_progress = (volatile int*)dp;
+    static const int dbg = getenv("OPH_LOOP_DBG") ? atoi(getenv("OPH_LOOP_DBG")) : 0;
+    a.dbg = dbg;
+    a.sigdbg = h->d_sigdbg;
     hipStreamWaitEvent(h->scone, h->ev_in, 0);
     g_cur = h->sdec;
     double bytes = 0, flops = 0;
@@ -993,7 +1001,7 @@ int decode_loop(oph_handle* h, int t_end, int stop_mode) {
         (void)nl; (void)i;
     }
     h->pbegin(PC_DECLOOP);
-    launch_dec_loop(a, h->loop_slices, rows_per_group, h->loop_kmax, h->sdec);
+    launch_dec_loop(a, h->loop_slices, h->loop_kmax, h->sdec);
     h->pend(PC_DECLOOP, bytes * t_end, flops * t_end);
     // side stream: cone(t) after the attention of step t-1, then the word the loop kernel polls before AudioDec(t)
     g_cur = h->scone;
@@ -1009,9 +1017,13 @@ int decode_loop(oph_handle* h, int t_end, int stop_mode) {
         }
         const int stopped_at = h->host_prog[1];
         if (stopped_at != INT_MAX && t > stopped_at + 1) break;       // step stop+1 still runs (stores off) and polls its cone
-        hipStreamWaitValue32(h->scone, h->d_sig, h->sig_base + (uint32_t)t, hipStreamWaitValueGte, 0xffffffffu);
-        launch_cone(h, t);
-        hipStreamWriteValue32(h->scone, h->d_sig + 16, h->sig_base + (uint32_t)t, 0);
+        static const bool stream_ops = getenv("OPH_LOOP_STREAM_OPS") != nullptr;      // the slow flavour, kept for the record
+        if (stream_ops) hipStreamWaitValue32(h->scone, h->d_sig, h->sig_base + (uint32_t)t, hipStreamWaitValueGte, 0xffffffffu);
+        else launch_sig_wait(h->d_sig, h->sig_base + (uint32_t)t, h->d_ctl + 2, h->d_sigdbg ? h->d_sigdbg + (size_t)t * 8 : nullptr, h->scone);
+        static const bool skip_cone = getenv("OPH_SKIP_CONE") != nullptr;      // timing experiments only: results are wrong
+        if (!skip_cone) launch_cone(h, t);
+        if (stream_ops) hipStreamWriteValue32(h->scone, h->d_sig + 16, h->sig_base + (uint32_t)t, 0);
+        else launch_sig_set(h->d_sig + 16, h->sig_base + (uint32_t)t, h->d_sigdbg ? h->d_sigdbg + (size_t)t * 8 : nullptr, h->scone);
     }
     if (g_trace) {
         const double enq = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_host0).count() * 1e3;
@@ -1199,7 +1211,18 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
         hipStreamSynchronize(h->sdec);
         h->run_epoch = 0;
     }
-    const bool loop_mode = h->use_loop && !h->fixed_att && !h->capturing && t_begin == 0 && t_end >= 1;
+    bool loop_mode = h->use_loop && !h->fixed_att && !h->capturing && t_begin == 0 && t_end >= 1;
+    if (loop_mode) {
+        // every workgroup of the loop kernel must be resident at once (its row groups meet at the per-step cone signal):
+        // larger batches than the critical stream's CUs can hold take the two-launches-per-step path
+        if (!h->d_loop_layers) { const int rc = build_loop_layers(h); if (rc) return rc; }
+        if (h->loop_capacity < 0) {
+            int ncu = h->ndec_cus;
+            if (ncu <= 0) { hipDeviceProp_t prop; ncu = hipGetDeviceProperties(&prop, h->device) == hipSuccess ? prop.multiProcessorCount : 0; }
+            h->loop_capacity = dec_loop_blocks_per_cu(h->loop_kmax) * ncu;
+        }
+        if (h->loop_slices * (h->Bpad / dec_loop_rows()) > h->loop_capacity) loop_mode = false;
+    }
     if (h->use_sigval || loop_mode) {
         // a fresh value range for this loop: every value of an earlier loop is below sig_base + 1
         if (h->sig_base > 0x7fff0000u) {       // wrap guard (once per ~10 million batches): start over from a quiet state
@@ -1255,8 +1278,22 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
             const int nruns = loop_mode ? 1 : 2, stride = loop_mode ? LOOP_MAX_LAYERS : RUN_MAX_LAYERS;
             std::vector<long long> st((size_t)2 * 32 * LOOP_MAX_LAYERS * 8);
             hipMemcpy(st.data(), h->d_stamps, st.size() * 8, hipMemcpyDeviceToHost);
+            if (loop_mode && h->d_sigdbg) {
+                std::vector<long long> sd((size_t)m.max_T * 8);
+                hipMemcpy(sd.data(), h->d_sigdbg, sd.size() * 8, hipMemcpyDeviceToHost);
+                for (int t : {50, 51, 100, 101, 150}) {
+                    if (t >= m.max_T) continue;
+                    const long long* q = &sd[(size_t)t * 8];
+                    TRACE("signals of step %d (us after attention(t-1) raised sig[0]): side wait kernel started %+.2f, saw it %+.2f, set kernel wrote sig[16] %+.2f; loop kernel first looked %+.2f, saw it %+.2f",
+                          t, (q[1] - q[0]) * 0.01, (q[2] - q[0]) * 0.01, (q[3] - q[0]) * 0.01, (q[5] - q[0]) * 0.01, (q[4] - q[0]) * 0.01);
+                }
+            }
+            if (loop_mode) {
+                const long long* q = &st[(size_t)(LOOP_MAX_LAYERS - 1) * 8];
+                if (q[1] > q[0]) TRACE("stamped step: %.2f us, shader clock %.0f MHz", (double)(q[1] - q[0]) * 0.01, (double)(q[3] - q[2]) / ((double)(q[1] - q[0]) * 0.01));
+            }
             for (int run = 0; run < nruns; ++run)
-                for (int l = 0; l < stride; ++l) {
+                for (int l = 0; l < stride - (loop_mode ? 1 : 0); ++l) {
                     double d[5] = {0, 0, 0, 0, 0}, passes = 0, start = 0; int n = 0;
                     const long long t00 = st[((size_t)run * 32 + 0) * stride * 8 + 0];
                     for (int g = 0; g < 32; ++g) {
@@ -1265,8 +1302,14 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
                         for (int k = 0; k < 5; ++k) d[k] += (double)(s_[k + 1] - s_[k]) * 0.01;
                         passes += (double)s_[6]; start += (double)(s_[0] - t00) * 0.01; ++n;
                     }
-                    if (n) TRACE("run %d layer %2d (%2d slices): start %+7.2f  sweep %.2f (%.1f passes)  prologue+stage %.2f  barrier %.2f  fma+prefetch %.2f  reduce+publish %.2f",
-                                 run, l, n, start / n, d[0] / n, passes / n, d[1] / n, d[2] / n, d[3] / n, d[4] / n);
+                    double fma = 0;
+                    for (int g = 0; g < 32; ++g) {
+                        const long long* s_ = &st[(((size_t)run * 32 + g) * stride + l) * 8];
+                        if (s_[0] == 0 || s_[5] == 0 || s_[7] == 0) continue;
+                        fma += (double)(s_[7] - s_[3]) * 0.01;
+                    }
+                    if (n) TRACE("run %d layer %2d (%2d slices): start %+7.2f  sweep %.2f (%.1f passes)  prologue+stage %.2f  barrier %.2f  fma+prefetch %.2f (fma %.2f)  reduce+publish %.2f",
+                                 run, l, n, start / n, d[0] / n, passes / n, d[1] / n, d[2] / n, d[3] / n, fma / n, d[4] / n);
                 }
         }
     }
@@ -1279,7 +1322,7 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
     if (steps_run || stop_mode == OPH_STOP_REFERENCE || h->use_run) {
         HIPCHK(h, hipMemcpyAsync(ctl, h->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (ctl[2] != 0) { h->fail(ctl[2] == 2 ? "decoder loop: the side stream's cone never signalled (time-out)" : "decoder run: a workgroup hand-off timed out (workgroups of one run were not co-resident)"); return OPH_ERR_DEVICE; }
+        if (ctl[2] != 0) { h->fail(ctl[2] == 3 ? "decoder loop: the side stream never saw the attention signal (time-out)" : ctl[2] == 2 ? "decoder loop: the side stream's cone never signalled (time-out)" : "decoder run: a workgroup hand-off timed out (workgroups of one run were not co-resident)"); return OPH_ERR_DEVICE; }
     }
     if (steps_run) *steps_run = ctl[1] != INT_MAX ? ctl[1] + 1 : last;
     HIPCHK(h, hipGetLastError());
@@ -1374,6 +1417,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
             // are created here, once: critical chain | cone | SSRN partitions.
             h->mask_words = words;
             if (hipExtStreamCreateWithCUMask(&h->sdec, words, m_dec) != hipSuccess) { h->sdec = nullptr; h->mask_words = 0; }
+            h->ndec_cus = h->sdec ? ndec : ncu;
             if (h->mask_words && hipExtStreamCreateWithCUMask(&h->scone, words, m_conep) != hipSuccess) h->scone = nullptr;
             if (h->mask_words && hipExtStreamCreateWithCUMask(&h->sssrn, words, m_ssrn) != hipSuccess) h->sssrn = nullptr;
         }

@@ -39,7 +39,7 @@ static __device__ __forceinline__ void granule_store(u64* p, unsigned epoch, flo
 // c2..c2+3 of the second half when `two`).  Bounded: on a time-out (or when another wave already failed) the error word
 // is set and the run continues with whatever was read, so the launch always terminates.
 static __device__ __forceinline__ int sweep_row(const u64* row, int c, bool cok, int c2, bool two, unsigned epoch, int lane,
-                                                int* err, f32x4& av, f32x4& uv) {
+                                                int* err, f32x4& av, f32x4& uv, bool once = false) {
     long long t0 = 0;
     const u64 want = (u64)epoch << 32;
     for (int it = 0;; ++it) {
@@ -58,7 +58,7 @@ static __device__ __forceinline__ int sweep_row(const u64* row, int c, bool cok,
             give_up = now - t0 > RUN_TIMEOUT_TICKS || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
             if (give_up && lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (__all(ok) || give_up) {
+        if (__all(ok) || give_up || once) {      // once: timing ablation only
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 av[e] = __uint_as_float((unsigned)ga[e]);
@@ -327,16 +327,24 @@ static __device__ __forceinline__ void st_coherent(float* p, const f32x4& v) {
 }
 typedef const __attribute__((address_space(4))) LoopLayer* LoopLayerConstPtr;     // descriptors are read with scalar loads
 
+// Contraction on v_mfma_f32_4x4x1_16B_f32 (16 independent 4x4 outer products per instruction, exact fp32): the 4 rows
+// of the group are the M of every block; block (cg, kk) = lanes 16cg + 4kk .. +3 owns columns 4cg..4cg+3 and k-lane kk
+// of each 16-wide chunk:  A[lane] = x[row lane&3][16 ch + 4 kk + e],  B[lane] = Wt[n0 + 4cg + (lane&3)][16 ch + 4 kk + e],
+// D[lane][reg i] += A[4 blk + i] * B[lane]  (profiles/mfma4x4_probe.hip).  One ds_read_b128 + 4 MFMAs per chunk instead of
+// 4 reads + 16 FMAs: the contraction of a highway layer drops from ~1.0 us to ~0.25 us per wave (profiles/r02 stamps).
+constexpr int LOOP_R = 4;
 template <int R>
 __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
-    constexpr int PF = (RUN_KMAX / 16 + R - 1) / R, GC = 16 / R;
+    static_assert(R == LOOP_R, "the 4x4x1 MFMA mapping is written for 4 rows per workgroup");
+    constexpr int PF = (RUN_KMAX / 16 + R - 1) / R;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* part = smem;                          // [R waves][4 k-quarters][16 columns][R rows]
-    float* xs = smem + R * 4 * 16 * R;           // [R][ldxs]
+    float* part = smem;                          // [R waves][64 lanes][4 rows] K-split partial sums
+    float* xs = smem + R * 64 * 4;               // [R][ldxs]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = blockIdx.x, n0 = g * 16, row0 = blockIdx.y * R, grow = row0 + w;
-    const int r16 = lane & 15, kq = lane >> 4, c = lane * 4;
+    const int c = lane * 4;
+    const int mq = lane & 3, mkk = (lane >> 2) & 3, mcol = 4 * (lane >> 4) + mq;     // MFMA roles of this lane
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const int NL = a.nlayers, Bpad = a.Bpad;
     LoopLayerConstPtr Ls = (LoopLayerConstPtr)a.L;
@@ -353,17 +361,15 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
     auto fetch_layer = [&](int l, int t) {       // weights, bias and the two older taps of layer l at step t
         const int ntaps = Ls[l].ntaps, kc = Ls[l].kc;
         const int nch = (ntaps * kc) >> 4;
-        const bool cols = n0 < Ls[l].N;
-        const float* wrow = Ls[l].Wt + (size_t)(n0 + r16) * Ls[l].ldw + kq * 4;
+        if (n0 < Ls[l].N && !(a.dbg & 1)) {       // chunks past the layer's K are never multiplied: load a valid address instead of branching
+            const float* wrow = Ls[l].Wt + (size_t)(n0 + mcol) * Ls[l].ldw + mkk * 4;
 #pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const int ch = w + R * i;
-            bfrag[i] = (cols && ch < nch) ? *(const f32x4*)(wrow + ch * 16) : zero4;
+            for (int i = 0; i < PF; ++i) bfrag[i] = *(const f32x4*)(wrow + min(w + R * i, nch - 1) * 16);
+            bias_v = Ls[l].bias[n0 + (tid & 15)];
         }
-        bias_v = cols ? Ls[l].bias[n0 + (tid & 15)] : 0.f;
         const int kind = Ls[l].tapkind;
         tp0 = zero4; tp1 = zero4;
-        if (kind != 0 && c < kc) {
+        if (kind != 0 && c < kc && !(a.dbg & 4)) {
             const int o0 = Ls[l].off0, o1 = Ls[l].off1;
             if (kind == 1) {
                 const float* hb = Ls[l].hist;
@@ -385,6 +391,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
         if (__hip_atomic_load(stop_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= t - 2) break;
         long long* const stp = (a.stamps && t == a.stamp_t && w == 0 && blockIdx.y == 0) ? a.stamps + (size_t)g * LOOP_MAX_LAYERS * 8 : nullptr;
 #define LOOP_STAMP(K) do { if (stp && lane == 0) stp[l * 8 + (K)] = wall_clock64(); } while (0)
+        const long long step_w0 = stp ? wall_clock64() : 0, step_c0 = stp ? clock64() : 0;
         for (int l = 0; l < NL; ++l) {
             const bool first = l == 0, no_input = first && t == 0;      // S[0] = 0 (architectures.py:191)
             const int pre = Ls[l].pre, cin = Ls[l].cin, nonorm = Ls[l].nonorm, kc = Ls[l].kc, ntaps = Ls[l].ntaps;
@@ -401,6 +408,19 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
             if (g == 0) stop_v = __hip_atomic_load(stop_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned sigc = 0;
             if (is_attn && t >= 1) sigc = __hip_atomic_load(a.sig + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // attention window [p, p+win): its K and V rows depend on p alone -- requested before the hand-off, not inside
+            // the softmax loops (each was an exposed ~1.5 us round trip: profiles/r02 stamps, 10 us per step)
+            constexpr int AW = 4;
+            f32x4 kwin[AW], vwin[AW];
+            if (is_attn) {
+                const float* KVb = a.KV + (size_t)grow * a.N_keys * 2 * cin;
+#pragma unroll
+                for (int i = 0; i < AW; ++i) {
+                    const bool in = cok && i < a.win && p + i < a.N_keys;
+                    kwin[i] = in ? *(const f32x4*)(KVb + (size_t)(p + i) * 2 * cin + c) : zero4;
+                    vwin[i] = in ? *(const f32x4*)(KVb + cin + (size_t)(p + i) * 2 * cin + c) : zero4;
+                }
+            }
 
             // ---- 2. this wave's raw row of the producing layer (layer 0: the last layer of the previous step)
             LOOP_STAMP(0);
@@ -409,14 +429,14 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
             if (!no_input) {
                 const int slot = first ? NL - 1 : l - 1;
                 const unsigned ep = a.epoch0 + (unsigned)((first ? t - 1 : t) * LOOP_MAX_LAYERS + slot + 1);
-                passes = sweep_row(a.gbuf + ((size_t)slot * Bpad + grow) * RUN_GCOLS, c, cok, cin + c, two, ep, lane, err, av, uv);
+                passes = sweep_row(a.gbuf + ((size_t)slot * Bpad + grow) * RUN_GCOLS, c, cok, cin + c, two, ep, lane, err, av, uv, (a.dbg & 2) != 0);
             }
             LOOP_STAMP(1);
             if (stp && lane == 0) stp[l * 8 + 6] = passes;
 
             // ---- 3. prologue math (one row per wave)
             f32x4 x = av;
-            if (pre != RUN_COPY) {
+            if (pre != RUN_COPY && !(a.dbg & 8)) {
                 const float invc = __builtin_amdgcn_rcpf((float)cin);
                 float s1 = av[0] + av[1] + av[2] + av[3], s2 = uv[0] + uv[1] + uv[2] + uv[3];
                 s1 = wave_sum(s1);
@@ -438,12 +458,23 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
                     for (int e = 0; e < 4; ++e) {
                         const float h1 = av[e] * r1 * g1v[e] + b1v[e], h2 = uv[e] * r2 * g2v[e] + b2v[e];
                         const float gte = fast_sigmoid(h1);
-                        x[e] = cok ? gte * h2 + (1.0f - gte) * xprev[e] : 0.f;
+                        const float y = gte * h2 + (1.0f - gte) * xprev[e];
+                        x[e] = cok ? y : 0.f;
                     }
                 } else {
                     const int act = Ls[l].act;
+                    f32x4 y;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) x[e] = cok ? fast_act(av[e] * r1 * g1v[e] + b1v[e], act) : 0.f;
+                    for (int e = 0; e < 4; ++e) y[e] = av[e] * r1 * g1v[e] + b1v[e];
+                    if (act == ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+                    } else if (act == ACT_SIGMOID) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] = fast_sigmoid(y[e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = cok ? y[e] : 0.f;
                 }
             }
             if (no_input) x = zero4;
@@ -457,6 +488,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
             }
             if (is_attn && t >= 1) {
                 // the cone of this step (side stream) must have landed before its rows are requested as taps
+                if (a.sigdbg && g == 0 && blockIdx.y == 0 && w == 0 && lane == 0) a.sigdbg[t * 8 + 5] = wall_clock64();
                 long long t0 = 0;
                 for (int it = 0; (int)(sigc - (a.sig_base + (unsigned)t)) < 0; ++it) {
                     __builtin_amdgcn_s_sleep(2);
@@ -470,10 +502,11 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
                         }
                     }
                 }
+                if (a.sigdbg && g == 0 && blockIdx.y == 0 && w == 0 && lane == 0) a.sigdbg[t * 8 + 4] = wall_clock64();
             }
 
             // ---- 4. stage the operand row: [tap x[t-2r] | tap x[t-r] | current]
-            const int Ktot = ntaps * kc, ldxs = Ktot + 4, cur = (ntaps - 1) * kc;
+            const int Ktot = ntaps * kc, ldxs = Ktot + 16, cur = (ntaps - 1) * kc;     // +16: the 4 rows' b128 reads hit disjoint banks
             float* xrow = xs + w * ldxs;
             const bool live = t <= stop_v;
             if (pre == RUN_ATTN) {
@@ -483,7 +516,14 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
                 const int nwin = min(a.win, a.N_keys - p);
                 const float scale = fast_rsqrt((float)d);
                 float scl = -INFINITY;
-                for (int i = 0; i < nwin; ++i) {
+#pragma unroll
+                for (int i = 0; i < AW; ++i) {
+                    if (i < nwin) {
+                        const float sdot = wave_sum(x[0] * kwin[i][0] + x[1] * kwin[i][1] + x[2] * kwin[i][2] + x[3] * kwin[i][3]) * scale;
+                        if (lane == i) scl = sdot;
+                    }
+                }
+                for (int i = AW; i < nwin; ++i) {           // windows wider than the prefetched ones
                     const f32x4 kv = cok ? *(const f32x4*)(KVb + (size_t)(p + i) * 2 * d + c) : zero4;
                     const float sdot = wave_sum(x[0] * kv[0] + x[1] * kv[1] + x[2] * kv[2] + x[3] * kv[3]) * scale;
                     if (lane == i) scl = sdot;
@@ -497,9 +537,18 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
                 int arg = 0;
                 float best = -1.f;
                 f32x4 ctx = zero4;
-                for (int i = 0; i < nwin; ++i) {
+#pragma unroll
+                for (int i = 0; i < AW; ++i) {
+                    if (i < nwin) {
+                        const float pi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, prl), i));
+                        if (pi > best) { best = pi; arg = i; }       // first maximum, like tf.argmax
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ctx[e] += pi * vwin[i][e];
+                    }
+                }
+                for (int i = AW; i < nwin; ++i) {
                     const float pi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, prl), i));
-                    if (pi > best) { best = pi; arg = i; }       // first maximum, like tf.argmax
+                    if (pi > best) { best = pi; arg = i; }
                     const f32x4 vv = cok ? *(const f32x4*)(KVb + d + (size_t)(p + i) * 2 * d + c) : zero4;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ctx[e] += pi * vv[e];
@@ -545,37 +594,25 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
             __syncthreads();
             LOOP_STAMP(3);
 
-            // ---- 5. R x 16 slice (see dec_run); the LDS reads of a 256-k group are all issued before its FMAs
+            // ---- 5. 4 x 16 slice on the 4x4x1 MFMA, K split round-robin over the 4 waves
             if (cols) {
-                float acc[R][4];
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[r][e] = 0.f;
-                const float* xa = xs + kq * 4;
+                f32x4 acc0 = zero4, acc1 = zero4;
+                const float* xa = xs + mq * ldxs + mkk * 4;
                 const int nch = Ktot >> 4;
 #pragma unroll
-                for (int grp = 0; grp < PF / GC; ++grp) {
-                    if (grp * 16 < nch) {
-                        f32x4 xf[GC][R];
-#pragma unroll
-                        for (int ii = 0; ii < GC; ++ii) {
-                            const int ch = min(w + R * (grp * GC + ii), nch - 1);
-#pragma unroll
-                            for (int r = 0; r < R; ++r) xf[ii][r] = *(const f32x4*)(xa + r * ldxs + ch * 16);
-                        }
-#pragma unroll
-                        for (int ii = 0; ii < GC; ++ii)
-#pragma unroll
-                            for (int r = 0; r < R; ++r)
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) acc[r][e] = fmaf(xf[ii][r][e], bfrag[grp * GC + ii][e], acc[r][e]);
+                for (int i = 0; i < PF; ++i) {
+                    const int ch = w + R * i;
+                    if (ch < nch) {
+                        const f32x4 xf = *(const f32x4*)(xa + ch * 16);
+                        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(xf[0], bfrag[i][0], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(xf[1], bfrag[i][1], acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(xf[2], bfrag[i][2], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(xf[3], bfrag[i][3], acc1, 0, 0, 0);
                     }
                 }
-                float* pw = part + ((w * 4 + kq) * 16 + r16) * R;
-#pragma unroll
-                for (int r = 0; r < R; ++r) pw[r] = (acc[r][0] + acc[r][1]) + (acc[r][2] + acc[r][3]);
+                *(f32x4*)(part + (w * 64 + lane) * 4) = acc0 + acc1;      // [row i] of (column mcol, k-lane mkk)
             }
+            LOOP_STAMP(7);
             const float bias_cur = bias_v;
             if (l + 1 < NL) fetch_layer(l + 1, t);
             else if (t + 1 < a.t_end) fetch_layer(0, t + 1);
@@ -584,8 +621,11 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
             if (cols && tid < 16 * R) {
                 const int row = tid >> 4, col = tid & 15;
                 float v = bias_cur;
+                const float* pr = part + (16 * (col >> 2) + (col & 3)) * 4 + row;
 #pragma unroll
-                for (int wk = 0; wk < 4 * R; ++wk) v += part[(wk * 16 + col) * R + row];
+                for (int ww = 0; ww < R; ++ww)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) v += pr[(ww * 64 + 4 * kk) * 4];
                 granule_store(a.gbuf + ((size_t)l * Bpad + row0 + row) * RUN_GCOLS + n0 + col,
                               a.epoch0 + (unsigned)(t * LOOP_MAX_LAYERS + l + 1), v);
             }
@@ -600,9 +640,14 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
                     if (old + 1 == (Bpad / R) * (t + 1)) {
                         __hip_atomic_fetch_max(a.sig, a.sig_base + (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         __hip_atomic_store((int*)a.host_progress, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (a.sigdbg && t + 1 < a.max_T) a.sigdbg[(t + 1) * 8 + 0] = wall_clock64();
                     }
                 }
             }
+        }
+        if (stp && lane == 0) {     // shader clock over this step: (c1 - c0) cycles in (w1 - w0) * 10 ns
+            long long* q = stp + (LOOP_MAX_LAYERS - 1) * 8;
+            q[0] = step_w0; q[1] = wall_clock64(); q[2] = step_c0; q[3] = clock64();
         }
 #undef LOOP_STAMP
     }
@@ -637,19 +682,55 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
         __hip_atomic_fetch_max(a.sig, a.sig_base + (unsigned)a.max_T + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Side-stream ends of the two dependencies of dec_loop, as one-wave kernels in stream order instead of
+// hipStreamWaitValue32 / hipStreamWriteValue32: measured on this runtime, a wait-value + write-value pair on an otherwise
+// idle stream turns around in ~150 us (profiles/r02 ablations: with every phase of the loop kernel switched off a step
+// still took 150 us, all of it waiting here), a spinning kernel and a storing kernel in ~5 us.
+__global__ void sig_wait_kernel(const unsigned* sig, unsigned want, int* err, long long* stamp) {
+    long long t0 = 0;
+    if (stamp && threadIdx.x == 0) stamp[1] = wall_clock64();
+    for (int it = 0; (int)(__hip_atomic_load(sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0; ++it) {
+        __builtin_amdgcn_s_sleep(4);
+        if ((it & 255) == 255) {
+            const long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            if (now - t0 > RUN_TIMEOUT_TICKS || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                __hip_atomic_store(err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        }
+    }
+    if (stamp && threadIdx.x == 0) stamp[2] = wall_clock64();
+}
+__global__ void sig_set_kernel(unsigned* sig, unsigned value, long long* stamp) {
+    // the kernels before this one in the stream have completed (their stores are written back at kernel end)
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_max(sig, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (stamp) stamp[3] = wall_clock64();
+    }
+}
+void launch_sig_wait(const unsigned* sig, unsigned want, int* err, long long* stamp, hipStream_t s) { hipLaunchKernelGGL(sig_wait_kernel, dim3(1), dim3(64), 0, s, sig, want, err, stamp); }
+void launch_sig_set(unsigned* sig, unsigned value, long long* stamp, hipStream_t s) { hipLaunchKernelGGL(sig_set_kernel, dim3(1), dim3(64), 0, s, sig, value, stamp); }
+
 template <int R>
 static void launch_dec_loop_t(const LoopArgs& a, int col_slices, int kmax, hipStream_t s) {
     static thread_local std::map<int, size_t> done;
-    const size_t lds_bytes = (size_t)(R * 4 * 16 * R + R * (kmax + 4)) * 4;
+    const size_t lds_bytes = (size_t)(R * 64 * 4 + R * (kmax + 16)) * 4;
     int dev = 0;
     (void)hipGetDevice(&dev);
     size_t& d = done[dev];
     if (d < lds_bytes) { (void)hipFuncSetAttribute((const void*)dec_loop<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); d = lds_bytes; }
     hipLaunchKernelGGL(dec_loop<R>, dim3(col_slices, a.Bpad / R), dim3(64 * R), lds_bytes, s, a);
 }
-void launch_dec_loop(const LoopArgs& a, int col_slices, int rows_per_group, int kmax, hipStream_t s) {
-    if (rows_per_group == 8) launch_dec_loop_t<8>(a, col_slices, kmax, s);
-    else launch_dec_loop_t<4>(a, col_slices, kmax, s);
+void launch_dec_loop(const LoopArgs& a, int col_slices, int kmax, hipStream_t s) { launch_dec_loop_t<LOOP_R>(a, col_slices, kmax, s); }
+int dec_loop_rows() { return LOOP_R; }
+// workgroups of dec_loop that fit on one CU at once (the loop kernel needs ALL of its workgroups resident)
+int dec_loop_blocks_per_cu(int kmax) {
+    const size_t lds_bytes = (size_t)(LOOP_R * 64 * 4 + LOOP_R * (kmax + 16)) * 4;
+    (void)hipFuncSetAttribute((const void*)dec_loop<LOOP_R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)dec_loop<LOOP_R>, 64 * LOOP_R, lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
 }
 
 template <int R>

@@ -193,8 +193,15 @@ struct LoopArgs {
     float* Qhist; float* align; float* Yout; int ldy; float* Ytm;
     unsigned* sig; unsigned sig_base;
     volatile int* host_progress;        // pinned host words: [0] last step whose attention is done, [1] stop step (or INT_MAX)
+    long long* sigdbg;                  // diagnostics: [max_T][8] clock stamps of the two signals, or null
+    int dbg;                            // ablation switches for timing experiments (OPH_LOOP_DBG; results are wrong when set):
+                                        // 1 no weight loads, 2 single-pass sweeps (no waiting), 4 no tap loads, 8 no prologue math
 };
-void launch_dec_loop(const LoopArgs& a, int col_slices, int rows_per_group, int kmax, hipStream_t s);
+void launch_dec_loop(const LoopArgs& a, int col_slices, int kmax, hipStream_t s);
+int dec_loop_rows();          // rows (utterances) per workgroup of dec_loop
+int dec_loop_blocks_per_cu(int kmax);
+void launch_sig_wait(const unsigned* sig, unsigned want, int* err, long long* stamp, hipStream_t s);     // one wave spins until *sig >= want
+void launch_sig_set(unsigned* sig, unsigned value, long long* stamp, hipStream_t s);                     // *sig = max(*sig, value)
 
 // launchers (oph_kernels.hip)
 void launch_row_chain(const RowChainArgs& a, hipStream_t s);

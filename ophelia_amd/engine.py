@@ -154,6 +154,32 @@ class Engine(object):
                                                   _lib.fptr(Y), _lib.iptr(t_ends), _lib.fptr(al), C.byref(steps)))
         return Y, t_ends, al, steps.value
 
+    def text2mel_graph(self, K, V, mels, prev_max_attentions, ends=None, speaker_data=None):
+        """ONE evaluation of the synthesis graph at fixed feeds = one sess.run of the reference's loop
+        (synthesize.py:172,181-183): every max_T position under the one mask of prev_max_attentions.  Returns a dict
+        with Q, R, Y_logits, Y, alignments, max_attentions (architectures.py:188-239).  O(max_T) per call: the fetch
+        surface for validation and feed/fetch-style callers; the decode loop proper is text2mel()."""
+        K = np.ascontiguousarray(K, dtype=np.float32)
+        V = np.ascontiguousarray(V, dtype=np.float32)
+        B = K.shape[0]
+        d = self.dims
+        assert K.shape == V.shape == (B, d.max_N, d.d)
+        mels = np.ascontiguousarray(mels, dtype=np.float32)
+        assert mels.shape == (B, d.max_T, d.n_mels), mels.shape
+        pm = np.ascontiguousarray(np.asarray(prev_max_attentions).reshape(B), dtype=np.int32)
+        ep = None
+        if ends is not None:
+            ends = np.ascontiguousarray(np.asarray(ends).reshape(B), dtype=np.int32)
+            ep = _lib.iptr(ends)
+        out = dict(Q=np.empty((B, d.max_T, d.d), np.float32), R=np.empty((B, d.max_T, 2 * d.d), np.float32),
+                   Y_logits=np.empty((B, d.max_T, d.n_mels), np.float32), Y=np.empty((B, d.max_T, d.n_mels), np.float32),
+                   alignments=np.empty((B, d.max_N, d.max_T), np.float32), max_attentions=np.empty((B, d.max_T), np.int32))
+        s, sp = self._spk(speaker_data, B)
+        self._chk(self.lib.oph_text2mel_graph(self._h, _lib.fptr(K), _lib.fptr(V), _lib.fptr(mels), _lib.iptr(pm), ep, sp, B,
+                                              _lib.fptr(out["Q"]), _lib.fptr(out["R"]), _lib.fptr(out["Y_logits"]),
+                                              _lib.fptr(out["Y"]), _lib.fptr(out["alignments"]), _lib.iptr(out["max_attentions"])))
+        return out
+
     def ssrn(self, Y):
         Y = np.ascontiguousarray(Y, dtype=np.float32)
         B, T, nm = Y.shape

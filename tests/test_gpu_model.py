@@ -167,3 +167,61 @@ def test_pipelined_batches_equal_sequential(c2):
     assert np.array_equal(Y3, Ya) and np.array_equal(Z3, Za)
     eng.run_resident(stop_mode=1, run_ssrn=True, pipelined=False)      # switch back
     assert np.array_equal(eng.fetch_mag(), Za)
+
+
+@pytest.mark.parametrize("tag", ["lj_stop", "vctk_spk", "proj_nomono"])
+def test_session_run_in_the_reference_feed_fetch_style(tag):
+    """Row a12: the loop of synthesize.py:150-230 written against Session.run with the graph's tensor handles as fetches
+    and feed-dict keys (architectures.py:69-81, 188-239), one whole-graph evaluation per step like the reference's
+    sess.run -- compared with the goldens the reference's own loop produced, including g.Q at step 0."""
+    from ophelia_amd.architectures import Session, SSRNGraph, Text2MelGraph
+    hp, meta, g0 = load_wiring_case(tag)
+    W = O.random_weights(hp, meta["weight_seed"])
+    L, ends = g0["L"], g0["ends"]
+    speaker_data = g0.get("speakers")
+    g = Text2MelGraph(hp, mode="synthesize")
+    g2 = SSRNGraph(hp, mode="synthesize")
+    with Session(hp, device=0) as sess:
+        sess.assign(W)
+        feeddict = {g.L: L}
+        if hp.multispeaker:
+            feeddict[g.speakers] = speaker_data
+        K, V = sess.run([g.K, g.V], feeddict)                                   # encode_text, synthesize.py:232-240
+        assert np.abs(K - g0["K"]).max() < TOL and np.abs(V - g0["V"]).max() < TOL
+        Y = np.zeros((len(K), hp.max_T, hp.n_mels), np.float32)
+        alignments = np.zeros((len(ends), hp.max_N, hp.max_T), np.float32)
+        prev_max_attentions = np.zeros((len(K),), np.int32)
+        t_ends = np.ones(ends.shape, dtype=int) * hp.max_T
+        feeddict = {g.K: K, g.V: V, g.mels: Y, g.prev_max_attentions: prev_max_attentions}
+        if hp.multispeaker:
+            feeddict[g.speakers] = speaker_data
+        steps = 0
+        for j in range(hp.max_T):
+            fetches = [g.Y, g.max_attentions, g.alignments] + ([g.Q, g.R, g.Y_logits] if j == 0 else [])
+            out = sess.run(fetches, feeddict)
+            _Y, _max_attentions, _alignments = out[:3]
+            if j == 0:
+                Q, R, Y_logits = out[3:]
+                assert np.abs(Q - g0["Q_step0"]).max() < TOL                     # AudioEnc of the all-zero input
+                assert R.shape == (len(K), hp.max_T, 2 * hp.d) and np.array_equal(R[:, :, hp.d:], Q)   # R' = concat(R, Q)
+                assert np.abs(1.0 / (1.0 + np.exp(-Y_logits)) - _Y).max() < 1e-6
+            Y[:, j, :] = _Y[:, j, :]
+            alignments[:, :, j] = _alignments[:, :, j]
+            prev_max_attentions = _max_attentions[:, j]
+            feeddict[g.mels] = Y
+            feeddict[g.prev_max_attentions] = prev_max_attentions
+            steps += 1
+            assert np.array_equal(prev_max_attentions, g0["max_attentions_trace"][j])
+            for i in range(len(ends)):
+                if t_ends[i] == hp.max_T and prev_max_attentions[i] >= ends[i]:
+                    t_ends[i] = j
+            if (t_ends < hp.max_T).all():
+                break
+        assert steps == int(g0["steps_run"]) and t_ends.tolist() == g0["t_ends"].tolist()
+        assert np.abs(Y - g0["Y"]).max() < TOL and np.abs(alignments - g0["alignments"]).max() < TOL
+        sess.engine.set_ssrn_precision(0)
+        Z = sess.run(g2.Z, {g2.mels: Y})                                        # synth_mel2mag, synthesize.py:257
+        assert np.abs(Z - g0["Z"]).max() < TOL
+        Zl = sess.run(g2.Z_logits, {g2.mels: Y})
+        inner = (Z > 1e-6) & (Z < 1 - 1e-6)
+        assert np.abs(1.0 / (1.0 + np.exp(-Zl[inner])) - Z[inner]).max() < 1e-5

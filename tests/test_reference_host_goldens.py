@@ -1,0 +1,100 @@
+"""Host-side rows a13-a17 against goldens that the REFERENCE's own synthesize() produced (tests/golden/make_golden.py
+drives /root/reference/synthesize.py itself through tests/golden/ref_host.py): the CDP / Ain report, the per-utterance
+trimming, the output directory and file naming, and synth_mel2mag's Python-2 chunking.  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_wiring_case
+from ophelia_amd import calculate_CDP_Ain_Aout as CDP
+from ophelia_amd import synthesize as S
+
+CASES = ["lj_free", "lj_stop", "vctk_spk", "proj_nomono", "g1abc_nonorm", "nn_spk_in", "vctk02_spk_end", "vctk03_lcc",
+         "g1ab_extdur", "vctk_spk_audioenc"]
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_attention_report_matches_reference(tag):
+    """getCDP / getAP on the trimmed alignments (synthesize.py:592-598) give the numbers the reference printed"""
+    hp, meta, g = load_wiring_case(tag)
+    for i in range(meta["B"]):
+        A = g["alignments"][i, :g["ends"][i], :g["t_ends"][i]]
+        if A.shape[1] == 0:
+            # lengths[i] == 0: the reference's getEnt divides by zero here (calculate_CDP_Ain_Aout.py:39) and synthesize()
+            # dies in its report loop -- recorded by the generator as NaN + reference_report_crashes
+            assert meta["reference_report_crashes"] and np.isnan(g["ain"][i])
+            continue
+        # (a one-frame utterance normalises by log(1) = 0: NaN in the reference as well)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            assert np.isclose(CDP.getCDP(A), g["cdp"][i], rtol=1e-6, atol=1e-9, equal_nan=True)
+            ain, aout = CDP.getAP(A)
+        assert np.isclose(ain, g["ain"][i], rtol=1e-6, atol=1e-9, equal_nan=True)
+        assert np.isclose(aout, g["aout"][i], rtol=1e-6, atol=1e-9, equal_nan=True)
+    # and the printed lines carry those numbers with the reference's format
+    lines = [l for l in meta["report_lines"] if l.split(" | ")[0] in meta["bases"]]
+    for i, l in enumerate(lines):
+        if not np.isnan(g["ain"][i]) and not np.isnan(g["cdp"][i]):
+            assert l == "%s | %.2f | %.2f" % (meta["bases"][i], g["cdp"][i], g["ain"][i])
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_trimming_and_naming_match_reference(tag):
+    """mag[:lengths[i]*r] (synthesize.py:608), outdir t2m{E}_ssrn{E}[_speaker-{id}] (:582-586), {base}.wav / {base}.png"""
+    hp, meta, g = load_wiring_case(tag)
+    assert g["wav_rows"].tolist() == (g["t_ends"] * hp.r).tolist()
+    outdir = "t2m%s_ssrn%s" % ("1000", "900")          # the epochs the generator's restore stand-ins returned
+    if meta["speaker_id"]:
+        outdir += "_speaker-%s" % meta["speaker_id"]
+    assert meta["outdir"] == outdir
+    assert meta["wav_files"] == [os.path.join(outdir, b + ".wav") for b in meta["bases"]]
+    assert meta["plot_files"] == [os.path.join(outdir, b) for b in meta["bases"]]
+    assert meta["plot_shapes"] == [[int(g["ends"][i]), int(g["t_ends"][i])] for i in range(meta["B"])]
+    # split_batch applies the same lengths to the mels
+    parts = S.split_batch(g["Y"], g["t_ends"])
+    assert [p.shape[0] for p in parts] == g["t_ends"].tolist()
+    # one sess.run per SSRN chunk: the whole (small) batch in one piece
+    assert meta["ssrn_batches"] == [meta["B"]]
+
+
+def test_mel2mag_chunking_is_the_reference_python2_arithmetic():
+    """synth_mel2mag (synthesize.py:250-260) run by the reference itself with a recording session: chunk sizes for many
+    (n utterances, batchsize) pairs; nbatches = max(1, n / batchsize) is an integer division there"""
+    ref = json.load(open(os.path.join(GOLDEN, "mel2mag_chunks.json")))
+
+    class Eng(object):
+        def __init__(self):
+            self.sizes = []
+
+        def ssrn(self, Y):
+            self.sizes.append(len(Y))
+            return np.zeros((len(Y), 1, 1), np.float32)
+
+    class Sess(object):
+        def __init__(self):
+            self.eng = Eng()
+
+        def ensure_ready(self):
+            return self.eng
+
+    assert len(ref) >= 80
+    for key, sizes in ref.items():
+        n, bs = (int(v) for v in key.split(","))
+        sess = Sess()
+        Z = S.synth_mel2mag(None, np.zeros((n, 1, 1), np.float32), None, sess, batchsize=bs)
+        assert sess.eng.sizes == sizes, key
+        assert len(Z) == n
+
+
+def test_q_step0_of_the_oracle():
+    """g.Q at the first decode step (mels = 0, prev_max = 0), fetched from the reference graph by the generator"""
+    from oracle import ophelia_oracle as O
+    for tag in ("lj_free", "vctk_spk", "vctk03_lcc", "vctk_spk_audioenc"):
+        hp, meta, g = load_wiring_case(tag)
+        W = O.random_weights(hp, meta["weight_seed"], scopes=("Text2Mel/Audio",))
+        B = meta["B"]
+        S0 = np.zeros((B, hp.max_T, hp.n_mels), np.float32)             # S = concat(zeros, mels[:, :-1]) with mels = 0
+        Q = O.audio_enc(hp, S0, W, speakers=g.get("speakers"))
+        assert Q.shape == g["Q_step0"].shape
+        assert np.abs(Q - g["Q_step0"]).max() < 2e-5
