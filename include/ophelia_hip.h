@@ -196,6 +196,11 @@ int oph_op_attention(int device, const float* Q, const float* K, const float* V,
                      const int32_t* prev_max, int B, int T, int N, int d, int win,
                      float* R /*(B,T,2d)*/, float* alignments /*(B,N,T)*/,
                      int64_t* max_attentions /*(B,T)*/);
+/* oph_bench_conv1d_transpose: device-resident timing of the conv1d_transpose launches (SSRN D_4 / D_7) on seeded random
+ * data already in HBM -- the measurement behind bench.py's kernel_rooflines.  precision: 0 exact fp32 MFMA, 1 split-bf16 x3.
+ * Returns the average time of one layer evaluation and its ALGORITHMIC bytes / flops. */
+int oph_bench_conv1d_transpose(int device, int B, int T, int Cin, int Cout, int precision, int warmup, int iters,
+                               double* avg_us, double* alg_bytes, double* alg_flops);
 const char* oph_op_last_error(void);
 
 #ifdef __cplusplus

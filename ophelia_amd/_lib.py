@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libophelia_hip.so")
-SOURCES = ["oph_kernels.hip", "oph_decrun.hip", "oph_api.hip"]
+SOURCES = ["oph_kernels.hip", "oph_decrun.hip", "oph_cone.hip", "oph_api.hip"]
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
@@ -74,6 +74,7 @@ SIGNATURES = {
     "oph_op_hc": (C.c_int, [C.c_int, c_f32p] + [C.c_int] * 6 + [c_f32p] * 7),
     "oph_op_conv1d_transpose": (C.c_int, [C.c_int, c_f32p] + [C.c_int] * 4 + [c_f32p] * 5),
     "oph_op_attention": (C.c_int, [C.c_int, c_f32p, c_f32p, c_f32p, c_i32p] + [C.c_int] * 5 + [c_f32p, c_f32p, c_i64p]),
+    "oph_bench_conv1d_transpose": (C.c_int, [C.c_int] * 8 + [c_f64p, c_f64p, c_f64p]),
     "oph_op_last_error": (C.c_char_p, []),
 }
 

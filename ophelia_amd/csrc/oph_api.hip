@@ -65,6 +65,7 @@ struct Layer {
     float *Wt = nullptr, *bias = nullptr;       // conv / hc ; convT: even phase (taps x[t], x[t-1])
     float *Wt2 = nullptr;                        // convT odd phase (tap x[t])
     float *Wkn = nullptr; int ldn = 0;           // k=1 layers with N<=256: [kc][ldn] n-contiguous copy for row_chain
+    float *Wt_cone = nullptr, *bias_cone = nullptr;   // AudioDec highway layers: columns interleaved 32 H1 | 32 H2 per 64-column tile (oph_cone.hip)
     float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
 };
 
@@ -77,7 +78,7 @@ struct ProfClass {
     double ms = 0;
 };
 constexpr int CONE_KSPLIT = 4;   // split-K of the latency-bound decoder-cone GEMMs (partials summed by ln_rows)
-enum { PC_GEMM = 0, PC_GEMM64, PC_GEMM_BF16, PC_LN, PC_DEC, PC_ROWCHAIN, PC_ATTN_ROWS, PC_MISC, PC_DECRUN, PC_DECLOOP, PC_COUNT };   // PC_GEMM = the <128,128> instance
+enum { PC_GEMM = 0, PC_GEMM64, PC_GEMM_BF16, PC_LN, PC_DEC, PC_ROWCHAIN, PC_ATTN_ROWS, PC_MISC, PC_DECRUN, PC_DECLOOP, PC_CONE, PC_CONE1, PC_CONE2, PC_CONE3, PC_CONE4, PC_CONE5, PC_CONE6, PC_COUNT };   // PC_CONE + i: i-th fused cone layer of a step   // PC_GEMM = the <128,128> instance
 
 }  // namespace
 
@@ -124,6 +125,7 @@ struct oph_handle {
     volatile int* host_prog = nullptr;  // [0] last step whose attention is done  [1] stop step or INT_MAX
     int ndec_cus = 0;                   // CUs the critical stream may use (its CU mask, or the whole chip)
     int loop_capacity = -1;             // workgroups of dec_loop that can be resident at once (-1: not yet asked)
+    int loop_rows = 8;                  // rows (utterances) per workgroup of dec_loop: 8 (default) or 4 (OPH_RUN_ROWS)
     std::string err;
     bool finalized = false;
     // expected variables (TF names) and host copies
@@ -145,6 +147,10 @@ struct oph_handle {
     int B = 0, Bpad = 0;
     int *d_L = nullptr, *d_ends = nullptr, *d_spk = nullptr, *d_p = nullptr, *d_tends = nullptr, *d_ctl = nullptr;  // ctl[0]=n_ended ctl[1]=stop_after
     float *KV = nullptr, *Yout = nullptr, *Ytm = nullptr, *align = nullptr, *Z = nullptr;
+    // pipelined batches: TextEnc of the NEXT batch runs ahead on the SSRN partition while this batch decodes
+    float* KV2[2] = {nullptr, nullptr}; int kv_cur = 0;
+    bool want_preenc = false;           // set around a pipelined decode: queue the next batch's TextEnc once the loop kernel is launched
+    hipEvent_t ev_preenc = nullptr; bool preenc_valid = false; uint64_t preenc_epoch = 0, stage_epoch = 0;
     float *Qhist = nullptr, *Rrow = nullptr;
     std::vector<float*> ae_hist, ae_raw;          // AudioEnc per-layer input history / raw outputs
     std::vector<float*> ad_raw, ad_xrow;          // AudioDec row chain
@@ -154,6 +160,9 @@ struct oph_handle {
     std::vector<int*> d_tab, d_need, d_res;       // per hc layer h<n-1: tables for computing layer h over Hset[h+1]
     int* d_off0 = nullptr;                        // Hset[0] on device
     std::vector<float*> cone[2];                  // cone[t&1][h]: [|Hset[h]|][Bpad][256], ping-pong over steps
+    bool cone_fused = false;                      // cone layers as fused GEMM + LayerNorm launches (oph_cone.hip)
+    unsigned long long* d_cone_stats = nullptr;   // row-statistics granules of the fused cone layers
+    uint32_t cone_epoch = 0;
     float *coneR = nullptr, *coneRaw = nullptr, *coneTmp = nullptr;
     int ldy = 0;
     // timing
@@ -457,6 +466,25 @@ int pack_layer(oph_handle* h, Layer& l) {
     return (l.Wt && l.bias && l.g1 && l.b1) ? 0 : -1;
 }
 
+// AudioDec highway layer for the fused cone kernel (oph_cone.hip): column n' of tile j = n'/32 is H1 channel 16j + i
+// for i = n'%32 < 16, H2 channel 16j + i - 16 otherwise, so that one 32-column tile holds both halves of its channels.
+int pack_cone_layer(oph_handle* h, Layer& l) {
+    const std::vector<float>& k = *getw(h, l.scope + "/conv1d/kernel");      // (size, cin, 2C)
+    const std::vector<float>& b = *getw(h, l.scope + "/conv1d/bias");
+    const int C = l.cout, N = 2 * C;
+    std::vector<float> w((size_t)l.Nalloc * l.size * l.kc, 0.f), bb((size_t)l.Nalloc, 0.f);
+    for (int np = 0; np < N; ++np) {
+        const int j = np / 32, i = np % 32;
+        const int n = i < 16 ? 16 * j + i : C + 16 * j + (i - 16);
+        bb[np] = b[n];
+        for (int t = 0; t < l.size; ++t)
+            for (int c = 0; c < l.cin; ++c) w[(size_t)np * l.size * l.kc + (size_t)t * l.kc + c] = k[((size_t)t * l.cin + c) * N + n];
+    }
+    l.Wt_cone = upload(h, w);
+    l.bias_cone = upload(h, bb);
+    return (l.Wt_cone && l.bias_cone) ? 0 : -1;
+}
+
 // ------------------------------------------------------------------ launch wrappers with accounting
 void run_gemm(oph_handle* h, const GemmArgs& a, int cin_true, int prec = 0) {
     const int cls = prec ? PC_GEMM_BF16 : (conv_gemm_tile_m(a.M, a.N) == 128 ? PC_GEMM : PC_GEMM64);
@@ -576,7 +604,7 @@ int ensure_decode_state(oph_handle* h, int B) {
         h->ae_hist.clear(); h->ae_raw.clear(); h->ad_raw.clear(); h->ad_xrow.clear();
         h->cone[0].clear(); h->cone[1].clear(); h->d_tab.clear(); h->d_need.clear(); h->d_res.clear(); h->Hset.clear();
         for (auto& ge : h->dec_graph) if (ge) { hipGraphExecDestroy(ge); ge = nullptr; }
-        h->KV = nullptr; h->capB = 0; h->actA = h->actB = h->raw = h->actA2 = h->actB2 = h->raw2 = nullptr;
+        h->KV = nullptr; h->KV2[0] = h->KV2[1] = nullptr; h->preenc_valid = false; h->capB = 0; h->actA = h->actB = h->raw = h->actA2 = h->actB2 = h->raw2 = nullptr;
         h->d_loop_layers = nullptr;
         h->pipelined = false; h->buf = 0; h->ssrn_inflight[0] = h->ssrn_inflight[1] = false;
     }
@@ -597,7 +625,8 @@ int ensure_decode_state(oph_handle* h, int B) {
         h->d_stamps = h->dalloc<long long>((size_t)2 * 32 * LOOP_MAX_LAYERS * 8);
         h->d_sigdbg = h->dalloc<long long>((size_t)m.max_T * 8);
     }
-    h->KV = h->dalloc<float>((size_t)Bpad * m.max_N * 2 * d);
+    for (int i = 0; i < 2; ++i) h->KV2[i] = h->dalloc<float>((size_t)Bpad * m.max_N * 2 * d);
+    h->kv_cur = 0; h->KV = h->KV2[0]; h->preenc_valid = false;
     for (int i = 0; i < 2; ++i) h->Yout2[i] = h->dalloc<float>((size_t)Bpad * m.max_T * h->ldy);
     h->Yout = h->Yout2[0];
     h->Ytm = h->dalloc<float>((size_t)(m.max_T + 1) * Bpad * h->ldy);
@@ -662,6 +691,8 @@ int ensure_decode_state(oph_handle* h, int B) {
     h->coneR = h->dalloc<float>(maxrows * Bpad * 2 * d);
     h->coneRaw = h->dalloc<float>((size_t)CONE_KSPLIT * maxrows * Bpad * (size_t)round_up(2 * d, 128));
     h->coneTmp = h->dalloc<float>(maxrows * Bpad * (size_t)ld_cat);
+    h->d_cone_stats = h->dalloc<unsigned long long>(((maxrows * Bpad + 31) / 32) * 16 * 64 * 4);
+    h->cone_epoch = 0;
     hipStreamSynchronize(h->stream);
     if (!h->coneTmp || !h->Z2[1] || !h->Yout2[1]) { h->fail("out of device memory for decode state"); return OPH_ERR_DEVICE; }
     return ensure_batched_capacity(h, B);
@@ -711,6 +742,51 @@ void launch_cone(oph_handle* h, int t) {
     h->pbegin(PC_ATTN_ROWS);
     launch_attn_rows(ar, g_cur);
     h->pend(PC_ATTN_ROWS, (double)n0 * B * 3.0 * d * 4.0, (double)n0 * B * 4.0 * m.attention_win_size * d);
+    if (h->cone_fused) {
+        // every cone layer = ONE launch: conv GEMM with LayerNorm (+ gate + residual) in the epilogue (oph_cone.hip)
+        int fused_idx = 0;
+        auto run_fused = [&](ConeGemmArgs& c, const Layer& l, int cls_rows) {
+            const int cls = PC_CONE + std::min(fused_idx++, 6);
+            c.stats = h->d_cone_stats; c.epoch = ++h->cone_epoch;
+            c.stop_after = stop_after; c.t = t; c.err = h->d_ctl + 2;
+            c.kc = l.kc; c.ntaps = l.ntaps; c.nonorm = !l.ln;
+            h->pbegin(cls);
+            launch_cone_gemm(c, c.M <= 256 ? 1 : 0, g_cur);
+            const double K = (double)l.ntaps * l.cin;
+            h->pend(cls, ((double)c.M * (K / l.ntaps) + (double)c.M * l.cout + (double)l.N * K) * 4.0, 2.0 * c.M * l.N * K);
+            (void)cls_rows;
+        };
+        const float* x = h->coneR; int ldx = 2 * d;
+        for (int k = 0; k < pre; ++k) {
+            const Layer& l = h->audiodec[k];
+            ConeGemmArgs c{};
+            c.X = x; c.ldx = ldx; c.Wt = l.Wt; c.ldw = l.kc; c.bias = l.bias; c.M = n0 * Bpad; c.NT = (l.N + 31) / 32; c.dense = 1; c.Bpad = Bpad;
+            c.hc = 0; c.C = l.cout; c.g1 = l.g1; c.b1 = l.b1; c.act = l.act;
+            const bool spk_next = (k + 1 < pre) && h->audiodec[k + 1].ccat > 0;
+            if (spk_next) {
+                const Layer& nx = h->audiodec[k + 1];
+                c.Y = h->coneTmp; c.ldy = nx.kc; c.spk_table = h->emb_spk; c.spk_ids = h->d_spk; c.spk_dim = nx.ccat;
+                x = h->coneTmp; ldx = nx.kc;
+            } else {
+                c.Y = cone[0]; c.ldy = h->audiodec[pre].kc;
+                x = cone[0]; ldx = c.ldy;
+            }
+            run_fused(c, l, 0);
+        }
+        for (int k = 0; k + 1 < nh; ++k) {
+            const Layer& l = h->audiodec[pre + k];
+            const int n_out = (int)h->Hset[k + 1].size();
+            ConeGemmArgs c{};
+            c.X = cone[k]; c.ldx = l.kc; c.Wt = l.Wt_cone; c.ldw = 3 * l.kc; c.bias = l.bias_cone; c.M = n_out * Bpad; c.NT = (l.N + 31) / 32;
+            c.dense = 0; c.Bpad = Bpad; c.n_out = n_out; c.j = t; c.tab = h->d_tab[k]; c.need = h->d_need[k];
+            c.hc = 1; c.C = l.cout; c.g1 = l.g1; c.b1 = l.b1; c.g2 = l.g2; c.b2 = l.b2;
+            c.Xres = cone[k]; c.ldres = l.kc; c.restab = h->d_res[k];
+            c.Y = cone[k + 1]; c.ldy = h->audiodec[pre + k + 1].kc;
+            run_fused(c, l, 0);
+        }
+        g_cur = saved;
+        return;
+    }
     // k=1 layers before the highway stack, on all Hset[0] positions
     const float* x = h->coneR; int ldx = 2 * d;
     for (int k = 0; k < pre; ++k) {
@@ -912,6 +988,8 @@ bool run_supported(const oph_handle* h) {
     return true;
 }
 
+int run_encode_into(oph_handle* h, float* KVdst, hipStream_t stream, int wsi);      // defined with the batched networks below
+
 // ---------------------------------------------------------------- whole-decode launch (dec_loop)
 // Static layer table of a decode: AudioEnc (layer 0 consumes the previous step's last AudioDec layer) -> attention +
 // AudioDec input convs -> AudioDec highway layers (taps from the cone ping-pong buffers) -> k=1 tail.
@@ -1001,8 +1079,15 @@ int decode_loop(oph_handle* h, int t_end, int stop_mode) {
         (void)nl; (void)i;
     }
     h->pbegin(PC_DECLOOP);
-    launch_dec_loop(a, h->loop_slices, h->loop_kmax, h->sdec);
+    launch_dec_loop(a, h->loop_slices, h->loop_rows, h->loop_kmax, h->sdec);
     h->pend(PC_DECLOOP, bytes * t_end, flops * t_end);
+    if (h->want_preenc) {
+        // the staged text's K,V for the NEXT call, into the other KV buffer, on the SSRN stream (own CU partition, own
+        // workspace; in stream order behind the previous batch's SSRN and ahead of this batch's)
+        if (run_encode_into(h, h->KV2[h->kv_cur ^ 1], h->sssrn, 1) == OPH_OK && hipEventRecord(h->ev_preenc, h->sssrn) == hipSuccess) {
+            h->preenc_valid = true; h->preenc_epoch = h->stage_epoch;
+        }
+    }
     // side stream: cone(t) after the attention of step t-1, then the word the loop kernel polls before AudioDec(t)
     g_cur = h->scone;
     const auto t_host0 = std::chrono::steady_clock::now();
@@ -1219,9 +1304,10 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
         if (h->loop_capacity < 0) {
             int ncu = h->ndec_cus;
             if (ncu <= 0) { hipDeviceProp_t prop; ncu = hipGetDeviceProperties(&prop, h->device) == hipSuccess ? prop.multiProcessorCount : 0; }
-            h->loop_capacity = dec_loop_blocks_per_cu(h->loop_kmax) * ncu;
+            if (const char* rr = getenv("OPH_RUN_ROWS")) h->loop_rows = atoi(rr) == 4 ? 4 : 8;
+            h->loop_capacity = dec_loop_blocks_per_cu(h->loop_rows, h->loop_kmax) * ncu;
         }
-        if (h->loop_slices * (h->Bpad / dec_loop_rows()) > h->loop_capacity) loop_mode = false;
+        if (h->loop_slices * (h->Bpad / h->loop_rows) > h->loop_capacity) loop_mode = false;
     }
     if (h->use_sigval || loop_mode) {
         // a fresh value range for this loop: every value of an earlier loop is below sig_base + 1
@@ -1322,30 +1408,35 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
     if (steps_run || stop_mode == OPH_STOP_REFERENCE || h->use_run) {
         HIPCHK(h, hipMemcpyAsync(ctl, h->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (ctl[2] != 0) { h->fail(ctl[2] == 3 ? "decoder loop: the side stream never saw the attention signal (time-out)" : ctl[2] == 2 ? "decoder loop: the side stream's cone never signalled (time-out)" : "decoder run: a workgroup hand-off timed out (workgroups of one run were not co-resident)"); return OPH_ERR_DEVICE; }
+        if (ctl[2] != 0) { h->fail(ctl[2] == 4 ? "cone layer: the row-statistics hand-off timed out" : ctl[2] == 3 ? "decoder loop: the side stream never saw the attention signal (time-out)" : ctl[2] == 2 ? "decoder loop: the side stream's cone never signalled (time-out)" : "decoder run: a workgroup hand-off timed out (workgroups of one run were not co-resident)"); return OPH_ERR_DEVICE; }
     }
     if (steps_run) *steps_run = ctl[1] != INT_MAX ? ctl[1] + 1 : last;
     HIPCHK(h, hipGetLastError());
     return OPH_OK;
 }
 
-int run_encode(oph_handle* h) {
+// TextEnc (networks.py:121-212) of the staged text into `KVdst` on `stream` with workspace set `wsi`
+int run_encode_into(oph_handle* h, float* KVdst, hipStream_t stream, int wsi) {
     const oph_dims& m = h->dm;
-    g_cur = h->stream;
+    hipStream_t saved = g_cur;
+    g_cur = stream;
     const int B = h->B;
+    float* ws = wsi ? h->actA2 : h->actA;
     // embed_1 (modules.py:15-44) -> rows [B*max_N][e]
     const Layer& first = h->textenc[0];
     const int ld0 = first.kc;                     // round_up(e [+ speaker embedding], 32)
     h->pbegin(PC_MISC);
-    launch_embed(h->d_L, (long long)B * m.max_N, h->emb_text, m.e, h->actA, ld0, h->stream);
+    launch_embed(h->d_L, (long long)B * m.max_N, h->emb_text, m.e, ws, ld0, stream);
     h->pend(PC_MISC, (double)B * m.max_N * m.e * 4.0, 0);
     if (first.cat_table)                          // 'text_encoder_input': [embed(L) | embed(speaker)]  networks.py:138-144
-        launch_spk_append_rows(h->actA, ld0, (long long)B * m.max_N, m.max_N, m.e, first.cat_table, h->d_spk, first.ccat, h->stream);
+        launch_spk_append_rows(ws, ld0, (long long)B * m.max_N, m.max_N, m.e, first.cat_table, h->d_spk, first.ccat, stream);
     // last highway layer writes K|V rows straight into the resident KV buffer [B][N][2d]
-    run_batched(h, h->textenc, h->actA, ld0, B, m.max_N, 0, 0, h->KV, 2 * m.d, 2 * m.d, nullptr, nullptr);
+    run_batched(h, h->textenc, ws, ld0, B, m.max_N, wsi, 0, KVdst, 2 * m.d, 2 * m.d, nullptr, nullptr);
+    g_cur = saved;
     HIPCHK(h, hipGetLastError());
     return OPH_OK;
 }
+int run_encode(oph_handle* h) { return run_encode_into(h, h->KV, h->stream, 0); }
 
 int run_ssrn_on(oph_handle* h, const float* Yrows, int ldy, int B, int T, float* Zout, int wsi = 0) {
     const oph_dims& m = h->dm;
@@ -1388,7 +1479,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
     oph_handle* h = new oph_handle();
     h->dm = m;
     h->device = device;
-    static const char* names[PC_COUNT] = {"conv_gemm_f32<128,128>", "conv_gemm_f32<64,64>", "conv_gemm_bf16x3", "ln_rows", "dec_layer16", "row_chain", "attn_rows", "misc", "dec_run", "dec_loop"};
+    static const char* names[PC_COUNT] = {"conv_gemm_f32<128,128>", "conv_gemm_f32<64,64>", "conv_gemm_bf16x3", "ln_rows", "dec_layer16", "row_chain", "attn_rows", "misc", "dec_run", "dec_loop", "cone_gemm_ln[0]", "cone_gemm_ln[1]", "cone_gemm_ln[2]", "cone_gemm_ln[3]", "cone_gemm_ln[4]", "cone_gemm_ln[5]", "cone_gemm_ln[6]"};
     for (int i = 0; i < PC_COUNT; ++i) h->prof[i].name = names[i];
     // CU partition for the decode loop (MI355X: 256 CUs, mask bit i -> XCD i%8): the ~25 dependent
     // tiny launches of a step get a private slice of 8 CUs in every XCD so the concurrently running
@@ -1431,6 +1522,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
         hipEventCreateWithFlags(&h->ev_ssrn_done[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_ssrn_done[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_preenc, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_attn, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_cone, hipEventDisableTiming) != hipSuccess ||
@@ -1474,7 +1566,7 @@ int oph_destroy(oph_handle* h) {
     for (auto& ge : h->dec_graph) if (ge) hipGraphExecDestroy(ge);
     for (auto& pc : h->prof)
         for (auto& e : pc.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    for (hipEvent_t e : {h->ev0, h->ev1, h->ev_attn, h->ev_cone, h->ev_in, h->ev_out, h->ev_dec_done, h->ev_ssrn_done[0], h->ev_ssrn_done[1]})
+    for (hipEvent_t e : {h->ev0, h->ev1, h->ev_attn, h->ev_cone, h->ev_in, h->ev_out, h->ev_dec_done, h->ev_ssrn_done[0], h->ev_ssrn_done[1], h->ev_preenc})
         if (e) hipEventDestroy(e);
     TRACE("destroy: free");
     for (void* p : h->allocs) hipFree(p);
@@ -1531,6 +1623,11 @@ int oph_finalize_weights(oph_handle* h) {
     for (auto* net : {&h->textenc, &h->audioenc, &h->audiodec, &h->ssrn})
         for (Layer& l : *net)
             if (pack_layer(h, l) != 0) { h->fail("out of device memory packing %s", l.scope.c_str()); return OPH_ERR_DEVICE; }
+    // fused cone layers: every AudioDec highway layer but the last is re-evaluated over history positions
+    h->cone_fused = getenv("OPH_CONE_FUSED") && !getenv("OPH_NO_CONE_FUSED") && !(h->dm.flags & OPH_FLAG_LCC) && h->dm.d % 16 == 0;
+    if (h->cone_fused)
+        for (int k = 0; k + 1 < h->n_hc_dec; ++k)
+            if (pack_cone_layer(h, h->audiodec[h->dec_pre + k]) != 0) { h->fail("out of device memory packing the cone weights"); return OPH_ERR_DEVICE; }
     h->emb_text = upload(h, h->hostw["Text2Mel/TextEnc/embed_1/lookup_table"]);
     if (h->dm.flags & OPH_FLAG_SPK_AUDIO_DECODER_INPUT) h->emb_spk = upload(h, h->hostw["Text2Mel/AudioDec/embed_2/lookup_table"]);
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1569,6 +1666,7 @@ int oph_stage_text(oph_handle* h, const int32_t* L, const int32_t* ends, const i
     HIPCHK(h, hipMemcpyAsync(h->d_ends, ends, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
     if (ms) HIPCHK(h, hipMemcpyAsync(h->d_spk, spk, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->stage_epoch++;                     // a pre-encoded K,V of the previous text no longer applies
     return OPH_OK;
 }
 
@@ -1614,11 +1712,23 @@ int oph_run_resident(oph_handle* h, int stop_mode, int run_ssrn, int32_t* steps_
     if (rc) return rc;
     TRACE("mode set; encode");
     g_cur = h->stream;
-    if ((rc = run_encode(h))) return rc;
+    static const bool no_preenc = getenv("OPH_NO_PREENCODE") != nullptr;
+    if (pipe && h->preenc_valid && h->preenc_epoch == h->stage_epoch) {
+        // K,V of the staged text were computed ahead (on the SSRN partition, during the previous batch's decode)
+        h->kv_cur ^= 1; h->KV = h->KV2[h->kv_cur];
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_preenc, 0));
+    } else {
+        if (h->preenc_valid) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_preenc, 0));    // a stale pre-encode still owns its buffers
+        if ((rc = run_encode(h))) return rc;
+    }
+    h->preenc_valid = false;
     TRACE("encode queued; reset");
     reset_decode(h);
     TRACE("reset done; decode");
-    if ((rc = decode_range(h, 0, h->dm.max_T, stop_mode, steps_run))) return rc;
+    h->want_preenc = pipe && !no_preenc && h->ev_preenc != nullptr;
+    rc = decode_range(h, 0, h->dm.max_T, stop_mode, steps_run);
+    h->want_preenc = false;
+    if (rc) return rc;
     TRACE("decode done");
     if (pipe) {
         HIPCHK(h, hipEventRecord(h->ev_dec_done, h->stream));
@@ -1852,14 +1962,16 @@ int oph_ssrn(oph_handle* h, const float* Y, int B, int T, float* Z) {
     float* dY = nullptr; float* dZ = nullptr;
     const size_t zn = (size_t)B * T * m.r * m.full_dim;
     HIPCHK(h, hipMalloc((void**)&dY, (size_t)B * T * m.n_mels * 4));
-    HIPCHK(h, hipMalloc((void**)&dZ, zn * 4));
-    hipMemcpyAsync(dY, Y, (size_t)B * T * m.n_mels * 4, hipMemcpyHostToDevice, h->stream);
-    launch_pad_rows(dY, m.n_mels, h->actB, ldy, (long long)B * T, m.n_mels, h->stream);
-    rc = run_ssrn_on(h, h->actB, ldy, B, T, dZ);
-    hipMemcpyAsync(Z, dZ, zn * 4, hipMemcpyDeviceToHost, h->stream);
-    hipError_t e = hipStreamSynchronize(h->stream);
+    if (hipMalloc((void**)&dZ, zn * 4) != hipSuccess) { hipFree(dY); (void)hipGetLastError(); h->fail("out of device memory for the SSRN output"); return OPH_ERR_DEVICE; }
+    hipError_t e = hipMemcpyAsync(dY, Y, (size_t)B * T * m.n_mels * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        launch_pad_rows(dY, m.n_mels, h->actB, ldy, (long long)B * T, m.n_mels, h->stream);
+        rc = run_ssrn_on(h, h->actB, ldy, B, T, dZ);
+        e = hipMemcpyAsync(Z, dZ, zn * 4, hipMemcpyDeviceToHost, h->stream);
+    }
+    const hipError_t es = hipStreamSynchronize(h->stream);
     hipFree(dY); hipFree(dZ);
-    if (e != hipSuccess) { h->fail("ssrn failed: %s", hipGetErrorString(e)); return OPH_ERR_DEVICE; }
+    if (e != hipSuccess || es != hipSuccess) { h->fail("ssrn failed: %s", hipGetErrorString(e != hipSuccess ? e : es)); return OPH_ERR_DEVICE; }
     return rc;
 }
 
@@ -2061,6 +2173,62 @@ int oph_op_conv1d_transpose(int device, const float* x, int B, int T, int Cin, i
     e.H = dh; e.ldh = Nalloc; e.M = 2 * M; e.C = Cout; e.mode = PRE_CONV; e.act = ACT_NONE; e.g1 = dg; e.b1 = db; e.Y = dy; e.ldy = Cout; e.ypad = Cout;
     launch_epilogue(e, c.s);
     hipMemcpyAsync(y, dy, (size_t)2 * M * Cout * 4, hipMemcpyDeviceToHost, c.s);
+    return c.finish();
+}
+
+// Device-resident timing of modules.conv1d_transpose (SSRN D_4 / D_7, networks.py:483-486) for the roofline report:
+// the same launches as oph_op_conv1d_transpose / the SSRN path (even-phase GEMM, odd-phase GEMM, LayerNorm rows), on
+// seeded random device data, `iters` repetitions bracketed by HIP events after `warmup` untimed ones.
+int oph_bench_conv1d_transpose(int device, int B, int T, int Cin, int Cout, int precision, int warmup, int iters,
+                               double* avg_us, double* alg_bytes, double* alg_flops) {
+    OpCtx c(device);
+    if (!c.ok) return OPH_ERR_DEVICE;
+    if (Cout > 1280 || B < 1 || T < 1 || iters < 1 || !avg_us) { g_op_error = "bad argument"; return OPH_ERR_INVALID; }
+    const int kc = round_up(Cin, 32), Nalloc = round_up(Cout, 128), M = B * T;
+    std::vector<float> we((size_t)Nalloc * 2 * kc, 0.f), wo((size_t)Nalloc * kc, 0.f), xh((size_t)M * kc, 0.f), bh((size_t)Nalloc, 0.f);
+    uint32_t st = 12345u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.0f - 0.5f; };
+    const float ws = sqrtf(2.6f / (3.0f * Cin));
+    for (int n = 0; n < Cout; ++n) {
+        bh[n] = 0.02f * rnd();
+        for (int ci = 0; ci < Cin; ++ci) { we[(size_t)n * 2 * kc + ci] = ws * rnd(); we[(size_t)n * 2 * kc + kc + ci] = ws * rnd(); wo[(size_t)n * kc + ci] = ws * rnd(); }
+    }
+    for (int m = 0; m < M; ++m) for (int ci = 0; ci < Cin; ++ci) xh[(size_t)m * kc + ci] = rnd();
+    std::vector<float> gh((size_t)round_up(Cout, 256), 1.f), zh((size_t)round_up(Cout, 256), 0.f);
+    float* dx = c.up(xh.data(), xh.size());
+    float* dwe = c.up(we.data(), we.size()); float* dwo = c.up(wo.data(), wo.size());
+    float* dbias = c.up(bh.data(), bh.size());
+    float* dh = c.alloc<float>((size_t)2 * M * Nalloc);
+    float* dy = c.alloc<float>((size_t)2 * M * Cout);
+    float* dg = c.up(gh.data(), gh.size()); float* db = c.up(zh.data(), zh.size());
+    if (!c.ok) return OPH_ERR_DEVICE;
+    hipStreamSynchronize(c.s);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { g_op_error = "event creation failed"; return OPH_ERR_DEVICE; }
+    auto once = [&]() {
+        GemmArgs g{};
+        g.X = dx; g.ldx = kc; g.bias = dbias; g.ldh = 2 * Nalloc; g.M = M; g.N = Cout; g.kc = kc; g.mode = 0; g.T = T;
+        g.Wt = dwe; g.ldw = 2 * kc; g.ntaps = 2; g.off[0] = 0; g.off[1] = -1; g.H = dh;
+        if (precision) launch_conv_gemm_bf16x3(g, c.s); else launch_conv_gemm(g, c.s);
+        g.Wt = dwo; g.ldw = kc; g.ntaps = 1; g.off[0] = 0; g.H = dh + Nalloc;
+        if (precision) launch_conv_gemm_bf16x3(g, c.s); else launch_conv_gemm(g, c.s);
+        EpiArgs e{};
+        e.H = dh; e.ldh = Nalloc; e.M = 2 * M; e.C = Cout; e.mode = PRE_CONV; e.act = ACT_NONE; e.g1 = dg; e.b1 = db; e.Y = dy; e.ldy = Cout; e.ypad = Cout;
+        launch_epilogue(e, c.s);
+    };
+    for (int i = 0; i < warmup; ++i) once();
+    hipEventRecord(e0, c.s);
+    for (int i = 0; i < iters; ++i) once();
+    hipEventRecord(e1, c.s);
+    float ms = 0.f;
+    hipError_t er = hipEventSynchronize(e1);
+    if (er == hipSuccess) er = hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    if (er != hipSuccess) { g_op_error = hipGetErrorString(er); return OPH_ERR_DEVICE; }
+    *avg_us = (double)ms * 1e3 / iters;
+    // per input row Cin*4 B in + 2*Cout*4 B out, + the 3*Cin*Cout weights once per call; 2*3*Cin*Cout flop per input row
+    if (alg_bytes) *alg_bytes = ((double)M * Cin + 2.0 * M * Cout + 3.0 * Cin * Cout) * 4.0;
+    if (alg_flops) *alg_flops = 2.0 * 3.0 * (double)M * Cin * Cout;
     return c.finish();
 }
 

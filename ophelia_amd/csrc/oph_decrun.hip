@@ -332,14 +332,16 @@ typedef const __attribute__((address_space(4))) LoopLayer* LoopLayerConstPtr;   
 // of each 16-wide chunk:  A[lane] = x[row lane&3][16 ch + 4 kk + e],  B[lane] = Wt[n0 + 4cg + (lane&3)][16 ch + 4 kk + e],
 // D[lane][reg i] += A[4 blk + i] * B[lane]  (profiles/mfma4x4_probe.hip).  One ds_read_b128 + 4 MFMAs per chunk instead of
 // 4 reads + 16 FMAs: the contraction of a highway layer drops from ~1.0 us to ~0.25 us per wave (profiles/r02 stamps).
-constexpr int LOOP_R = 4;
+// R rows per workgroup = R/4 row quads that share every weight fragment (R = 8: half the weight traffic of R = 4 per
+// row, the dominant issue cost of a highway layer -- profiles/r02 ablations).
 template <int R>
 __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
-    static_assert(R == LOOP_R, "the 4x4x1 MFMA mapping is written for 4 rows per workgroup");
+    static_assert(R == 4 || R == 8, "rows per workgroup: one or two quads of the 4x4x1 MFMA");
+    constexpr int RQ = R / 4;
     constexpr int PF = (RUN_KMAX / 16 + R - 1) / R;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* part = smem;                          // [R waves][64 lanes][4 rows] K-split partial sums
-    float* xs = smem + R * 64 * 4;               // [R][ldxs]
+    float* part = smem;                          // [R waves][64 lanes][RQ quads][4 rows] K-split partial sums
+    float* xs = smem + R * 64 * RQ * 4;          // [R][ldxs]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = blockIdx.x, n0 = g * 16, row0 = blockIdx.y * R, grow = row0 + w;
@@ -397,6 +399,29 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
             const int pre = Ls[l].pre, cin = Ls[l].cin, nonorm = Ls[l].nonorm, kc = Ls[l].kc, ntaps = Ls[l].ntaps;
             const bool cok = c < cin, two = pre >= RUN_HC, cols = n0 < Ls[l].N;
             const bool is_attn = l == a.attn_layer;
+
+            // A column slice beyond this layer's width (k=1 layers are 256 or n_mels wide, highway layers 512) has
+            // nothing to contract here.  It needs the layer's input only as the highway residual of the next prologue --
+            // which the consumer of a k=1 layer never uses -- so it sits the layer out: fewer pollers on the hand-off.
+            if (!cols && (l + 1 < NL ? Ls[l + 1].pre : Ls[0].pre) < RUN_HC && !(a.dbg & 16)) {
+                if (is_attn && t >= 1) {
+                    long long t0 = 0;
+                    for (int it = 0; (int)(__hip_atomic_load(a.sig + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - (a.sig_base + (unsigned)t)) < 0; ++it) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if ((it & 63) == 63) {
+                            const long long now = wall_clock64();
+                            if (t0 == 0) t0 = now;
+                            if (now - t0 > RUN_TIMEOUT_TICKS || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                                if (lane == 0) __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                break;
+                            }
+                        }
+                    }
+                }
+                if (l + 1 < NL) fetch_layer(l + 1, t);
+                else if (t + 1 < a.t_end) fetch_layer(0, t + 1);
+                continue;
+            }
 
             // ---- 1. requests that do not depend on the hand-off
             f32x4 g1v = zero4, b1v = zero4, g2v = zero4, b2v = zero4;
@@ -594,23 +619,36 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
             __syncthreads();
             LOOP_STAMP(3);
 
-            // ---- 5. 4 x 16 slice on the 4x4x1 MFMA, K split round-robin over the 4 waves
+            // ---- 5. R x 16 slice on the 4x4x1 MFMA, K split round-robin over the R waves; every LDS read of the layer is
+            //         issued before the first MFMA, two accumulators per row quad
             if (cols) {
-                f32x4 acc0 = zero4, acc1 = zero4;
+                f32x4 acc[RQ][2];
+#pragma unroll
+                for (int rq = 0; rq < RQ; ++rq) { acc[rq][0] = zero4; acc[rq][1] = zero4; }
                 const float* xa = xs + mq * ldxs + mkk * 4;
                 const int nch = Ktot >> 4;
+                f32x4 xf[PF][RQ];
 #pragma unroll
                 for (int i = 0; i < PF; ++i) {
-                    const int ch = w + R * i;
-                    if (ch < nch) {
-                        const f32x4 xf = *(const f32x4*)(xa + ch * 16);
-                        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(xf[0], bfrag[i][0], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(xf[1], bfrag[i][1], acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(xf[2], bfrag[i][2], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(xf[3], bfrag[i][3], acc1, 0, 0, 0);
+                    const int ch = min(w + R * i, nch - 1);
+#pragma unroll
+                    for (int rq = 0; rq < RQ; ++rq) xf[i][rq] = *(const f32x4*)(xa + rq * 4 * ldxs + ch * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < PF; ++i) {
+                    if (w + R * i < nch) {
+#pragma unroll
+                        for (int rq = 0; rq < RQ; ++rq) {
+                            acc[rq][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xf[i][rq][0], bfrag[i][0], acc[rq][0], 0, 0, 0);
+                            acc[rq][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xf[i][rq][1], bfrag[i][1], acc[rq][1], 0, 0, 0);
+                            acc[rq][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xf[i][rq][2], bfrag[i][2], acc[rq][0], 0, 0, 0);
+                            acc[rq][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xf[i][rq][3], bfrag[i][3], acc[rq][1], 0, 0, 0);
+                        }
                     }
                 }
-                *(f32x4*)(part + (w * 64 + lane) * 4) = acc0 + acc1;      // [row i] of (column mcol, k-lane mkk)
+#pragma unroll
+                for (int rq = 0; rq < RQ; ++rq)
+                    *(f32x4*)(part + ((w * 64 + lane) * RQ + rq) * 4) = acc[rq][0] + acc[rq][1];      // [row i] of (quad rq, column mcol, k-lane mkk)
             }
             LOOP_STAMP(7);
             const float bias_cur = bias_v;
@@ -621,11 +659,11 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
             if (cols && tid < 16 * R) {
                 const int row = tid >> 4, col = tid & 15;
                 float v = bias_cur;
-                const float* pr = part + (16 * (col >> 2) + (col & 3)) * 4 + row;
+                const float* pr = part + ((16 * (col >> 2) + (col & 3)) * RQ + (row >> 2)) * 4 + (row & 3);
 #pragma unroll
                 for (int ww = 0; ww < R; ++ww)
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) v += pr[(ww * 64 + 4 * kk) * 4];
+                    for (int kk = 0; kk < 4; ++kk) v += pr[(ww * 64 + 4 * kk) * RQ * 4];
                 granule_store(a.gbuf + ((size_t)l * Bpad + row0 + row) * RUN_GCOLS + n0 + col,
                               a.epoch0 + (unsigned)(t * LOOP_MAX_LAYERS + l + 1), v);
             }
@@ -715,23 +753,27 @@ void launch_sig_set(unsigned* sig, unsigned value, long long* stamp, hipStream_t
 template <int R>
 static void launch_dec_loop_t(const LoopArgs& a, int col_slices, int kmax, hipStream_t s) {
     static thread_local std::map<int, size_t> done;
-    const size_t lds_bytes = (size_t)(R * 64 * 4 + R * (kmax + 16)) * 4;
+    const size_t lds_bytes = (size_t)(R * 64 * (R / 4) * 4 + R * (kmax + 16)) * 4;
     int dev = 0;
     (void)hipGetDevice(&dev);
     size_t& d = done[dev];
     if (d < lds_bytes) { (void)hipFuncSetAttribute((const void*)dec_loop<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); d = lds_bytes; }
     hipLaunchKernelGGL(dec_loop<R>, dim3(col_slices, a.Bpad / R), dim3(64 * R), lds_bytes, s, a);
 }
-void launch_dec_loop(const LoopArgs& a, int col_slices, int kmax, hipStream_t s) { launch_dec_loop_t<LOOP_R>(a, col_slices, kmax, s); }
-int dec_loop_rows() { return LOOP_R; }
+void launch_dec_loop(const LoopArgs& a, int col_slices, int rows_per_group, int kmax, hipStream_t s) {
+    if (rows_per_group == 4) launch_dec_loop_t<4>(a, col_slices, kmax, s);
+    else launch_dec_loop_t<8>(a, col_slices, kmax, s);
+}
 // workgroups of dec_loop that fit on one CU at once (the loop kernel needs ALL of its workgroups resident)
-int dec_loop_blocks_per_cu(int kmax) {
-    const size_t lds_bytes = (size_t)(LOOP_R * 64 * 4 + LOOP_R * (kmax + 16)) * 4;
-    (void)hipFuncSetAttribute((const void*)dec_loop<LOOP_R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+template <int R>
+static int blocks_per_cu_t(int kmax) {
+    const size_t lds_bytes = (size_t)(R * 64 * (R / 4) * 4 + R * (kmax + 16)) * 4;
+    (void)hipFuncSetAttribute((const void*)dec_loop<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)dec_loop<LOOP_R>, 64 * LOOP_R, lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)dec_loop<R>, 64 * R, lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return n;
 }
+int dec_loop_blocks_per_cu(int rows_per_group, int kmax) { return rows_per_group == 4 ? blocks_per_cu_t<4>(kmax) : blocks_per_cu_t<8>(kmax); }
 
 template <int R>
 static void launch_dec_run_t(const RunArgs& a, int col_slices, int kmax, hipStream_t s) {

@@ -195,13 +195,33 @@ struct LoopArgs {
     volatile int* host_progress;        // pinned host words: [0] last step whose attention is done, [1] stop step (or INT_MAX)
     long long* sigdbg;                  // diagnostics: [max_T][8] clock stamps of the two signals, or null
     int dbg;                            // ablation switches for timing experiments (OPH_LOOP_DBG; results are wrong when set):
-                                        // 1 no weight loads, 2 single-pass sweeps (no waiting), 4 no tap loads, 8 no prologue math
+                                        // 1 no weight loads, 2 single-pass sweeps (no waiting), 4 no tap loads, 8 no prologue math,
+                                        // 16 idle column slices do not sit layers out (results stay right)
 };
-void launch_dec_loop(const LoopArgs& a, int col_slices, int kmax, hipStream_t s);
-int dec_loop_rows();          // rows (utterances) per workgroup of dec_loop
-int dec_loop_blocks_per_cu(int kmax);
+void launch_dec_loop(const LoopArgs& a, int col_slices, int rows_per_group, int kmax, hipStream_t s);   // rows_per_group 4 or 8
+int dec_loop_blocks_per_cu(int rows_per_group, int kmax);
 void launch_sig_wait(const unsigned* sig, unsigned want, int* err, long long* stamp, hipStream_t s);     // one wave spins until *sig >= want
 void launch_sig_set(unsigned* sig, unsigned value, long long* stamp, hipStream_t s);                     // *sig = max(*sig, value)
+
+// ---- one AudioDec cone layer as one launch: conv GEMM + LayerNorm (+ gate + residual) epilogue (oph_cone.hip)
+struct ConeGemmArgs {
+    const float* X; int ldx;            // input rows
+    const float* Wt; int ldw;           // packed weights [Nalloc][ntaps*kc]; highway layers: columns interleaved 16 H1 | 16 H2 per tile
+    const float* bias;                  // in the same column order
+    int M, NT, kc, ntaps;               // output rows; 32-column tiles; per-tap K; taps
+    int dense;                          // 1: source row = output row (k=1 layers); 0: table-mapped rows (highway layers)
+    int Bpad, n_out, j; const int* tab; const int* need;      // as GemmArgs mode 1
+    int hc;                             // 1 highway layer, 0 conv layer
+    int C;                              // output channels
+    const float *g1, *b1, *g2, *b2; int act; int nonorm;
+    const float* Xres; int ldres; const int* restab;           // highway residual rows: restab[m / Bpad] * Bpad + m % Bpad
+    float* Y; int ldy;                  // output rows
+    const float* spk_table; const int* spk_ids; int spk_dim;   // conv layer: speaker embedding appended after the C channels
+    unsigned long long* stats; unsigned epoch;                 // row-statistics granules [row block][NT][64][4]
+    const int* stop_after; int t; int* err;
+};
+void launch_cone_gemm(const ConeGemmArgs& a, int small_rows, hipStream_t s);  // small_rows: 32-row tiles (few-row layers), else 64-row tiles
+int cone_gemm_tile_cols();
 
 // launchers (oph_kernels.hip)
 void launch_row_chain(const RowChainArgs& a, hipStream_t s);

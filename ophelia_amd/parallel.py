@@ -16,7 +16,11 @@ def shard_range(n_items, rank, world):
 
 
 def _dist():
-    import torch.distributed as dist
+    """torch.distributed when a process group is up, else None.  Single-GPU synthesis does not need torch at all."""
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return None
     return dist if (dist.is_available() and dist.is_initialized()) else None
 
 

@@ -181,6 +181,15 @@ def synth_waves(hp, mags, outfiles, device=0):
     utterance (`-ncores`)."""
     if hp.vocoder != "griffin_lim":
         return [synth_wave(hp, m, f) for m, f in zip(mags, outfiles)]
+    # An utterance whose attention reached the end of the text at step 0 has no frames (t_end = 0), one frame gives no
+    # samples either (hop * (T - 1)): they get an empty wav and stay out of the Griffin-Lim batch, which needs >= 2 frames
+    short = [k for k, m in enumerate(mags) if len(m) < 2]
+    if short:
+        for k in short:
+            print("Warning: %s has %d spectrogram frame(s); writing an empty wav" % (outfiles[k], len(mags[k])))
+            synth_wave(hp, mags[k], outfiles[k], wav=np.zeros((0,), np.float32))
+        keep = [k for k in range(len(mags)) if k not in set(short)]
+        mags, outfiles = [mags[k] for k in keep], [outfiles[k] for k in keep]
     voc = vocoder._vocoder_for(hp, device)
     i = 0
     while i < len(mags):
@@ -217,6 +226,10 @@ def synthesize(hp, speaker_id="", num_sentences=0, ncores=1, topoutdir="", t2m_e
         duration_data = dataset["durations"]
         if num_sentences > 0:
             duration_data = duration_data[:num_sentences, :, :]
+    if world > len(L):
+        # more ranks than utterances would leave ranks with an empty shard: they cannot stage a batch, and skipping the
+        # collectives of the others would hang them -- refuse up front, on every rank, before any collective
+        sys.exit("%d ranks for %d utterance(s): start at most one rank per utterance (or raise -N)" % (world, len(L)))
     lo, hi = parallel.shard_range(len(L), rank, world)       # contiguous utterance shard of this GPU
     L, bases = L[lo:hi], bases[lo:hi]
     if duration_data is not None:

@@ -182,3 +182,45 @@ def test_option_variants_map_to_abi_flags():
     hp = hp_from_snapshot("project/baseline.cfg", max_N=300)
     with pytest.raises(NotImplementedError):
         dims_from_hp(hp)                      # full-key attention keeps one key per lane slot: max_N <= 256
+
+
+def test_degenerate_utterances_do_not_break_the_wav_batch(tmp_path, monkeypatch):
+    """An utterance whose attention reaches the end of the text at step 0 has t_end = 0 -> no spectrogram frames (the
+    reference's own report loop crashes on it, see tests/golden/wiring_lj_stop.json).  It must get an empty wav and stay
+    out of the Griffin-Lim batch, which needs >= 2 frames per utterance; the others are vocoded as usual."""
+    from types import SimpleNamespace
+    from ophelia_amd import synthesize as S
+    from ophelia_amd import vocoder as V
+    calls = []
+
+    class FakeVoc(object):
+        def spectrogram2wav_batch(self, mags):
+            calls.append([len(m) for m in mags])
+            assert all(len(m) >= 2 for m in mags)
+            return [np.full(10 * (len(m) - 1), 0.25, np.float32) for m in mags]
+    monkeypatch.setattr(V, "_vocoder_for", lambda hp, device: FakeVoc())
+    hp = SimpleNamespace(vocoder="griffin_lim", store_synth_features=False, sr=22050)
+    mags = [np.zeros((8, 5), np.float32), np.zeros((0, 5), np.float32), np.zeros((1, 5), np.float32), np.zeros((3, 5), np.float32)]
+    files = [str(tmp_path / ("u%d.wav" % i)) for i in range(4)]
+    S.synth_waves(hp, mags, files, device=0)
+    assert calls == [[8, 3]]
+    import wave
+    n = [wave.open(f).getnframes() for f in files]
+    assert n == [70, 0, 0, 20]
+
+
+def test_more_ranks_than_utterances_is_refused_before_any_collective(monkeypatch, tmp_path):
+    """A rank with an empty shard cannot stage a batch; skipping the others' collectives would hang them."""
+    from ophelia_amd import synthesize as S
+    from ophelia_amd import parallel
+
+    class FakeDist(object):
+        def get_rank(self): return 1
+        def get_world_size(self): return 4
+    monkeypatch.setattr(parallel, "_dist", lambda: FakeDist())
+    hp = hp_from_snapshot("lj_tutorial.cfg")
+    hp.test_transcript = os.path.join(GOLDEN, "test_transcript_lj_tutorial.csv")
+    hp.vocoder = "griffin_lim"
+    hp.waveforms = str(tmp_path)                     # (the snapshot fixture leaves the site-specific paths out)
+    with pytest.raises(SystemExit, match="4 ranks for 2 utterance"):
+        S.synthesize(hp, num_sentences=2, topoutdir=str(tmp_path), weights={})
