@@ -77,7 +77,17 @@ struct ProfClass {
     size_t used = 0;
     double ms = 0;
 };
-constexpr int CONE_KSPLIT = 4;   // split-K of the latency-bound decoder-cone GEMMs (partials summed by ln_rows)
+constexpr int CONE_KSPLIT = 4;   // split-K of the latency-bound decoder-cone GEMMs (partials summed by ln_rows); buffers are sized for it
+// per-layer choice: many-row layers have enough tiles to fill the cone's CUs with less splitting (fewer partials to write
+// and re-read); OPH_CONE_KSPLIT="big,small" overrides (each 1..4) for experiments
+static int cone_ksplit(int M) {
+    static int big = -1, small_ = -1;
+    if (big < 0) {
+        big = 3; small_ = CONE_KSPLIT;        // measured (profiles/r02): 4,4 31.7 ms | 3,4 30.1 | 2,4 31.1 | 1,4 33.8 | 2,2 33.1 per batch
+        if (const char* e = getenv("OPH_CONE_KSPLIT")) { int a_ = 0, b_ = 0; if (sscanf(e, "%d,%d", &a_, &b_) == 2 && a_ >= 1 && a_ <= CONE_KSPLIT && b_ >= 1 && b_ <= CONE_KSPLIT) { big = a_; small_ = b_; } }
+    }
+    return M >= 512 ? big : small_;
+}
 enum { PC_GEMM = 0, PC_GEMM64, PC_GEMM_BF16, PC_LN, PC_DEC, PC_ROWCHAIN, PC_ATTN_ROWS, PC_MISC, PC_DECRUN, PC_DECLOOP, PC_CONE, PC_CONE1, PC_CONE2, PC_CONE3, PC_CONE4, PC_CONE5, PC_CONE6, PC_COUNT };   // PC_CONE + i: i-th fused cone layer of a step   // PC_GEMM = the <128,128> instance
 
 }  // namespace
@@ -163,6 +173,9 @@ struct oph_handle {
     bool cone_fused = false;                      // cone layers as fused GEMM + LayerNorm launches (oph_cone.hip)
     unsigned long long* d_cone_stats = nullptr;   // row-statistics granules of the fused cone layers
     uint32_t cone_epoch = 0;
+    // dec_loop mode: the cone waits / signals inside its own first / last launch
+    bool cone_inline_sig = false; uint32_t cone_wait_val = 0, cone_done_val = 0, cone_done_total = 0;
+    unsigned* d_cone_count = nullptr;
     float *coneR = nullptr, *coneRaw = nullptr, *coneTmp = nullptr;
     int ldy = 0;
     // timing
@@ -692,6 +705,7 @@ int ensure_decode_state(oph_handle* h, int B) {
     h->coneRaw = h->dalloc<float>((size_t)CONE_KSPLIT * maxrows * Bpad * (size_t)round_up(2 * d, 128));
     h->coneTmp = h->dalloc<float>(maxrows * Bpad * (size_t)ld_cat);
     h->d_cone_stats = h->dalloc<unsigned long long>(((maxrows * Bpad + 31) / 32) * 16 * 64 * 4);
+    h->d_cone_count = h->dalloc<unsigned>(4); h->cone_done_total = 0;
     h->cone_epoch = 0;
     hipStreamSynchronize(h->stream);
     if (!h->coneTmp || !h->Z2[1] || !h->Yout2[1]) { h->fail("out of device memory for decode state"); return OPH_ERR_DEVICE; }
@@ -739,6 +753,7 @@ void launch_cone(oph_handle* h, int t) {
     ar.R = h->coneR; ar.ldr = 2 * d; ar.stop_after = stop_after; ar.t = t;
     if (m.flags & OPH_FLAG_NO_MONOTONIC) ar.ends = h->d_ends;
     if (h->fixed_att) ar.ptab = h->d_ptab;
+    if (h->cone_inline_sig) { ar.wait_sig = h->d_sig; ar.wait_val = h->cone_wait_val; ar.wait_err = h->d_ctl + 2; }
     h->pbegin(PC_ATTN_ROWS);
     launch_attn_rows(ar, g_cur);
     h->pend(PC_ATTN_ROWS, (double)n0 * B * 3.0 * d * 4.0, (double)n0 * B * 4.0 * m.attention_win_size * d);
@@ -795,7 +810,7 @@ void launch_cone(oph_handle* h, int t) {
         g.X = x; g.ldx = ldx; g.Wt = l.Wt; g.ldw = l.kc; g.bias = l.bias; g.H = h->coneRaw; g.ldh = l.Nalloc;
         g.M = n0 * Bpad; g.N = l.N; g.kc = l.kc; g.ntaps = 1; g.mode = 0; g.T = g.M; g.off[0] = 0;
         g.stop_after = stop_after; g.t = t;
-        g.ksplit = CONE_KSPLIT; g.split_stride = (long long)g.M * l.Nalloc;
+        g.ksplit = cone_ksplit(g.M); g.split_stride = (long long)g.M * l.Nalloc;
         run_gemm(h, g, l.cin);
         EpiArgs e{};
         e.nsplit = g.ksplit; e.split_stride = g.split_stride;
@@ -822,7 +837,7 @@ void launch_cone(oph_handle* h, int t) {
         g.X = cone[k]; g.ldx = l.kc; g.Wt = l.Wt; g.ldw = 3 * l.kc; g.bias = l.bias; g.H = h->coneRaw; g.ldh = l.Nalloc;
         g.M = n_out * Bpad; g.N = l.N; g.kc = l.kc; g.ntaps = 3; g.mode = 1; g.Bpad = Bpad; g.n_out = n_out; g.j = t;
         g.tab = h->d_tab[k]; g.need = h->d_need[k]; g.stop_after = stop_after; g.t = t;
-        g.ksplit = CONE_KSPLIT; g.split_stride = (long long)g.M * l.Nalloc;
+        g.ksplit = cone_ksplit(g.M); g.split_stride = (long long)g.M * l.Nalloc;
         run_gemm(h, g, l.cin);
         EpiArgs e{};
         e.nsplit = g.ksplit; e.split_stride = g.split_stride;
@@ -832,6 +847,10 @@ void launch_cone(oph_handle* h, int t) {
         e.lcc = l.lcc_gate; e.lcc_ids = h->d_spk; e.lcc_T = 0;
         const Layer& nx = h->audiodec[pre + k + 1];
         e.Y = cone[k + 1]; e.ldy = nx.kc; e.ypad = nx.kc; e.stop_after = stop_after; e.t = t;
+        if (h->cone_inline_sig && k + 2 == nh) {
+            h->cone_done_total += (uint32_t)((e.M + 3) / 4);
+            e.done_sig = h->d_sig + 16; e.done_val = h->cone_done_val; e.done_count = h->d_cone_count; e.done_target = h->cone_done_total;
+        }
         run_epi(h, e);
     }
     g_cur = saved;
@@ -989,6 +1008,7 @@ bool run_supported(const oph_handle* h) {
 }
 
 int run_encode_into(oph_handle* h, float* KVdst, hipStream_t stream, int wsi);      // defined with the batched networks below
+static bool skip_cone_env() { static const bool v = getenv("OPH_SKIP_CONE") != nullptr; return v; }
 
 // ---------------------------------------------------------------- whole-decode launch (dec_loop)
 // Static layer table of a decode: AudioEnc (layer 0 consumes the previous step's last AudioDec layer) -> attention +
@@ -1102,6 +1122,13 @@ int decode_loop(oph_handle* h, int t_end, int stop_mode) {
         }
         const int stopped_at = h->host_prog[1];
         if (stopped_at != INT_MAX && t > stopped_at + 1) break;       // step stop+1 still runs (stores off) and polls its cone
+        static const bool sig_kernels = getenv("OPH_LOOP_SIG_KERNELS") != nullptr;    // separate wait / set launches (2 x ~6 us per step)
+        if (!sig_kernels && !h->cone_fused && !skip_cone_env()) {
+            h->cone_inline_sig = true; h->cone_wait_val = h->sig_base + (uint32_t)t; h->cone_done_val = h->sig_base + (uint32_t)t;
+            launch_cone(h, t);
+            h->cone_inline_sig = false;
+            continue;
+        }
         static const bool stream_ops = getenv("OPH_LOOP_STREAM_OPS") != nullptr;      // the slow flavour, kept for the record
         if (stream_ops) hipStreamWaitValue32(h->scone, h->d_sig, h->sig_base + (uint32_t)t, hipStreamWaitValueGte, 0xffffffffu);
         else launch_sig_wait(h->d_sig, h->sig_base + (uint32_t)t, h->d_ctl + 2, h->d_sigdbg ? h->d_sigdbg + (size_t)t * 8 : nullptr, h->scone);

@@ -52,6 +52,9 @@ struct EpiArgs {
     // learned channel contributions (modules.py:78-88): per-speaker channel gate sigmoid(lcc_embed[spk]) stored as a
     // table [nspeakers][C]; conv: y = gate * act(LN(h)) (a final squash sigmoid comes after the gate); hc: H2 *= gate
     const float* lcc; const int* lcc_ids; int lcc_T;   // utterance of row m: lcc_T > 0 ? m / lcc_T : m % Bpad
+    // optional completion signal (last launch of a cone): after its rows are written back every workgroup adds 1 to
+    // *done_count; the one that makes it done_target raises *done_sig to done_val
+    unsigned* done_sig; unsigned done_val; unsigned* done_count; unsigned done_target;
 };
 
 // ---- fused M=16 decode layer (prologue = previous layer's LN/gate, then 16xK . KxN slice)
@@ -88,6 +91,7 @@ struct AttnRowsArgs {
     float* R; int ldr;
     float* align; long long* amax;  // mode 1 outputs (B,N,T) and (B,T)
     const int* stop_after; int t;
+    const unsigned* wait_sig; unsigned wait_val; int* wait_err;   // optional: spin until *wait_sig >= wait_val before anything else
 };
 
 // ---- row-parallel fused chain of k=1 layers (LayerNorm is row-local, so a run of k=1 convs needs no

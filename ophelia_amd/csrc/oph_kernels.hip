@@ -387,7 +387,7 @@ __device__ __forceinline__ void ln_vec(f32x4 (&x)[NV], int C, int lane, const fl
 }
 
 template <int NV>
-__global__ __launch_bounds__(256) void ln_rows(EpiArgs a) {
+__device__ __forceinline__ void ln_rows_body(const EpiArgs& a) {
     if (stopped(a.stop_after, a.t)) return;
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -476,6 +476,21 @@ __global__ __launch_bounds__(256) void ln_rows(EpiArgs a) {
         ctot += a.spk_dim;
     }
     for (int c = ctot + lane; c < a.ypad; c += 64) y[c] = 0.f;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_rows(EpiArgs a) {
+    ln_rows_body<NV>(a);
+    if (a.done_sig) {
+        // last launch of a cone: once every workgroup's rows are written back, one lane raises the word the decoder loop
+        // kernel polls (instead of a signalling kernel behind this one: ~6 us of the cone's critical path per step)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            const unsigned old = atomicAdd(a.done_count, 1u);
+            if (old + 1u == a.done_target) __hip_atomic_fetch_max(a.done_sig, a.done_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 void launch_epilogue(const EpiArgs& a, hipStream_t s) {
@@ -754,6 +769,25 @@ void launch_dec_layer(const DecArgs& a, int Npad16, hipStream_t s) {
 // attn_rows: generic rows.  mode 0 = decoder history rows (position-major, current mask p);
 // mode 1 = batched operator over (b,t) with alignments + argmax outputs.
 __global__ __launch_bounds__(256) void attn_rows(AttnRowsArgs a) {
+    if (a.wait_sig) {
+        // first launch of a cone: its inputs (prev_max, Q[t-1]) exist once the decoder loop kernel has raised this word
+        if (threadIdx.x == 0) {
+            long long t0 = 0;
+            for (int it = 0; (int)(__hip_atomic_load(a.wait_sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.wait_val) < 0; ++it) {
+                __builtin_amdgcn_s_sleep(8);
+                if ((it & 255) == 255) {
+                    const long long now = wall_clock64();
+                    if (t0 == 0) t0 = now;
+                    if (now - t0 > 200000000LL || __hip_atomic_load(a.wait_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                        __hip_atomic_store(a.wait_err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // the loop kernel wrote Q and prev_max through; drop stale L1 lines
+        }
+        __syncthreads();
+    }
     if (stopped(a.stop_after, a.t)) return;
     const int lane = threadIdx.x & 63;
     const int rid = blockIdx.x * 4 + (threadIdx.x >> 6);
