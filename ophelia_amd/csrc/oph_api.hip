@@ -88,7 +88,7 @@ static int cone_ksplit(int M) {
     }
     return M >= 512 ? big : small_;
 }
-enum { PC_GEMM = 0, PC_GEMM64, PC_GEMM_BF16, PC_LN, PC_DEC, PC_ROWCHAIN, PC_ATTN_ROWS, PC_MISC, PC_DECRUN, PC_DECLOOP, PC_CONE, PC_CONE1, PC_CONE2, PC_CONE3, PC_CONE4, PC_CONE5, PC_CONE6, PC_COUNT };   // PC_CONE + i: i-th fused cone layer of a step   // PC_GEMM = the <128,128> instance
+enum { PC_GEMM = 0, PC_GEMM64, PC_GEMM_BF16, PC_LN, PC_DEC, PC_ROWCHAIN, PC_ATTN_ROWS, PC_MISC, PC_DECRUN, PC_DECLOOP, PC_CONEHEAD, PC_CONE, PC_CONE1, PC_CONE2, PC_CONE3, PC_CONE4, PC_CONE5, PC_CONE6, PC_COUNT };   // PC_CONE + i: i-th fused cone layer of a step   // PC_GEMM = the <128,128> instance
 
 }  // namespace
 
@@ -171,6 +171,9 @@ struct oph_handle {
     int* d_off0 = nullptr;                        // Hset[0] on device
     std::vector<float*> cone[2];                  // cone[t&1][h]: [|Hset[h]|][Bpad][256], ping-pong over steps
     bool cone_fused = false;                      // cone layers as fused GEMM + LayerNorm launches (oph_cone.hip)
+    // cone head in one launch (cone_head): V . Wc per batch, Q . Wq + bias per position
+    bool cone_head_ok = false;
+    float *Wt_c = nullptr, *VW = nullptr, *QWhist = nullptr; int kc_c = 0, ldvw = 0;
     unsigned long long* d_cone_stats = nullptr;   // row-statistics granules of the fused cone layers
     uint32_t cone_epoch = 0;
     // dec_loop mode: the cone waits / signals inside its own first / last launch
@@ -706,6 +709,10 @@ int ensure_decode_state(oph_handle* h, int B) {
     h->coneTmp = h->dalloc<float>(maxrows * Bpad * (size_t)ld_cat);
     h->d_cone_stats = h->dalloc<unsigned long long>(((maxrows * Bpad + 31) / 32) * 16 * 64 * 4);
     h->d_cone_count = h->dalloc<unsigned>(4); h->cone_done_total = 0;
+    if (h->cone_head_ok) {
+        h->VW = h->dalloc<float>((size_t)Bpad * m.max_N * h->ldvw);
+        h->QWhist = h->dalloc<float>((size_t)m.max_T * Bpad * d);
+    }
     h->cone_epoch = 0;
     hipStreamSynchronize(h->stream);
     if (!h->coneTmp || !h->Z2[1] || !h->Yout2[1]) { h->fail("out of device memory for decode state"); return OPH_ERR_DEVICE; }
@@ -727,6 +734,16 @@ void reset_decode(oph_handle* h) {
     launch_fill_int(h->d_tends, m.max_T, h->Bpad, h->stream);
     const int ctl[4] = {0, INT_MAX, 0, 0};
     hipMemcpyAsync(h->d_ctl, ctl, sizeof ctl, hipMemcpyHostToDevice, h->stream);
+    if (h->cone_head_ok) {
+        // V . Wc for every text position of the batch (one small GEMM; the cone head adds prob-weighted rows of it)
+        GemmArgs g{};
+        g.X = h->KV + m.d; g.ldx = 2 * m.d; g.Wt = h->Wt_c; g.ldw = h->kc_c; g.bias = h->d_zeros; g.H = h->VW; g.ldh = h->ldvw;
+        g.M = h->B * m.max_N; g.N = m.d; g.kc = h->kc_c; g.ntaps = 1; g.mode = 0; g.T = g.M; g.off[0] = 0;
+        hipStream_t saved = g_cur;
+        g_cur = h->stream;
+        run_gemm(h, g, m.d);
+        g_cur = saved;
+    }
     hipStreamSynchronize(h->stream);
 }
 
@@ -754,9 +771,102 @@ void launch_cone(oph_handle* h, int t) {
     if (m.flags & OPH_FLAG_NO_MONOTONIC) ar.ends = h->d_ends;
     if (h->fixed_att) ar.ptab = h->d_ptab;
     if (h->cone_inline_sig) { ar.wait_sig = h->d_sig; ar.wait_val = h->cone_wait_val; ar.wait_err = h->d_ctl + 2; }
+    int pre_first = 0;               // first k=1 layer still to run as GEMM + LayerNorm
+    const bool head = h->cone_head_ok && !h->fixed_att;
+    if (head) {
+        const Layer& c1 = h->audiodec[0];
+        ConeHeadArgs ch{};
+        ch.Q = h->Qhist; ch.d = d; ch.KV = h->KV; ch.N_keys = m.max_N; ch.win = m.attention_win_size; ch.VW = h->VW; ch.ldvw = h->ldvw;
+        ch.QW = h->QWhist; ch.Wq = c1.Wkn + (size_t)d * c1.ldn; ch.ldn = c1.ldn; ch.bias = c1.bias; ch.gamma = c1.g1; ch.beta = c1.b1; ch.nonorm = !c1.ln;
+        ch.p = pcur; ch.B = B; ch.Bpad = Bpad; ch.nrows = n0 * Bpad; ch.off = h->d_off0; ch.j = t;
+        const bool spk_next = pre > 1 && h->audiodec[1].ccat > 0;
+        if (spk_next) { ch.Y = h->coneTmp; ch.ldy = h->audiodec[1].kc; ch.spk_table = h->emb_spk; ch.spk_ids = h->d_spk; ch.spk_dim = h->audiodec[1].ccat; }
+        else { ch.Y = cone[0]; ch.ldy = h->audiodec[pre].kc; }
+        ch.stop_after = stop_after; ch.t = t;
+        {   // the newest history position's Q . Wq + bias first (it also carries the wait for the attention signal)
+            ConeHeadArgs cq = ch;
+            cq.wait_sig = ar.wait_sig; cq.wait_val = ar.wait_val; cq.wait_err = ar.wait_err;
+            h->pbegin(PC_CONEHEAD);
+            launch_cone_qw(cq, t - h->Hset[0][0], g_cur);
+            h->pend(PC_CONEHEAD, (double)d * d * 4.0, 2.0 * B * d * d);
+        }
+        static const bool head_check = getenv("OPH_CONE_HEAD_CHECK") != nullptr;
+        if (head_check && !spk_next) {
+            // debugging aid: evaluate the head both ways at this step and report the difference on the valid rows
+            float* tmp = nullptr;
+            const size_t nfl = (size_t)n0 * Bpad * ch.ldy;
+            hipMalloc((void**)&tmp, nfl * 4);
+            ConeHeadArgs c2 = ch; c2.Y = tmp; c2.wait_sig = nullptr;
+            hipStreamSynchronize(h->sdec); hipStreamSynchronize(g_cur);
+            launch_cone_qw(c2, t - h->Hset[0][0], g_cur);
+            launch_cone_head(c2, g_cur);
+            AttnRowsArgs a2 = ar; a2.wait_sig = nullptr;
+            launch_attn_rows(a2, g_cur);
+            GemmArgs g{};
+            g.X = h->coneR; g.ldx = 2 * d; g.Wt = c1.Wt; g.ldw = c1.kc; g.bias = c1.bias; g.H = h->coneRaw; g.ldh = c1.Nalloc;
+            g.M = n0 * Bpad; g.N = c1.N; g.kc = c1.kc; g.ntaps = 1; g.mode = 0; g.T = g.M; g.off[0] = 0; g.stop_after = stop_after; g.t = t;
+            launch_conv_gemm(g, g_cur);
+            EpiArgs e{};
+            e.H = h->coneRaw; e.ldh = c1.Nalloc; e.M = g.M; e.C = c1.cout; e.mode = PRE_CONV; e.act = c1.act; e.g1 = c1.g1; e.b1 = c1.b1; e.nonorm = !c1.ln;
+            e.Bpad = Bpad; e.stop_after = stop_after; e.t = t; e.Y = cone[0]; e.ldy = ch.ldy; e.ypad = ch.ldy;
+            launch_epilogue(e, g_cur);
+            hipStreamSynchronize(g_cur);
+            std::vector<float> A(nfl), Bv(nfl);
+            hipMemcpy(A.data(), tmp, nfl * 4, hipMemcpyDeviceToHost);
+            hipMemcpy(Bv.data(), cone[0], nfl * 4, hipMemcpyDeviceToHost);
+            double mx = 0; int wi = -1, wb = -1;
+            for (int i = 0; i < n0; ++i)
+                for (int b = 0; b < B; ++b) {
+                    if (t - h->Hset[0][i] < 0) continue;
+                    for (int c = 0; c < d; ++c) {
+                        const double df = fabs((double)A[((size_t)i * Bpad + b) * ch.ldy + c] - Bv[((size_t)i * Bpad + b) * ch.ldy + c]);
+                        if (df > mx) { mx = df; wi = i; wb = b; }
+                    }
+                }
+            fprintf(stderr, "[oph] cone head check step %d: max |head - legacy| = %.3e (position idx %d, utterance %d)\n", t, mx, wi, wb);
+            if (wi >= 0) {
+                // components of the worst row, against a host evaluation from the device copies of the operands
+                const int tq = t - h->Hset[0][wi];
+                std::vector<float> Wk((size_t)c1.kc * c1.ldn), q(d), qw(d), bias(d), kv((size_t)m.max_N * 2 * d), vw((size_t)m.max_N * h->ldvw);
+                std::vector<int> pv(Bpad);
+                hipMemcpy(Wk.data(), c1.Wkn, Wk.size() * 4, hipMemcpyDeviceToHost);
+                hipMemcpy(q.data(), h->Qhist + ((size_t)tq * Bpad + wb) * d, d * 4, hipMemcpyDeviceToHost);
+                hipMemcpy(qw.data(), h->QWhist + ((size_t)tq * Bpad + wb) * d, d * 4, hipMemcpyDeviceToHost);
+                hipMemcpy(bias.data(), c1.bias, d * 4, hipMemcpyDeviceToHost);
+                hipMemcpy(kv.data(), h->KV + (size_t)wb * m.max_N * 2 * d, kv.size() * 4, hipMemcpyDeviceToHost);
+                hipMemcpy(vw.data(), h->VW + (size_t)wb * m.max_N * h->ldvw, vw.size() * 4, hipMemcpyDeviceToHost);
+                hipMemcpy(pv.data(), pcur, Bpad * 4, hipMemcpyDeviceToHost);
+                double eq = 0, ev = 0;
+                for (int n = 0; n < d; ++n) {
+                    double sq = bias[n], sv = 0;
+                    for (int k = 0; k < d; ++k) { sq += (double)q[k] * Wk[(size_t)(d + k) * c1.ldn + n]; sv += (double)kv[(size_t)pv[wb] * 2 * d + d + k] * Wk[(size_t)k * c1.ldn + n]; }
+                    eq = std::max(eq, fabs(sq - qw[n])); ev = std::max(ev, fabs(sv - vw[(size_t)pv[wb] * h->ldvw + n]));
+                }
+                fprintf(stderr, "[oph]   worst row: time %d, p %d: max |QW - (Q.Wq+b)| = %.3e, max |VW[p] - V[p].Wc| = %.3e\n", tq, pv[wb], eq, ev);
+                double h1 = 0, h2 = 0, h3 = 0;
+                for (int n = 0; n < d; ++n) {
+                    double a1 = bias[n], a2 = 0, a3 = bias[n];
+                    for (int k = 0; k < d; ++k) {
+                        a1 += (double)q[k] * Wk[(size_t)k * c1.ldn + n];            // wrong half
+                        a2 += (double)q[k] * Wk[(size_t)(d + k) * c1.ldn + n];      // no bias
+                        a3 += (double)q[k & ~3] * Wk[(size_t)(d + k) * c1.ldn + n]; // readlane always element 0
+                    }
+                    h1 = std::max(h1, fabs(a1 - qw[n])); h2 = std::max(h2, fabs(a2 - qw[n])); h3 = std::max(h3, fabs(a3 - qw[n]));
+                }
+                fprintf(stderr, "[oph]   hypotheses: Wc half %.3e, no bias %.3e, element-0 broadcast %.3e; qw[0..3] = %g %g %g %g, q[0..3] = %g %g %g %g\n",
+                        h1, h2, h3, qw[0], qw[1], qw[2], qw[3], q[0], q[1], q[2], q[3]);
+            }
+            hipFree(tmp);
+        }
+        h->pbegin(PC_CONEHEAD);
+        launch_cone_head(ch, g_cur);
+        h->pend(PC_CONEHEAD, (double)n0 * B * (3.0 * d + 2.0 * m.attention_win_size * d) * 4.0, (double)n0 * B * 4.0 * m.attention_win_size * d);
+        pre_first = 1;
+    } else {
     h->pbegin(PC_ATTN_ROWS);
     launch_attn_rows(ar, g_cur);
     h->pend(PC_ATTN_ROWS, (double)n0 * B * 3.0 * d * 4.0, (double)n0 * B * 4.0 * m.attention_win_size * d);
+    }
     if (h->cone_fused) {
         // every cone layer = ONE launch: conv GEMM with LayerNorm (+ gate + residual) in the epilogue (oph_cone.hip)
         int fused_idx = 0;
@@ -772,7 +882,8 @@ void launch_cone(oph_handle* h, int t) {
             (void)cls_rows;
         };
         const float* x = h->coneR; int ldx = 2 * d;
-        for (int k = 0; k < pre; ++k) {
+        if (pre_first == 1 && pre > 1) { x = h->coneTmp; ldx = h->audiodec[1].kc; }
+        for (int k = pre_first; k < pre; ++k) {
             const Layer& l = h->audiodec[k];
             ConeGemmArgs c{};
             c.X = x; c.ldx = ldx; c.Wt = l.Wt; c.ldw = l.kc; c.bias = l.bias; c.M = n0 * Bpad; c.NT = (l.N + 31) / 32; c.dense = 1; c.Bpad = Bpad;
@@ -804,7 +915,8 @@ void launch_cone(oph_handle* h, int t) {
     }
     // k=1 layers before the highway stack, on all Hset[0] positions
     const float* x = h->coneR; int ldx = 2 * d;
-    for (int k = 0; k < pre; ++k) {
+    if (pre_first == 1 && pre > 1) { x = h->coneTmp; ldx = h->audiodec[1].kc; }
+    for (int k = pre_first; k < pre; ++k) {
         const Layer& l = h->audiodec[k];
         GemmArgs g{};
         g.X = x; g.ldx = ldx; g.Wt = l.Wt; g.ldw = l.kc; g.bias = l.bias; g.H = h->coneRaw; g.ldh = l.Nalloc;
@@ -1506,7 +1618,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
     oph_handle* h = new oph_handle();
     h->dm = m;
     h->device = device;
-    static const char* names[PC_COUNT] = {"conv_gemm_f32<128,128>", "conv_gemm_f32<64,64>", "conv_gemm_bf16x3", "ln_rows", "dec_layer16", "row_chain", "attn_rows", "misc", "dec_run", "dec_loop", "cone_gemm_ln[0]", "cone_gemm_ln[1]", "cone_gemm_ln[2]", "cone_gemm_ln[3]", "cone_gemm_ln[4]", "cone_gemm_ln[5]", "cone_gemm_ln[6]"};
+    static const char* names[PC_COUNT] = {"conv_gemm_f32<128,128>", "conv_gemm_f32<64,64>", "conv_gemm_bf16x3", "ln_rows", "dec_layer16", "row_chain", "attn_rows", "misc", "dec_run", "dec_loop", "cone_head", "cone_gemm_ln[0]", "cone_gemm_ln[1]", "cone_gemm_ln[2]", "cone_gemm_ln[3]", "cone_gemm_ln[4]", "cone_gemm_ln[5]", "cone_gemm_ln[6]"};
     for (int i = 0; i < PC_COUNT; ++i) h->prof[i].name = names[i];
     // CU partition for the decode loop (MI355X: 256 CUs, mask bit i -> XCD i%8): the ~25 dependent
     // tiny launches of a step get a private slice of 8 CUs in every XCD so the concurrently running
@@ -1655,6 +1767,19 @@ int oph_finalize_weights(oph_handle* h) {
     if (h->cone_fused)
         for (int k = 0; k + 1 < h->n_hc_dec; ++k)
             if (pack_cone_layer(h, h->audiodec[h->dec_pre + k]) != 0) { h->fail("out of device memory packing the cone weights"); return OPH_ERR_DEVICE; }
+    h->cone_head_ok = !getenv("OPH_NO_CONE_HEAD") && !(h->dm.flags & OPH_FLAG_NO_MONOTONIC) && h->audiodec[0].Wkn != nullptr;
+    if (h->cone_head_ok) {
+        // Wc = the rows of AudioDec C_1's kernel (1, 2d, d) that multiply the attention context (R' = [ctx | Q], networks.py:316-319)
+        const Layer& c1 = h->audiodec[0];
+        const std::vector<float>& k = *getw(h, c1.scope + "/conv1d/kernel");
+        const int d = h->dm.d;
+        h->kc_c = round_up(d, 32); h->ldvw = round_up(d, 128);
+        std::vector<float> w((size_t)h->ldvw * h->kc_c, 0.f);
+        for (int c = 0; c < d; ++c)
+            for (int n = 0; n < d; ++n) w[(size_t)n * h->kc_c + c] = k[(size_t)c * d + n];
+        h->Wt_c = upload(h, w);
+        if (!h->Wt_c) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
+    }
     h->emb_text = upload(h, h->hostw["Text2Mel/TextEnc/embed_1/lookup_table"]);
     if (h->dm.flags & OPH_FLAG_SPK_AUDIO_DECODER_INPUT) h->emb_spk = upload(h, h->hostw["Text2Mel/AudioDec/embed_2/lookup_table"]);
     HIPCHK(h, hipStreamSynchronize(h->stream));

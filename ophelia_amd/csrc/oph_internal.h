@@ -94,6 +94,28 @@ struct AttnRowsArgs {
     const unsigned* wait_sig; unsigned wait_val; int* wait_err;   // optional: spin until *wait_sig >= wait_val before anything else
 };
 
+// ---- head of the AudioDec history cone in one launch (oph_kernels.hip: cone_head)
+// AudioDec's first layer C_1 is a k=1 conv of R' = [ctx | Q] (networks.py:316-319, 376): it is linear, so
+//   C_1(R')[t'] = sum_i prob_i(t') * (V[p+i] . Wc)  +  (Q[t'] . Wq + bias)
+// with VW = V . Wc computed once per batch and QW[t'] = Q[t'] . Wq + bias once per position (each history position is
+// new exactly once: at offset 1; cone_qw computes it).  One wave per (position, utterance) row: attention window, the
+// two cached terms, LayerNorm -- instead of attn_rows + a [1344 x 512 x 256] GEMM + ln_rows every step.
+struct ConeHeadArgs {
+    const float* Q; int d;              // Qhist [max_T][Bpad][d]
+    const float* KV; int N_keys; int win;   // K | V rows [B][N][2d]
+    const float* VW; int ldvw;          // [B][N][ldvw] = V . Wc
+    float* QW;                          // [max_T][Bpad][d] cache of Q . Wq + bias
+    const float* Wq; int ldn;           // [d][ldn] n-contiguous rows of the Q half of C_1's kernel
+    const float* bias; const float* gamma; const float* beta; int nonorm;
+    const int* p; int B; int Bpad; int nrows; const int* off; int j;     // row i*Bpad+b <-> time j - off[i]
+    float* Y; int ldy;                  // output rows (layer input of the next cone stage)
+    const float* spk_table; const int* spk_ids; int spk_dim;            // optional embedding appended after the d channels
+    const int* stop_after; int t;
+    const unsigned* wait_sig; unsigned wait_val; int* wait_err;
+};
+void launch_cone_head(const ConeHeadArgs& a, hipStream_t s);
+void launch_cone_qw(const ConeHeadArgs& a, int tq, hipStream_t s);       // QW[tq] = Q[tq] . Wq + bias (the position that is new this step)
+
 // ---- row-parallel fused chain of k=1 layers (LayerNorm is row-local, so a run of k=1 convs needs no
 // cross-workgroup exchange): one workgroup per utterance streams each layer's full [K][N] weights.
 struct RowLayer {

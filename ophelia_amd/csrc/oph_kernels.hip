@@ -873,6 +873,137 @@ __global__ __launch_bounds__(256) void attn_rows(AttnRowsArgs a) {
     }
 }
 
+// cone_head: see ConeHeadArgs (oph_internal.h).  256 threads = 4 rows; lane l owns channels 4l..4l+3 (d <= 256).
+__global__ __launch_bounds__(256) void cone_head(ConeHeadArgs a) {
+    if (a.wait_sig) {
+        if (threadIdx.x == 0) {
+            long long t0 = 0;
+            for (int it = 0; (int)(__hip_atomic_load(a.wait_sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.wait_val) < 0; ++it) {
+                __builtin_amdgcn_s_sleep(8);
+                if ((it & 255) == 255) {
+                    const long long now = wall_clock64();
+                    if (t0 == 0) t0 = now;
+                    if (now - t0 > 200000000LL || __hip_atomic_load(a.wait_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                        __hip_atomic_store(a.wait_err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
+    if (stopped(a.stop_after, a.t)) return;
+    const int lane = threadIdx.x & 63;
+    const int rid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (rid >= a.nrows) return;
+    const int i = rid / a.Bpad, b = rid - i * a.Bpad;
+    const int tq = a.j - a.off[i];
+    if (b >= a.B || tq < 0) return;
+    const int d = a.d, c = lane * 4;
+    const bool cok = c < d;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const size_t qrow = ((size_t)tq * a.Bpad + b) * d;
+    const f32x4 q = cok ? *(const f32x4*)(a.Q + qrow + c) : zero4;
+    // Q . Wq + bias of this position: written by cone_qw when the position was new (offset 1; this step for the newest)
+    const f32x4 qw = cok ? *(const f32x4*)(a.QW + qrow + c) : zero4;
+    // attention window [p, p+win) under the CURRENT mask (networks.py:300-315)
+    const int p = a.p[b];
+    const int nwin = min(a.win, a.N_keys - p);
+    const float* Kb = a.KV + (size_t)b * a.N_keys * 2 * d;
+    const float* VWb = a.VW + (size_t)b * a.N_keys * a.ldvw;
+    const float scale = 1.0f / sqrtf((float)d);
+    float sc[ATT_WMAX], mx = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < ATT_WMAX; ++w) {
+        sc[w] = -INFINITY;
+        if (w < nwin) {
+            const f32x4 kv = cok ? *(const f32x4*)(Kb + (size_t)(p + w) * 2 * d + c) : zero4;
+            sc[w] = wave_sum(q[0] * kv[0] + q[1] * kv[1] + q[2] * kv[2] + q[3] * kv[3]) * scale;
+            mx = fmaxf(mx, sc[w]);
+        }
+    }
+    float den = 0.f, pr[ATT_WMAX];
+#pragma unroll
+    for (int w = 0; w < ATT_WMAX; ++w) { pr[w] = w < nwin ? expf(sc[w] - mx) : 0.f; den += pr[w]; }
+    f32x4 h = qw;
+#pragma unroll
+    for (int w = 0; w < ATT_WMAX; ++w) {
+        if (w < nwin) {
+            const float pw = pr[w] / den;
+            const f32x4 vw = cok ? *(const f32x4*)(VWb + (size_t)(p + w) * a.ldvw + c) : zero4;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) h[n] = fmaf(pw, vw[n], h[n]);
+        }
+    }
+    // LayerNorm (modules.py:137-139; C_1 has no activation)
+    const float invd = 1.0f / (float)d;
+    const float mean = a.nonorm ? 0.f : wave_sum(h[0] + h[1] + h[2] + h[3]) * invd;
+    float qq = 0.f;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) { const float dl = cok ? h[n] - mean : 0.f; h[n] = dl; qq += dl * dl; }
+    const float rstd = a.nonorm ? 1.0f : 1.0f / sqrtf(wave_sum(qq) * invd + LN_EPS);
+    float* y = a.Y + (size_t)rid * a.ldy;
+    if (cok) {
+        const f32x4 g = *(const f32x4*)(a.gamma + c), bt = *(const f32x4*)(a.beta + c);
+        f32x4 o;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) o[n] = h[n] * rstd * g[n] + bt[n];
+        *(f32x4*)(y + c) = o;
+    }
+    int ctot = d;
+    if (a.spk_table) {
+        const int id = a.spk_ids[b];
+        for (int c2 = lane; c2 < a.spk_dim; c2 += 64) y[d + c2] = id == 0 ? 0.f : a.spk_table[(size_t)id * a.spk_dim + c2];
+        ctot += a.spk_dim;
+    }
+    for (int c2 = ctot + lane; c2 < a.ldy; c2 += 64) y[c2] = 0.f;
+}
+// cone_qw: QW[t'] = Q[t'] . Wq + bias for the position that became history this step (one workgroup per utterance,
+// 1024 threads = 4 k-quarters x 256 output channels; the Q row is broadcast from LDS, weight rows are coalesced).
+// First launch of a cone in dec_loop mode: waits for the loop kernel's attention signal.
+__global__ __launch_bounds__(1024) void cone_qw(ConeHeadArgs a, int tq) {
+    if (a.wait_sig) {
+        if (threadIdx.x == 0) {
+            long long t0 = 0;
+            for (int it = 0; (int)(__hip_atomic_load(a.wait_sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.wait_val) < 0; ++it) {
+                __builtin_amdgcn_s_sleep(8);
+                if ((it & 255) == 255) {
+                    const long long now = wall_clock64();
+                    if (t0 == 0) t0 = now;
+                    if (now - t0 > 200000000LL || __hip_atomic_load(a.wait_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                        __hip_atomic_store(a.wait_err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
+    if (stopped(a.stop_after, a.t) || tq < 0) return;
+    __shared__ float qs[256];
+    __shared__ float ps[4][256];
+    const int b = blockIdx.x, n = threadIdx.x & 255, kq = threadIdx.x >> 8, d = a.d;
+    const size_t qrow = ((size_t)tq * a.Bpad + b) * d;
+    if (threadIdx.x < d) qs[threadIdx.x] = a.Q[qrow + threadIdx.x];
+    __syncthreads();
+    const int kper = (d + 3) / 4, k0 = kq * kper, k1 = min(d, k0 + kper);
+    float acc = 0.f;
+    if (n < d)
+        for (int k = k0; k < k1; ++k) acc = fmaf(qs[k], a.Wq[(size_t)k * a.ldn + n], acc);
+    ps[kq][n] = acc;
+    __syncthreads();
+    if (kq == 0 && n < d) a.QW[qrow + n] = a.bias[n] + ((ps[0][n] + ps[1][n]) + (ps[2][n] + ps[3][n]));
+}
+void launch_cone_qw(const ConeHeadArgs& a, int tq, hipStream_t s) {
+    hipLaunchKernelGGL(cone_qw, dim3(a.B), dim3(1024), 0, s, a, tq);
+}
+
+void launch_cone_head(const ConeHeadArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(cone_head, dim3((a.nrows + 3) / 4), dim3(256), 0, s, a);
+}
+
 void launch_attn_rows(const AttnRowsArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(attn_rows, dim3((a.nrows + 3) / 4), dim3(256), 0, s, a);
 }
