@@ -130,7 +130,7 @@ struct oph_handle {
     long long* d_stamps = nullptr;      // OPH_RUN_STAMPS diagnostics: [2 launches][32 slices][LOOP_MAX_LAYERS][8]
     // whole-decode persistent launch (dec_loop): static layer descriptions in device memory, progress words in pinned host memory
     bool use_loop = false;
-    LoopLayer* d_loop_layers = nullptr;
+    unsigned* d_loop_layers = nullptr;  // packed descriptors [nlayers][LOOP_DESC_STRIDE]
     int loop_nlayers = 0, loop_attn = 0, loop_slices = 0, loop_kmax = 0;
     volatile int* host_prog = nullptr;  // [0] last step whose attention is done  [1] stop step or INT_MAX
     int ndec_cus = 0;                   // CUs the critical stream may use (its CU mask, or the whole chip)
@@ -1162,9 +1162,36 @@ int build_loop_layers(oph_handle* h) {
     h->loop_nlayers = (int)v.size();
     h->loop_slices = 1; h->loop_kmax = 32;
     for (const LoopLayer& q : v) { h->loop_slices = std::max(h->loop_slices, round_up(q.N, 16) / 16); h->loop_kmax = std::max(h->loop_kmax, q.ntaps * q.kc); }
-    h->d_loop_layers = h->dalloc<LoopLayer>(v.size());
+    std::vector<unsigned> words(v.size() * LOOP_DESC_STRIDE, 0u);
+    for (size_t i = 0; i < v.size(); ++i) {
+        const LoopLayer& q = v[i];
+        unsigned* w = &words[i * LOOP_DESC_STRIDE];
+        const int ls = round_up(std::max(q.cin, 4), 4);
+        float* lnp = nullptr;
+        if (q.g1) {       // the prologue's LayerNorm parameters side by side: one pointer instead of four
+            lnp = h->dalloc<float>((size_t)4 * ls);
+            if (!lnp) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
+            hipMemset(lnp, 0, (size_t)4 * ls * sizeof(float));
+            const float* src[4] = {q.g1, q.b1, q.g2, q.b2};
+            for (int k = 0; k < 4; ++k)
+                if (src[k] && hipMemcpy(lnp + (size_t)k * ls, src[k], (size_t)q.cin * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess) { h->fail("descriptor upload failed"); return OPH_ERR_DEVICE; }
+        }
+        auto put = [&](int at, const void* ptr) { const uint64_t u = (uint64_t)(uintptr_t)ptr; w[at] = (unsigned)u; w[at + 1] = (unsigned)(u >> 32); };
+        put(0, q.Wt); put(2, q.bias); put(4, lnp); put(6, q.cat_table); put(8, q.hist); put(10, q.cone0); put(12, q.cone1);
+        const LoopLayer& nx = v[(i + 1) % v.size()];
+        if (q.cin > 0xffff || q.kc > 0xffff || q.N > 0xffff || q.ldw > 0xffff || q.ccat > 0xffff || q.off0 > 0xffff || q.off1 > 0xffff || q.idx0 > 0xffff || q.idx1 > 0xffff || q.off0 < 0 || q.off1 < 0) {
+            h->fail("internal: layer geometry does not fit the packed descriptor"); return OPH_ERR_STATE;
+        }
+        w[14] = (unsigned)q.pre | (unsigned)q.act << 4 | (unsigned)(q.nonorm ? 1 : 0) << 8 | (unsigned)q.ntaps << 12 | (unsigned)q.tapkind << 16 | (unsigned)nx.pre << 20;
+        w[15] = (unsigned)q.cin | (unsigned)q.kc << 16;
+        w[16] = (unsigned)q.N | (unsigned)q.ldw << 16;
+        w[17] = (unsigned)q.ccat | (unsigned)ls << 16;
+        w[18] = (unsigned)q.off0 | (unsigned)q.off1 << 16;
+        w[19] = (unsigned)q.idx0 | (unsigned)q.idx1 << 16;
+    }
+    h->d_loop_layers = h->dalloc<unsigned>(words.size());
     if (!h->d_loop_layers) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
-    if (hipMemcpy(h->d_loop_layers, v.data(), v.size() * sizeof(LoopLayer), hipMemcpyHostToDevice) != hipSuccess) { h->fail("descriptor upload failed"); return OPH_ERR_DEVICE; }
+    if (hipMemcpy(h->d_loop_layers, words.data(), words.size() * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) { h->fail("descriptor upload failed"); return OPH_ERR_DEVICE; }
     (void)m;
     return OPH_OK;
 }
@@ -1632,6 +1659,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
         const int words = (ncu + 31) / 32;
         int ndec = ncu / 4, nconep = ncu / 2;               // 64 | 128 | 64 of 256 CUs (sweep in DESIGN.md)
         if (const char* sp = getenv("OPH_CU_SPLIT")) { int a_ = 0, b_ = 0; if (sscanf(sp, "%d,%d", &a_, &b_) == 2 && a_ > 0 && b_ > 0 && a_ + b_ < ncu) { ndec = a_; nconep = b_; } }
+        const bool cone_all = getenv("OPH_CONE_ALL") != nullptr;     // experiment: the cone may also use the SSRN partition
         if (ncu >= 64 && words <= 16 && !getenv("OPH_NO_CU_MASK")) {
             for (int i = 0; i < ncu; ++i) {
                 const uint32_t bit = 1u << (i % 32);
@@ -1639,6 +1667,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
                 else {
                     m_cone[i / 32] |= bit;
                     (i < ndec + nconep ? m_conep : m_ssrn)[i / 32] |= bit;
+                    if (cone_all) m_conep[i / 32] |= bit;
                 }
             }
             // CU-masked queues are a scarce resource: with four alive the queues get time-sliced and even

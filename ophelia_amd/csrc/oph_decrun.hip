@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64 * R) void dec_run(RunArgs a) {
         }
 
         // ---- 4. stage the operand row: [tap x[t-2r] | tap x[t-r] | current]
-        const int Ktot = L.ntaps * L.kc, ldxs = Ktot + 4, cur = (L.ntaps - 1) * L.kc;
+        const int Ktot = L.ntaps * L.kc, ldxs = Ktot + 4, xcur = (L.ntaps - 1) * L.kc;
         float* xrow = xs + w * ldxs;
         if (L.pre == RUN_ATTN) {
             // R' = concat(softmax(Q K^T / sqrt(d)) V, Q) for row t under the current mask (networks.py:300-319)
@@ -238,11 +238,11 @@ __global__ __launch_bounds__(64 * R) void dec_run(RunArgs a) {
                 }
             }
         } else {
-            if (c < L.kc) *(f32x4*)(xrow + cur + c) = x;
-            for (int c2 = 256 + c; c2 < L.kc; c2 += 256) *(f32x4*)(xrow + cur + c2) = zero4;
+            if (c < L.kc) *(f32x4*)(xrow + xcur + c) = x;
+            for (int c2 = 256 + c; c2 < L.kc; c2 += 256) *(f32x4*)(xrow + xcur + c2) = zero4;
             if (L.ccat > 0)     // speaker embedding appended to the input (row 0 of the table reads as zeros, modules.py:38-40)
                 for (int j = lane; j < L.ccat; j += 64)
-                    xrow[cur + cin + j] = spk == 0 ? 0.f : L.cat_table[(size_t)spk * L.ccat + j];
+                    xrow[xcur + cin + j] = spk == 0 ? 0.f : L.cat_table[(size_t)spk * L.ccat + j];
             if (L.ntaps == 3 && c < L.kc) {
                 *(f32x4*)(xrow + c) = tp0;
                 *(f32x4*)(xrow + L.kc + c) = tp1;
@@ -325,7 +325,49 @@ static __device__ __forceinline__ void st_coherent(float* p, const f32x4& v) {
     __hip_atomic_store((u64*)p, (u64)__float_as_uint(v[0]) | ((u64)__float_as_uint(v[1]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store((u64*)p + 1, (u64)__float_as_uint(v[2]) | ((u64)__float_as_uint(v[3]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-typedef const __attribute__((address_space(4))) LoopLayer* LoopLayerConstPtr;     // descriptors are read with scalar loads
+// Packed layer descriptor (oph_internal.h: LOOP_DESC_WORDS) held in scalar registers.  desc_load only ISSUES the scalar
+// loads; desc_pin is the one place their results are waited for (an empty asm that needs every word in an SGPR) -- put
+// after a wait that is long anyway (the hand-off sweep), so that no field access later stalls on the scalar cache.
+typedef const __attribute__((address_space(4))) unsigned* LoopDescPtr;
+struct LoopDesc {
+    unsigned w[LOOP_DESC_WORDS];
+    // global address space spelled out: a pointer assembled from two words is otherwise generic (flat_load, which also
+    // ties up the LDS counter)
+    __device__ __forceinline__ const float* ptr(int i) const {
+        return (const float*)(const __attribute__((address_space(1))) float*)(((u64)w[i + 1] << 32) | (u64)w[i]);
+    }
+    __device__ __forceinline__ const float* Wt() const { return ptr(0); }
+    __device__ __forceinline__ const float* bias() const { return ptr(2); }
+    __device__ __forceinline__ const float* lnp() const { return ptr(4); }
+    __device__ __forceinline__ const float* cat_table() const { return ptr(6); }
+    __device__ __forceinline__ float* hist() const { return (float*)ptr(8); }
+    __device__ __forceinline__ const float* cone(int odd) const { return odd ? ptr(12) : ptr(10); }
+    __device__ __forceinline__ int pre() const { return w[14] & 15; }
+    __device__ __forceinline__ int act() const { return (w[14] >> 4) & 15; }
+    __device__ __forceinline__ int nonorm() const { return (w[14] >> 8) & 1; }
+    __device__ __forceinline__ int ntaps() const { return (w[14] >> 12) & 3; }
+    __device__ __forceinline__ int tapkind() const { return (w[14] >> 16) & 3; }
+    __device__ __forceinline__ int next_pre() const { return (w[14] >> 20) & 15; }
+    __device__ __forceinline__ int cin() const { return w[15] & 0xffff; }
+    __device__ __forceinline__ int kc() const { return w[15] >> 16; }
+    __device__ __forceinline__ int N() const { return w[16] & 0xffff; }
+    __device__ __forceinline__ int ldw() const { return w[16] >> 16; }
+    __device__ __forceinline__ int ccat() const { return w[17] & 0xffff; }
+    __device__ __forceinline__ int ls() const { return w[17] >> 16; }
+    __device__ __forceinline__ int off0() const { return w[18] & 0xffff; }
+    __device__ __forceinline__ int off1() const { return w[18] >> 16; }
+    __device__ __forceinline__ int idx0() const { return w[19] & 0xffff; }
+    __device__ __forceinline__ int idx1() const { return w[19] >> 16; }
+};
+static __device__ __forceinline__ void desc_load(LoopDescPtr base, int l, LoopDesc& d) {
+    LoopDescPtr p = base + l * LOOP_DESC_STRIDE;
+#pragma unroll
+    for (int i = 0; i < LOOP_DESC_WORDS; ++i) d.w[i] = p[i];
+}
+static __device__ __forceinline__ void desc_pin(LoopDesc& d) {
+#pragma unroll
+    for (int i = 0; i < LOOP_DESC_WORDS; ++i) asm volatile("" : "+s"(d.w[i]));
+}
 
 // Contraction on v_mfma_f32_4x4x1_16B_f32 (16 independent 4x4 outer products per instruction, exact fp32): the 4 rows
 // of the group are the M of every block; block (cg, kk) = lanes 16cg + 4kk .. +3 owns columns 4cg..4cg+3 and k-lane kk
@@ -340,8 +382,8 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
     constexpr int RQ = R / 4;
     constexpr int PF = (RUN_KMAX / 16 + R - 1) / R;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* part = smem;                          // [R waves][64 lanes][RQ quads][4 rows] K-split partial sums
-    float* xs = smem + R * 64 * RQ * 4;          // [R][ldxs]
+    float* part = smem;                          // [R waves][16 columns][RQ quads][4 rows] K-split partial sums
+    float* xs = smem + R * 16 * RQ * 4;          // [R][ldxs]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = blockIdx.x, n0 = g * 16, row0 = blockIdx.y * R, grow = row0 + w;
@@ -349,7 +391,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
     const int mq = lane & 3, mkk = (lane >> 2) & 3, mcol = 4 * (lane >> 4) + mq;     // MFMA roles of this lane
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const int NL = a.nlayers, Bpad = a.Bpad;
-    LoopLayerConstPtr Ls = (LoopLayerConstPtr)a.L;
+    LoopDescPtr Ls = (LoopDescPtr)a.L;
     const int spk = a.spk_ids ? a.spk_ids[grow < a.B ? grow : 0] : 0;
     const int my_end = __builtin_amdgcn_readfirstlane(a.ends[grow]);
     int my_tend = a.max_T;                       // t_ends[grow] (reset to max_T before the launch); only column slice 0 records it
@@ -359,32 +401,33 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
 
     f32x4 xprev = zero4;
     f32x4 bfrag[PF], tp0 = zero4, tp1 = zero4;
+    bool tpok0 = false, tpok1 = false;
     float bias_v = 0.f;
-    auto fetch_layer = [&](int l, int t) {       // weights, bias and the two older taps of layer l at step t
-        const int ntaps = Ls[l].ntaps, kc = Ls[l].kc;
+    auto fetch_layer = [&](const LoopDesc& D, int t) {       // weights, bias and the two older taps of layer D at step t
+        const int ntaps = D.ntaps(), kc = D.kc();
         const int nch = (ntaps * kc) >> 4;
-        if (n0 < Ls[l].N && !(a.dbg & 1)) {       // chunks past the layer's K are never multiplied: load a valid address instead of branching
-            const float* wrow = Ls[l].Wt + (size_t)(n0 + mcol) * Ls[l].ldw + mkk * 4;
+        if (n0 < D.N() && !(a.dbg & 1)) {       // chunks past the layer's K are never multiplied: load a valid address instead of branching
+            const float* wrow = D.Wt() + (size_t)(n0 + mcol) * D.ldw() + mkk * 4;
 #pragma unroll
             for (int i = 0; i < PF; ++i) bfrag[i] = *(const f32x4*)(wrow + min(w + R * i, nch - 1) * 16);
-            bias_v = Ls[l].bias[n0 + (tid & 15)];
+            bias_v = D.bias()[n0 + (tid & 15)];
         }
-        const int kind = Ls[l].tapkind;
-        tp0 = zero4; tp1 = zero4;
+        // the two older taps: always requested from a valid row (clamped), masked where they are staged -- no branch, no
+        // register copy between the request and its use
+        const int kind = D.tapkind();
         if (kind != 0 && c < kc && !(a.dbg & 4)) {
-            const int o0 = Ls[l].off0, o1 = Ls[l].off1;
-            if (kind == 1) {
-                const float* hb = Ls[l].hist;
-                if (t - o0 >= 0) tp0 = ld_coherent(hb + ((size_t)(t - o0) * Bpad + grow) * kc + c);
-                if (t - o1 >= 0) tp1 = ld_coherent(hb + ((size_t)(t - o1) * Bpad + grow) * kc + c);
-            } else {
-                const float* cb = (t & 1) ? Ls[l].cone1 : Ls[l].cone0;
-                if (t - o0 >= 0) tp0 = ld_coherent(cb + ((size_t)Ls[l].idx0 * Bpad + grow) * kc + c);
-                if (t - o1 >= 0) tp1 = ld_coherent(cb + ((size_t)Ls[l].idx1 * Bpad + grow) * kc + c);
-            }
+            const int o0 = D.off0(), o1 = D.off1();
+            const float* tb = kind == 1 ? (const float*)D.hist() : D.cone(t & 1);
+            const int r0 = kind == 1 ? max(t - o0, 0) : D.idx0(), r1 = kind == 1 ? max(t - o1, 0) : D.idx1();
+            tp0 = ld_coherent(tb + ((size_t)r0 * Bpad + grow) * kc + c);
+            tp1 = ld_coherent(tb + ((size_t)r1 * Bpad + grow) * kc + c);
+            tpok0 = t - o0 >= 0; tpok1 = t - o1 >= 0;
         }
     };
-    fetch_layer(0, 0);
+    LoopDesc cur, nxt;
+    desc_load(Ls, 0, cur);
+    desc_pin(cur);
+    fetch_layer(cur, 0);
 
     int t = 0;
     for (; t < a.t_end; ++t) {
@@ -396,14 +439,15 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
         const long long step_w0 = stp ? wall_clock64() : 0, step_c0 = stp ? clock64() : 0;
         for (int l = 0; l < NL; ++l) {
             const bool first = l == 0, no_input = first && t == 0;      // S[0] = 0 (architectures.py:191)
-            const int pre = Ls[l].pre, cin = Ls[l].cin, nonorm = Ls[l].nonorm, kc = Ls[l].kc, ntaps = Ls[l].ntaps;
-            const bool cok = c < cin, two = pre >= RUN_HC, cols = n0 < Ls[l].N;
+            desc_load(Ls, l + 1 < NL ? l + 1 : 0, nxt);      // in flight across the hand-off wait below
+            const int pre = cur.pre(), cin = cur.cin(), nonorm = cur.nonorm(), kc = cur.kc(), ntaps = cur.ntaps();
+            const bool cok = c < cin, two = pre >= RUN_HC, cols = n0 < cur.N();
             const bool is_attn = l == a.attn_layer;
 
             // A column slice beyond this layer's width (k=1 layers are 256 or n_mels wide, highway layers 512) has
             // nothing to contract here.  It needs the layer's input only as the highway residual of the next prologue --
             // which the consumer of a k=1 layer never uses -- so it sits the layer out: fewer pollers on the hand-off.
-            if (!cols && (l + 1 < NL ? Ls[l + 1].pre : Ls[0].pre) < RUN_HC && !(a.dbg & 16)) {
+            if (!cols && cur.next_pre() < RUN_HC && !(a.dbg & 16)) {
                 if (is_attn && t >= 1) {
                     long long t0 = 0;
                     for (int it = 0; (int)(__hip_atomic_load(a.sig + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - (a.sig_base + (unsigned)t)) < 0; ++it) {
@@ -418,16 +462,19 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
                         }
                     }
                 }
-                if (l + 1 < NL) fetch_layer(l + 1, t);
-                else if (t + 1 < a.t_end) fetch_layer(0, t + 1);
+                desc_pin(nxt);
+                fetch_layer(nxt, l + 1 < NL ? t : t + 1);
+                cur = nxt;
                 continue;
             }
 
             // ---- 1. requests that do not depend on the hand-off
             f32x4 g1v = zero4, b1v = zero4, g2v = zero4, b2v = zero4;
             if (pre != RUN_COPY && cok) {
-                g1v = *(const f32x4*)(Ls[l].g1 + c); b1v = *(const f32x4*)(Ls[l].b1 + c);
-                if (two) { g2v = *(const f32x4*)(Ls[l].g2 + c); b2v = *(const f32x4*)(Ls[l].b2 + c); }
+                const float* lnp = cur.lnp() + c;
+                const int ls = cur.ls();
+                g1v = *(const f32x4*)lnp; b1v = *(const f32x4*)(lnp + ls);
+                if (two) { g2v = *(const f32x4*)(lnp + 2 * ls); b2v = *(const f32x4*)(lnp + 3 * ls); }
             }
             int stop_v = 0x7fffffff;
             if (g == 0) stop_v = __hip_atomic_load(stop_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -458,6 +505,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
             }
             LOOP_STAMP(1);
             if (stp && lane == 0) stp[l * 8 + 6] = passes;
+            desc_pin(nxt);
 
             // ---- 3. prologue math (one row per wave)
             f32x4 x = av;
@@ -487,7 +535,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
                         x[e] = cok ? y : 0.f;
                     }
                 } else {
-                    const int act = Ls[l].act;
+                    const int act = cur.act();
                     f32x4 y;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) y[e] = av[e] * r1 * g1v[e] + b1v[e];
@@ -531,7 +579,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
             }
 
             // ---- 4. stage the operand row: [tap x[t-2r] | tap x[t-r] | current]
-            const int Ktot = ntaps * kc, ldxs = Ktot + 16, cur = (ntaps - 1) * kc;     // +16: the 4 rows' b128 reads hit disjoint banks
+            const int Ktot = ntaps * kc, ldxs = Ktot + 16, xcur = (ntaps - 1) * kc;     // +16: the 4 rows' b128 reads hit disjoint banks
             float* xrow = xs + w * ldxs;
             const bool live = t <= stop_v;
             if (pre == RUN_ATTN) {
@@ -602,18 +650,18 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
                 } else if (my_tend == a.max_T && m >= my_end) my_tend = t;
                 p = m;
             } else {
-                if (c < kc) *(f32x4*)(xrow + cur + c) = x;
-                for (int c2 = 256 + c; c2 < kc; c2 += 256) *(f32x4*)(xrow + cur + c2) = zero4;
-                const int ccat = Ls[l].ccat;
+                if (c < kc) *(f32x4*)(xrow + xcur + c) = x;
+                for (int c2 = 256 + c; c2 < kc; c2 += 256) *(f32x4*)(xrow + xcur + c2) = zero4;
+                const int ccat = cur.ccat();
                 if (ccat > 0) {
-                    const float* tab = Ls[l].cat_table;
-                    for (int j = lane; j < ccat; j += 64) xrow[cur + cin + j] = spk == 0 ? 0.f : tab[(size_t)spk * ccat + j];
+                    const float* tab = cur.cat_table();
+                    for (int j = lane; j < ccat; j += 64) xrow[xcur + cin + j] = spk == 0 ? 0.f : tab[(size_t)spk * ccat + j];
                 }
                 if (ntaps == 3 && c < kc) {
-                    *(f32x4*)(xrow + c) = tp0;
-                    *(f32x4*)(xrow + kc + c) = tp1;
+                    *(f32x4*)(xrow + c) = tpok0 ? tp0 : zero4;
+                    *(f32x4*)(xrow + kc + c) = tpok1 ? tp1 : zero4;
                 }
-                if (Ls[l].tapkind == 1 && g == 0 && live && c < kc) st_coherent(Ls[l].hist + ((size_t)t * Bpad + grow) * kc + c, x);
+                if (cur.tapkind() == 1 && g == 0 && live && c < kc) st_coherent(cur.hist() + ((size_t)t * Bpad + grow) * kc + c, x);
             }
             LOOP_STAMP(2);
             __syncthreads();
@@ -646,24 +694,35 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
                         }
                     }
                 }
+                // the 4 k-lanes of a column sit 4 lanes apart in one 16-lane row: two DPP row rotations sum them in
+                // registers, and k-lane 0 alone writes (the reducer then reads R values per output, not 4 R)
 #pragma unroll
-                for (int rq = 0; rq < RQ; ++rq)
-                    *(f32x4*)(part + ((w * 64 + lane) * RQ + rq) * 4) = acc[rq][0] + acc[rq][1];      // [row i] of (quad rq, column mcol, k-lane mkk)
+                for (int rq = 0; rq < RQ; ++rq) {
+                    f32x4 v = acc[rq][0] + acc[rq][1];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float y = v[e];
+                        y += dpp_mov<0x124>(y);      // row_ror:4
+                        y += dpp_mov<0x128>(y);      // row_ror:8
+                        v[e] = y;
+                    }
+                    if (mkk == 0) *(f32x4*)(part + ((w * 16 + mcol) * RQ + rq) * 4) = v;      // [row i] of (quad rq, column mcol)
+                }
             }
             LOOP_STAMP(7);
             const float bias_cur = bias_v;
-            if (l + 1 < NL) fetch_layer(l + 1, t);
-            else if (t + 1 < a.t_end) fetch_layer(0, t + 1);
+            fetch_layer(nxt, l + 1 < NL ? t : t + 1);       // (after the last step: layer 0 of a step that never runs -- valid rows, unused)
             LOOP_STAMP(4);
             __syncthreads();
             if (cols && tid < 16 * R) {
                 const int row = tid >> 4, col = tid & 15;
+                const float* pr = part + (col * RQ + (row >> 2)) * 4 + (row & 3);
+                float pv[R];
+#pragma unroll
+                for (int ww = 0; ww < R; ++ww) pv[ww] = pr[ww * 16 * RQ * 4];
                 float v = bias_cur;
-                const float* pr = part + ((16 * (col >> 2) + (col & 3)) * RQ + (row >> 2)) * 4 + (row & 3);
 #pragma unroll
-                for (int ww = 0; ww < R; ++ww)
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) v += pr[(ww * 64 + 4 * kk) * RQ * 4];
+                for (int ww = 0; ww < R; ww += 2) v += pv[ww] + pv[ww + 1];
                 granule_store(a.gbuf + ((size_t)l * Bpad + row0 + row) * RUN_GCOLS + n0 + col,
                               a.epoch0 + (unsigned)(t * LOOP_MAX_LAYERS + l + 1), v);
             }
@@ -682,6 +741,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
                     }
                 }
             }
+            cur = nxt;
         }
         if (stp && lane == 0) {     // shader clock over this step: (c1 - c0) cycles in (w1 - w0) * 10 ns
             long long* q = stp + (LOOP_MAX_LAYERS - 1) * 8;
@@ -694,18 +754,19 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
     if (g == 0 && t_last >= 0) {
         const int stop_v = __hip_atomic_load(stop_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t_last <= stop_v) {
-            const int cin = Ls[0].cin;
+            desc_load(Ls, 0, cur);
+            const int cin = cur.cin();
             const bool cok = c < cin;
             f32x4 g1v = zero4, b1v = zero4, av = zero4, uv = zero4;
-            if (cok) { g1v = *(const f32x4*)(Ls[0].g1 + c); b1v = *(const f32x4*)(Ls[0].b1 + c); }
+            if (cok) { g1v = *(const f32x4*)(cur.lnp() + c); b1v = *(const f32x4*)(cur.lnp() + cur.ls() + c); }
             sweep_row(a.gbuf + ((size_t)(NL - 1) * Bpad + grow) * RUN_GCOLS, c, cok, cin + c, false,
                       a.epoch0 + (unsigned)(t_last * LOOP_MAX_LAYERS + NL), lane, err, av, uv);
             const float invc = __builtin_amdgcn_rcpf((float)cin);
-            const float m1 = Ls[0].nonorm ? 0.f : wave_sum(av[0] + av[1] + av[2] + av[3]) * invc;
+            const float m1 = cur.nonorm() ? 0.f : wave_sum(av[0] + av[1] + av[2] + av[3]) * invc;
             float q1 = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float d1 = cok ? av[e] - m1 : 0.f; av[e] = d1; q1 += d1 * d1; }
-            const float r1 = Ls[0].nonorm ? 1.0f : fast_rsqrt(wave_sum(q1) * invc + LN_EPS);
+            const float r1 = cur.nonorm() ? 1.0f : fast_rsqrt(wave_sum(q1) * invc + LN_EPS);
             f32x4 x;
 #pragma unroll
             for (int e = 0; e < 4; ++e) x[e] = cok ? fast_sigmoid(av[e] * r1 * g1v[e] + b1v[e]) : 0.f;
@@ -753,7 +814,7 @@ void launch_sig_set(unsigned* sig, unsigned value, long long* stamp, hipStream_t
 template <int R>
 static void launch_dec_loop_t(const LoopArgs& a, int col_slices, int kmax, hipStream_t s) {
     static thread_local std::map<int, size_t> done;
-    const size_t lds_bytes = (size_t)(R * 64 * (R / 4) * 4 + R * (kmax + 16)) * 4;
+    const size_t lds_bytes = (size_t)(R * 16 * (R / 4) * 4 + R * (kmax + 16)) * 4;
     int dev = 0;
     (void)hipGetDevice(&dev);
     size_t& d = done[dev];
@@ -767,7 +828,7 @@ void launch_dec_loop(const LoopArgs& a, int col_slices, int rows_per_group, int 
 // workgroups of dec_loop that fit on one CU at once (the loop kernel needs ALL of its workgroups resident)
 template <int R>
 static int blocks_per_cu_t(int kmax) {
-    const size_t lds_bytes = (size_t)(R * 64 * (R / 4) * 4 + R * (kmax + 16)) * 4;
+    const size_t lds_bytes = (size_t)(R * 16 * (R / 4) * 4 + R * (kmax + 16)) * 4;
     (void)hipFuncSetAttribute((const void*)dec_loop<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)dec_loop<R>, 64 * R, lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }

@@ -204,10 +204,17 @@ struct LoopLayer {
     float* hist;                        // tapkind 1: this layer's input history, x[t] is stored here by column slice 0
     const float* cone0; const float* cone1;
 };
+// What dec_loop reads: the same layer as 20 packed dwords at a 32-dword stride, fetched one layer ahead with scalar
+// loads that are all issued together (a field-by-field walk of LoopLayer cost ~10 dependent scalar-cache round trips
+// per layer: profiles/r02 stamps, ~2 us of a 6 us layer).
+//   w0-1 Wt   w2-3 bias   w4-5 lnp (g1 | b1 | g2 | b2, each `ls` floats)   w6-7 cat_table   w8-9 hist   w10-11 cone0   w12-13 cone1
+//   w14 pre | act << 4 | nonorm << 8 | ntaps << 12 | tapkind << 16 | (pre of the NEXT layer, cyclic) << 20
+//   w15 cin | kc << 16     w16 N | ldw << 16     w17 ccat | ls << 16     w18 off0 | off1 << 16     w19 idx0 | idx1 << 16
+constexpr int LOOP_DESC_WORDS = 20, LOOP_DESC_STRIDE = 32;
 struct LoopArgs {
     int nlayers; int B; int Bpad; int t_end; int stop_mode;
     int attn_layer;                     // index of the RUN_ATTN layer
-    const LoopLayer* L;                 // device memory, [nlayers]
+    const unsigned* L;                  // device memory, [nlayers][LOOP_DESC_STRIDE] packed descriptors
     int* ctl;                           // [0] n_ended  [1] stop_after  [2] error  [3] attention arrivals
     const int* spk_ids;
     unsigned long long* gbuf;           // granules [LOOP_MAX_LAYERS][Bpad][RUN_GCOLS]
