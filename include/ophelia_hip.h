@@ -162,7 +162,9 @@ int oph_timer_stop(oph_handle* h, float* elapsed_ms);      /* synchronises */
 /* Per-kernel-class accounting: when enabled every launch of each kernel class is
  * bracketed by HIP events on the launch stream.  oph_profile_get returns, for
  * class index i, its name, number of launches, summed device time, and the summed
- * ALGORITHMIC bytes and flops of those launches (DESIGN.md gives the formulas).   */
+ * ALGORITHMIC bytes and flops of those launches (DESIGN.md gives the formulas).
+ * on = 2 brackets only the whole-decode launch (dec_loop: one event pair per decode,
+ * cheap enough to stay on inside a timed region); 1 = every class; 0 = off.       */
 int oph_profile_enable(oph_handle* h, int on);
 int oph_profile_reset(oph_handle* h);
 int oph_profile_count(const oph_handle* h);

@@ -118,7 +118,7 @@ struct oph_handle {
     // ~4 us / ~2 us (profiles/launch_rate_probe.hip).  Values grow monotonically: sig_base + step.
     int* d_ptab = nullptr;              // FixedAttention: key index per (t, b), time-major [max_T][Bpad], -1 = no key
     bool fixed_att = false;             // the current decode uses d_ptab instead of the attention softmax
-    uint32_t* d_sig = nullptr;          // [0] attention of step t done (written on sdec), [16] cone of step t done (scone)
+    uint32_t* d_sig = nullptr;          // [0] attention of step t done (written on sdec), [16] cone of step t done (scone), [LOOP_SIG_LEVEL0 + 16 k] cone level k done
     uint32_t sig_base = 0;
     bool use_sigval = false;
     bool can_sigval = false;            // stream value operations work on this device
@@ -177,13 +177,14 @@ struct oph_handle {
     unsigned long long* d_cone_stats = nullptr;   // row-statistics granules of the fused cone layers
     uint32_t cone_epoch = 0;
     // dec_loop mode: the cone waits / signals inside its own first / last launch
-    bool cone_inline_sig = false; uint32_t cone_wait_val = 0, cone_done_val = 0, cone_done_total = 0;
+    bool cone_inline_sig = false; uint32_t cone_wait_val = 0, cone_done_val = 0, cone_done_total[LOOP_MAX_LEVELS] = {0};     // per cone level: arrivals so far
     unsigned* d_cone_count = nullptr;
     float *coneR = nullptr, *coneRaw = nullptr, *coneTmp = nullptr;
     int ldy = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool profiling = false;
+    int profiling = 0;                  // 0 off; 1 every kernel class; 2 only the whole-decode launch (one event pair per decode: cheap enough for a timed region)
+    bool prof_on(int cls) const { return profiling == 1 || (profiling == 2 && cls == PC_DECLOOP); }
     ProfClass prof[PC_COUNT];
 
     void fail(const char* fmt, ...) {
@@ -205,7 +206,7 @@ struct oph_handle {
     }
     // ---- profiling brackets
     void pbegin(int cls) {
-        if (!profiling || capturing || g_group_cls == cls) return;
+        if (!prof_on(cls) || capturing || g_group_cls == cls) return;
         ProfClass& pc = prof[cls];
         if (pc.used == pc.ev.size()) {
             hipEvent_t a, b;
@@ -220,7 +221,7 @@ struct oph_handle {
     void gbegin(int cls) { pbegin(cls); g_group_cls = cls; }
     void gend(int cls) {
         g_group_cls = -1;
-        if (!profiling || capturing) return;
+        if (!prof_on(cls) || capturing) return;
         ProfClass& pc = prof[cls];
         hipEventRecord(pc.ev[pc.used].second, g_cur);
         pc.used++;
@@ -230,7 +231,7 @@ struct oph_handle {
         pc.launches++;
         pc.bytes += bytes;
         pc.flops += flops;
-        if (!profiling || capturing || g_group_cls == cls) return;
+        if (!prof_on(cls) || capturing || g_group_cls == cls) return;
         hipEventRecord(pc.ev[pc.used].second, g_cur);
         pc.used++;
     }
@@ -708,7 +709,7 @@ int ensure_decode_state(oph_handle* h, int B) {
     h->coneRaw = h->dalloc<float>((size_t)CONE_KSPLIT * maxrows * Bpad * (size_t)round_up(2 * d, 128));
     h->coneTmp = h->dalloc<float>(maxrows * Bpad * (size_t)ld_cat);
     h->d_cone_stats = h->dalloc<unsigned long long>(((maxrows * Bpad + 31) / 32) * 16 * 64 * 4);
-    h->d_cone_count = h->dalloc<unsigned>(4); h->cone_done_total = 0;
+    h->d_cone_count = h->dalloc<unsigned>(LOOP_MAX_LEVELS); for (uint32_t& v : h->cone_done_total) v = 0;
     if (h->cone_head_ok) {
         h->VW = h->dalloc<float>((size_t)Bpad * m.max_N * h->ldvw);
         h->QWhist = h->dalloc<float>((size_t)m.max_T * Bpad * d);
@@ -773,6 +774,14 @@ void launch_cone(oph_handle* h, int t) {
     if (h->cone_inline_sig) { ar.wait_sig = h->d_sig; ar.wait_val = h->cone_wait_val; ar.wait_err = h->d_ctl + 2; }
     int pre_first = 0;               // first k=1 layer still to run as GEMM + LayerNorm
     const bool head = h->cone_head_ok && !h->fixed_att;
+    // dec_loop mode: the launch that completes cone level `lvl` (nblocks workgroups) raises that level's word
+    auto level_done = [&](int lvl, unsigned*& sig, unsigned& val, unsigned*& count, unsigned& target, int& coh0, int& coh1) {
+        if (!h->cone_inline_sig || lvl < 0 || lvl >= LOOP_MAX_LEVELS || lvl >= nh) return;
+        const Layer& tl = h->audiodec[pre + lvl];         // the chain layer whose taps read this level (build_loop_layers)
+        coh0 = idx_of(h->Hset[lvl], -tl.off[0]); coh1 = idx_of(h->Hset[lvl], -tl.off[1]);
+        h->cone_done_total[lvl] += (unsigned)((coh0 >= 0) + (coh1 >= 0 && coh1 != coh0)) * (unsigned)(Bpad / 4);
+        sig = h->d_sig + LOOP_SIG_LEVEL0 + 16 * lvl; val = h->cone_done_val; count = h->d_cone_count + lvl; target = h->cone_done_total[lvl];
+    };
     if (head) {
         const Layer& c1 = h->audiodec[0];
         ConeHeadArgs ch{};
@@ -790,74 +799,7 @@ void launch_cone(oph_handle* h, int t) {
             launch_cone_qw(cq, t - h->Hset[0][0], g_cur);
             h->pend(PC_CONEHEAD, (double)d * d * 4.0, 2.0 * B * d * d);
         }
-        static const bool head_check = getenv("OPH_CONE_HEAD_CHECK") != nullptr;
-        if (head_check && !spk_next) {
-            // debugging aid: evaluate the head both ways at this step and report the difference on the valid rows
-            float* tmp = nullptr;
-            const size_t nfl = (size_t)n0 * Bpad * ch.ldy;
-            hipMalloc((void**)&tmp, nfl * 4);
-            ConeHeadArgs c2 = ch; c2.Y = tmp; c2.wait_sig = nullptr;
-            hipStreamSynchronize(h->sdec); hipStreamSynchronize(g_cur);
-            launch_cone_qw(c2, t - h->Hset[0][0], g_cur);
-            launch_cone_head(c2, g_cur);
-            AttnRowsArgs a2 = ar; a2.wait_sig = nullptr;
-            launch_attn_rows(a2, g_cur);
-            GemmArgs g{};
-            g.X = h->coneR; g.ldx = 2 * d; g.Wt = c1.Wt; g.ldw = c1.kc; g.bias = c1.bias; g.H = h->coneRaw; g.ldh = c1.Nalloc;
-            g.M = n0 * Bpad; g.N = c1.N; g.kc = c1.kc; g.ntaps = 1; g.mode = 0; g.T = g.M; g.off[0] = 0; g.stop_after = stop_after; g.t = t;
-            launch_conv_gemm(g, g_cur);
-            EpiArgs e{};
-            e.H = h->coneRaw; e.ldh = c1.Nalloc; e.M = g.M; e.C = c1.cout; e.mode = PRE_CONV; e.act = c1.act; e.g1 = c1.g1; e.b1 = c1.b1; e.nonorm = !c1.ln;
-            e.Bpad = Bpad; e.stop_after = stop_after; e.t = t; e.Y = cone[0]; e.ldy = ch.ldy; e.ypad = ch.ldy;
-            launch_epilogue(e, g_cur);
-            hipStreamSynchronize(g_cur);
-            std::vector<float> A(nfl), Bv(nfl);
-            hipMemcpy(A.data(), tmp, nfl * 4, hipMemcpyDeviceToHost);
-            hipMemcpy(Bv.data(), cone[0], nfl * 4, hipMemcpyDeviceToHost);
-            double mx = 0; int wi = -1, wb = -1;
-            for (int i = 0; i < n0; ++i)
-                for (int b = 0; b < B; ++b) {
-                    if (t - h->Hset[0][i] < 0) continue;
-                    for (int c = 0; c < d; ++c) {
-                        const double df = fabs((double)A[((size_t)i * Bpad + b) * ch.ldy + c] - Bv[((size_t)i * Bpad + b) * ch.ldy + c]);
-                        if (df > mx) { mx = df; wi = i; wb = b; }
-                    }
-                }
-            fprintf(stderr, "[oph] cone head check step %d: max |head - legacy| = %.3e (position idx %d, utterance %d)\n", t, mx, wi, wb);
-            if (wi >= 0) {
-                // components of the worst row, against a host evaluation from the device copies of the operands
-                const int tq = t - h->Hset[0][wi];
-                std::vector<float> Wk((size_t)c1.kc * c1.ldn), q(d), qw(d), bias(d), kv((size_t)m.max_N * 2 * d), vw((size_t)m.max_N * h->ldvw);
-                std::vector<int> pv(Bpad);
-                hipMemcpy(Wk.data(), c1.Wkn, Wk.size() * 4, hipMemcpyDeviceToHost);
-                hipMemcpy(q.data(), h->Qhist + ((size_t)tq * Bpad + wb) * d, d * 4, hipMemcpyDeviceToHost);
-                hipMemcpy(qw.data(), h->QWhist + ((size_t)tq * Bpad + wb) * d, d * 4, hipMemcpyDeviceToHost);
-                hipMemcpy(bias.data(), c1.bias, d * 4, hipMemcpyDeviceToHost);
-                hipMemcpy(kv.data(), h->KV + (size_t)wb * m.max_N * 2 * d, kv.size() * 4, hipMemcpyDeviceToHost);
-                hipMemcpy(vw.data(), h->VW + (size_t)wb * m.max_N * h->ldvw, vw.size() * 4, hipMemcpyDeviceToHost);
-                hipMemcpy(pv.data(), pcur, Bpad * 4, hipMemcpyDeviceToHost);
-                double eq = 0, ev = 0;
-                for (int n = 0; n < d; ++n) {
-                    double sq = bias[n], sv = 0;
-                    for (int k = 0; k < d; ++k) { sq += (double)q[k] * Wk[(size_t)(d + k) * c1.ldn + n]; sv += (double)kv[(size_t)pv[wb] * 2 * d + d + k] * Wk[(size_t)k * c1.ldn + n]; }
-                    eq = std::max(eq, fabs(sq - qw[n])); ev = std::max(ev, fabs(sv - vw[(size_t)pv[wb] * h->ldvw + n]));
-                }
-                fprintf(stderr, "[oph]   worst row: time %d, p %d: max |QW - (Q.Wq+b)| = %.3e, max |VW[p] - V[p].Wc| = %.3e\n", tq, pv[wb], eq, ev);
-                double h1 = 0, h2 = 0, h3 = 0;
-                for (int n = 0; n < d; ++n) {
-                    double a1 = bias[n], a2 = 0, a3 = bias[n];
-                    for (int k = 0; k < d; ++k) {
-                        a1 += (double)q[k] * Wk[(size_t)k * c1.ldn + n];            // wrong half
-                        a2 += (double)q[k] * Wk[(size_t)(d + k) * c1.ldn + n];      // no bias
-                        a3 += (double)q[k & ~3] * Wk[(size_t)(d + k) * c1.ldn + n]; // readlane always element 0
-                    }
-                    h1 = std::max(h1, fabs(a1 - qw[n])); h2 = std::max(h2, fabs(a2 - qw[n])); h3 = std::max(h3, fabs(a3 - qw[n]));
-                }
-                fprintf(stderr, "[oph]   hypotheses: Wc half %.3e, no bias %.3e, element-0 broadcast %.3e; qw[0..3] = %g %g %g %g, q[0..3] = %g %g %g %g\n",
-                        h1, h2, h3, qw[0], qw[1], qw[2], qw[3], q[0], q[1], q[2], q[3]);
-            }
-            hipFree(tmp);
-        }
+        if (!spk_next) level_done(0, ch.done_sig, ch.done_val, ch.done_count, ch.done_target, ch.coh0, ch.coh1);
         h->pbegin(PC_CONEHEAD);
         launch_cone_head(ch, g_cur);
         h->pend(PC_CONEHEAD, (double)n0 * B * (3.0 * d + 2.0 * m.attention_win_size * d) * 4.0, (double)n0 * B * 4.0 * m.attention_win_size * d);
@@ -939,6 +881,7 @@ void launch_cone(oph_handle* h, int t) {
             const Layer& hc0 = h->audiodec[pre];
             e.Y = cone[0]; e.ldy = hc0.kc; e.ypad = hc0.kc;
             x = cone[0]; ldx = hc0.kc;
+            level_done(0, e.done_sig, e.done_val, e.done_count, e.done_target, e.coh0, e.coh1);
         }
         run_epi(h, e);
     }
@@ -959,10 +902,7 @@ void launch_cone(oph_handle* h, int t) {
         e.lcc = l.lcc_gate; e.lcc_ids = h->d_spk; e.lcc_T = 0;
         const Layer& nx = h->audiodec[pre + k + 1];
         e.Y = cone[k + 1]; e.ldy = nx.kc; e.ypad = nx.kc; e.stop_after = stop_after; e.t = t;
-        if (h->cone_inline_sig && k + 2 == nh) {
-            h->cone_done_total += (uint32_t)((e.M + 3) / 4);
-            e.done_sig = h->d_sig + 16; e.done_val = h->cone_done_val; e.done_count = h->d_cone_count; e.done_target = h->cone_done_total;
-        }
+        level_done(k + 1, e.done_sig, e.done_val, e.done_count, e.done_target, e.coh0, e.coh1);
         run_epi(h, e);
     }
     g_cur = saved;
@@ -1151,7 +1091,7 @@ int build_loop_layers(oph_handle* h) {
         if (l.ccat > 0) q.cat_table = h->emb_spk;
         const int k = (int)li - pre;
         if (k >= 0 && k < nh) {
-            q.tapkind = 2; q.off0 = -l.off[0]; q.off1 = -l.off[1];
+            q.tapkind = 2; q.off0 = -l.off[0]; q.off1 = -l.off[1]; q.level1 = k + 1;
             q.idx0 = idx_of(h->Hset[k], q.off0); q.idx1 = idx_of(h->Hset[k], q.off1);
             q.cone0 = h->cone[0][k]; q.cone1 = h->cone[1][k];
             if (q.idx0 < 0 || q.idx1 < 0) { h->fail("internal: cone tap not in the position set"); return OPH_ERR_STATE; }
@@ -1182,7 +1122,8 @@ int build_loop_layers(oph_handle* h) {
         if (q.cin > 0xffff || q.kc > 0xffff || q.N > 0xffff || q.ldw > 0xffff || q.ccat > 0xffff || q.off0 > 0xffff || q.off1 > 0xffff || q.idx0 > 0xffff || q.idx1 > 0xffff || q.off0 < 0 || q.off1 < 0) {
             h->fail("internal: layer geometry does not fit the packed descriptor"); return OPH_ERR_STATE;
         }
-        w[14] = (unsigned)q.pre | (unsigned)q.act << 4 | (unsigned)(q.nonorm ? 1 : 0) << 8 | (unsigned)q.ntaps << 12 | (unsigned)q.tapkind << 16 | (unsigned)nx.pre << 20;
+        w[14] = (unsigned)q.pre | (unsigned)q.act << 4 | (unsigned)(q.nonorm ? 1 : 0) << 8 | (unsigned)q.ntaps << 12 | (unsigned)q.tapkind << 16 | (unsigned)nx.pre << 20 |
+                (unsigned)q.level1 << 24 | (unsigned)nx.level1 << 28;
         w[15] = (unsigned)q.cin | (unsigned)q.kc << 16;
         w[16] = (unsigned)q.N | (unsigned)q.ldw << 16;
         w[17] = (unsigned)q.ccat | (unsigned)ls << 16;
@@ -1237,6 +1178,7 @@ int decode_loop(oph_handle* h, int t_end, int stop_mode) {
             for (const Layer& l : *net) { const double K = (double)l.ntaps * l.cin; bytes += ((double)l.N * K + (double)h->B * (K + l.N)) * 4.0; flops += 2.0 * h->B * l.N * K; ++i; }
         (void)nl; (void)i;
     }
+    if (h->d_sigdbg) hipMemsetAsync(h->d_sigdbg, 0, (size_t)m.max_T * 8 * sizeof(long long), h->sdec);
     h->pbegin(PC_DECLOOP);
     launch_dec_loop(a, h->loop_slices, h->loop_rows, h->loop_kmax, h->sdec);
     h->pend(PC_DECLOOP, bytes * t_end, flops * t_end);
@@ -1250,7 +1192,7 @@ int decode_loop(oph_handle* h, int t_end, int stop_mode) {
     // side stream: cone(t) after the attention of step t-1, then the word the loop kernel polls before AudioDec(t)
     g_cur = h->scone;
     const auto t_host0 = std::chrono::steady_clock::now();
-    for (int t = 1; t < t_end; ++t) {
+    for (int t = 1; t < t_end && !(dbg & 32); ++t) {
         // bounded run-ahead, so that an early stop leaves at most `lookahead` queued cones (they early-out on the device)
         auto t_wait0 = std::chrono::steady_clock::now();
         while (h->host_prog[0] < t - 1 - lookahead && h->host_prog[1] == INT_MAX) {
@@ -1273,8 +1215,8 @@ int decode_loop(oph_handle* h, int t_end, int stop_mode) {
         else launch_sig_wait(h->d_sig, h->sig_base + (uint32_t)t, h->d_ctl + 2, h->d_sigdbg ? h->d_sigdbg + (size_t)t * 8 : nullptr, h->scone);
         static const bool skip_cone = getenv("OPH_SKIP_CONE") != nullptr;      // timing experiments only: results are wrong
         if (!skip_cone) launch_cone(h, t);
-        if (stream_ops) hipStreamWriteValue32(h->scone, h->d_sig + 16, h->sig_base + (uint32_t)t, 0);
-        else launch_sig_set(h->d_sig + 16, h->sig_base + (uint32_t)t, h->d_sigdbg ? h->d_sigdbg + (size_t)t * 8 : nullptr, h->scone);
+        if (stream_ops) { for (int k = 0; k < h->n_hc_dec; ++k) hipStreamWriteValue32(h->scone, h->d_sig + LOOP_SIG_LEVEL0 + 16 * k, h->sig_base + (uint32_t)t, 0); }
+        else launch_sig_set(h->d_sig + LOOP_SIG_LEVEL0, h->sig_base + (uint32_t)t, h->n_hc_dec, h->d_sigdbg ? h->d_sigdbg + (size_t)t * 8 : nullptr, h->scone);
     }
     if (g_trace) {
         const double enq = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_host0).count() * 1e3;
@@ -1432,7 +1374,7 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
     // while the host enqueues the cone).  Capture all max_T steps once per (stop_mode, B) and replay.
     // After the stop step every node early-outs on the device, so outputs are identical.
     // (the persistent-run path stamps a fresh epoch into every launch: a replayed graph would reuse old ones)
-    const bool graphable = h->use_graph && !h->use_run && !h->profiling && !h->fixed_att && t_begin == 0 && t_end == m.max_T && stop_mode >= 0 && stop_mode <= 1;
+    const bool graphable = h->use_graph && !h->use_run && h->profiling != 1 && !h->fixed_att && t_begin == 0 && t_end == m.max_T && stop_mode >= 0 && stop_mode <= 1;
     if (graphable) {
         hipGraphExec_t& ge = h->dec_graph[stop_mode];
         if (ge && h->dec_graph_B[stop_mode] != h->B) { hipGraphExecDestroy(ge); ge = nullptr; }
@@ -1479,7 +1421,7 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
         // a fresh value range for this loop: every value of an earlier loop is below sig_base + 1
         if (h->sig_base > 0x7fff0000u) {       // wrap guard (once per ~10 million batches): start over from a quiet state
             hipStreamSynchronize(h->sdec); hipStreamSynchronize(h->scone);
-            hipMemsetAsync(h->d_sig, 0, 32 * sizeof(uint32_t), h->stream);
+            hipMemsetAsync(h->d_sig, 0, LOOP_SIG_WORDS * sizeof(uint32_t), h->stream);
             hipStreamSynchronize(h->stream);
             h->sig_base = 0;
         }
@@ -1536,8 +1478,8 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
                 for (int t : {50, 51, 100, 101, 150}) {
                     if (t >= m.max_T) continue;
                     const long long* q = &sd[(size_t)t * 8];
-                    TRACE("signals of step %d (us after attention(t-1) raised sig[0]): side wait kernel started %+.2f, saw it %+.2f, set kernel wrote sig[16] %+.2f; loop kernel first looked %+.2f, saw it %+.2f",
-                          t, (q[1] - q[0]) * 0.01, (q[2] - q[0]) * 0.01, (q[3] - q[0]) * 0.01, (q[5] - q[0]) * 0.01, (q[4] - q[0]) * 0.01);
+                    TRACE("step %d: the loop kernel spun for cone levels 0..5: %.2f %.2f %.2f %.2f %.2f %.2f us", t,
+                          q[1] * 0.01, q[2] * 0.01, q[3] * 0.01, q[4] * 0.01, q[5] * 0.01, q[6] * 0.01);
                 }
             }
             if (loop_mode) {
@@ -1708,7 +1650,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
         // the run deadlocks; events are understood by the profiler.
         const char* sv = getenv("OPH_STREAM_VALUE");
         if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) == hipSuccess && can) {
-            h->d_sig = h->dalloc<uint32_t>(32);
+            h->d_sig = h->dalloc<uint32_t>(LOOP_SIG_WORDS);
             h->can_sigval = h->d_sig != nullptr && hipStreamWriteValue32(h->stream, h->d_sig, 0, 0) == hipSuccess &&
                             hipStreamSynchronize(h->stream) == hipSuccess;
             h->use_sigval = h->can_sigval && sv && atoi(sv) != 0;
@@ -2173,7 +2115,7 @@ int oph_timer_stop(oph_handle* h, float* ms) {
     HIPCHK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
     return OPH_OK;
 }
-int oph_profile_enable(oph_handle* h, int on) { if (!h) return OPH_ERR_INVALID; h->profiling = on != 0; return OPH_OK; }
+int oph_profile_enable(oph_handle* h, int on) { if (!h) return OPH_ERR_INVALID; h->profiling = on == 2 ? 2 : (on != 0); return OPH_OK; }
 int oph_profile_reset(oph_handle* h) {
     if (!h) return OPH_ERR_INVALID;
     hipStreamSynchronize(h->stream);

@@ -313,18 +313,6 @@ __global__ __launch_bounds__(64 * R) void dec_run(RunArgs a) {
 // wrote while this launch was running (cone rows): moved as two 8-byte agent-scope relaxed atomics (sc1: past the CU's
 // L1, coherent across the XCDs' L2s, write-through), never as plain accesses -- a launch-long kernel gets no cache
 // maintenance at step boundaries.
-static __device__ __forceinline__ f32x4 ld_coherent(const float* p) {
-    const u64 lo = __hip_atomic_load((const u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const u64 hi = __hip_atomic_load((const u64*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    f32x4 v;
-    v[0] = __uint_as_float((unsigned)lo); v[1] = __uint_as_float((unsigned)(lo >> 32));
-    v[2] = __uint_as_float((unsigned)hi); v[3] = __uint_as_float((unsigned)(hi >> 32));
-    return v;
-}
-static __device__ __forceinline__ void st_coherent(float* p, const f32x4& v) {
-    __hip_atomic_store((u64*)p, (u64)__float_as_uint(v[0]) | ((u64)__float_as_uint(v[1]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store((u64*)p + 1, (u64)__float_as_uint(v[2]) | ((u64)__float_as_uint(v[3]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 // Packed layer descriptor (oph_internal.h: LOOP_DESC_WORDS) held in scalar registers.  desc_load only ISSUES the scalar
 // loads; desc_pin is the one place their results are waited for (an empty asm that needs every word in an SGPR) -- put
 // after a wait that is long anyway (the hand-off sweep), so that no field access later stalls on the scalar cache.
@@ -348,6 +336,7 @@ struct LoopDesc {
     __device__ __forceinline__ int ntaps() const { return (w[14] >> 12) & 3; }
     __device__ __forceinline__ int tapkind() const { return (w[14] >> 16) & 3; }
     __device__ __forceinline__ int next_pre() const { return (w[14] >> 20) & 15; }
+    __device__ __forceinline__ int next_level() const { return (w[14] >> 28) & 15; }      // 1 + cone level read by the next layer's taps
     __device__ __forceinline__ int cin() const { return w[15] & 0xffff; }
     __device__ __forceinline__ int kc() const { return w[15] >> 16; }
     __device__ __forceinline__ int N() const { return w[16] & 0xffff; }
@@ -424,6 +413,32 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
             tpok0 = t - o0 >= 0; tpok1 = t - o1 >= 0;
         }
     };
+    // The taps of an AudioDec highway layer read one LEVEL of this step's cone (side stream).  Each level has its own
+    // word, raised by the launch that completes it; a layer waits only for the level it reads, so the cone's later
+    // levels overlap the chain's first tap layers.  `seen` is a value requested earlier (one layer ahead).
+    auto level_wait = [&](int lv1, int t, unsigned seen, bool have) {
+        if (lv1 == 0 || t < 1 || (a.dbg & 32)) return;
+        const unsigned* word = a.sig + LOOP_SIG_LEVEL0 + 16 * (lv1 - 1);
+        const unsigned want = a.sig_base + (unsigned)t;
+        if (!have) seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int)(seen - want) >= 0) return;
+        const bool dbgw = a.sigdbg && g == 0 && blockIdx.y == 0 && w == 0 && lane == 0 && lv1 < 8;
+        const long long tw0 = dbgw ? wall_clock64() : 0;
+        long long t0 = 0;
+        for (int it = 0; (int)(seen - want) < 0; ++it) {
+            __builtin_amdgcn_s_sleep(2);
+            seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((it & 63) == 63) {
+                const long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                if (now - t0 > RUN_TIMEOUT_TICKS || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                    if (lane == 0) __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        if (dbgw) a.sigdbg[t * 8 + lv1] = wall_clock64() - tw0;
+    };
     LoopDesc cur, nxt;
     desc_load(Ls, 0, cur);
     desc_pin(cur);
@@ -448,20 +463,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
             // nothing to contract here.  It needs the layer's input only as the highway residual of the next prologue --
             // which the consumer of a k=1 layer never uses -- so it sits the layer out: fewer pollers on the hand-off.
             if (!cols && cur.next_pre() < RUN_HC && !(a.dbg & 16)) {
-                if (is_attn && t >= 1) {
-                    long long t0 = 0;
-                    for (int it = 0; (int)(__hip_atomic_load(a.sig + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - (a.sig_base + (unsigned)t)) < 0; ++it) {
-                        __builtin_amdgcn_s_sleep(8);
-                        if ((it & 63) == 63) {
-                            const long long now = wall_clock64();
-                            if (t0 == 0) t0 = now;
-                            if (now - t0 > RUN_TIMEOUT_TICKS || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                                if (lane == 0) __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                break;
-                            }
-                        }
-                    }
-                }
+                level_wait(cur.next_level(), t, 0u, false);
                 desc_pin(nxt);
                 fetch_layer(nxt, l + 1 < NL ? t : t + 1);
                 cur = nxt;
@@ -478,8 +480,9 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
             }
             int stop_v = 0x7fffffff;
             if (g == 0) stop_v = __hip_atomic_load(stop_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned sigc = 0;
-            if (is_attn && t >= 1) sigc = __hip_atomic_load(a.sig + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const int nlv = cur.next_level();
+            unsigned sigl = 0;
+            if (nlv && t >= 1) sigl = __hip_atomic_load(a.sig + LOOP_SIG_LEVEL0 + 16 * (nlv - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             // attention window [p, p+win): its K and V rows depend on p alone -- requested before the hand-off, not inside
             // the softmax loops (each was an exposed ~1.5 us round trip: profiles/r02 stamps, 10 us per step)
             constexpr int AW = 4;
@@ -559,25 +562,6 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
                     *(f32x4*)(a.Ytm + ((size_t)t * Bpad + grow) * a.ldy + c) = x;
                 }
             }
-            if (is_attn && t >= 1) {
-                // the cone of this step (side stream) must have landed before its rows are requested as taps
-                if (a.sigdbg && g == 0 && blockIdx.y == 0 && w == 0 && lane == 0) a.sigdbg[t * 8 + 5] = wall_clock64();
-                long long t0 = 0;
-                for (int it = 0; (int)(sigc - (a.sig_base + (unsigned)t)) < 0; ++it) {
-                    __builtin_amdgcn_s_sleep(2);
-                    sigc = __hip_atomic_load(a.sig + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if ((it & 63) == 63) {
-                        const long long now = wall_clock64();
-                        if (t0 == 0) t0 = now;
-                        if (now - t0 > RUN_TIMEOUT_TICKS || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                            if (lane == 0) __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            break;
-                        }
-                    }
-                }
-                if (a.sigdbg && g == 0 && blockIdx.y == 0 && w == 0 && lane == 0) a.sigdbg[t * 8 + 4] = wall_clock64();
-            }
-
             // ---- 4. stage the operand row: [tap x[t-2r] | tap x[t-r] | current]
             const int Ktot = ntaps * kc, ldxs = Ktot + 16, xcur = (ntaps - 1) * kc;     // +16: the 4 rows' b128 reads hit disjoint banks
             float* xrow = xs + w * ldxs;
@@ -711,6 +695,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
             }
             LOOP_STAMP(7);
             const float bias_cur = bias_v;
+            level_wait(nlv, t, sigl, true);
             fetch_layer(nxt, l + 1 < NL ? t : t + 1);       // (after the last step: layer 0 of a step that never runs -- valid rows, unused)
             LOOP_STAMP(4);
             __syncthreads();
@@ -787,7 +772,6 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
 // still took 150 us, all of it waiting here), a spinning kernel and a storing kernel in ~5 us.
 __global__ void sig_wait_kernel(const unsigned* sig, unsigned want, int* err, long long* stamp) {
     long long t0 = 0;
-    if (stamp && threadIdx.x == 0) stamp[1] = wall_clock64();
     for (int it = 0; (int)(__hip_atomic_load(sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0; ++it) {
         __builtin_amdgcn_s_sleep(4);
         if ((it & 255) == 255) {
@@ -799,17 +783,15 @@ __global__ void sig_wait_kernel(const unsigned* sig, unsigned want, int* err, lo
             }
         }
     }
-    if (stamp && threadIdx.x == 0) stamp[2] = wall_clock64();
+    (void)stamp;
 }
-__global__ void sig_set_kernel(unsigned* sig, unsigned value, long long* stamp) {
+__global__ void sig_set_kernel(unsigned* sig, unsigned value, int nwords, long long* stamp) {
     // the kernels before this one in the stream have completed (their stores are written back at kernel end)
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_max(sig, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (stamp) stamp[3] = wall_clock64();
-    }
+    if ((int)threadIdx.x < nwords) __hip_atomic_fetch_max(sig + 16 * threadIdx.x, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (stamp && threadIdx.x == 0) stamp[7] = wall_clock64();
 }
 void launch_sig_wait(const unsigned* sig, unsigned want, int* err, long long* stamp, hipStream_t s) { hipLaunchKernelGGL(sig_wait_kernel, dim3(1), dim3(64), 0, s, sig, want, err, stamp); }
-void launch_sig_set(unsigned* sig, unsigned value, long long* stamp, hipStream_t s) { hipLaunchKernelGGL(sig_set_kernel, dim3(1), dim3(64), 0, s, sig, value, stamp); }
+void launch_sig_set(unsigned* sig, unsigned value, int nwords, long long* stamp, hipStream_t s) { hipLaunchKernelGGL(sig_set_kernel, dim3(1), dim3(64), 0, s, sig, value, nwords, stamp); }
 
 template <int R>
 static void launch_dec_loop_t(const LoopArgs& a, int col_slices, int kmax, hipStream_t s) {

@@ -39,6 +39,22 @@ static __device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_a
 static __device__ __forceinline__ float fast_act(float x, int act) {
     return act == ACT_RELU ? fmaxf(x, 0.0f) : (act == ACT_SIGMOID ? fast_sigmoid(x) : x);
 }
+// 16-byte row pieces exchanged with a kernel that is RUNNING (no kernel boundary, so no cache maintenance): two 8-byte
+// agent-scope relaxed atomics (sc1: past the CU's L1, coherent across the XCDs' L2s, write-through), never plain accesses.
+static __device__ __forceinline__ f32x4 ld_coherent(const float* p) {
+    typedef unsigned long long u64_;
+    const u64_ lo = __hip_atomic_load((const u64_*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64_ hi = __hip_atomic_load((const u64_*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    f32x4 v;
+    v[0] = __uint_as_float((unsigned)lo); v[1] = __uint_as_float((unsigned)(lo >> 32));
+    v[2] = __uint_as_float((unsigned)hi); v[3] = __uint_as_float((unsigned)(hi >> 32));
+    return v;
+}
+static __device__ __forceinline__ void st_coherent(float* p, const f32x4& v) {
+    typedef unsigned long long u64_;
+    __hip_atomic_store((u64_*)p, (u64_)__float_as_uint(v[0]) | ((u64_)__float_as_uint(v[1]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((u64_*)p + 1, (u64_)__float_as_uint(v[2]) | ((u64_)__float_as_uint(v[3]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 static __device__ __forceinline__ bool stopped(const int* stop_after, int t) {
     return stop_after != nullptr && t > *stop_after;
 }

@@ -52,9 +52,11 @@ struct EpiArgs {
     // learned channel contributions (modules.py:78-88): per-speaker channel gate sigmoid(lcc_embed[spk]) stored as a
     // table [nspeakers][C]; conv: y = gate * act(LN(h)) (a final squash sigmoid comes after the gate); hc: H2 *= gate
     const float* lcc; const int* lcc_ids; int lcc_T;   // utterance of row m: lcc_T > 0 ? m / lcc_T : m % Bpad
-    // optional completion signal (last launch of a cone): after its rows are written back every workgroup adds 1 to
-    // *done_count; the one that makes it done_target raises *done_sig to done_val
-    unsigned* done_sig; unsigned done_val; unsigned* done_count; unsigned done_target;
+    // optional completion signal (the launch that writes a cone level in dec_loop mode): the rows of positions coh0 and
+    // coh1 -- the only ones the loop kernel reads as taps -- are stored write-through (8-byte sc1 stores, no fence); each
+    // workgroup holding such rows waits for its stores, adds 1 to *done_count, and the one that makes it done_target
+    // raises *done_sig to done_val
+    unsigned* done_sig; unsigned done_val; unsigned* done_count; unsigned done_target; int coh0, coh1;
 };
 
 // ---- fused M=16 decode layer (prologue = previous layer's LN/gate, then 16xK . KxN slice)
@@ -112,6 +114,7 @@ struct ConeHeadArgs {
     const float* spk_table; const int* spk_ids; int spk_dim;            // optional embedding appended after the d channels
     const int* stop_after; int t;
     const unsigned* wait_sig; unsigned wait_val; int* wait_err;
+    unsigned* done_sig; unsigned done_val; unsigned* done_count; unsigned done_target; int coh0, coh1;      // as EpiArgs: cone level 0 written
 };
 void launch_cone_head(const ConeHeadArgs& a, hipStream_t s);
 void launch_cone_qw(const ConeHeadArgs& a, int tq, hipStream_t s);       // QW[tq] = Q[tq] . Wq + bias (the position that is new this step)
@@ -201,6 +204,7 @@ struct LoopLayer {
     const float* Wt; int ldw; const float* bias;
     int tapkind;                        // 0 none; 1 history: hist[t - off][Bpad][kc]; 2 cone: cone[t & 1][idx][Bpad][kc]
     int off0, off1, idx0, idx1;         // time offsets (off0 > off1 > 0) of the two older taps, their row-block indices in a cone buffer
+    int level1;                         // tapkind 2: 1 + cone level the taps read (its own completion word), else 0
     float* hist;                        // tapkind 1: this layer's input history, x[t] is stored here by column slice 0
     const float* cone0; const float* cone1;
 };
@@ -211,6 +215,11 @@ struct LoopLayer {
 //   w14 pre | act << 4 | nonorm << 8 | ntaps << 12 | tapkind << 16 | (pre of the NEXT layer, cyclic) << 20
 //   w15 cin | kc << 16     w16 N | ldw << 16     w17 ccat | ls << 16     w18 off0 | off1 << 16     w19 idx0 | idx1 << 16
 constexpr int LOOP_DESC_WORDS = 20, LOOP_DESC_STRIDE = 32;
+//   w14 also: (1 + cone level of this layer's taps) << 24 | (1 + cone level of the NEXT layer's taps) << 28   (0 = none)
+// Cross-stream words (u32, one per 64-byte line): sig[0] attention of step t done; sig[16] whole cone of step t done (per-layer
+// modes); sig[LOOP_SIG_LEVEL0 + 16 k] level k of the cone of step t written (dec_loop: the layer whose taps read level k
+// waits for that word only -- the cone's later levels are still being computed while the chain's first tap layers run).
+constexpr int LOOP_SIG_LEVEL0 = 32, LOOP_SIG_WORDS = 256, LOOP_MAX_LEVELS = 8;
 struct LoopArgs {
     int nlayers; int B; int Bpad; int t_end; int stop_mode;
     int attn_layer;                     // index of the RUN_ATTN layer
@@ -234,7 +243,7 @@ struct LoopArgs {
 void launch_dec_loop(const LoopArgs& a, int col_slices, int rows_per_group, int kmax, hipStream_t s);   // rows_per_group 4 or 8
 int dec_loop_blocks_per_cu(int rows_per_group, int kmax);
 void launch_sig_wait(const unsigned* sig, unsigned want, int* err, long long* stamp, hipStream_t s);     // one wave spins until *sig >= want
-void launch_sig_set(unsigned* sig, unsigned value, long long* stamp, hipStream_t s);                     // *sig = max(*sig, value)
+void launch_sig_set(unsigned* sig, unsigned value, int nwords, long long* stamp, hipStream_t s);      // words sig[16 i], i < nwords                     // *sig = max(*sig, value)
 
 // ---- one AudioDec cone layer as one launch: conv GEMM + LayerNorm (+ gate + residual) epilogue (oph_cone.hip)
 struct ConeGemmArgs {

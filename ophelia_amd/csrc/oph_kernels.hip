@@ -457,11 +457,15 @@ __device__ __forceinline__ void ln_rows_body(const EpiArgs& a) {
     }
     float* y = a.Y + (size_t)m * a.ldy;
     const bool vec_ok = (a.ldy & 3) == 0;
+    const int pos = a.done_sig ? m / a.Bpad : -1;
+    const bool coh = a.done_sig && (pos == a.coh0 || pos == a.coh1);      // rows a running dec_loop reads
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const int c = (v * 64 + lane) * 4;
-        if (c + 3 < C && vec_ok) *(f32x4*)(y + c) = x[v];
-        else {
+        if (c + 3 < C && vec_ok) {
+            if (coh) st_coherent(y + c, x[v]);
+            else *(f32x4*)(y + c) = x[v];
+        } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (c + e < C) y[c + e] = x[v][e];
@@ -481,12 +485,13 @@ __device__ __forceinline__ void ln_rows_body(const EpiArgs& a) {
 template <int NV>
 __global__ __launch_bounds__(256) void ln_rows(EpiArgs a) {
     ln_rows_body<NV>(a);
-    if (a.done_sig) {
-        // last launch of a cone: once every workgroup's rows are written back, one lane raises the word the decoder loop
-        // kernel polls (instead of a signalling kernel behind this one: ~6 us of the cone's critical path per step)
+    const int pos_b = a.done_sig ? (int)(blockIdx.x * 4) / a.Bpad : -1;       // Bpad % 4 == 0: a workgroup's 4 rows share a position
+    if (a.done_sig && (pos_b == a.coh0 || pos_b == a.coh1)) {
+        // this launch writes a level of a cone: once the tap rows have left (write-through stores, no fence), one lane
+        // raises the word the decoder loop kernel polls for that level (instead of a signalling kernel behind the cone)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
-            __threadfence();
             const unsigned old = atomicAdd(a.done_count, 1u);
             if (old + 1u == a.done_target) __hip_atomic_fetch_max(a.done_sig, a.done_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -874,7 +879,7 @@ __global__ __launch_bounds__(256) void attn_rows(AttnRowsArgs a) {
 }
 
 // cone_head: see ConeHeadArgs (oph_internal.h).  256 threads = 4 rows; lane l owns channels 4l..4l+3 (d <= 256).
-__global__ __launch_bounds__(256) void cone_head(ConeHeadArgs a) {
+static __device__ __forceinline__ void cone_head_body(const ConeHeadArgs& a) {
     if (a.wait_sig) {
         if (threadIdx.x == 0) {
             long long t0 = 0;
@@ -949,7 +954,8 @@ __global__ __launch_bounds__(256) void cone_head(ConeHeadArgs a) {
         f32x4 o;
 #pragma unroll
         for (int n = 0; n < 4; ++n) o[n] = h[n] * rstd * g[n] + bt[n];
-        *(f32x4*)(y + c) = o;
+        if (a.done_sig && (i == a.coh0 || i == a.coh1)) st_coherent(y + c, o);
+        else *(f32x4*)(y + c) = o;
     }
     int ctot = d;
     if (a.spk_table) {
@@ -958,6 +964,18 @@ __global__ __launch_bounds__(256) void cone_head(ConeHeadArgs a) {
         ctot += a.spk_dim;
     }
     for (int c2 = ctot + lane; c2 < a.ldy; c2 += 64) y[c2] = 0.f;
+}
+__global__ __launch_bounds__(256) void cone_head(ConeHeadArgs a) {
+    cone_head_body(a);
+    const int pos_b = a.done_sig ? (int)(blockIdx.x * 4) / a.Bpad : -1;
+    if (a.done_sig && (pos_b == a.coh0 || pos_b == a.coh1)) {       // cone level 0: its tap rows are written, raise its word (see ln_rows)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned old = atomicAdd(a.done_count, 1u);
+            if (old + 1u == a.done_target) __hip_atomic_fetch_max(a.done_sig, a.done_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 // cone_qw: QW[t'] = Q[t'] . Wq + bias for the position that became history this step (one workgroup per utterance,
 // 1024 threads = 4 k-quarters x 256 output channels; the Q row is broadcast from LDS, weight rows are coalesced).

@@ -30,14 +30,26 @@ def agg(path):
     return d
 
 
-shutil.copy(os.path.join(src, "trace", tag + "_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
+def find(sub, suffix):
+    """rocprofv3 writes <dir>/<tag>_<suffix> or nests it under a host directory, depending on the version"""
+    direct = os.path.join(src, sub, tag + "_" + suffix)
+    if os.path.exists(direct):
+        return direct
+    for root, _, files in os.walk(os.path.join(src, sub)):
+        for f in files:
+            if f.endswith(suffix):
+                return os.path.join(root, f)
+    raise SystemExit("no %s under %s" % (suffix, os.path.join(src, sub)))
+
+
+shutil.copy(find("trace", "kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
 if os.path.exists(os.path.join(src, "bench.json")):
     shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, tag + "_bench.json"))
-fetch = agg(os.path.join(src, "pmc_fetch", tag + "_counter_collection.csv"))
-write = agg(os.path.join(src, "pmc_write", tag + "_counter_collection.csv"))
-mfma = agg(os.path.join(src, "pmc_mfma", tag + "_counter_collection.csv"))
+fetch = agg(find("pmc_fetch", "counter_collection.csv"))
+write = agg(find("pmc_write", "counter_collection.csv"))
+mfma = agg(find("pmc_mfma", "counter_collection.csv"))
 dur = collections.defaultdict(list)
-for r in csv.DictReader(open(os.path.join(src, "trace", tag + "_kernel_trace.csv"))):
+for r in csv.DictReader(open(find("trace", "kernel_trace.csv"))):
     dur[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 rows, traffic = [], {}
 for k in sorted(dur):
