@@ -168,6 +168,9 @@ struct oph_handle {
     int n_hc_dec = 0, dec_pre = 0;                // #hc layers, #k=1 layers before them
     std::vector<std::vector<int>> Hset;           // Hset[h] sorted offsets (>=1) at which hc layer h's INPUT is needed
     std::vector<int*> d_tab, d_need, d_res;       // per hc layer h<n-1: tables for computing layer h over Hset[h+1]
+    std::vector<int*> d_extra; std::vector<int> n_extra;   // per hc layer: level positions only the loop kernel reads (cone_fc16)
+    float* coneRawB = nullptr;                    // second raw buffer: consecutive cone_fc16 launches ping-pong
+    int cone_fc_rows = 64;                        // cone levels with at most this many output rows run as cone_fc16 (0: never)
     int* d_off0 = nullptr;                        // Hset[0] on device
     std::vector<float*> cone[2];                  // cone[t&1][h]: [|Hset[h]|][Bpad][256], ping-pong over steps
     bool cone_fused = false;                      // cone layers as fused GEMM + LayerNorm launches (oph_cone.hip)
@@ -619,7 +622,7 @@ int ensure_decode_state(oph_handle* h, int B) {
         for (size_t i = h->n_weight_allocs; i < h->allocs.size(); ++i) hipFree(h->allocs[i]);
         h->allocs.resize(h->n_weight_allocs);
         h->ae_hist.clear(); h->ae_raw.clear(); h->ad_raw.clear(); h->ad_xrow.clear();
-        h->cone[0].clear(); h->cone[1].clear(); h->d_tab.clear(); h->d_need.clear(); h->d_res.clear(); h->Hset.clear();
+        h->cone[0].clear(); h->cone[1].clear(); h->d_tab.clear(); h->d_need.clear(); h->d_res.clear(); h->d_extra.clear(); h->n_extra.clear(); h->Hset.clear();
         for (auto& ge : h->dec_graph) if (ge) { hipGraphExecDestroy(ge); ge = nullptr; }
         h->KV = nullptr; h->KV2[0] = h->KV2[1] = nullptr; h->preenc_valid = false; h->capB = 0; h->actA = h->actB = h->raw = h->actA2 = h->actB2 = h->raw2 = nullptr;
         h->d_loop_layers = nullptr;
@@ -702,11 +705,24 @@ int ensure_decode_state(oph_handle* h, int B) {
             hipMemcpyAsync(dr, res.data(), res.size() * 4, hipMemcpyHostToDevice, h->stream);
             hipStreamSynchronize(h->stream);
             h->d_tab.push_back(dt); h->d_need.push_back(dn); h->d_res.push_back(dr);
+            // the positions of level k that the loop kernel's taps read (offsets r, 2r) but no output of layer k has as its
+            // current position: cone_fc16 normalises and stores them in extra row groups
+            std::vector<int> extra;
+            for (int o : {r, 2 * r}) {
+                const int ip = idx_of(h->Hset[k], o);
+                bool is_cur = false;
+                for (int i = 0; i < n_out; ++i) is_cur = is_cur || tab[2 * n_out + i] == ip;
+                if (ip >= 0 && !is_cur) extra.push_back(ip);
+            }
+            int* de = h->dalloc<int>(std::max<size_t>(extra.size(), 1));
+            if (!extra.empty()) hipMemcpy(de, extra.data(), extra.size() * 4, hipMemcpyHostToDevice);
+            h->d_extra.push_back(de); h->n_extra.push_back((int)extra.size());
         }
     }
     const int ld_cat = round_up(d + m.speaker_embedding_size, 32);
     h->coneR = h->dalloc<float>(maxrows * Bpad * 2 * d);
     h->coneRaw = h->dalloc<float>((size_t)CONE_KSPLIT * maxrows * Bpad * (size_t)round_up(2 * d, 128));
+    h->coneRawB = h->dalloc<float>((size_t)maxrows * Bpad * (size_t)round_up(2 * d, 128));
     h->coneTmp = h->dalloc<float>(maxrows * Bpad * (size_t)ld_cat);
     h->d_cone_stats = h->dalloc<unsigned long long>(((maxrows * Bpad + 31) / 32) * 16 * 64 * 4);
     h->d_cone_count = h->dalloc<unsigned>(LOOP_MAX_LEVELS); for (uint32_t& v : h->cone_done_total) v = 0;
@@ -885,18 +901,58 @@ void launch_cone(oph_handle* h, int t) {
         }
         run_epi(h, e);
     }
+    // Small levels (few output rows) as ONE launch each: the previous layer's LayerNorm / gate as the prologue of this
+    // layer's contraction (cone_fc16) instead of ln_rows + a split-K GEMM.  From the first such level to the end.
+    static const int fc_rows_env = getenv("OPH_CONE_FC_ROWS") ? atoi(getenv("OPH_CONE_FC_ROWS")) : -1;
+    const int fc_rows = fc_rows_env >= 0 ? fc_rows_env : h->cone_fc_rows;
+    int fc_from = nh;             // first layer index evaluated by cone_fc16
+    for (int k = nh - 2; k >= 1; --k) {
+        const Layer& l = h->audiodec[pre + k]; const Layer& lp = h->audiodec[pre + k - 1];
+        const bool ok = (int)h->Hset[k + 1].size() * Bpad <= fc_rows && lp.cout <= 256 && l.cin == lp.cout && l.kc <= 512 && l.ntaps == 3 &&
+                        !l.lcc_gate && !lp.lcc_gate && l.ccat == 0 && (Bpad % 16) == 0;
+        if (!ok) break;
+        fc_from = k;
+    }
+    float* raw_in = h->coneRaw; int raw_split = 1; long long raw_stride = 0;
     for (int k = 0; k + 1 < nh; ++k) {
         const Layer& l = h->audiodec[pre + k];
         const int n_out = (int)h->Hset[k + 1].size();
-        GemmArgs g{};
-        g.X = cone[k]; g.ldx = l.kc; g.Wt = l.Wt; g.ldw = 3 * l.kc; g.bias = l.bias; g.H = h->coneRaw; g.ldh = l.Nalloc;
-        g.M = n_out * Bpad; g.N = l.N; g.kc = l.kc; g.ntaps = 3; g.mode = 1; g.Bpad = Bpad; g.n_out = n_out; g.j = t;
-        g.tab = h->d_tab[k]; g.need = h->d_need[k]; g.stop_after = stop_after; g.t = t;
-        g.ksplit = cone_ksplit(g.M); g.split_stride = (long long)g.M * l.Nalloc;
-        run_gemm(h, g, l.cin);
+        if (k >= fc_from) {
+            const Layer& lp = h->audiodec[pre + k - 1];
+            ConeFcArgs c{};
+            c.rawp = raw_in; c.ldrawp = lp.Nalloc; c.nsplit = raw_split; c.split_stride = raw_stride;
+            c.g1 = lp.g1; c.b1 = lp.b1; c.g2 = lp.g2; c.b2 = lp.b2; c.nonorm = !lp.ln; c.C = lp.cout;
+            c.xres = cone[k - 1]; c.ldres = lp.kc; c.restab = h->d_res[k - 1];
+            c.tab = h->d_tab[k]; c.need = h->d_need[k]; c.n_out = n_out; c.j = t;
+            c.extra = h->d_extra[k]; c.n_extra = h->n_extra[k];
+            c.xstore = cone[k]; c.ldx = l.kc;
+            c.Wt = l.Wt; c.ldw = 3 * l.kc; c.bias = l.bias; c.kc = l.kc; c.N = l.N;
+            c.H = raw_in == h->coneRaw ? h->coneRawB : h->coneRaw; c.ldh = l.Nalloc;
+            c.Bpad = Bpad; c.stop_after = stop_after; c.t = t;
+            if (h->cone_inline_sig && k < LOOP_MAX_LEVELS) {
+                const Layer& tl = h->audiodec[pre + k];
+                c.coh0 = idx_of(h->Hset[k], -tl.off[0]); c.coh1 = idx_of(h->Hset[k], -tl.off[1]);
+                h->cone_done_total[k] += (unsigned)((n_out + c.n_extra) * (Bpad / 16));
+                c.done_sig = h->d_sig + LOOP_SIG_LEVEL0 + 16 * k; c.done_val = h->cone_done_val; c.done_count = h->d_cone_count + k; c.done_target = h->cone_done_total[k];
+            }
+            h->pbegin(PC_DEC);
+            launch_cone_fc16(c, g_cur);
+            const double K = 3.0 * l.cin;
+            h->pend(PC_DEC, ((double)l.N * K + (double)n_out * B * (3.0 * 3.0 * lp.cout + l.N)) * 4.0, 2.0 * n_out * B * l.N * K);
+            raw_in = c.H; raw_split = 1; raw_stride = 0;
+        } else {
+            GemmArgs g{};
+            g.X = cone[k]; g.ldx = l.kc; g.Wt = l.Wt; g.ldw = 3 * l.kc; g.bias = l.bias; g.H = h->coneRaw; g.ldh = l.Nalloc;
+            g.M = n_out * Bpad; g.N = l.N; g.kc = l.kc; g.ntaps = 3; g.mode = 1; g.Bpad = Bpad; g.n_out = n_out; g.j = t;
+            g.tab = h->d_tab[k]; g.need = h->d_need[k]; g.stop_after = stop_after; g.t = t;
+            g.ksplit = cone_ksplit(g.M); g.split_stride = (long long)g.M * l.Nalloc;
+            run_gemm(h, g, l.cin);
+            raw_in = h->coneRaw; raw_split = g.ksplit; raw_stride = g.split_stride;
+        }
+        if (k + 1 >= fc_from && k + 2 < nh) continue;       // the next level's cone_fc16 normalises these rows itself
         EpiArgs e{};
-        e.nsplit = g.ksplit; e.split_stride = g.split_stride;
-        e.H = h->coneRaw; e.ldh = l.Nalloc; e.M = g.M; e.C = l.cout; e.mode = PRE_HC;
+        e.nsplit = raw_split; e.split_stride = raw_stride;
+        e.H = raw_in; e.ldh = l.Nalloc; e.M = n_out * Bpad; e.C = l.cout; e.mode = PRE_HC;
         e.g1 = l.g1; e.b1 = l.b1; e.g2 = l.g2; e.b2 = l.b2; e.Xres = cone[k]; e.ldres = l.kc; e.restab = h->d_res[k]; e.Bpad = Bpad;
         e.nonorm = !l.ln;
         e.lcc = l.lcc_gate; e.lcc_ids = h->d_spk; e.lcc_T = 0;
@@ -1738,7 +1794,7 @@ int oph_finalize_weights(oph_handle* h) {
     if (h->cone_fused)
         for (int k = 0; k + 1 < h->n_hc_dec; ++k)
             if (pack_cone_layer(h, h->audiodec[h->dec_pre + k]) != 0) { h->fail("out of device memory packing the cone weights"); return OPH_ERR_DEVICE; }
-    h->cone_head_ok = !getenv("OPH_NO_CONE_HEAD") && !(h->dm.flags & OPH_FLAG_NO_MONOTONIC) && h->audiodec[0].Wkn != nullptr;
+    h->cone_head_ok = !getenv("OPH_NO_CONE_HEAD") && !(h->dm.flags & OPH_FLAG_NO_MONOTONIC) && h->audiodec[0].Wkn != nullptr && h->dm.d <= 256 && (h->dm.d % 4) == 0;
     if (h->cone_head_ok) {
         // Wc = the rows of AudioDec C_1's kernel (1, 2d, d) that multiply the attention context (R' = [ctx | Q], networks.py:316-319)
         const Layer& c1 = h->audiodec[0];

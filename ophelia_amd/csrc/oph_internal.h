@@ -119,6 +119,27 @@ struct ConeHeadArgs {
 void launch_cone_head(const ConeHeadArgs& a, hipStream_t s);
 void launch_cone_qw(const ConeHeadArgs& a, int tq, hipStream_t s);       // QW[tq] = Q[tq] . Wq + bias (the position that is new this step)
 
+// ---- cone_fc16: a SMALL cone level in one launch (oph_kernels.hip).  Highway layer k of the AudioDec cone evaluated at
+// its n_out output positions, with the LayerNorm / gate / highway mix of layer k-1 (the launch ln_rows would be) as the
+// prologue of the workgroups that need those rows: per output position the three gathered input positions are
+// normalised from layer k-1's raw rows, staged, and contracted (16 x 16 slices, K split over 16 waves, as dec_layer16).
+// Column slice 0 stores the x rows it produced (level k of the cone); `extra` positions are rows only the loop kernel
+// reads (prologue + store, no contraction).
+struct ConeFcArgs {
+    const float* rawp; int ldrawp; int nsplit; long long split_stride;     // raw rows of layer k-1 [n_k * Bpad][2C] (sum of nsplit partials)
+    const float *g1, *b1, *g2, *b2; int nonorm; int C;                     // LayerNorm parameters of layer k-1
+    const float* xres; int ldres; const int* restab;                       // level k-1 rows; restab[i] = its position index for level-k position i
+    const int* tab; const int* need; int n_out; int j;                     // [3][n_out] level-k position per tap (oldest first), valid iff j >= need
+    const int* extra; int n_extra;                                         // level-k positions that are stored only
+    float* xstore; int ldx;                                                // level k rows [n_k * Bpad][ldx] (ldx = kc of layer k)
+    const float* Wt; int ldw; const float* bias; int kc; int N;            // layer k: [Nalloc][3 kc]
+    float* H; int ldh;                                                     // raw rows of layer k [n_out * Bpad][ldh]
+    int Bpad;
+    const int* stop_after; int t;
+    unsigned* done_sig; unsigned done_val; unsigned* done_count; unsigned done_target; int coh0, coh1;   // level k completion (see EpiArgs)
+};
+void launch_cone_fc16(const ConeFcArgs& a, hipStream_t s);
+
 // ---- row-parallel fused chain of k=1 layers (LayerNorm is row-local, so a run of k=1 convs needs no
 // cross-workgroup exchange): one workgroup per utterance streams each layer's full [K][N] weights.
 struct RowLayer {

@@ -771,6 +771,166 @@ void launch_dec_layer(const DecArgs& a, int Npad16, hipStream_t s) {
     else { if (wide) launch_dec_t<2, PRE_HC>(a, grid, lds, s); else launch_dec_t<1, PRE_HC>(a, grid, lds, s); }
 }
 
+// =====================================================================================
+// cone_fc16 (ConeFcArgs): see oph_internal.h.  grid = (Npad/16, (n_out + n_extra) * Bpad/16), 16 waves; wave w owns
+// utterance row w of the group for the three gathered positions.
+// =====================================================================================
+constexpr int FC_CT = 4;          // 16-column MFMA tiles per workgroup: the prologue is redone per column slice, so slices are wide (64 columns)
+__global__ __launch_bounds__(64 * DEC_WAVES) void cone_fc16(ConeFcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Ktot = 3 * a.kc, ldxs = Ktot + 4;
+    float* xs = smem;                 // [16][ldxs]
+    float* part = smem + 16 * ldxs;   // [DEC_WAVES][FC_CT][256]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int UB = a.Bpad >> 4;
+    const int grp = blockIdx.y / UB, ub = blockIdx.y - grp * UB;
+    const bool is_extra = grp >= a.n_out;
+    const int n0 = blockIdx.x * 16 * FC_CT;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int nchunks = Ktot >> 4;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const bool live = !stopped(a.stop_after, a.t);
+    const bool store_blk = blockIdx.x == 0;
+    if (live && !(is_extra && !store_blk)) {
+        // ---- independent requests first: weight fragments, then the raw / residual rows of this wave's three positions
+        f32x4 bfrag[FC_CT][DEC_PF];
+#pragma unroll
+        for (int ct = 0; ct < FC_CT; ++ct) {
+            const float* wrow = a.Wt + (size_t)(n0 + ct * 16 + r16) * a.ldw + kq * 4;
+            const bool cols = !is_extra && n0 + ct * 16 < a.N;
+#pragma unroll
+            for (int i = 0; i < DEC_PF; ++i) {
+                const int ch = w + DEC_WAVES * i;
+                bfrag[ct][i] = (cols && ch < nchunks) ? *(const f32x4*)(wrow + ch * 16) : zero4;
+            }
+        }
+        const int ocol = n0 + (tid >> 8) * 16 + (tid & 15);          // reducer role: thread -> (tile tid >> 8, row (tid >> 4) & 15, column tid & 15)
+        const float bias_v = (!is_extra && ocol < a.N) ? a.bias[ocol] : 0.f;
+        const int C = a.C, c = lane * 4;
+        const bool cok = c < C;
+        const int urow = ub * 16 + w;
+        int pos[3]; bool ok[3];
+#pragma unroll
+        for (int tp = 0; tp < 3; ++tp) {
+            if (is_extra) { pos[tp] = a.extra[grp - a.n_out]; ok[tp] = tp == 2; }
+            else { pos[tp] = a.tab[tp * a.n_out + grp]; ok[tp] = a.j >= a.need[tp * a.n_out + grp]; }
+        }
+        f32x4 h1[3], h2[3], xr[3];
+#pragma unroll
+        for (int tp = 0; tp < 3; ++tp) {
+            h1[tp] = zero4; h2[tp] = zero4; xr[tp] = zero4;
+            if (ok[tp] && cok) {
+                const float* hp = a.rawp + ((size_t)pos[tp] * a.Bpad + urow) * a.ldrawp;
+                h1[tp] = *(const f32x4*)(hp + c); h2[tp] = *(const f32x4*)(hp + C + c);
+                for (int sp = 1; sp < a.nsplit; ++sp) {
+                    h1[tp] += *(const f32x4*)(hp + sp * a.split_stride + c);
+                    h2[tp] += *(const f32x4*)(hp + sp * a.split_stride + C + c);
+                }
+                xr[tp] = *(const f32x4*)(a.xres + ((size_t)a.restab[pos[tp]] * a.Bpad + urow) * a.ldres + c);
+            }
+        }
+        f32x4 g1v = zero4, b1v = zero4, g2v = zero4, b2v = zero4;
+        if (cok) { g1v = *(const f32x4*)(a.g1 + c); b1v = *(const f32x4*)(a.b1 + c); g2v = *(const f32x4*)(a.g2 + c); b2v = *(const f32x4*)(a.b2 + c); }
+        // ---- prologue: x = sigmoid(LN1(h1)) * LN2(h2) + (1 - sigmoid) * residual  (modules.py:194-203); the three rows'
+        //      reductions are independent and interleave
+        const float invc = 1.0f / (float)C;
+        float s1[3], s2[3], q1[3], q2[3];
+#pragma unroll
+        for (int tp = 0; tp < 3; ++tp) {
+            s1[tp] = wave_sum(h1[tp][0] + h1[tp][1] + h1[tp][2] + h1[tp][3]);
+            s2[tp] = wave_sum(h2[tp][0] + h2[tp][1] + h2[tp][2] + h2[tp][3]);
+        }
+#pragma unroll
+        for (int tp = 0; tp < 3; ++tp) {
+            const float m1 = a.nonorm ? 0.f : s1[tp] * invc, m2 = a.nonorm ? 0.f : s2[tp] * invc;
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d1 = cok ? h1[tp][e] - m1 : 0.f, d2 = cok ? h2[tp][e] - m2 : 0.f;
+                h1[tp][e] = d1; h2[tp][e] = d2; a1 += d1 * d1; a2 += d2 * d2;
+            }
+            q1[tp] = wave_sum(a1); q2[tp] = wave_sum(a2);
+        }
+#pragma unroll
+        for (int tp = 0; tp < 3; ++tp) {
+            const float r1 = a.nonorm ? 1.0f : fast_rsqrt(q1[tp] * invc + LN_EPS), r2 = a.nonorm ? 1.0f : fast_rsqrt(q2[tp] * invc + LN_EPS);
+            f32x4 x = zero4;
+            if (ok[tp] && cok) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gte = fast_sigmoid(h1[tp][e] * r1 * g1v[e] + b1v[e]);
+                    x[e] = gte * (h2[tp][e] * r2 * g2v[e] + b2v[e]) + (1.0f - gte) * xr[tp][e];
+                }
+            }
+            if (c < a.kc) *(f32x4*)(xs + w * ldxs + tp * a.kc + c) = x;
+            for (int c2 = 256 + c; c2 < a.kc; c2 += 256) *(f32x4*)(xs + w * ldxs + tp * a.kc + c2) = zero4;
+            // level k of the cone: column slice 0 keeps the rows of the CURRENT position (next level's residual, the
+            // loop kernel's taps where the position is one of them)
+            if (store_blk && tp == 2 && ok[tp] && c < a.ldx) {
+                float* y = a.xstore + ((size_t)pos[tp] * a.Bpad + urow) * a.ldx + c;
+                if (a.done_sig && (pos[tp] == a.coh0 || pos[tp] == a.coh1)) st_coherent(y, x);
+                else *(f32x4*)y = x;
+            }
+        }
+        if (!is_extra) {
+            __syncthreads();
+            // ---- 16 x 64 slice (FC_CT MFMA tiles), K split over the waves (dec_layer16)
+            f32x4 acc[FC_CT][2];
+#pragma unroll
+            for (int ct = 0; ct < FC_CT; ++ct) { acc[ct][0] = zero4; acc[ct][1] = zero4; }
+            const float* xa = xs + r16 * ldxs + kq * 4;
+#pragma unroll
+            for (int i = 0; i < DEC_PF; ++i) {
+                const int ch = w + DEC_WAVES * i;
+                if (ch < nchunks) {
+                    const f32x4 av = *(const f32x4*)(xa + ch * 16);
+#pragma unroll
+                    for (int ct = 0; ct < FC_CT; ++ct) {
+                        acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bfrag[ct][i][0], acc[ct][0], 0, 0, 0);
+                        acc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bfrag[ct][i][1], acc[ct][1], 0, 0, 0);
+                        acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bfrag[ct][i][2], acc[ct][0], 0, 0, 0);
+                        acc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bfrag[ct][i][3], acc[ct][1], 0, 0, 0);
+                    }
+                }
+            }
+            // C/D layout of the 16x16 MFMA: column = lane & 15, row = 4 (lane >> 4) + register
+#pragma unroll
+            for (int ct = 0; ct < FC_CT; ++ct)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part[(w * FC_CT + ct) * 256 + (kq * 4 + e) * 16 + r16] = acc[ct][0][e] + acc[ct][1][e];
+            __syncthreads();
+            {
+                const int ct = tid >> 8, rc = tid & 255, row = rc >> 4;
+                float pv[DEC_WAVES];
+#pragma unroll
+                for (int ww = 0; ww < DEC_WAVES; ++ww) pv[ww] = part[(ww * FC_CT + ct) * 256 + rc];
+                float v = bias_v;
+#pragma unroll
+                for (int ww = 0; ww < DEC_WAVES; ++ww) v += pv[ww];
+                if (ocol < a.N) a.H[((size_t)grp * a.Bpad + ub * 16 + row) * a.ldh + ocol] = v;
+            }
+        }
+    }
+    if (a.done_sig && store_blk) {      // every storing workgroup arrives (block-uniform)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned old = atomicAdd(a.done_count, 1u);
+            if (old + 1u == a.done_target) __hip_atomic_fetch_max(a.done_sig, a.done_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+void launch_cone_fc16(const ConeFcArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)(16 * (3 * a.kc + 4) + 256 * DEC_WAVES * FC_CT) * 4;
+    static thread_local std::map<int, size_t> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t& d = done[dev];
+    if (d < lds) { (void)hipFuncSetAttribute((const void*)cone_fc16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); d = lds; }
+    const dim3 grid(round_up(a.N, 16 * FC_CT) / (16 * FC_CT), (a.n_out + a.n_extra) * (a.Bpad / 16));
+    hipLaunchKernelGGL(cone_fc16, grid, dim3(64 * DEC_WAVES), lds, s, a);
+}
+
 // attn_rows: generic rows.  mode 0 = decoder history rows (position-major, current mask p);
 // mode 1 = batched operator over (b,t) with alignments + argmax outputs.
 __global__ __launch_bounds__(256) void attn_rows(AttnRowsArgs a) {
@@ -1000,19 +1160,39 @@ __global__ __launch_bounds__(1024) void cone_qw(ConeHeadArgs a, int tq) {
         __syncthreads();
     }
     if (stopped(a.stop_after, a.t) || tq < 0) return;
-    __shared__ float qs[256];
-    __shared__ float ps[4][256];
-    const int b = blockIdx.x, n = threadIdx.x & 255, kq = threadIdx.x >> 8, d = a.d;
+    // wave w owns k in [k0, k0 + kper), lane owns 4 output channels per 256-channel group: every weight request of the wave
+    // is issued before the first one is used (the k loop has one memory latency, not kper of them)
+    __shared__ float ps[16][256];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6, d = a.d;
     const size_t qrow = ((size_t)tq * a.Bpad + b) * d;
-    if (threadIdx.x < d) qs[threadIdx.x] = a.Q[qrow + threadIdx.x];
-    __syncthreads();
-    const int kper = (d + 3) / 4, k0 = kq * kper, k1 = min(d, k0 + kper);
-    float acc = 0.f;
-    if (n < d)
-        for (int k = k0; k < k1; ++k) acc = fmaf(qs[k], a.Wq[(size_t)k * a.ldn + n], acc);
-    ps[kq][n] = acc;
-    __syncthreads();
-    if (kq == 0 && n < d) a.QW[qrow + n] = a.bias[n] + ((ps[0][n] + ps[1][n]) + (ps[2][n] + ps[3][n]));
+    const int kper = (d + 15) / 16, k0 = w * kper;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < d; c0 += 256) {
+        const int c = c0 + lane * 4;
+        f32x4 wv[16]; float qv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int k = k0 + i;
+            const bool in = i < kper && k < d && c < d;
+            wv[i] = in ? *(const f32x4*)(a.Wq + (size_t)k * a.ldn + c) : zero4;
+            qv[i] = (i < kper && k < d) ? a.Q[qrow + k] : 0.f;
+        }
+        f32x4 acc = zero4;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(qv[i], wv[i][e], acc[e]);
+        __syncthreads();
+        *(f32x4*)&ps[w][lane * 4] = acc;
+        __syncthreads();
+        if (threadIdx.x < 256 && c0 + (int)threadIdx.x < d) {
+            const int n = c0 + threadIdx.x;
+            float v = a.bias[n];
+#pragma unroll
+            for (int ww = 0; ww < 16; ++ww) v += ps[ww][threadIdx.x];
+            a.QW[qrow + n] = v;
+        }
+    }
 }
 void launch_cone_qw(const ConeHeadArgs& a, int tq, hipStream_t s) {
     hipLaunchKernelGGL(cone_qw, dim3(a.B), dim3(1024), 0, s, a, tq);
