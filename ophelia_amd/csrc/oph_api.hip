@@ -69,6 +69,8 @@ struct Layer {
     float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
 };
 
+struct FcTables { bool valid; short tab[3][CONE_FC_MAXOUT], need[3][CONE_FC_MAXOUT], res[3][CONE_FC_MAXOUT]; short extra[CONE_FC_MAXEXTRA], extra_res[CONE_FC_MAXEXTRA]; int n_extra; };
+
 struct ProfClass {
     const char* name;
     long long launches = 0;
@@ -168,7 +170,7 @@ struct oph_handle {
     int n_hc_dec = 0, dec_pre = 0;                // #hc layers, #k=1 layers before them
     std::vector<std::vector<int>> Hset;           // Hset[h] sorted offsets (>=1) at which hc layer h's INPUT is needed
     std::vector<int*> d_tab, d_need, d_res;       // per hc layer h<n-1: tables for computing layer h over Hset[h+1]
-    std::vector<int*> d_extra; std::vector<int> n_extra;   // per hc layer: level positions only the loop kernel reads (cone_fc16)
+    std::vector<FcTables> fc_tab;                 // per hc layer: cone_fc16's index tables (kernel arguments)
     float* coneRawB = nullptr;                    // second raw buffer: consecutive cone_fc16 launches ping-pong
     int cone_fc_rows = 64;                        // cone levels with at most this many output rows run as cone_fc16 (0: never)
     int* d_off0 = nullptr;                        // Hset[0] on device
@@ -622,7 +624,7 @@ int ensure_decode_state(oph_handle* h, int B) {
         for (size_t i = h->n_weight_allocs; i < h->allocs.size(); ++i) hipFree(h->allocs[i]);
         h->allocs.resize(h->n_weight_allocs);
         h->ae_hist.clear(); h->ae_raw.clear(); h->ad_raw.clear(); h->ad_xrow.clear();
-        h->cone[0].clear(); h->cone[1].clear(); h->d_tab.clear(); h->d_need.clear(); h->d_res.clear(); h->d_extra.clear(); h->n_extra.clear(); h->Hset.clear();
+        h->cone[0].clear(); h->cone[1].clear(); h->d_tab.clear(); h->d_need.clear(); h->d_res.clear(); h->fc_tab.clear(); h->Hset.clear();
         for (auto& ge : h->dec_graph) if (ge) { hipGraphExecDestroy(ge); ge = nullptr; }
         h->KV = nullptr; h->KV2[0] = h->KV2[1] = nullptr; h->preenc_valid = false; h->capB = 0; h->actA = h->actB = h->raw = h->actA2 = h->actB2 = h->raw2 = nullptr;
         h->d_loop_layers = nullptr;
@@ -705,18 +707,29 @@ int ensure_decode_state(oph_handle* h, int B) {
             hipMemcpyAsync(dr, res.data(), res.size() * 4, hipMemcpyHostToDevice, h->stream);
             hipStreamSynchronize(h->stream);
             h->d_tab.push_back(dt); h->d_need.push_back(dn); h->d_res.push_back(dr);
-            // the positions of level k that the loop kernel's taps read (offsets r, 2r) but no output of layer k has as its
-            // current position: cone_fc16 normalises and stores them in extra row groups
-            std::vector<int> extra;
-            for (int o : {r, 2 * r}) {
-                const int ip = idx_of(h->Hset[k], o);
-                bool is_cur = false;
-                for (int i = 0; i < n_out; ++i) is_cur = is_cur || tab[2 * n_out + i] == ip;
-                if (ip >= 0 && !is_cur) extra.push_back(ip);
+            // cone_fc16's tables for layer k (k >= 1): per output its three level-k positions and their level k-1 residual
+            // positions; plus the positions of level k that the loop kernel's taps read (offsets r, 2r) but no output has
+            // as its current position -- normalised and stored in extra row groups
+            FcTables ft{};
+            ft.valid = k >= 1 && n_out <= CONE_FC_MAXOUT;
+            if (ft.valid) {
+                for (int i = 0; i < n_out; ++i)
+                    for (int t = 0; t < 3; ++t) {
+                        ft.tab[t][i] = (short)tab[t * n_out + i]; ft.need[t][i] = (short)need[t * n_out + i];
+                        ft.res[t][i] = (short)idx_of(h->Hset[k - 1], h->Hset[k][tab[t * n_out + i]]);
+                        if (ft.res[t][i] < 0) ft.valid = false;
+                    }
+                for (int o : {r, 2 * r}) {
+                    const int ip = idx_of(h->Hset[k], o);
+                    bool is_cur = false;
+                    for (int i = 0; i < n_out; ++i) is_cur = is_cur || tab[2 * n_out + i] == ip;
+                    if (ip >= 0 && !is_cur) {
+                        if (ft.n_extra >= CONE_FC_MAXEXTRA) { ft.valid = false; break; }
+                        ft.extra[ft.n_extra] = (short)ip; ft.extra_res[ft.n_extra] = (short)idx_of(h->Hset[k - 1], o); ++ft.n_extra;
+                    }
+                }
             }
-            int* de = h->dalloc<int>(std::max<size_t>(extra.size(), 1));
-            if (!extra.empty()) hipMemcpy(de, extra.data(), extra.size() * 4, hipMemcpyHostToDevice);
-            h->d_extra.push_back(de); h->n_extra.push_back((int)extra.size());
+            h->fc_tab.push_back(ft);
         }
     }
     const int ld_cat = round_up(d + m.speaker_embedding_size, 32);
@@ -905,10 +918,11 @@ void launch_cone(oph_handle* h, int t) {
     // layer's contraction (cone_fc16) instead of ln_rows + a split-K GEMM.  From the first such level to the end.
     static const int fc_rows_env = getenv("OPH_CONE_FC_ROWS") ? atoi(getenv("OPH_CONE_FC_ROWS")) : -1;
     const int fc_rows = fc_rows_env >= 0 ? fc_rows_env : h->cone_fc_rows;
+    static const int fc_in_split = getenv("OPH_CONE_FC_INSPLIT") ? std::max(1, atoi(getenv("OPH_CONE_FC_INSPLIT"))) : 2;
     int fc_from = nh;             // first layer index evaluated by cone_fc16
     for (int k = nh - 2; k >= 1; --k) {
         const Layer& l = h->audiodec[pre + k]; const Layer& lp = h->audiodec[pre + k - 1];
-        const bool ok = (int)h->Hset[k + 1].size() * Bpad <= fc_rows && lp.cout <= 256 && l.cin == lp.cout && l.kc <= 512 && l.ntaps == 3 &&
+        const bool ok = (int)h->Hset[k + 1].size() * Bpad <= fc_rows && h->fc_tab[k].valid && lp.cout <= 256 && l.cin == lp.cout && l.kc <= 512 && l.ntaps == 3 &&
                         !l.lcc_gate && !lp.lcc_gate && l.ccat == 0 && (Bpad % 16) == 0;
         if (!ok) break;
         fc_from = k;
@@ -922,9 +936,10 @@ void launch_cone(oph_handle* h, int t) {
             ConeFcArgs c{};
             c.rawp = raw_in; c.ldrawp = lp.Nalloc; c.nsplit = raw_split; c.split_stride = raw_stride;
             c.g1 = lp.g1; c.b1 = lp.b1; c.g2 = lp.g2; c.b2 = lp.b2; c.nonorm = !lp.ln; c.C = lp.cout;
-            c.xres = cone[k - 1]; c.ldres = lp.kc; c.restab = h->d_res[k - 1];
-            c.tab = h->d_tab[k]; c.need = h->d_need[k]; c.n_out = n_out; c.j = t;
-            c.extra = h->d_extra[k]; c.n_extra = h->n_extra[k];
+            c.xres = cone[k - 1]; c.ldres = lp.kc; c.n_out = n_out; c.j = t;
+            const FcTables& ft = h->fc_tab[k];
+            memcpy(c.tab, ft.tab, sizeof c.tab); memcpy(c.need, ft.need, sizeof c.need); memcpy(c.res, ft.res, sizeof c.res);
+            memcpy(c.extra, ft.extra, sizeof c.extra); memcpy(c.extra_res, ft.extra_res, sizeof c.extra_res); c.n_extra = ft.n_extra;
             c.xstore = cone[k]; c.ldx = l.kc;
             c.Wt = l.Wt; c.ldw = 3 * l.kc; c.bias = l.bias; c.kc = l.kc; c.N = l.N;
             c.H = raw_in == h->coneRaw ? h->coneRawB : h->coneRaw; c.ldh = l.Nalloc;
@@ -945,7 +960,9 @@ void launch_cone(oph_handle* h, int t) {
             g.X = cone[k]; g.ldx = l.kc; g.Wt = l.Wt; g.ldw = 3 * l.kc; g.bias = l.bias; g.H = h->coneRaw; g.ldh = l.Nalloc;
             g.M = n_out * Bpad; g.N = l.N; g.kc = l.kc; g.ntaps = 3; g.mode = 1; g.Bpad = Bpad; g.n_out = n_out; g.j = t;
             g.tab = h->d_tab[k]; g.need = h->d_need[k]; g.stop_after = stop_after; g.t = t;
-            g.ksplit = cone_ksplit(g.M); g.split_stride = (long long)g.M * l.Nalloc;
+            g.ksplit = cone_ksplit(g.M);
+            if (k + 1 >= fc_from && k + 2 < nh) g.ksplit = std::min(g.ksplit, fc_in_split);     // its consumer is a cone_fc16: fewer partials to sum there
+            g.split_stride = (long long)g.M * l.Nalloc;
             run_gemm(h, g, l.cin);
             raw_in = h->coneRaw; raw_split = g.ksplit; raw_stride = g.split_stride;
         }
@@ -1158,9 +1175,37 @@ int build_loop_layers(oph_handle* h) {
     h->loop_nlayers = (int)v.size();
     h->loop_slices = 1; h->loop_kmax = 32;
     for (const LoopLayer& q : v) { h->loop_slices = std::max(h->loop_slices, round_up(q.N, 16) / 16); h->loop_kmax = std::max(h->loop_kmax, q.ntaps * q.kc); }
+    if (const char* rr = getenv("OPH_RUN_ROWS")) h->loop_rows = atoi(rr) == 4 ? 4 : 8;
+    const int R = h->loop_rows, PF = (768 / 16 + R - 1) / R;       // as dec_loop<R> (RUN_KMAX = 768)
+    if (h->loop_kmax > 768) { h->fail("internal: layer K exceeds the loop kernel's"); return OPH_ERR_STATE; }
     std::vector<unsigned> words(v.size() * LOOP_DESC_STRIDE, 0u);
     for (size_t i = 0; i < v.size(); ++i) {
-        const LoopLayer& q = v[i];
+        LoopLayer& q = v[i];
+        // The weights in the order the loop kernel's lanes hold them: [column slice g][wave w][chunk i][lane][4] with
+        // chunk = w + R i, column = 16 g + 4 (lane >> 4) + (lane & 3), k = 16 chunk + 4 ((lane >> 2) & 3) + e -- one
+        // fragment request of a wave is 1 KB contiguous (8 full lines) instead of 16 half lines 3 KB apart: the CU's
+        // address unit was the bottleneck of the weight prefetch (profiles/r02 ablation: 0.9 us of a 5.3 us layer).
+        {
+            const int slices = round_up(q.N, 16) / 16, nch = (q.ntaps * q.kc) / 16;
+            std::vector<float> Wh((size_t)slices * 16 * q.ldw, 0.f);
+            const size_t rows_have = (size_t)std::min(slices * 16, round_up(q.N, 16));
+            if (hipMemcpy(Wh.data(), q.Wt, rows_have * q.ldw * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { h->fail("weight read-back failed"); return OPH_ERR_DEVICE; }
+            std::vector<float> Ws((size_t)slices * R * PF * 64 * 4, 0.f);
+            for (int g = 0; g < slices; ++g)
+                for (int w = 0; w < R; ++w)
+                    for (int pf = 0; pf < PF; ++pf) {
+                        const int ch = std::min(w + R * pf, nch - 1);
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int col = 16 * g + 4 * (lane >> 4) + (lane & 3), k = 16 * ch + 4 * ((lane >> 2) & 3);
+                            float* dst = &Ws[((((size_t)g * R + w) * PF + pf) * 64 + lane) * 4];
+                            for (int e = 0; e < 4; ++e) dst[e] = Wh[(size_t)col * q.ldw + k + e];
+                        }
+                    }
+            float* dsw = h->dalloc<float>(Ws.size());
+            if (!dsw) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
+            if (hipMemcpy(dsw, Ws.data(), Ws.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { h->fail("weight upload failed"); return OPH_ERR_DEVICE; }
+            q.Wt = dsw;
+        }
         unsigned* w = &words[i * LOOP_DESC_STRIDE];
         const int ls = round_up(std::max(q.cin, 4), 4);
         float* lnp = nullptr;
@@ -1468,7 +1513,6 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
         if (h->loop_capacity < 0) {
             int ncu = h->ndec_cus;
             if (ncu <= 0) { hipDeviceProp_t prop; ncu = hipGetDeviceProperties(&prop, h->device) == hipSuccess ? prop.multiProcessorCount : 0; }
-            if (const char* rr = getenv("OPH_RUN_ROWS")) h->loop_rows = atoi(rr) == 4 ? 4 : 8;
             h->loop_capacity = dec_loop_blocks_per_cu(h->loop_rows, h->loop_kmax) * ncu;
         }
         if (h->loop_slices * (h->Bpad / h->loop_rows) > h->loop_capacity) loop_mode = false;

@@ -396,9 +396,10 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
         const int ntaps = D.ntaps(), kc = D.kc();
         const int nch = (ntaps * kc) >> 4;
         if (n0 < D.N() && !(a.dbg & 1)) {       // chunks past the layer's K are never multiplied: load a valid address instead of branching
-            const float* wrow = D.Wt() + (size_t)(n0 + mcol) * D.ldw() + mkk * 4;
+            // pre-swizzled on the host (build_loop_layers): [slice g][wave w][chunk i][lane] -- 1 KB contiguous per request
+            const f32x4* wsw = (const f32x4*)D.Wt() + ((size_t)(g * R + w) * PF) * 64 + lane;
 #pragma unroll
-            for (int i = 0; i < PF; ++i) bfrag[i] = *(const f32x4*)(wrow + min(w + R * i, nch - 1) * 16);
+            for (int i = 0; i < PF; ++i) bfrag[i] = wsw[i * 64];
             bias_v = D.bias()[n0 + (tid & 15)];
         }
         // the two older taps: always requested from a valid row (clamped), masked where they are staged -- no branch, no

@@ -125,12 +125,16 @@ void launch_cone_qw(const ConeHeadArgs& a, int tq, hipStream_t s);       // QW[t
 // normalised from layer k-1's raw rows, staged, and contracted (16 x 16 slices, K split over 16 waves, as dec_layer16).
 // Column slice 0 stores the x rows it produced (level k of the cone); `extra` positions are rows only the loop kernel
 // reads (prologue + store, no contraction).
+constexpr int CONE_FC_MAXOUT = 16, CONE_FC_MAXEXTRA = 4;
 struct ConeFcArgs {
     const float* rawp; int ldrawp; int nsplit; long long split_stride;     // raw rows of layer k-1 [n_k * Bpad][2C] (sum of nsplit partials)
     const float *g1, *b1, *g2, *b2; int nonorm; int C;                     // LayerNorm parameters of layer k-1
-    const float* xres; int ldres; const int* restab;                       // level k-1 rows; restab[i] = its position index for level-k position i
-    const int* tab; const int* need; int n_out; int j;                     // [3][n_out] level-k position per tap (oldest first), valid iff j >= need
-    const int* extra; int n_extra;                                         // level-k positions that are stored only
+    // the small index tables travel in the kernel arguments (scalar loads, no dependent global round trips)
+    const float* xres; int ldres;                                          // level k-1 rows
+    short tab[3][CONE_FC_MAXOUT]; short need[3][CONE_FC_MAXOUT];           // level-k position per tap (oldest first), valid iff j >= need
+    short res[3][CONE_FC_MAXOUT];                                          // level k-1 position of that level-k position (residual row)
+    short extra[CONE_FC_MAXEXTRA]; short extra_res[CONE_FC_MAXEXTRA];      // level-k positions that are stored only (+ their residual positions)
+    int n_out; int n_extra; int j;
     float* xstore; int ldx;                                                // level k rows [n_k * Bpad][ldx] (ldx = kc of layer k)
     const float* Wt; int ldw; const float* bias; int kc; int N;            // layer k: [Nalloc][3 kc]
     float* H; int ldh;                                                     // raw rows of layer k [n_out * Bpad][ldh]

@@ -775,7 +775,9 @@ void launch_dec_layer(const DecArgs& a, int Npad16, hipStream_t s) {
 // cone_fc16 (ConeFcArgs): see oph_internal.h.  grid = (Npad/16, (n_out + n_extra) * Bpad/16), 16 waves; wave w owns
 // utterance row w of the group for the three gathered positions.
 // =====================================================================================
-constexpr int FC_CT = 4;          // 16-column MFMA tiles per workgroup: the prologue is redone per column slice, so slices are wide (64 columns)
+// FC_CT: 16-column MFMA tiles per workgroup.  The prologue is redone per column slice, so slices are wide (64 columns) when
+// there are many row groups and 32 columns when few (more CUs share the contraction).
+template <int NS, int FC_CT>       // NS: split-K partials of the producing GEMM (1: a cone_fc16 or an unsplit GEMM, 2, 4)
 __global__ __launch_bounds__(64 * DEC_WAVES) void cone_fc16(ConeFcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Ktot = 3 * a.kc, ldxs = Ktot + 4;
@@ -792,43 +794,55 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void cone_fc16(ConeFcArgs a) {
     const bool live = !stopped(a.stop_after, a.t);
     const bool store_blk = blockIdx.x == 0;
     if (live && !(is_extra && !store_blk)) {
-        // ---- independent requests first: weight fragments, then the raw / residual rows of this wave's three positions
+        // ---- independent requests: weight fragments and the raw / residual rows of this wave's three positions.  With
+        //      split-K partials to sum the fragments are requested after the sums (128 registers per lane at 16 waves)
         f32x4 bfrag[FC_CT][DEC_PF];
+        auto fetch_w = [&]() {
 #pragma unroll
-        for (int ct = 0; ct < FC_CT; ++ct) {
-            const float* wrow = a.Wt + (size_t)(n0 + ct * 16 + r16) * a.ldw + kq * 4;
-            const bool cols = !is_extra && n0 + ct * 16 < a.N;
+            for (int ct = 0; ct < FC_CT; ++ct) {
+                const float* wrow = a.Wt + (size_t)(n0 + ct * 16 + r16) * a.ldw + kq * 4;
+                const bool cols = !is_extra && n0 + ct * 16 < a.N;
 #pragma unroll
-            for (int i = 0; i < DEC_PF; ++i) {
-                const int ch = w + DEC_WAVES * i;
-                bfrag[ct][i] = (cols && ch < nchunks) ? *(const f32x4*)(wrow + ch * 16) : zero4;
+                for (int i = 0; i < DEC_PF; ++i) {
+                    const int ch = w + DEC_WAVES * i;
+                    bfrag[ct][i] = (cols && ch < nchunks) ? *(const f32x4*)(wrow + ch * 16) : zero4;
+                }
             }
-        }
+        };
+        if (NS == 1) fetch_w();
         const int ocol = n0 + (tid >> 8) * 16 + (tid & 15);          // reducer role: thread -> (tile tid >> 8, row (tid >> 4) & 15, column tid & 15)
-        const float bias_v = (!is_extra && ocol < a.N) ? a.bias[ocol] : 0.f;
+        const bool reducer = (tid >> 8) < FC_CT;
+        const float bias_v = (!is_extra && reducer && ocol < a.N) ? a.bias[ocol] : 0.f;
         const int C = a.C, c = lane * 4;
         const bool cok = c < C;
         const int urow = ub * 16 + w;
-        int pos[3]; bool ok[3];
+        int pos[3], rpos[3]; bool ok[3];
 #pragma unroll
         for (int tp = 0; tp < 3; ++tp) {
-            if (is_extra) { pos[tp] = a.extra[grp - a.n_out]; ok[tp] = tp == 2; }
-            else { pos[tp] = a.tab[tp * a.n_out + grp]; ok[tp] = a.j >= a.need[tp * a.n_out + grp]; }
+            if (is_extra) { pos[tp] = a.extra[grp - a.n_out]; rpos[tp] = a.extra_res[grp - a.n_out]; ok[tp] = tp == 2; }
+            else { pos[tp] = a.tab[tp][grp]; rpos[tp] = a.res[tp][grp]; ok[tp] = a.j >= a.need[tp][grp]; }
         }
-        f32x4 h1[3], h2[3], xr[3];
+        // every request of the three rows (and of all split-K partials) before the first use
+        f32x4 h1[3], h2[3], xr[3], p1[3][NS], p2[3][NS];        // ([NS - 1] used)
 #pragma unroll
         for (int tp = 0; tp < 3; ++tp) {
             h1[tp] = zero4; h2[tp] = zero4; xr[tp] = zero4;
-            if (ok[tp] && cok) {
-                const float* hp = a.rawp + ((size_t)pos[tp] * a.Bpad + urow) * a.ldrawp;
-                h1[tp] = *(const f32x4*)(hp + c); h2[tp] = *(const f32x4*)(hp + C + c);
-                for (int sp = 1; sp < a.nsplit; ++sp) {
-                    h1[tp] += *(const f32x4*)(hp + sp * a.split_stride + c);
-                    h2[tp] += *(const f32x4*)(hp + sp * a.split_stride + C + c);
-                }
-                xr[tp] = *(const f32x4*)(a.xres + ((size_t)a.restab[pos[tp]] * a.Bpad + urow) * a.ldres + c);
+            const bool in = ok[tp] && cok;
+            const float* hp = a.rawp + ((size_t)pos[tp] * a.Bpad + urow) * a.ldrawp;
+            if (in) { h1[tp] = *(const f32x4*)(hp + c); h2[tp] = *(const f32x4*)(hp + C + c); }
+#pragma unroll
+            for (int sp = 1; sp < NS; ++sp) {
+                const bool ins = in && sp < a.nsplit;
+                p1[tp][sp - 1] = ins ? *(const f32x4*)(hp + sp * a.split_stride + c) : zero4;
+                p2[tp][sp - 1] = ins ? *(const f32x4*)(hp + sp * a.split_stride + C + c) : zero4;
             }
+            if (in) xr[tp] = *(const f32x4*)(a.xres + ((size_t)rpos[tp] * a.Bpad + urow) * a.ldres + c);
         }
+#pragma unroll
+        for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+            for (int sp = 0; sp + 1 < NS; ++sp) { h1[tp] += p1[tp][sp]; h2[tp] += p2[tp][sp]; }      // same order as ln_rows: partial 0 + 1 + 2 + 3
+        if (NS > 1) { asm volatile("" ::: "memory"); fetch_w(); }
         f32x4 g1v = zero4, b1v = zero4, g2v = zero4, b2v = zero4;
         if (cok) { g1v = *(const f32x4*)(a.g1 + c); b1v = *(const f32x4*)(a.b1 + c); g2v = *(const f32x4*)(a.g2 + c); b2v = *(const f32x4*)(a.b2 + c); }
         // ---- prologue: x = sigmoid(LN1(h1)) * LN2(h2) + (1 - sigmoid) * residual  (modules.py:194-203); the three rows'
@@ -899,7 +913,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void cone_fc16(ConeFcArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) part[(w * FC_CT + ct) * 256 + (kq * 4 + e) * 16 + r16] = acc[ct][0][e] + acc[ct][1][e];
             __syncthreads();
-            {
+            if (reducer) {
                 const int ct = tid >> 8, rc = tid & 255, row = rc >> 4;
                 float pv[DEC_WAVES];
 #pragma unroll
@@ -920,15 +934,23 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void cone_fc16(ConeFcArgs a) {
         }
     }
 }
-void launch_cone_fc16(const ConeFcArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)(16 * (3 * a.kc + 4) + 256 * DEC_WAVES * FC_CT) * 4;
+template <int NS, int CT>
+static void launch_cone_fc16_t(const ConeFcArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)(16 * (3 * a.kc + 4) + 256 * DEC_WAVES * CT) * 4;
     static thread_local std::map<int, size_t> done;
     int dev = 0;
     (void)hipGetDevice(&dev);
     size_t& d = done[dev];
-    if (d < lds) { (void)hipFuncSetAttribute((const void*)cone_fc16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); d = lds; }
-    const dim3 grid(round_up(a.N, 16 * FC_CT) / (16 * FC_CT), (a.n_out + a.n_extra) * (a.Bpad / 16));
-    hipLaunchKernelGGL(cone_fc16, grid, dim3(64 * DEC_WAVES), lds, s, a);
+    if (d < lds) { (void)hipFuncSetAttribute((const void*)cone_fc16<NS, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); d = lds; }
+    const dim3 grid(round_up(a.N, 16 * CT) / (16 * CT), (a.n_out + a.n_extra) * (a.Bpad / 16));
+    hipLaunchKernelGGL((cone_fc16<NS, CT>), grid, dim3(64 * DEC_WAVES), lds, s, a);
+}
+void launch_cone_fc16(const ConeFcArgs& a, hipStream_t s) {
+    // 32-column slices while that still leaves at most ~one workgroup per CU of the cone's partition
+    const bool narrow = (a.n_out + a.n_extra) * (a.Bpad / 16) * (round_up(a.N, 32) / 32) <= 128;
+    if (a.nsplit <= 1) { if (narrow) launch_cone_fc16_t<1, 2>(a, s); else launch_cone_fc16_t<1, 4>(a, s); }
+    else if (a.nsplit == 2) { if (narrow) launch_cone_fc16_t<2, 2>(a, s); else launch_cone_fc16_t<2, 4>(a, s); }
+    else { if (narrow) launch_cone_fc16_t<4, 2>(a, s); else launch_cone_fc16_t<4, 4>(a, s); }
 }
 
 // attn_rows: generic rows.  mode 0 = decoder history rows (position-major, current mask p);
