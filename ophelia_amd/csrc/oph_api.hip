@@ -821,17 +821,20 @@ void launch_cone(oph_handle* h, int t) {
         if (spk_next) { ch.Y = h->coneTmp; ch.ldy = h->audiodec[1].kc; ch.spk_table = h->emb_spk; ch.spk_ids = h->d_spk; ch.spk_dim = h->audiodec[1].ccat; }
         else { ch.Y = cone[0]; ch.ldy = h->audiodec[pre].kc; }
         ch.stop_after = stop_after; ch.t = t;
-        {   // the newest history position's Q . Wq + bias first (it also carries the wait for the attention signal)
-            ConeHeadArgs cq = ch;
-            cq.wait_sig = ar.wait_sig; cq.wait_val = ar.wait_val; cq.wait_err = ar.wait_err;
-            h->pbegin(PC_CONEHEAD);
-            launch_cone_qw(cq, t - h->Hset[0][0], g_cur);
-            h->pend(PC_CONEHEAD, (double)d * d * 4.0, 2.0 * B * d * d);
+        ch.wait_sig = ar.wait_sig; ch.wait_val = ar.wait_val; ch.wait_err = ar.wait_err;
+        ch.npos = n0; ch.i_new = 0;
+        for (int i = 1; i < n0; ++i) if (h->Hset[0][i] < h->Hset[0][ch.i_new]) ch.i_new = i;
+        if (!spk_next && h->cone_inline_sig) {
+            // level 0's tap rows: the newest position is spread over B workgroups (one per utterance), any other over Bpad/16
+            const Layer& tl = h->audiodec[pre];
+            ch.coh0 = idx_of(h->Hset[0], -tl.off[0]); ch.coh1 = idx_of(h->Hset[0], -tl.off[1]);
+            auto blocks_of = [&](int pos) { return pos < 0 ? 0u : (pos == ch.i_new ? (unsigned)B : (unsigned)(Bpad / 16)); };
+            h->cone_done_total[0] += blocks_of(ch.coh0) + (ch.coh1 != ch.coh0 ? blocks_of(ch.coh1) : 0u);
+            ch.done_sig = h->d_sig + LOOP_SIG_LEVEL0; ch.done_val = h->cone_done_val; ch.done_count = h->d_cone_count; ch.done_target = h->cone_done_total[0];
         }
-        if (!spk_next) level_done(0, ch.done_sig, ch.done_val, ch.done_count, ch.done_target, ch.coh0, ch.coh1);
         h->pbegin(PC_CONEHEAD);
         launch_cone_head(ch, g_cur);
-        h->pend(PC_CONEHEAD, (double)n0 * B * (3.0 * d + 2.0 * m.attention_win_size * d) * 4.0, (double)n0 * B * 4.0 * m.attention_win_size * d);
+        h->pend(PC_CONEHEAD, ((double)n0 * B * (3.0 * d + 2.0 * m.attention_win_size * d) + (double)d * d) * 4.0, (double)n0 * B * 4.0 * m.attention_win_size * d + 2.0 * B * d * d);
         pre_first = 1;
     } else {
     h->pbegin(PC_ATTN_ROWS);

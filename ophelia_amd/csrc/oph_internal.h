@@ -100,7 +100,7 @@ struct AttnRowsArgs {
 // AudioDec's first layer C_1 is a k=1 conv of R' = [ctx | Q] (networks.py:316-319, 376): it is linear, so
 //   C_1(R')[t'] = sum_i prob_i(t') * (V[p+i] . Wc)  +  (Q[t'] . Wq + bias)
 // with VW = V . Wc computed once per batch and QW[t'] = Q[t'] . Wq + bias once per position (each history position is
-// new exactly once: at offset 1; cone_qw computes it).  One wave per (position, utterance) row: attention window, the
+// new exactly once: at offset 1; the workgroups of that position compute it).  One wave per (position, utterance) row: attention window, the
 // two cached terms, LayerNorm -- instead of attn_rows + a [1344 x 512 x 256] GEMM + ln_rows every step.
 struct ConeHeadArgs {
     const float* Q; int d;              // Qhist [max_T][Bpad][d]
@@ -110,6 +110,7 @@ struct ConeHeadArgs {
     const float* Wq; int ldn;           // [d][ldn] n-contiguous rows of the Q half of C_1's kernel
     const float* bias; const float* gamma; const float* beta; int nonorm;
     const int* p; int B; int Bpad; int nrows; const int* off; int j;     // row i*Bpad+b <-> time j - off[i]
+    int npos; int i_new;                // positions (nrows = npos * Bpad); index of the newest one (smallest offset)
     float* Y; int ldy;                  // output rows (layer input of the next cone stage)
     const float* spk_table; const int* spk_ids; int spk_dim;            // optional embedding appended after the d channels
     const int* stop_after; int t;
@@ -117,7 +118,6 @@ struct ConeHeadArgs {
     unsigned* done_sig; unsigned done_val; unsigned* done_count; unsigned done_target; int coh0, coh1;      // as EpiArgs: cone level 0 written
 };
 void launch_cone_head(const ConeHeadArgs& a, hipStream_t s);
-void launch_cone_qw(const ConeHeadArgs& a, int tq, hipStream_t s);       // QW[tq] = Q[tq] . Wq + bias (the position that is new this step)
 
 // ---- cone_fc16: a SMALL cone level in one launch (oph_kernels.hip).  Highway layer k of the AudioDec cone evaluated at
 // its n_out output positions, with the LayerNorm / gate / highway mix of layer k-1 (the launch ln_rows would be) as the

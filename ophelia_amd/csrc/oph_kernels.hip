@@ -1060,40 +1060,17 @@ __global__ __launch_bounds__(256) void attn_rows(AttnRowsArgs a) {
     }
 }
 
-// cone_head: see ConeHeadArgs (oph_internal.h).  256 threads = 4 rows; lane l owns channels 4l..4l+3 (d <= 256).
-static __device__ __forceinline__ void cone_head_body(const ConeHeadArgs& a) {
-    if (a.wait_sig) {
-        if (threadIdx.x == 0) {
-            long long t0 = 0;
-            for (int it = 0; (int)(__hip_atomic_load(a.wait_sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.wait_val) < 0; ++it) {
-                __builtin_amdgcn_s_sleep(8);
-                if ((it & 255) == 255) {
-                    const long long now = wall_clock64();
-                    if (t0 == 0) t0 = now;
-                    if (now - t0 > 200000000LL || __hip_atomic_load(a.wait_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                        __hip_atomic_store(a.wait_err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-    }
-    if (stopped(a.stop_after, a.t)) return;
-    const int lane = threadIdx.x & 63;
-    const int rid = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (rid >= a.nrows) return;
-    const int i = rid / a.Bpad, b = rid - i * a.Bpad;
-    const int tq = a.j - a.off[i];
-    if (b >= a.B || tq < 0) return;
+// cone_head: see ConeHeadArgs (oph_internal.h).  One launch, 16 waves per workgroup, lane l owns channels 4l..4l+3
+// (d <= 256).  Workgroup b < B belongs to utterance b's NEWEST history position (index i_new, time j - off[i_new]): its
+// 16 waves first compute that position's Q . Wq + bias row (K split over the waves, every weight request issued before
+// the first use), cache it in QW, and wave 0 finishes the row.  The other workgroups take 16 rows each of the remaining
+// positions, reading the cached QW.  First launch of a cone in dec_loop mode: waits for the loop kernel's signal.
+static __device__ __forceinline__ void cone_head_row(const ConeHeadArgs& a, int i, int b, int tq, const f32x4& qw, int lane) {
     const int d = a.d, c = lane * 4;
     const bool cok = c < d;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const size_t qrow = ((size_t)tq * a.Bpad + b) * d;
     const f32x4 q = cok ? *(const f32x4*)(a.Q + qrow + c) : zero4;
-    // Q . Wq + bias of this position: written by cone_qw when the position was new (offset 1; this step for the newest)
-    const f32x4 qw = cok ? *(const f32x4*)(a.QW + qrow + c) : zero4;
     // attention window [p, p+win) under the CURRENT mask (networks.py:300-315)
     const int p = a.p[b];
     const int nwin = min(a.win, a.N_keys - p);
@@ -1130,7 +1107,7 @@ static __device__ __forceinline__ void cone_head_body(const ConeHeadArgs& a) {
 #pragma unroll
     for (int n = 0; n < 4; ++n) { const float dl = cok ? h[n] - mean : 0.f; h[n] = dl; qq += dl * dl; }
     const float rstd = a.nonorm ? 1.0f : 1.0f / sqrtf(wave_sum(qq) * invd + LN_EPS);
-    float* y = a.Y + (size_t)rid * a.ldy;
+    float* y = a.Y + ((size_t)i * a.Bpad + b) * a.ldy;
     if (cok) {
         const f32x4 g = *(const f32x4*)(a.gamma + c), bt = *(const f32x4*)(a.beta + c);
         f32x4 o;
@@ -1147,22 +1124,13 @@ static __device__ __forceinline__ void cone_head_body(const ConeHeadArgs& a) {
     }
     for (int c2 = ctot + lane; c2 < a.ldy; c2 += 64) y[c2] = 0.f;
 }
-__global__ __launch_bounds__(256) void cone_head(ConeHeadArgs a) {
-    cone_head_body(a);
-    const int pos_b = a.done_sig ? (int)(blockIdx.x * 4) / a.Bpad : -1;
-    if (a.done_sig && (pos_b == a.coh0 || pos_b == a.coh1)) {       // cone level 0: its tap rows are written, raise its word (see ln_rows)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned old = atomicAdd(a.done_count, 1u);
-            if (old + 1u == a.done_target) __hip_atomic_fetch_max(a.done_sig, a.done_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-}
-// cone_qw: QW[t'] = Q[t'] . Wq + bias for the position that became history this step (one workgroup per utterance,
-// 1024 threads = 4 k-quarters x 256 output channels; the Q row is broadcast from LDS, weight rows are coalesced).
-// First launch of a cone in dec_loop mode: waits for the loop kernel's attention signal.
-__global__ __launch_bounds__(1024) void cone_qw(ConeHeadArgs a, int tq) {
+__global__ __launch_bounds__(1024) void cone_head(ConeHeadArgs a) {
+    __shared__ float ps[16][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool newest = (int)blockIdx.x < a.B;
+    int pos_b;                              // position index this workgroup's rows belong to (one position: Bpad % 16 == 0)
+    if (newest) pos_b = a.i_new;
+    else { pos_b = ((int)blockIdx.x - a.B) * 16 / a.Bpad; if (pos_b >= a.i_new) ++pos_b; }
     if (a.wait_sig) {
         if (threadIdx.x == 0) {
             long long t0 = 0;
@@ -1181,47 +1149,65 @@ __global__ __launch_bounds__(1024) void cone_qw(ConeHeadArgs a, int tq) {
         }
         __syncthreads();
     }
-    if (stopped(a.stop_after, a.t) || tq < 0) return;
-    // wave w owns k in [k0, k0 + kper), lane owns 4 output channels per 256-channel group: every weight request of the wave
-    // is issued before the first one is used (the k loop has one memory latency, not kper of them)
-    __shared__ float ps[16][256];
-    const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6, d = a.d;
-    const size_t qrow = ((size_t)tq * a.Bpad + b) * d;
-    const int kper = (d + 15) / 16, k0 = w * kper;
+    const bool live = !stopped(a.stop_after, a.t);
+    const int d = a.d;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    for (int c0 = 0; c0 < d; c0 += 256) {
-        const int c = c0 + lane * 4;
-        f32x4 wv[16]; float qv[16];
+    if (live && newest) {
+        const int b = blockIdx.x, tq = a.j - a.off[a.i_new];
+        if (tq >= 0) {                      // block-uniform
+            const size_t qrow = ((size_t)tq * a.Bpad + b) * d;
+            const int kper = (d + 15) / 16, k0 = w * kper, c = lane * 4;
+            f32x4 wv[16]; float qv[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int k = k0 + i;
-            const bool in = i < kper && k < d && c < d;
-            wv[i] = in ? *(const f32x4*)(a.Wq + (size_t)k * a.ldn + c) : zero4;
-            qv[i] = (i < kper && k < d) ? a.Q[qrow + k] : 0.f;
+            for (int i = 0; i < 16; ++i) {
+                const int k = k0 + i;
+                const bool in = i < kper && k < d;
+                wv[i] = (in && c < d) ? *(const f32x4*)(a.Wq + (size_t)k * a.ldn + c) : zero4;
+                qv[i] = in ? a.Q[qrow + k] : 0.f;
+            }
+            f32x4 acc = zero4;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(qv[i], wv[i][e], acc[e]);
+            *(f32x4*)&ps[w][lane * 4] = acc;
+            __syncthreads();
+            if (w == 0) {
+                f32x4 qw = zero4;
+                if (c < d) {
+                    qw = *(const f32x4*)(a.bias + c);
+#pragma unroll
+                    for (int ww = 0; ww < 16; ++ww) qw += *(const f32x4*)&ps[ww][c];
+                    *(f32x4*)(a.QW + qrow + c) = qw;          // cached: every later step reads this position's term
+                }
+                cone_head_row(a, a.i_new, b, tq, qw, lane);
+            }
         }
-        f32x4 acc = zero4;
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = fmaf(qv[i], wv[i][e], acc[e]);
+    } else if (live) {
+        const int rl = ((int)blockIdx.x - a.B) * 16 + w;          // row among the positions other than the newest
+        int i = rl / a.Bpad; const int b = rl - i * a.Bpad;
+        if (i >= a.i_new) ++i;
+        if (i < a.npos && b < a.B) {
+            const int tq = a.j - a.off[i];
+            if (tq >= 0) {
+                const int c = lane * 4;
+                const f32x4 qw = c < d ? *(const f32x4*)(a.QW + ((size_t)tq * a.Bpad + b) * d + c) : zero4;
+                cone_head_row(a, i, b, tq, qw, lane);
+            }
+        }
+    }
+    if (a.done_sig && (pos_b == a.coh0 || pos_b == a.coh1)) {       // cone level 0: its tap rows are written, raise its word (see ln_rows)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        *(f32x4*)&ps[w][lane * 4] = acc;
-        __syncthreads();
-        if (threadIdx.x < 256 && c0 + (int)threadIdx.x < d) {
-            const int n = c0 + threadIdx.x;
-            float v = a.bias[n];
-#pragma unroll
-            for (int ww = 0; ww < 16; ++ww) v += ps[ww][threadIdx.x];
-            a.QW[qrow + n] = v;
+        if (threadIdx.x == 0) {
+            const unsigned old = atomicAdd(a.done_count, 1u);
+            if (old + 1u == a.done_target) __hip_atomic_fetch_max(a.done_sig, a.done_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
-void launch_cone_qw(const ConeHeadArgs& a, int tq, hipStream_t s) {
-    hipLaunchKernelGGL(cone_qw, dim3(a.B), dim3(1024), 0, s, a, tq);
-}
-
 void launch_cone_head(const ConeHeadArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(cone_head, dim3((a.nrows + 3) / 4), dim3(256), 0, s, a);
+    const int others = (a.npos - 1) * a.Bpad;
+    hipLaunchKernelGGL(cone_head, dim3(a.B + (others + 15) / 16), dim3(1024), 0, s, a);
 }
 
 void launch_attn_rows(const AttnRowsArgs& a, hipStream_t s) {

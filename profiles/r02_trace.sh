@@ -13,7 +13,7 @@ rows=list(csv.DictReader(open(sys.argv[1])))
 print(rows[0].keys())
 # cone kernels are on their own queue: take the dispatches between two consecutive attn_rows launches in the middle of a decode
 names=[r['Kernel_Name'] for r in rows]
-idx=[i for i,n in enumerate(names) if 'cone_qw' in n or 'attn_rows' in n]
+idx=[i for i,n in enumerate(names) if 'cone_head' in n or 'attn_rows' in n]
 print(len(rows),'dispatches;',len(idx),'cone starts')
 mid=idx[len(idx)//2+100] if len(idx)>300 else idx[len(idx)//2]
 q=rows[mid]['Queue_Id']
