@@ -65,6 +65,7 @@ struct Layer {
     float *Wt = nullptr, *bias = nullptr;       // conv / hc ; convT: even phase (taps x[t], x[t-1])
     float *Wt2 = nullptr;                        // convT odd phase (tap x[t])
     float *Wkn = nullptr; int ldn = 0;           // k=1 layers with N<=256: [kc][ldn] n-contiguous copy for row_chain
+    void *Wh = nullptr, *Wl = nullptr, *Wh2 = nullptr, *Wl2 = nullptr;   // SSRN layers: Wt / Wt2 split into hi + lo bf16 planes (conv_gemm_bf16x3)
     float *Wt_cone = nullptr, *bias_cone = nullptr;   // AudioDec highway layers: columns interleaved 32 H1 | 32 H2 per 64-column tile (oph_cone.hip)
     float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
 };
@@ -565,17 +566,23 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
         if (l.kind == K_CONVT) {
             // even rows: taps (x[t], x[t-1]); odd rows: tap x[t]; raw rows interleaved 2t / 2t+1
             g.N = l.N; g.ldh = 2 * l.Nalloc; g.M = M;
-            g.Wt = l.Wt; g.ldw = 2 * l.kc; g.ntaps = 2; g.off[0] = 0; g.off[1] = -1;
-            run_gemm(h, g, l.cin, prec);
-            g.Wt = l.Wt2; g.ldw = l.kc; g.ntaps = 1; g.off[0] = 0; g.H = wsraw + l.Nalloc;
-            run_gemm(h, g, l.cin, prec);
+            g.Wt = l.Wt; g.Wh = l.Wh; g.Wl = l.Wl; g.ldw = 2 * l.kc; g.ntaps = 2; g.off[0] = 0; g.off[1] = -1;
+            GemmArgs g2 = g;
+            g2.Wt = l.Wt2; g2.Wh = l.Wh2; g2.Wl = l.Wl2; g2.ldw = l.kc; g2.ntaps = 1; g2.off[0] = 0; g2.H = wsraw + l.Nalloc;
+            {   // both phases in one launch
+                const int p2 = (prec && l.Wh && l.Wh2) ? 1 : 0;
+                const int cls = p2 ? PC_GEMM_BF16 : (conv_gemm_tile_m(g.M, g.N) == 128 ? PC_GEMM : PC_GEMM64);
+                h->pbegin(cls);
+                launch_conv_gemm_pair(g, g2, p2, g_cur);
+                h->pend(cls, ((double)g.M * l.cin + 2.0 * g.M * g.N + 3.0 * g.N * l.cin) * 4.0, 2.0 * g.M * g.N * 3.0 * l.cin);
+            }
             Tcur *= 2;
             e.ldh = l.Nalloc; e.M = B * Tcur; e.C = l.cout; e.mode = PRE_CONV; e.act = ACT_NONE;
             run_epi(h, e);
         } else {
-            g.N = l.N; g.ldh = l.Nalloc; g.M = M; g.Wt = l.Wt; g.ldw = l.ntaps * l.kc; g.ntaps = l.ntaps;
+            g.N = l.N; g.ldh = l.Nalloc; g.M = M; g.Wt = l.Wt; g.Wh = l.Wh; g.Wl = l.Wl; g.ldw = l.ntaps * l.kc; g.ntaps = l.ntaps;
             for (int t = 0; t < 3; ++t) g.off[t] = l.off[t];
-            run_gemm(h, g, l.cin, prec);
+            run_gemm(h, g, l.cin, prec && l.Wh);
             e.ldh = l.Nalloc; e.M = M; e.C = l.cout;
             if (l.kind == K_HC) { e.mode = PRE_HC; e.Xres = x; e.ldres = ldx; }
             else e.mode = PRE_CONV;
@@ -1836,6 +1843,19 @@ int oph_finalize_weights(oph_handle* h) {
     for (auto* net : {&h->textenc, &h->audioenc, &h->audiodec, &h->ssrn})
         for (Layer& l : *net)
             if (pack_layer(h, l) != 0) { h->fail("out of device memory packing %s", l.scope.c_str()); return OPH_ERR_DEVICE; }
+    // SSRN contractions run on bf16 MFMAs with every fp32 operand as hi + lo: the weights are split here, once
+    for (Layer& l : h->ssrn) {
+        auto split = [&](const float* wsrc, size_t n, void*& hi, void*& lo) {
+            hi = h->dalloc<unsigned short>(n); lo = h->dalloc<unsigned short>(n);
+            if (!hi || !lo) return false;
+            launch_split_bf16(wsrc, hi, lo, n, h->stream);
+            return true;
+        };
+        const size_t taps = l.kind == K_CONVT ? 2 : (size_t)l.ntaps;
+        if (l.Wt && !split(l.Wt, (size_t)l.Nalloc * taps * l.kc, l.Wh, l.Wl)) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
+        if (l.Wt2 && !split(l.Wt2, (size_t)l.Nalloc * l.kc, l.Wh2, l.Wl2)) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     // fused cone layers: every AudioDec highway layer but the last is re-evaluated over history positions
     h->cone_fused = getenv("OPH_CONE_FUSED") && !getenv("OPH_NO_CONE_FUSED") && !(h->dm.flags & OPH_FLAG_LCC) && h->dm.d % 16 == 0;
     if (h->cone_fused)
@@ -2427,17 +2447,22 @@ int oph_bench_conv1d_transpose(int device, int B, int T, int Cin, int Cout, int 
     float* dh = c.alloc<float>((size_t)2 * M * Nalloc);
     float* dy = c.alloc<float>((size_t)2 * M * Cout);
     float* dg = c.up(gh.data(), gh.size()); float* db = c.up(zh.data(), zh.size());
+    // the weights' hi / lo bf16 planes, split once as at load time
+    unsigned short* dweh = c.alloc<unsigned short>(we.size()); unsigned short* dwel = c.alloc<unsigned short>(we.size());
+    unsigned short* dwoh = c.alloc<unsigned short>(wo.size()); unsigned short* dwol = c.alloc<unsigned short>(wo.size());
     if (!c.ok) return OPH_ERR_DEVICE;
+    launch_split_bf16(dwe, dweh, dwel, we.size(), c.s);
+    launch_split_bf16(dwo, dwoh, dwol, wo.size(), c.s);
     hipStreamSynchronize(c.s);
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { g_op_error = "event creation failed"; return OPH_ERR_DEVICE; }
     auto once = [&]() {
         GemmArgs g{};
         g.X = dx; g.ldx = kc; g.bias = dbias; g.ldh = 2 * Nalloc; g.M = M; g.N = Cout; g.kc = kc; g.mode = 0; g.T = T;
-        g.Wt = dwe; g.ldw = 2 * kc; g.ntaps = 2; g.off[0] = 0; g.off[1] = -1; g.H = dh;
-        if (precision) launch_conv_gemm_bf16x3(g, c.s); else launch_conv_gemm(g, c.s);
-        g.Wt = dwo; g.ldw = kc; g.ntaps = 1; g.off[0] = 0; g.H = dh + Nalloc;
-        if (precision) launch_conv_gemm_bf16x3(g, c.s); else launch_conv_gemm(g, c.s);
+        g.Wt = dwe; g.Wh = dweh; g.Wl = dwel; g.ldw = 2 * kc; g.ntaps = 2; g.off[0] = 0; g.off[1] = -1; g.H = dh;
+        GemmArgs g2 = g;
+        g2.Wt = dwo; g2.Wh = dwoh; g2.Wl = dwol; g2.ldw = kc; g2.ntaps = 1; g2.off[0] = 0; g2.H = dh + Nalloc;
+        launch_conv_gemm_pair(g, g2, precision ? 1 : 0, c.s);
         EpiArgs e{};
         e.H = dh; e.ldh = Nalloc; e.M = 2 * M; e.C = Cout; e.mode = PRE_CONV; e.act = ACT_NONE; e.g1 = dg; e.b1 = db; e.Y = dy; e.ldy = Cout; e.ypad = Cout;
         launch_epilogue(e, c.s);

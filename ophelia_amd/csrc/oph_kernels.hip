@@ -26,7 +26,7 @@ namespace oph {
 // MFMA e pairs k+e with k+4+e) identically for A and B, so the sum is unchanged.
 // =====================================================================================
 template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void conv_gemm_f32(GemmArgs a) {
+static __device__ __forceinline__ void conv_gemm_f32_body(const GemmArgs& a) {
     if (stopped(a.stop_after, a.t)) return;
     constexpr int BK = 32, LD = 36;
     constexpr int AR = BM / 32, BR = BN / 32;     // float4 staging loads per thread
@@ -160,6 +160,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32(GemmArgs a) {
         }
 }
 
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_f32(GemmArgs a) { conv_gemm_f32_body<BM, BN>(a); }
+// Two contractions over the same rows in ONE launch (grid.z picks): the even- and odd-phase halves of a transposed
+// convolution (modules.py:209-258) are each too small to fill the chip, and each launch has a fixed ~5 us floor.
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_f32_pair(GemmArgs a0, GemmArgs a1) {
+    if (blockIdx.z == 0) conv_gemm_f32_body<BM, BN>(a0); else conv_gemm_f32_body<BM, BN>(a1);
+}
+
 int conv_gemm_tile_m(int M, int N) {
     const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
     return t128 >= 384 ? 128 : 64;
@@ -204,8 +213,19 @@ __device__ __forceinline__ void split_bf16(const f32x4& x, bf16x4& hi, bf16x4& l
     }
 }
 
+// The weights are split ONCE (launch_split_bf16 at load time) into hi / lo bf16 planes; only the activations are split
+// in the kernel, while they are staged.  Software pipeline as conv_gemm_f32 (prefetch distance 2): one K-step of bf16
+// MFMAs (~0.3 us for a 128x128 tile) covers nothing of an HBM round trip, two register sets in flight do.
+__global__ void split_bf16_kernel(const float* w, __bf16* hi, __bf16* lo, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const float x = w[i]; const __bf16 h = (__bf16)x; hi[i] = h; lo[i] = (__bf16)(x - (float)h); }
+}
+void launch_split_bf16(const float* w, void* hi, void* lo, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, (__bf16*)hi, (__bf16*)lo, n);
+}
+
 template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3(GemmArgs a) {
+static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) {
     constexpr int BK = 32, LDH = 40;               // bf16 elements per LDS row (32 + 8 pad)
     constexpr int AR = BM / 32, BR = BN / 32;
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -213,8 +233,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3(GemmArgs a) {
     __bf16* Ah = (__bf16*)smem;                    // [2][BM*LDH]
     __bf16* Al = Ah + 2 * BM * LDH;
     __bf16* Bh = Al + 2 * BM * LDH;                // [2][BN*LDH]
-    __bf16* Bl = Bh + 2 * BN * LDH;
-    int* srow_s = (int*)(Bl + 2 * BN * LDH);       // [3][BM]
+    __bf16* Bl = Bh + 2 * BN * LDH;                // (no source-row table in LDS: 4 planes x 2 buffers of a 128x128 tile are
+                                                   //  exactly half a CU's LDS, so two workgroups stay resident per CU)
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
@@ -230,33 +250,34 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3(GemmArgs a) {
     const int tm = first_m + (id % width) % gsz, tn = (id % width) / gsz;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    for (int i = tid; i < BM * a.ntaps; i += 256) {
-        const int tap = i / BM, m = m0 + (i - tap * BM);
-        int src = -1;
-        if (m < a.M) {
-            const int b = m / a.T, t = m - b * a.T, tt = t + a.off[tap];
-            if (tt >= 0 && tt < a.T) src = m + a.off[tap];
-        }
-        srow_s[i] = src;
-    }
-    __syncthreads();
-
     const int lrow = tid >> 3, kq = tid & 7;
+    int mt[AR];                                    // time index of this thread's staging rows (-1: past the last row)
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        mt[i] = m < a.M ? m % a.T : -1;
+    }
     const int kpt = a.kc / BK, nk = a.ntaps * kpt;
-    f32x4 ra[AR], rb[BR];
+    const __bf16* Wh = (const __bf16*)a.Wh; const __bf16* Wl = (const __bf16*)a.Wl;
+    f32x4 ra0[AR], ra1[AR];
+    bf16x4 bh0[BR], bl0[BR], bh1[BR], bl1[BR];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    auto load_global = [&](int s) {
+    auto load_global = [&](int s, f32x4 (&ra)[AR], bf16x4 (&bh)[BR], bf16x4 (&bl)[BR]) {
         const int tap = s / kpt, ko = (s - tap * kpt) * BK + kq * 4;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            const int src = srow_s[tap * BM + lrow + 32 * i];
-            ra[i] = src >= 0 ? *(const f32x4*)(a.X + (size_t)src * a.ldx + ko) : zero4;
+            const int tt = mt[i] + a.off[tap];
+            const bool in = mt[i] >= 0 && tt >= 0 && tt < a.T;
+            ra[i] = in ? *(const f32x4*)(a.X + (size_t)(m0 + lrow + 32 * i + a.off[tap]) * a.ldx + ko) : zero4;
         }
 #pragma unroll
-        for (int i = 0; i < BR; ++i)
-            rb[i] = *(const f32x4*)(a.Wt + (size_t)(n0 + lrow + 32 * i) * a.ldw + tap * a.kc + ko);
+        for (int i = 0; i < BR; ++i) {
+            const size_t o = (size_t)(n0 + lrow + 32 * i) * a.ldw + tap * a.kc + ko;
+            bh[i] = *(const bf16x4*)(Wh + o);
+            bl[i] = *(const bf16x4*)(Wl + o);
+        }
     };
-    auto store_lds = [&](int buf) {
+    auto store_lds = [&](int buf, const f32x4 (&ra)[AR], const bf16x4 (&bh)[BR], const bf16x4 (&bl)[BR]) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             bf16x4 hi, lo;
@@ -267,11 +288,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3(GemmArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
-            bf16x4 hi, lo;
-            split_bf16(rb[i], hi, lo);
             const int o = buf * BN * LDH + (lrow + 32 * i) * LDH + kq * 4;
-            *(bf16x4*)(Bh + o) = hi;
-            *(bf16x4*)(Bl + o) = lo;
+            *(bf16x4*)(Bh + o) = bh[i];
+            *(bf16x4*)(Bl + o) = bl[i];
         }
     };
 
@@ -285,12 +304,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3(GemmArgs a) {
 
     // 32x32x16 bf16 fragment: lane l holds row (l&31), k = 8*(l>>5) .. +7 of the 16-wide chunk
     const int wr = w >> 1, wc = w & 1, r32 = lane & 31, kh = lane >> 5;
-    load_global(0);
-    store_lds(0);
-    __syncthreads();
-    for (int s = 0; s < nk; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nk) load_global(s + 1);
+    auto compute = [&](int buf) {
         const int ao = buf * BM * LDH + (wr * (BM / 2) + r32) * LDH + kh * 8;
         const int bo = buf * BN * LDH + (wc * (BN / 2) + r32) * LDH + kh * 8;
 #pragma unroll
@@ -315,7 +329,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3(GemmArgs a) {
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[jn], acc[i][jn], 0, 0, 0);
                 }
         }
-        if (s + 1 < nk) store_lds(buf ^ 1);
+    };
+    load_global(0, ra0, bh0, bl0);
+    if (nk > 1) load_global(1, ra1, bh1, bl1);
+    store_lds(0, ra0, bh0, bl0);
+    __syncthreads();
+    for (int s = 0; s < nk; s += 2) {
+        if (s + 2 < nk) load_global(s + 2, ra0, bh0, bl0);
+        compute(0);
+        if (s + 1 < nk) store_lds(1, ra1, bh1, bl1);
+        __syncthreads();
+        if (s + 1 >= nk) break;
+        if (s + 3 < nk) load_global(s + 3, ra1, bh1, bl1);
+        compute(1);
+        if (s + 2 < nk) store_lds(0, ra0, bh0, bl0);
         __syncthreads();
     }
 #pragma unroll
@@ -333,9 +360,35 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3(GemmArgs a) {
 }
 
 template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3(GemmArgs a) { conv_gemm_bf16x3_body<BM, BN>(a); }
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3_pair(GemmArgs a0, GemmArgs a1) {
+    if (blockIdx.z == 0) conv_gemm_bf16x3_body<BM, BN>(a0); else conv_gemm_bf16x3_body<BM, BN>(a1);
+}
+template <int BM, int BN>
+static void launch_conv_gemm_pair_t(const GemmArgs& a0, const GemmArgs& a1, int prec, hipStream_t s) {
+    static bool attr_set[2][64] = {{false}};
+    const size_t lds = prec ? (size_t)(2 * (BM + BN) * 2 * 40) * 2 : (size_t)(2 * (BM + BN) * 36) * 4 + (size_t)3 * BM * 4;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[prec ? 1 : 0][dev & 63]) {
+        if (prec) (void)hipFuncSetAttribute((const void*)conv_gemm_bf16x3_pair<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else (void)hipFuncSetAttribute((const void*)conv_gemm_f32_pair<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set[prec ? 1 : 0][dev & 63] = true;
+    }
+    const int MT = (a0.M + BM - 1) / BM, NT = (a0.N + BN - 1) / BN;
+    if (prec) hipLaunchKernelGGL((conv_gemm_bf16x3_pair<BM, BN>), dim3(MT * NT, 1, 2), dim3(256), lds, s, a0, a1);
+    else hipLaunchKernelGGL((conv_gemm_f32_pair<BM, BN>), dim3(MT * NT, 1, 2), dim3(256), lds, s, a0, a1);
+}
+// same M and N, no split-K; prec != 0: split-bf16 contraction (both need Wh / Wl)
+void launch_conv_gemm_pair(const GemmArgs& a0, const GemmArgs& a1, int prec, hipStream_t s) {
+    if (conv_gemm_tile_m(a0.M, a0.N) == 128) launch_conv_gemm_pair_t<128, 128>(a0, a1, prec, s);
+    else launch_conv_gemm_pair_t<64, 64>(a0, a1, prec, s);
+}
+template <int BM, int BN>
 static void launch_conv_gemm_bf16x3_t(const GemmArgs& a, hipStream_t s) {
     static bool attr_set[64] = {false};
-    const size_t lds = (size_t)(2 * 2 * (BM + BN) * 40) * 2 + (size_t)3 * BM * 4;
+    const size_t lds = (size_t)(2 * (BM + BN) * 2 * 40) * 2;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr_set[dev & 63]) {
