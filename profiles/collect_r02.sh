@@ -8,11 +8,12 @@
 set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-vocoder --no-profile"
+CMD="python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-vocoder --no-profile --no-extra-legs"
 PMC="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vocoder --no-profile"
-echo "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-vocoder --no-profile   [counter passes: OPH_BENCH_PMC=1 rocprofv3 --pmc <counter> --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vocoder --no-profile]" > $O/command.txt
+echo "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-vocoder --no-profile --no-extra-legs   [counter passes: OPH_BENCH_PMC=1 rocprofv3 --pmc <counter> --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vocoder --no-profile]" > $O/command.txt
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o r02 -- $CMD > $O/trace.log 2>&1
 echo "trace rc=$?"
+grep '^{"metric"' $O/trace.log | tail -1 > $O/bench_traced.json      # the bench line of the traced run itself
 OPH_BENCH_PMC=1 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o r02 -- $PMC > $O/pmc_fetch.log 2>&1
 echo "fetch rc=$?"
 OPH_BENCH_PMC=1 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o r02 -- $PMC > $O/pmc_write.log 2>&1
@@ -24,6 +25,6 @@ find $O -name "*.csv" | head -20
 cd $R && timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
 tail -c 1500 $O/bench.json
 python profiles/summarize.py r02
-mkdir -p $R/gpurun_out/r02_summary && cp profiles/r02_kernel_stats.csv profiles/r02_pmc_summary.csv profiles/r02_traffic.json profiles/r02_bench.json $R/gpurun_out/r02_summary/
+mkdir -p $R/gpurun_out/r02_summary && cp $O/bench_traced.json profiles/r02_bench_traced.json; cp profiles/r02_kernel_stats.csv profiles/r02_pmc_summary.csv profiles/r02_traffic.json profiles/r02_bench.json profiles/r02_bench_traced.json $R/gpurun_out/r02_summary/
 tail -3 $O/trace.log $O/pmc_fetch.log
 rm -rf $O/trace $O/pmc_fetch $O/pmc_write $O/pmc_mfma
