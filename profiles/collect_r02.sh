@@ -21,10 +21,12 @@ echo "write rc=$?"
 OPH_BENCH_PMC=1 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -o r02 -- $PMC > $O/pmc_mfma.log 2>&1
 echo "mfma rc=$?"
 find $O -name "*.csv" | head -20
+# condense the counter passes first, so that the un-profiled bench line below can quote the PMC traffic of this build
+cd $R && python profiles/summarize.py r02
 # the un-profiled bench line of the same build (default flags)
-cd $R && timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
+timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
 tail -c 1500 $O/bench.json
-python profiles/summarize.py r02
+cp $O/bench.json profiles/r02_bench.json
 mkdir -p $R/gpurun_out/r02_summary && cp $O/bench_traced.json profiles/r02_bench_traced.json; cp profiles/r02_kernel_stats.csv profiles/r02_pmc_summary.csv profiles/r02_traffic.json profiles/r02_bench.json profiles/r02_bench_traced.json $R/gpurun_out/r02_summary/
-tail -3 $O/trace.log $O/pmc_fetch.log
+tail -n 3 $O/trace.log
 rm -rf $O/trace $O/pmc_fetch $O/pmc_write $O/pmc_mfma
