@@ -172,6 +172,7 @@ struct oph_handle {
     std::vector<std::vector<int>> Hset;           // Hset[h] sorted offsets (>=1) at which hc layer h's INPUT is needed
     std::vector<int*> d_tab, d_need, d_res;       // per hc layer h<n-1: tables for computing layer h over Hset[h+1]
     std::vector<FcTables> fc_tab;                 // per hc layer: cone_fc16's index tables (kernel arguments)
+    bool cone_bf16 = false;                      // OPH_CONE_BF16X3 experiment
     float* coneRawB = nullptr;                    // second raw buffer: consecutive cone_fc16 launches ping-pong
     int cone_fc_rows = 64;                        // cone levels with at most this many output rows run as cone_fc16 (0: never)
     int* d_off0 = nullptr;                        // Hset[0] on device
@@ -973,7 +974,8 @@ void launch_cone(oph_handle* h, int t) {
             g.ksplit = cone_ksplit(g.M);
             if (k + 1 >= fc_from && k + 2 < nh) g.ksplit = std::min(g.ksplit, fc_in_split);     // its consumer is a cone_fc16: fewer partials to sum there
             g.split_stride = (long long)g.M * l.Nalloc;
-            run_gemm(h, g, l.cin);
+            g.Wh = l.Wh; g.Wl = l.Wl;
+            run_gemm(h, g, l.cin, (h->cone_bf16 && l.Wh && g.M >= 512) ? 1 : 0);
             raw_in = h->coneRaw; raw_split = g.ksplit; raw_stride = g.split_stride;
         }
         if (k + 1 >= fc_from && k + 2 < nh) continue;       // the next level's cone_fc16 normalises these rows itself
@@ -1855,6 +1857,17 @@ int oph_finalize_weights(oph_handle* h) {
         if (l.Wt && !split(l.Wt, (size_t)l.Nalloc * taps * l.kc, l.Wh, l.Wl)) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
         if (l.Wt2 && !split(l.Wt2, (size_t)l.Nalloc * l.kc, l.Wh2, l.Wl2)) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
     }
+    // experiment (OPH_CONE_BF16X3=1, off by default): the two many-row cone contractions on the split-bf16 kernel as well.
+    // Text2Mel is otherwise exact fp32 because its outputs feed the attention argmax; DESIGN.md records what this buys.
+    h->cone_bf16 = getenv("OPH_CONE_BF16X3") != nullptr;
+    if (h->cone_bf16)
+        for (int k = 0; k + 1 < h->n_hc_dec; ++k) {
+            Layer& l = h->audiodec[h->dec_pre + k];
+            const size_t n = (size_t)l.Nalloc * l.ntaps * l.kc;
+            l.Wh = h->dalloc<unsigned short>(n); l.Wl = h->dalloc<unsigned short>(n);
+            if (!l.Wh || !l.Wl) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
+            launch_split_bf16(l.Wt, l.Wh, l.Wl, n, h->stream);
+        }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     // fused cone layers: every AudioDec highway layer but the last is re-evaluated over history positions
     h->cone_fused = getenv("OPH_CONE_FUSED") && !getenv("OPH_NO_CONE_FUSED") && !(h->dm.flags & OPH_FLAG_LCC) && h->dm.d % 16 == 0;

@@ -226,6 +226,7 @@ void launch_split_bf16(const float* w, void* hi, void* lo, size_t n, hipStream_t
 
 template <int BM, int BN>
 static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) {
+    if (stopped(a.stop_after, a.t)) return;
     constexpr int BK = 32, LDH = 40;               // bf16 elements per LDS row (32 + 8 pad)
     constexpr int AR = BM / 32, BR = BN / 32;
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -251,24 +252,41 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int lrow = tid >> 3, kq = tid & 7;
-    int mt[AR];                                    // time index of this thread's staging rows (-1: past the last row)
+    int mt[AR];                                    // dense rows: time index of this thread's staging rows (-1: past the last row)
+    int srow[3][AR];                               // table rows (decoder cone, mode 1): source row per tap (-1 = zeros)
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         const int m = m0 + lrow + 32 * i;
         mt[i] = m < a.M ? m % a.T : -1;
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            srow[tap][i] = -1;
+            if (a.mode == 1 && m < a.M && tap < a.ntaps) {
+                const int ip = m / a.Bpad, b = m - ip * a.Bpad;
+                if (a.j >= a.need[tap * a.n_out + ip]) srow[tap][i] = a.tab[tap * a.n_out + ip] * a.Bpad + b;
+            }
+        }
     }
-    const int kpt = a.kc / BK, nk = a.ntaps * kpt;
+    const int kpt = a.kc / BK, nk_all = a.ntaps * kpt;
+    const int ksplit = a.ksplit > 1 ? a.ksplit : 1, split = blockIdx.y;
+    const int ks0 = split * nk_all / ksplit, nk = (split + 1) * nk_all / ksplit - ks0;
     const __bf16* Wh = (const __bf16*)a.Wh; const __bf16* Wl = (const __bf16*)a.Wl;
     f32x4 ra0[AR], ra1[AR];
     bf16x4 bh0[BR], bl0[BR], bh1[BR], bl1[BR];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    auto load_global = [&](int s, f32x4 (&ra)[AR], bf16x4 (&bh)[BR], bf16x4 (&bl)[BR]) {
+    auto load_global = [&](int sl, f32x4 (&ra)[AR], bf16x4 (&bh)[BR], bf16x4 (&bl)[BR]) {
+        const int s = ks0 + sl;
         const int tap = s / kpt, ko = (s - tap * kpt) * BK + kq * 4;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            const int tt = mt[i] + a.off[tap];
-            const bool in = mt[i] >= 0 && tt >= 0 && tt < a.T;
-            ra[i] = in ? *(const f32x4*)(a.X + (size_t)(m0 + lrow + 32 * i + a.off[tap]) * a.ldx + ko) : zero4;
+            if (a.mode == 1) {
+                const int src = tap == 0 ? srow[0][i] : (tap == 1 ? srow[1][i] : srow[2][i]);
+                ra[i] = src >= 0 ? *(const f32x4*)(a.X + (size_t)src * a.ldx + ko) : zero4;
+            } else {
+                const int tt = mt[i] + a.off[tap];
+                const bool in = mt[i] >= 0 && tt >= 0 && tt < a.T;
+                ra[i] = in ? *(const f32x4*)(a.X + (size_t)(m0 + lrow + 32 * i + a.off[tap]) * a.ldx + ko) : zero4;
+            }
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
@@ -350,11 +368,12 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn) {
             const int col = n0 + wc * (BN / 2) + jn * 32 + r32;
-            const float bv = a.bias[col];
+            const float bv = split == 0 ? a.bias[col] : 0.f;
+            float* Hs = a.H + (size_t)split * a.split_stride;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-                if (row < a.M) a.H[(size_t)row * a.ldh + col] = acc[i][jn][e] + bv;
+                if (row < a.M) Hs[(size_t)row * a.ldh + col] = acc[i][jn][e] + bv;
             }
         }
 }
@@ -396,9 +415,9 @@ static void launch_conv_gemm_bf16x3_t(const GemmArgs& a, hipStream_t s) {
         attr_set[dev & 63] = true;
     }
     const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL((conv_gemm_bf16x3<BM, BN>), dim3(MT * NT), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_gemm_bf16x3<BM, BN>), dim3(MT * NT, a.ksplit > 1 ? a.ksplit : 1), dim3(256), lds, s, a);
 }
-void launch_conv_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {     // dense rows, no split-K
+void launch_conv_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {     // needs a.Wh / a.Wl
     if (conv_gemm_tile_m(a.M, a.N) == 128) launch_conv_gemm_bf16x3_t<128, 128>(a, s);
     else launch_conv_gemm_bf16x3_t<64, 64>(a, s);
 }
