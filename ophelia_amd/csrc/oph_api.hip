@@ -173,6 +173,8 @@ struct oph_handle {
     std::vector<int*> d_tab, d_need, d_res;       // per hc layer h<n-1: tables for computing layer h over Hset[h+1]
     std::vector<FcTables> fc_tab;                 // per hc layer: cone_fc16's index tables (kernel arguments)
     bool cone_bf16 = false;                      // OPH_CONE_BF16X3 experiment
+    float* coneRawC = nullptr;                    // raw buffer of the second cone stream
+    hipStream_t scone2 = nullptr; hipEvent_t ev_cone2 = nullptr; int cone_split_at = 0;    // OPH_CONE_SPLIT=k: cone levels from layer k on run on their own stream
     float* coneRawB = nullptr;                    // second raw buffer: consecutive cone_fc16 launches ping-pong
     int cone_fc_rows = 64;                        // cone levels with at most this many output rows run as cone_fc16 (0: never)
     int* d_off0 = nullptr;                        // Hset[0] on device
@@ -744,6 +746,7 @@ int ensure_decode_state(oph_handle* h, int B) {
     h->coneR = h->dalloc<float>(maxrows * Bpad * 2 * d);
     h->coneRaw = h->dalloc<float>((size_t)CONE_KSPLIT * maxrows * Bpad * (size_t)round_up(2 * d, 128));
     h->coneRawB = h->dalloc<float>((size_t)maxrows * Bpad * (size_t)round_up(2 * d, 128));
+    h->coneRawC = h->dalloc<float>((size_t)CONE_KSPLIT * maxrows * Bpad * (size_t)round_up(2 * d, 128));
     h->coneTmp = h->dalloc<float>(maxrows * Bpad * (size_t)ld_cat);
     h->d_cone_stats = h->dalloc<unsigned long long>(((maxrows * Bpad + 31) / 32) * 16 * 64 * 4);
     h->d_cone_count = h->dalloc<unsigned>(LOOP_MAX_LEVELS); for (uint32_t& v : h->cone_done_total) v = 0;
@@ -939,9 +942,14 @@ void launch_cone(oph_handle* h, int t) {
         fc_from = k;
     }
     float* raw_in = h->coneRaw; int raw_split = 1; long long raw_stride = 0;
+    // two-stream cone (dec_loop mode, OPH_CONE_SPLIT=ks): layers ks.. run on a second stream; the level ks they gather is
+    // written through completely by its producer (coh_all), whose completion word the first launch there waits for
+    const int ks_split = (h->cone_inline_sig && h->scone2 && h->cone_split_at >= 1 && h->cone_split_at < fc_from && h->cone_split_at + 1 < nh) ? h->cone_split_at : 0;
     for (int k = 0; k + 1 < nh; ++k) {
         const Layer& l = h->audiodec[pre + k];
         const int n_out = (int)h->Hset[k + 1].size();
+        if (ks_split && k == ks_split) g_cur = h->scone2;
+        float* const raw_gemm = (ks_split && k >= ks_split) ? h->coneRawC : h->coneRaw;
         if (k >= fc_from) {
             const Layer& lp = h->audiodec[pre + k - 1];
             ConeFcArgs c{};
@@ -953,7 +961,7 @@ void launch_cone(oph_handle* h, int t) {
             memcpy(c.extra, ft.extra, sizeof c.extra); memcpy(c.extra_res, ft.extra_res, sizeof c.extra_res); c.n_extra = ft.n_extra;
             c.xstore = cone[k]; c.ldx = l.kc;
             c.Wt = l.Wt; c.ldw = 3 * l.kc; c.bias = l.bias; c.kc = l.kc; c.N = l.N;
-            c.H = raw_in == h->coneRaw ? h->coneRawB : h->coneRaw; c.ldh = l.Nalloc;
+            c.H = raw_in == h->coneRawB ? raw_gemm : h->coneRawB; c.ldh = l.Nalloc;
             c.Bpad = Bpad; c.stop_after = stop_after; c.t = t;
             if (h->cone_inline_sig && k < LOOP_MAX_LEVELS) {
                 const Layer& tl = h->audiodec[pre + k];
@@ -968,15 +976,16 @@ void launch_cone(oph_handle* h, int t) {
             raw_in = c.H; raw_split = 1; raw_stride = 0;
         } else {
             GemmArgs g{};
-            g.X = cone[k]; g.ldx = l.kc; g.Wt = l.Wt; g.ldw = 3 * l.kc; g.bias = l.bias; g.H = h->coneRaw; g.ldh = l.Nalloc;
+            g.X = cone[k]; g.ldx = l.kc; g.Wt = l.Wt; g.ldw = 3 * l.kc; g.bias = l.bias; g.H = raw_gemm; g.ldh = l.Nalloc;
             g.M = n_out * Bpad; g.N = l.N; g.kc = l.kc; g.ntaps = 3; g.mode = 1; g.Bpad = Bpad; g.n_out = n_out; g.j = t;
             g.tab = h->d_tab[k]; g.need = h->d_need[k]; g.stop_after = stop_after; g.t = t;
+            if (ks_split && k == ks_split) { g.wait_sig = h->d_sig + LOOP_SIG_LEVEL0 + 16 * k; g.wait_val = h->cone_done_val; g.wait_err = h->d_ctl + 2; }
             g.ksplit = cone_ksplit(g.M);
             if (k + 1 >= fc_from && k + 2 < nh) g.ksplit = std::min(g.ksplit, fc_in_split);     // its consumer is a cone_fc16: fewer partials to sum there
             g.split_stride = (long long)g.M * l.Nalloc;
             g.Wh = l.Wh; g.Wl = l.Wl;
             run_gemm(h, g, l.cin, (h->cone_bf16 && l.Wh && g.M >= 512) ? 1 : 0);
-            raw_in = h->coneRaw; raw_split = g.ksplit; raw_stride = g.split_stride;
+            raw_in = raw_gemm; raw_split = g.ksplit; raw_stride = g.split_stride;
         }
         if (k + 1 >= fc_from && k + 2 < nh) continue;       // the next level's cone_fc16 normalises these rows itself
         EpiArgs e{};
@@ -988,6 +997,12 @@ void launch_cone(oph_handle* h, int t) {
         const Layer& nx = h->audiodec[pre + k + 1];
         e.Y = cone[k + 1]; e.ldy = nx.kc; e.ypad = nx.kc; e.stop_after = stop_after; e.t = t;
         level_done(k + 1, e.done_sig, e.done_val, e.done_count, e.done_target, e.coh0, e.coh1);
+        if (ks_split && k + 1 == ks_split && e.done_sig) {       // this level feeds the other stream: every row write-through, every workgroup arrives
+            e.coh_all = 1;
+            const unsigned counted = (unsigned)((e.coh0 >= 0) + (e.coh1 >= 0 && e.coh1 != e.coh0)) * (unsigned)(Bpad / 4);
+            h->cone_done_total[k + 1] += (unsigned)((e.M + 3) / 4) - counted;
+            e.done_target = h->cone_done_total[k + 1];
+        }
         run_epi(h, e);
     }
     g_cur = saved;
@@ -1282,6 +1297,7 @@ int decode_loop(oph_handle* h, int t_end, int stop_mode) {
     a.dbg = dbg;
     a.sigdbg = h->d_sigdbg;
     hipStreamWaitEvent(h->scone, h->ev_in, 0);
+    if (h->scone2) hipStreamWaitEvent(h->scone2, h->ev_in, 0);
     g_cur = h->sdec;
     double bytes = 0, flops = 0;
     {
@@ -1330,6 +1346,10 @@ int decode_loop(oph_handle* h, int t_end, int stop_mode) {
         if (!skip_cone) launch_cone(h, t);
         if (stream_ops) { for (int k = 0; k < h->n_hc_dec; ++k) hipStreamWriteValue32(h->scone, h->d_sig + LOOP_SIG_LEVEL0 + 16 * k, h->sig_base + (uint32_t)t, 0); }
         else launch_sig_set(h->d_sig + LOOP_SIG_LEVEL0, h->sig_base + (uint32_t)t, h->n_hc_dec, h->d_sigdbg ? h->d_sigdbg + (size_t)t * 8 : nullptr, h->scone);
+    }
+    if (h->scone2) {      // the second cone stream joins the first: every later wait on scone covers both
+        hipEventRecord(h->ev_cone2, h->scone2);
+        hipStreamWaitEvent(h->scone, h->ev_cone2, 0);
     }
     if (g_trace) {
         const double enq = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_host0).count() * 1e3;
@@ -1733,6 +1753,12 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
             h->ndec_cus = h->sdec ? ndec : ncu;
             if (h->mask_words && hipExtStreamCreateWithCUMask(&h->scone, words, m_conep) != hipSuccess) h->scone = nullptr;
             if (h->mask_words && hipExtStreamCreateWithCUMask(&h->sssrn, words, m_ssrn) != hipSuccess) h->sssrn = nullptr;
+            if (const char* cs = getenv("OPH_CONE_SPLIT")) {       // experiment: a FOURTH masked stream (same CUs as the cone) for the cone's tail
+                h->cone_split_at = atoi(cs);
+                if (getenv("OPH_CONE_SPLIT_PLAIN")) { if (hipStreamCreateWithFlags(&h->scone2, hipStreamNonBlocking) != hipSuccess) { h->scone2 = nullptr; h->cone_split_at = 0; } }      // unmasked: any CU
+                else if (h->cone_split_at > 0 && h->mask_words && hipExtStreamCreateWithCUMask(&h->scone2, words, m_conep) != hipSuccess) { h->scone2 = nullptr; h->cone_split_at = 0; }
+                if (h->scone2 && hipEventCreateWithFlags(&h->ev_cone2, hipEventDisableTiming) != hipSuccess) { h->cone_split_at = 0; }
+            }
         }
         (void)hipGetLastError();
     }
@@ -1794,7 +1820,7 @@ int oph_destroy(oph_handle* h) {
     for (void* p : h->allocs) hipFree(p);
     if (h->host_prog) hipHostFree((void*)h->host_prog);
     TRACE("destroy: streams");
-    for (hipStream_t st : {h->scone, h->sssrn, h->sdec, h->stream}) if (st) { TRACE("  destroy stream %p", (void*)st); hipStreamDestroy(st); }
+    for (hipStream_t st : {h->scone2, h->scone, h->sssrn, h->sdec, h->stream}) if (st) { TRACE("  destroy stream %p", (void*)st); hipStreamDestroy(st); }
     TRACE("destroy: done");
     delete h;
     return OPH_OK;

@@ -32,6 +32,7 @@ struct GemmArgs {
     const int* need;                // table: [ntaps][n_out] source valid iff j >= need
     const int* stop_after; int t;   // early-out when t > *stop_after (decode loop); stop_after may be null
     int ksplit; long long split_stride;  // split-K over K-steps: grid.y = ksplit, partial s written at H + s*split_stride (bias in split 0)
+    const unsigned* wait_sig; unsigned wait_val; int* wait_err;     // optional: spin until *wait_sig >= wait_val before the first read (a producer on another stream)
     // conv_gemm_bf16x3 only: Wt split once into hi = bf16(w), lo = bf16(w - hi), same [Nalloc][ntaps*kc] layout (2-byte elements)
     const void* Wh; const void* Wl;
 };
@@ -61,6 +62,8 @@ struct EpiArgs {
     // workgroup holding such rows waits for its stores, adds 1 to *done_count, and the one that makes it done_target
     // raises *done_sig to done_val
     unsigned* done_sig; unsigned done_val; unsigned* done_count; unsigned done_target; int coh0, coh1;
+    int coh_all;                    // every row is stored write-through and every workgroup arrives: consumers on ANOTHER stream may
+                                    // then read the level with plain loads once the word is up (two-stream cone)
 };
 
 // ---- fused M=16 decode layer (prologue = previous layer's LN/gate, then 16xK . KxN slice)

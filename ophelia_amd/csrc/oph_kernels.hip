@@ -27,6 +27,24 @@ namespace oph {
 // =====================================================================================
 template <int BM, int BN>
 static __device__ __forceinline__ void conv_gemm_f32_body(const GemmArgs& a) {
+    if (a.wait_sig) {       // the rows this launch gathers are produced by a launch on another stream (two-stream cone)
+        if (threadIdx.x == 0) {
+            long long t0 = 0;
+            for (int it = 0; (int)(__hip_atomic_load(a.wait_sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.wait_val) < 0; ++it) {
+                __builtin_amdgcn_s_sleep(8);
+                if ((it & 255) == 255) {
+                    const long long now = wall_clock64();
+                    if (t0 == 0) t0 = now;
+                    if (now - t0 > 200000000LL || __hip_atomic_load(a.wait_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                        __hip_atomic_store(a.wait_err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
     if (stopped(a.stop_after, a.t)) return;
     constexpr int BK = 32, LD = 36;
     constexpr int AR = BM / 32, BR = BN / 32;     // float4 staging loads per thread
@@ -530,7 +548,7 @@ __device__ __forceinline__ void ln_rows_body(const EpiArgs& a) {
     float* y = a.Y + (size_t)m * a.ldy;
     const bool vec_ok = (a.ldy & 3) == 0;
     const int pos = a.done_sig ? m / a.Bpad : -1;
-    const bool coh = a.done_sig && (pos == a.coh0 || pos == a.coh1);      // rows a running dec_loop reads
+    const bool coh = a.done_sig && (a.coh_all || pos == a.coh0 || pos == a.coh1);      // rows a running dec_loop (or another stream) reads
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const int c = (v * 64 + lane) * 4;
@@ -558,7 +576,7 @@ template <int NV>
 __global__ __launch_bounds__(256) void ln_rows(EpiArgs a) {
     ln_rows_body<NV>(a);
     const int pos_b = a.done_sig ? (int)(blockIdx.x * 4) / a.Bpad : -1;       // Bpad % 4 == 0: a workgroup's 4 rows share a position
-    if (a.done_sig && (pos_b == a.coh0 || pos_b == a.coh1)) {
+    if (a.done_sig && (a.coh_all || pos_b == a.coh0 || pos_b == a.coh1)) {
         // this launch writes a level of a cone: once the tap rows have left (write-through stores, no fence), one lane
         // raises the word the decoder loop kernel polls for that level (instead of a signalling kernel behind the cone)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
