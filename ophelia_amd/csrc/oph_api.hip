@@ -1733,6 +1733,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
         const int words = (ncu + 31) / 32;
         int ndec = ncu / 4, nconep = ncu / 2;               // 64 | 128 | 64 of 256 CUs (sweep in DESIGN.md)
         if (const char* sp = getenv("OPH_CU_SPLIT")) { int a_ = 0, b_ = 0; if (sscanf(sp, "%d,%d", &a_, &b_) == 2 && a_ > 0 && b_ > 0 && a_ + b_ < ncu) { ndec = a_; nconep = b_; } }
+        const bool ssrn_all = getenv("OPH_SSRN_ALL") != nullptr;     // experiment: SSRN may use every CU outside the chain's partition
         const bool cone_all = getenv("OPH_CONE_ALL") != nullptr;     // experiment: the cone may also use the SSRN partition
         if (ncu >= 64 && words <= 16 && !getenv("OPH_NO_CU_MASK")) {
             for (int i = 0; i < ncu; ++i) {
@@ -1742,6 +1743,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
                     m_cone[i / 32] |= bit;
                     (i < ndec + nconep ? m_conep : m_ssrn)[i / 32] |= bit;
                     if (cone_all) m_conep[i / 32] |= bit;
+                    if (ssrn_all) m_ssrn[i / 32] |= bit;
                 }
             }
             // CU-masked queues are a scarce resource: with four alive the queues get time-sliced and even
