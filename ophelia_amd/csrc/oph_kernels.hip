@@ -242,7 +242,7 @@ void launch_split_bf16(const float* w, void* hi, void* lo, size_t n, hipStream_t
     hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, (__bf16*)hi, (__bf16*)lo, n);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool TAB>      // TAB: table-mapped rows (decoder cone); a separate instance so that the dense one carries no row table
 static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) {
     if (stopped(a.stop_after, a.t)) return;
     constexpr int BK = 32, LDH = 40;               // bf16 elements per LDS row (32 + 8 pad)
@@ -271,17 +271,19 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
 
     const int lrow = tid >> 3, kq = tid & 7;
     int mt[AR];                                    // dense rows: time index of this thread's staging rows (-1: past the last row)
-    int srow[3][AR];                               // table rows (decoder cone, mode 1): source row per tap (-1 = zeros)
+    int srow[TAB ? 3 : 1][AR];                     // table rows (decoder cone, mode 1): source row per tap (-1 = zeros)
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         const int m = m0 + lrow + 32 * i;
-        mt[i] = m < a.M ? m % a.T : -1;
+        mt[i] = (!TAB && m < a.M) ? m % a.T : -1;
+        if constexpr (TAB) {
 #pragma unroll
-        for (int tap = 0; tap < 3; ++tap) {
-            srow[tap][i] = -1;
-            if (a.mode == 1 && m < a.M && tap < a.ntaps) {
-                const int ip = m / a.Bpad, b = m - ip * a.Bpad;
-                if (a.j >= a.need[tap * a.n_out + ip]) srow[tap][i] = a.tab[tap * a.n_out + ip] * a.Bpad + b;
+            for (int tap = 0; tap < 3; ++tap) {
+                srow[tap][i] = -1;
+                if (m < a.M && tap < a.ntaps) {
+                    const int ip = m / a.Bpad, b = m - ip * a.Bpad;
+                    if (a.j >= a.need[tap * a.n_out + ip]) srow[tap][i] = a.tab[tap * a.n_out + ip] * a.Bpad + b;
+                }
             }
         }
     }
@@ -297,7 +299,7 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
         const int tap = s / kpt, ko = (s - tap * kpt) * BK + kq * 4;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            if (a.mode == 1) {
+            if constexpr (TAB) {
                 const int src = tap == 0 ? srow[0][i] : (tap == 1 ? srow[1][i] : srow[2][i]);
                 ra[i] = src >= 0 ? *(const f32x4*)(a.X + (size_t)src * a.ldx + ko) : zero4;
             } else {
@@ -397,10 +399,12 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
 }
 
 template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3(GemmArgs a) { conv_gemm_bf16x3_body<BM, BN>(a); }
+__global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3(GemmArgs a) { conv_gemm_bf16x3_body<BM, BN, false>(a); }
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3_tab(GemmArgs a) { conv_gemm_bf16x3_body<BM, BN, true>(a); }
 template <int BM, int BN>
 __global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3_pair(GemmArgs a0, GemmArgs a1) {
-    if (blockIdx.z == 0) conv_gemm_bf16x3_body<BM, BN>(a0); else conv_gemm_bf16x3_body<BM, BN>(a1);
+    if (blockIdx.z == 0) conv_gemm_bf16x3_body<BM, BN, false>(a0); else conv_gemm_bf16x3_body<BM, BN, false>(a1);
 }
 template <int BM, int BN>
 static void launch_conv_gemm_pair_t(const GemmArgs& a0, const GemmArgs& a1, int prec, hipStream_t s) {
@@ -433,7 +437,12 @@ static void launch_conv_gemm_bf16x3_t(const GemmArgs& a, hipStream_t s) {
         attr_set[dev & 63] = true;
     }
     const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL((conv_gemm_bf16x3<BM, BN>), dim3(MT * NT, a.ksplit > 1 ? a.ksplit : 1), dim3(256), lds, s, a);
+    if (a.mode == 1) {
+        static bool tab_set[64] = {false};
+        if (!tab_set[dev & 63]) { (void)hipFuncSetAttribute((const void*)conv_gemm_bf16x3_tab<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); tab_set[dev & 63] = true; }
+        hipLaunchKernelGGL((conv_gemm_bf16x3_tab<BM, BN>), dim3(MT * NT, a.ksplit > 1 ? a.ksplit : 1), dim3(256), lds, s, a);
+    } else
+        hipLaunchKernelGGL((conv_gemm_bf16x3<BM, BN>), dim3(MT * NT, a.ksplit > 1 ? a.ksplit : 1), dim3(256), lds, s, a);
 }
 void launch_conv_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {     // needs a.Wh / a.Wl
     if (conv_gemm_tile_m(a.M, a.N) == 128) launch_conv_gemm_bf16x3_t<128, 128>(a, s);
