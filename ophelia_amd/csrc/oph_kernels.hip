@@ -358,14 +358,27 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
                 bh[jn] = *(const bf16x8*)(Bh + bo + jn * 32 * LDH + kc * 16);
                 bl[jn] = *(const bf16x8*)(Bl + bo + jn * 32 * LDH + kc * 16);
             }
+            // product by product over all tiles: with four tiles per wave consecutive MFMAs never share an accumulator (three
+            // back-to-back MFMAs on one accumulator serialise on its latency: 30 % of the wave cycles were issue stalls,
+            // profiles/r02_ssrn_pmc.sh; own accumulators for the small terms of the single-tile instance were measured slower:
+            // 168 instead of 116 registers cost it a workgroup of occupancy)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn) {
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[jn], acc[i][jn], 0, 0, 0);
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[jn], acc[i][jn], 0, 0, 0);
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[jn], acc[i][jn], 0, 0, 0);
                 }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) {
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[jn], acc[i][jn], 0, 0, 0);
+                }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[jn], acc[i][jn], 0, 0, 0);
         }
     };
     load_global(0, ra0, bh0, bl0);
