@@ -245,7 +245,11 @@ void launch_split_bf16(const float* w, void* hi, void* lo, size_t n, hipStream_t
 template <int BM, int BN, bool TAB>      // TAB: table-mapped rows (decoder cone); a separate instance so that the dense one carries no row table
 static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) {
     if (stopped(a.stop_after, a.t)) return;
-    constexpr int BK = 32, LDH = 40;               // bf16 elements per LDS row (32 + 8 pad)
+    // LDS rows are 32 bf16 = four 16-byte chunks, unpadded, with the chunk index XOR-ed by (row >> 2) & 3: the 8-byte staging
+    // stores of a wave (4 rows x 8 lanes per pass) then fall into four disjoint 16-bank ranges, and the 16-byte fragment reads
+    // of 16 consecutive rows into 16 distinct 4-bank groups -- both conflict-free (the padded [32 + 8] rows had two-way
+    // conflicts on every staging store: a third of the LDS cycles, profiles/r02_ssrn_pmc.sh)
+    constexpr int BK = 32, LDH = 32;
     constexpr int AR = BM / 32, BR = BN / 32;
     constexpr int TM = BM / 64, TN = BN / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -320,13 +324,13 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
         for (int i = 0; i < AR; ++i) {
             bf16x4 hi, lo;
             split_bf16(ra[i], hi, lo);
-            const int o = buf * BM * LDH + (lrow + 32 * i) * LDH + kq * 4;
+            const int o = buf * BM * LDH + (lrow + 32 * i) * LDH + (((kq >> 1) ^ ((lrow >> 2) & 3)) << 3) + ((kq & 1) << 2);
             *(bf16x4*)(Ah + o) = hi;
             *(bf16x4*)(Al + o) = lo;
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
-            const int o = buf * BN * LDH + (lrow + 32 * i) * LDH + kq * 4;
+            const int o = buf * BN * LDH + (lrow + 32 * i) * LDH + (((kq >> 1) ^ ((lrow >> 2) & 3)) << 3) + ((kq & 1) << 2);
             *(bf16x4*)(Bh + o) = bh[i];
             *(bf16x4*)(Bl + o) = bl[i];
         }
@@ -343,20 +347,21 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
     // 32x32x16 bf16 fragment: lane l holds row (l&31), k = 8*(l>>5) .. +7 of the 16-wide chunk
     const int wr = w >> 1, wc = w & 1, r32 = lane & 31, kh = lane >> 5;
     auto compute = [&](int buf) {
-        const int ao = buf * BM * LDH + (wr * (BM / 2) + r32) * LDH + kh * 8;
-        const int bo = buf * BN * LDH + (wc * (BN / 2) + r32) * LDH + kh * 8;
+        const int ao = buf * BM * LDH + (wr * (BM / 2) + r32) * LDH;
+        const int bo = buf * BN * LDH + (wc * (BN / 2) + r32) * LDH;
+        const int swr = (r32 >> 2) & 3;
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
             bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                ah[i] = *(const bf16x8*)(Ah + ao + i * 32 * LDH + kc * 16);
-                al[i] = *(const bf16x8*)(Al + ao + i * 32 * LDH + kc * 16);
+                ah[i] = *(const bf16x8*)(Ah + ao + i * 32 * LDH + (((kc * 2 + kh) ^ swr) << 3));
+                al[i] = *(const bf16x8*)(Al + ao + i * 32 * LDH + (((kc * 2 + kh) ^ swr) << 3));
             }
 #pragma unroll
             for (int jn = 0; jn < TN; ++jn) {
-                bh[jn] = *(const bf16x8*)(Bh + bo + jn * 32 * LDH + kc * 16);
-                bl[jn] = *(const bf16x8*)(Bl + bo + jn * 32 * LDH + kc * 16);
+                bh[jn] = *(const bf16x8*)(Bh + bo + jn * 32 * LDH + (((kc * 2 + kh) ^ swr) << 3));
+                bl[jn] = *(const bf16x8*)(Bl + bo + jn * 32 * LDH + (((kc * 2 + kh) ^ swr) << 3));
             }
             // product by product over all tiles: with four tiles per wave consecutive MFMAs never share an accumulator (three
             // back-to-back MFMAs on one accumulator serialise on its latency: 30 % of the wave cycles were issue stalls,
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3_pair(GemmArgs a0, Gem
 template <int BM, int BN>
 static void launch_conv_gemm_pair_t(const GemmArgs& a0, const GemmArgs& a1, int prec, hipStream_t s) {
     static bool attr_set[2][64] = {{false}};
-    const size_t lds = prec ? (size_t)(2 * (BM + BN) * 2 * 40) * 2 : (size_t)(2 * (BM + BN) * 36) * 4 + (size_t)3 * BM * 4;
+    const size_t lds = prec ? (size_t)(2 * (BM + BN) * 2 * 32) * 2 : (size_t)(2 * (BM + BN) * 36) * 4 + (size_t)3 * BM * 4;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr_set[prec ? 1 : 0][dev & 63]) {
@@ -442,7 +447,7 @@ void launch_conv_gemm_pair(const GemmArgs& a0, const GemmArgs& a1, int prec, hip
 template <int BM, int BN>
 static void launch_conv_gemm_bf16x3_t(const GemmArgs& a, hipStream_t s) {
     static bool attr_set[64] = {false};
-    const size_t lds = (size_t)(2 * (BM + BN) * 2 * 40) * 2;
+    const size_t lds = (size_t)(2 * (BM + BN) * 2 * 32) * 2;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr_set[dev & 63]) {
