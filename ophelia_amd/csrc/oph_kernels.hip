@@ -255,11 +255,14 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __bf16* Ah = (__bf16*)smem;                    // [2][BM*LDH]
     __bf16* Al = Ah + 2 * BM * LDH;
-    __bf16* Bh = Al + 2 * BM * LDH;                // [2][BN*LDH]
-    __bf16* Bl = Bh + 2 * BN * LDH;                // (no source-row table in LDS: 4 planes x 2 buffers of a 128x128 tile are
-                                                   //  exactly half a CU's LDS, so two workgroups stay resident per CU)
+    // The weight planes never pass through registers: global_load_lds_dwordx4 copies 16 bytes per lane straight into LDS
+    // (lane l's bytes land at the wave's base + 16 l, profiles/glds_probe.hip), two K-steps ahead, into a 3-slot ring; the
+    // chunk swizzle is applied on the global side.  A: 2 buffers x 2 planes; B: 3 slots x 2 planes -- for a 128x128 tile
+    // exactly half a CU's LDS, so two workgroups stay resident per CU (no source-row table in LDS for the same reason).
+    __bf16* Bh = Al + 2 * BM * LDH;                // [3][BN*LDH]
+    __bf16* Bl = Bh + 3 * BN * LDH;
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
     const int ntiles = MT * NT;
     int id;
@@ -296,9 +299,23 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
     const int ks0 = split * nk_all / ksplit, nk = (split + 1) * nk_all / ksplit - ks0;
     const __bf16* Wh = (const __bf16*)a.Wh; const __bf16* Wl = (const __bf16*)a.Wl;
     f32x4 ra0[AR], ra1[AR];
-    bf16x4 bh0[BR], bl0[BR], bh1[BR], bl1[BR];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    auto load_global = [&](int sl, f32x4 (&ra)[AR], bf16x4 (&bh)[BR], bf16x4 (&bl)[BR]) {
+    constexpr int NDMA = BN * 4 / 256;             // 16-byte chunks of one plane's K-step per thread
+    auto dma_b = [&](int sl) {                     // weight planes of K-step sl -> ring slot sl % 3
+        const int s = ks0 + sl;
+        const int tap = s / kpt, kb = (s - tap * kpt) * BK, slot = sl % 3;
+#pragma unroll
+        for (int q = 0; q < NDMA; ++q) {
+            const int id = q * 256 + tid, row = id >> 2, pos = id & 3;
+            const size_t o = (size_t)(n0 + row) * a.ldw + tap * a.kc + kb + ((pos ^ ((row >> 2) & 3)) << 3);
+            const int base = slot * BN * LDH + (q * 256 + w * 64) * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wh + o),
+                                             (__attribute__((address_space(3))) void*)(Bh + base), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wl + o),
+                                             (__attribute__((address_space(3))) void*)(Bl + base), 16, 0, 0);
+        }
+    };
+    auto load_global = [&](int sl, f32x4 (&ra)[AR]) {
         const int s = ks0 + sl;
         const int tap = s / kpt, ko = (s - tap * kpt) * BK + kq * 4;
 #pragma unroll
@@ -312,14 +329,8 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
                 ra[i] = in ? *(const f32x4*)(a.X + (size_t)(m0 + lrow + 32 * i + a.off[tap]) * a.ldx + ko) : zero4;
             }
         }
-#pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            const size_t o = (size_t)(n0 + lrow + 32 * i) * a.ldw + tap * a.kc + ko;
-            bh[i] = *(const bf16x4*)(Wh + o);
-            bl[i] = *(const bf16x4*)(Wl + o);
-        }
     };
-    auto store_lds = [&](int buf, const f32x4 (&ra)[AR], const bf16x4 (&bh)[BR], const bf16x4 (&bl)[BR]) {
+    auto store_lds = [&](int buf, const f32x4 (&ra)[AR]) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             bf16x4 hi, lo;
@@ -327,12 +338,6 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
             const int o = buf * BM * LDH + (lrow + 32 * i) * LDH + (((kq >> 1) ^ ((lrow >> 2) & 3)) << 3) + ((kq & 1) << 2);
             *(bf16x4*)(Ah + o) = hi;
             *(bf16x4*)(Al + o) = lo;
-        }
-#pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            const int o = buf * BN * LDH + (lrow + 32 * i) * LDH + (((kq >> 1) ^ ((lrow >> 2) & 3)) << 3) + ((kq & 1) << 2);
-            *(bf16x4*)(Bh + o) = bh[i];
-            *(bf16x4*)(Bl + o) = bl[i];
         }
     };
 
@@ -346,9 +351,9 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
 
     // 32x32x16 bf16 fragment: lane l holds row (l&31), k = 8*(l>>5) .. +7 of the 16-wide chunk
     const int wr = w >> 1, wc = w & 1, r32 = lane & 31, kh = lane >> 5;
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf, int bslot) {
         const int ao = buf * BM * LDH + (wr * (BM / 2) + r32) * LDH;
-        const int bo = buf * BN * LDH + (wc * (BN / 2) + r32) * LDH;
+        const int bo = bslot * BN * LDH + (wc * (BN / 2) + r32) * LDH;
         const int swr = (r32 >> 2) & 3;
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
@@ -386,19 +391,29 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[jn], acc[i][jn], 0, 0, 0);
         }
     };
-    load_global(0, ra0, bh0, bl0);
-    if (nk > 1) load_global(1, ra1, bh1, bl1);
-    store_lds(0, ra0, bh0, bl0);
+    // every VMEM operation of a step is issued before its compute; they complete in order, so "at most the operations of
+    // THIS step outstanding" means the previous step's (the weight planes the next compute reads) have landed
+    auto wait_older = [&](bool issued_now) {
+        if (issued_now) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AR + 2 * NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    load_global(0, ra0);
+    dma_b(0);
+    if (nk > 1) { load_global(1, ra1); dma_b(1); }
+    store_lds(0, ra0);
+    wait_older(nk > 1);
     __syncthreads();
     for (int s = 0; s < nk; s += 2) {
-        if (s + 2 < nk) load_global(s + 2, ra0, bh0, bl0);
-        compute(0);
-        if (s + 1 < nk) store_lds(1, ra1, bh1, bl1);
+        if (s + 2 < nk) { load_global(s + 2, ra0); dma_b(s + 2); }
+        compute(0, s % 3);
+        if (s + 1 < nk) store_lds(1, ra1);
+        wait_older(s + 2 < nk);
         __syncthreads();
         if (s + 1 >= nk) break;
-        if (s + 3 < nk) load_global(s + 3, ra1, bh1, bl1);
-        compute(1);
-        if (s + 2 < nk) store_lds(0, ra0, bh0, bl0);
+        if (s + 3 < nk) { load_global(s + 3, ra1); dma_b(s + 3); }
+        compute(1, (s + 1) % 3);
+        if (s + 2 < nk) store_lds(0, ra0);
+        wait_older(s + 3 < nk);
         __syncthreads();
     }
 #pragma unroll
@@ -427,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3_pair(GemmArgs a0, Gem
 template <int BM, int BN>
 static void launch_conv_gemm_pair_t(const GemmArgs& a0, const GemmArgs& a1, int prec, hipStream_t s) {
     static bool attr_set[2][64] = {{false}};
-    const size_t lds = prec ? (size_t)(2 * (BM + BN) * 2 * 32) * 2 : (size_t)(2 * (BM + BN) * 36) * 4 + (size_t)3 * BM * 4;
+    const size_t lds = prec ? (size_t)((2 * BM + 3 * BN) * 2 * 32) * 2 : (size_t)(2 * (BM + BN) * 36) * 4 + (size_t)3 * BM * 4;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr_set[prec ? 1 : 0][dev & 63]) {
@@ -447,7 +462,7 @@ void launch_conv_gemm_pair(const GemmArgs& a0, const GemmArgs& a1, int prec, hip
 template <int BM, int BN>
 static void launch_conv_gemm_bf16x3_t(const GemmArgs& a, hipStream_t s) {
     static bool attr_set[64] = {false};
-    const size_t lds = (size_t)(2 * (BM + BN) * 2 * 32) * 2;
+    const size_t lds = (size_t)((2 * BM + 3 * BN) * 2 * 32) * 2;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr_set[dev & 63]) {
