@@ -65,6 +65,7 @@ struct Layer {
     float *Wt = nullptr, *bias = nullptr;       // conv / hc ; convT: even phase (taps x[t], x[t-1])
     float *Wt2 = nullptr;                        // convT odd phase (tap x[t])
     float *Wkn = nullptr; int ldn = 0;           // k=1 layers with N<=256: [kc][ldn] n-contiguous copy for row_chain
+    void *W1 = nullptr, *W2 = nullptr, *W3 = nullptr;   // AudioDec highway layers: Wt as three bf16 terms (conv_gemm_bf16x6, the cone's many-row levels)
     void *Wh = nullptr, *Wl = nullptr, *Wh2 = nullptr, *Wl2 = nullptr;   // SSRN layers: Wt / Wt2 split into hi + lo bf16 planes (conv_gemm_bf16x3)
     float *Wt_cone = nullptr, *bias_cone = nullptr;   // AudioDec highway layers: columns interleaved 32 H1 | 32 H2 per 64-column tile (oph_cone.hip)
     float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
@@ -91,7 +92,7 @@ static int cone_ksplit(int M) {
     }
     return M >= 512 ? big : small_;
 }
-enum { PC_GEMM = 0, PC_GEMM64, PC_GEMM_BF16, PC_LN, PC_DEC, PC_ROWCHAIN, PC_ATTN_ROWS, PC_MISC, PC_DECRUN, PC_DECLOOP, PC_CONEHEAD, PC_CONE, PC_CONE1, PC_CONE2, PC_CONE3, PC_CONE4, PC_CONE5, PC_CONE6, PC_COUNT };   // PC_CONE + i: i-th fused cone layer of a step   // PC_GEMM = the <128,128> instance
+enum { PC_GEMM = 0, PC_GEMM64, PC_GEMM_BF16, PC_LN, PC_DEC, PC_ROWCHAIN, PC_ATTN_ROWS, PC_MISC, PC_DECRUN, PC_DECLOOP, PC_CONEHEAD, PC_GEMM_X6, PC_CONE, PC_CONE1, PC_CONE2, PC_CONE3, PC_CONE4, PC_CONE5, PC_CONE6, PC_COUNT };   // PC_CONE + i: i-th fused cone layer of a step   // PC_GEMM = the <128,128> instance
 
 }  // namespace
 
@@ -173,6 +174,7 @@ struct oph_handle {
     std::vector<int*> d_tab, d_need, d_res;       // per hc layer h<n-1: tables for computing layer h over Hset[h+1]
     std::vector<FcTables> fc_tab;                 // per hc layer: cone_fc16's index tables (kernel arguments)
     bool cone_bf16 = false;                      // OPH_CONE_BF16X3 experiment
+    bool cone_x6 = false;                        // many-row cone levels on conv_gemm_bf16x6
     float* coneRawC = nullptr;                    // raw buffer of the second cone stream
     hipStream_t scone2 = nullptr; hipEvent_t ev_cone2 = nullptr; int cone_split_at = 0;    // OPH_CONE_SPLIT=k: cone levels from layer k on run on their own stream
     float* coneRawB = nullptr;                    // second raw buffer: consecutive cone_fc16 launches ping-pong
@@ -512,10 +514,11 @@ int pack_cone_layer(oph_handle* h, Layer& l) {
 }
 
 // ------------------------------------------------------------------ launch wrappers with accounting
-void run_gemm(oph_handle* h, const GemmArgs& a, int cin_true, int prec = 0) {
-    const int cls = prec ? PC_GEMM_BF16 : (conv_gemm_tile_m(a.M, a.N) == 128 ? PC_GEMM : PC_GEMM64);
+void run_gemm(oph_handle* h, const GemmArgs& a, int cin_true, int prec = 0) {       // prec: 0 fp32 MFMA, 1 split-bf16 x3, 2 split-bf16 x6 (fp32-equivalent)
+    const int cls = prec == 2 ? PC_GEMM_X6 : (prec ? PC_GEMM_BF16 : (conv_gemm_tile_m(a.M, a.N) == 128 ? PC_GEMM : PC_GEMM64));
     h->pbegin(cls);
-    if (prec) launch_conv_gemm_bf16x3(a, g_cur);
+    if (prec == 2) launch_conv_gemm_bf16x6(a, g_cur);
+    else if (prec) launch_conv_gemm_bf16x3(a, g_cur);
     else launch_conv_gemm(a, g_cur);
     const double K = (double)a.ntaps * cin_true;
     h->pend(cls, ((double)a.M * cin_true + (double)a.M * a.N + (double)a.N * K) * 4.0, 2.0 * a.M * a.N * K);
@@ -983,8 +986,9 @@ void launch_cone(oph_handle* h, int t) {
             g.ksplit = cone_ksplit(g.M);
             if (k + 1 >= fc_from && k + 2 < nh) g.ksplit = std::min(g.ksplit, fc_in_split);     // its consumer is a cone_fc16: fewer partials to sum there
             g.split_stride = (long long)g.M * l.Nalloc;
-            g.Wh = l.Wh; g.Wl = l.Wl;
-            run_gemm(h, g, l.cin, (h->cone_bf16 && l.Wh && g.M >= 512) ? 1 : 0);
+            g.Wh = l.Wh; g.Wl = l.Wl; g.W1 = l.W1; g.W2 = l.W2; g.W3 = l.W3;
+            static const int x6_rows = getenv("OPH_CONE_X6_ROWS") ? atoi(getenv("OPH_CONE_X6_ROWS")) : 512;
+            run_gemm(h, g, l.cin, (h->cone_bf16 && l.Wh && g.M >= 512) ? 1 : ((h->cone_x6 && l.W1 && g.M >= x6_rows && g.N % 64 == 0 && g.kc % 32 == 0) ? 2 : 0));
             raw_in = raw_gemm; raw_split = g.ksplit; raw_stride = g.split_stride;
         }
         if (k + 1 >= fc_from && k + 2 < nh) continue;       // the next level's cone_fc16 normalises these rows itself
@@ -1719,7 +1723,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
     oph_handle* h = new oph_handle();
     h->dm = m;
     h->device = device;
-    static const char* names[PC_COUNT] = {"conv_gemm_f32<128,128>", "conv_gemm_f32<64,64>", "conv_gemm_bf16x3", "ln_rows", "dec_layer16", "row_chain", "attn_rows", "misc", "dec_run", "dec_loop", "cone_head", "cone_gemm_ln[0]", "cone_gemm_ln[1]", "cone_gemm_ln[2]", "cone_gemm_ln[3]", "cone_gemm_ln[4]", "cone_gemm_ln[5]", "cone_gemm_ln[6]"};
+    static const char* names[PC_COUNT] = {"conv_gemm_f32<128,128>", "conv_gemm_f32<64,64>", "conv_gemm_bf16x3", "ln_rows", "dec_layer16", "row_chain", "attn_rows", "misc", "dec_run", "dec_loop", "cone_head", "conv_gemm_bf16x6", "cone_gemm_ln[0]", "cone_gemm_ln[1]", "cone_gemm_ln[2]", "cone_gemm_ln[3]", "cone_gemm_ln[4]", "cone_gemm_ln[5]", "cone_gemm_ln[6]"};
     for (int i = 0; i < PC_COUNT; ++i) h->prof[i].name = names[i];
     // CU partition for the decode loop (MI355X: 256 CUs, mask bit i -> XCD i%8): the ~25 dependent
     // tiny launches of a step get a private slice of 8 CUs in every XCD so the concurrently running
@@ -1885,6 +1889,16 @@ int oph_finalize_weights(oph_handle* h) {
         if (l.Wt && !split(l.Wt, (size_t)l.Nalloc * taps * l.kc, l.Wh, l.Wl)) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
         if (l.Wt2 && !split(l.Wt2, (size_t)l.Nalloc * l.kc, l.Wh2, l.Wl2)) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
     }
+    // the cone's many-row levels: fp32-equivalent contraction on the bf16 MFMA (three-term split, six products)
+    h->cone_x6 = getenv("OPH_CONE_X6") != nullptr && !getenv("OPH_NO_CONE_X6");      // opt-in: measured slower than the fp32 MFMA kernel
+    if (h->cone_x6)
+        for (int k = 0; k + 1 < h->n_hc_dec; ++k) {
+            Layer& l = h->audiodec[h->dec_pre + k];
+            const size_t n = (size_t)l.Nalloc * l.ntaps * l.kc;
+            l.W1 = h->dalloc<unsigned short>(n); l.W2 = h->dalloc<unsigned short>(n); l.W3 = h->dalloc<unsigned short>(n);
+            if (!l.W1 || !l.W2 || !l.W3) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
+            launch_split_bf16_3(l.Wt, l.W1, l.W2, l.W3, n, h->stream);
+        }
     // experiment (OPH_CONE_BF16X3=1, off by default): the two many-row cone contractions on the split-bf16 kernel as well.
     // Text2Mel is otherwise exact fp32 because its outputs feed the attention argmax; DESIGN.md records what this buys.
     h->cone_bf16 = getenv("OPH_CONE_BF16X3") != nullptr;

@@ -35,7 +35,10 @@ struct GemmArgs {
     const unsigned* wait_sig; unsigned wait_val; int* wait_err;     // optional: spin until *wait_sig >= wait_val before the first read (a producer on another stream)
     // conv_gemm_bf16x3 only: Wt split once into hi = bf16(w), lo = bf16(w - hi), same [Nalloc][ntaps*kc] layout (2-byte elements)
     const void* Wh; const void* Wl;
+    const void* W1; const void* W2; const void* W3;       // conv_gemm_bf16x6: Wt as three bf16 terms w = w1 + w2 + w3 (24 significant bits: exact)
 };
+void launch_conv_gemm_bf16x6(const GemmArgs& a, hipStream_t s);       // table rows, split-K; fp32-equivalent (see oph_kernels.hip)
+void launch_split_bf16_3(const float* w, void* p1, void* p2, void* p3, size_t n, hipStream_t s);
 void launch_conv_gemm_pair(const GemmArgs& a0, const GemmArgs& a1, int prec, hipStream_t s);   // two contractions (same M, N, no split-K) in one launch
 void launch_split_bf16(const float* w, void* hi, void* lo, size_t n, hipStream_t s);      // hi/lo planes of n floats
 

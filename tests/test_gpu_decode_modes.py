@@ -42,13 +42,14 @@ FLAVOURS = {
     "loop_nofc": {"OPH_CONE_FC_ROWS": "0"},
     "loop_fc256": {"OPH_CONE_FC_ROWS": "256", "OPH_CONE_FC_INSPLIT": "1"},
     "loop_fusedcone": {"OPH_CONE_FUSED": "1"},
+    "loop_x6": {"OPH_CONE_X6": "1"},
 }
 
 
 def _run(tmp_path, name, env_extra, max_T, B, stop_mode):
     out = str(tmp_path / (name + ".npz"))
     env = dict(os.environ)
-    for k in ("OPH_DECODE", "OPH_RUN_ROWS", "OPH_NO_CONE_HEAD", "OPH_CONE_FC_ROWS", "OPH_CONE_FC_INSPLIT", "OPH_CONE_FUSED"):
+    for k in ("OPH_DECODE", "OPH_RUN_ROWS", "OPH_NO_CONE_HEAD", "OPH_CONE_FC_ROWS", "OPH_CONE_FC_INSPLIT", "OPH_CONE_FUSED", "OPH_NO_CONE_X6", "OPH_CONE_X6"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, "-c", CHILD, ROOT, out, str(max_T), str(B), str(stop_mode)], env=env,
