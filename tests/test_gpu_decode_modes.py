@@ -43,13 +43,18 @@ FLAVOURS = {
     "loop_fc256": {"OPH_CONE_FC_ROWS": "256", "OPH_CONE_FC_INSPLIT": "1"},
     "loop_fusedcone": {"OPH_CONE_FUSED": "1"},
     "loop_x6": {"OPH_CONE_X6": "1"},
+    "loop_conebf16": {"OPH_CONE_BF16X3": "1"},
 }
+
+
+# exact-fp32 flavours differ by summation order only; the split-bf16 x3 cone experiment drops terms below 2^-16
+TOL = {"loop_conebf16": 3e-4}
 
 
 def _run(tmp_path, name, env_extra, max_T, B, stop_mode):
     out = str(tmp_path / (name + ".npz"))
     env = dict(os.environ)
-    for k in ("OPH_DECODE", "OPH_RUN_ROWS", "OPH_NO_CONE_HEAD", "OPH_CONE_FC_ROWS", "OPH_CONE_FC_INSPLIT", "OPH_CONE_FUSED", "OPH_NO_CONE_X6", "OPH_CONE_X6"):
+    for k in ("OPH_DECODE", "OPH_RUN_ROWS", "OPH_NO_CONE_HEAD", "OPH_CONE_FC_ROWS", "OPH_CONE_FC_INSPLIT", "OPH_CONE_FUSED", "OPH_NO_CONE_X6", "OPH_CONE_X6", "OPH_CONE_BF16X3"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, "-c", CHILD, ROOT, out, str(max_T), str(B), str(stop_mode)], env=env,
@@ -73,7 +78,8 @@ def test_decode_flavours_agree(tmp_path, stop_mode, max_T, B):
         assert np.array_equal(got["al"].argmax(1), ref["al"].argmax(1)), "%s: attention trace differs" % name
         ey, ea = np.abs(got["Y"] - ref["Y"]).max(), np.abs(got["al"] - ref["al"]).max()
         print("%-16s vs loop: max-abs Y %.2e align %.2e" % (name, ey, ea))
-        assert ey < 2e-5 and ea < 2e-5, name
+        tol = TOL.get(name, 2e-5)
+        assert ey < tol and ea < tol, name
     # and the default flavour against the oracle (exact incremental algorithm) on the same K, V
     sys.path.insert(0, ROOT)
     from conftest import hp_from_snapshot
