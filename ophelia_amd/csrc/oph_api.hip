@@ -174,6 +174,7 @@ struct oph_handle {
     std::vector<int*> d_tab, d_need, d_res;       // per hc layer h<n-1: tables for computing layer h over Hset[h+1]
     std::vector<FcTables> fc_tab;                 // per hc layer: cone_fc16's index tables (kernel arguments)
     bool cone_bf16 = false;                      // OPH_CONE_BF16X3 experiment
+    bool qw_from_loop = false;                   // this decode's QW cache is filled by the loop kernel (cone_head computes nothing)
     bool cone_x6 = false;                        // many-row cone levels on conv_gemm_bf16x6
     float* coneRawC = nullptr;                    // raw buffer of the second cone stream
     hipStream_t scone2 = nullptr; hipEvent_t ev_cone2 = nullptr; int cone_split_at = 0;    // OPH_CONE_SPLIT=k: cone levels from layer k on run on their own stream
@@ -838,11 +839,12 @@ void launch_cone(oph_handle* h, int t) {
         ch.wait_sig = ar.wait_sig; ch.wait_val = ar.wait_val; ch.wait_err = ar.wait_err;
         ch.npos = n0; ch.i_new = 0;
         for (int i = 1; i < n0; ++i) if (h->Hset[0][i] < h->Hset[0][ch.i_new]) ch.i_new = i;
+        if (h->qw_from_loop) ch.i_new = -1;          // dec_loop's attention layer wrote QW[t-1] before it released this cone
         if (!spk_next && h->cone_inline_sig) {
             // level 0's tap rows: the newest position is spread over B workgroups (one per utterance), any other over Bpad/16
             const Layer& tl = h->audiodec[pre];
             ch.coh0 = idx_of(h->Hset[0], -tl.off[0]); ch.coh1 = idx_of(h->Hset[0], -tl.off[1]);
-            auto blocks_of = [&](int pos) { return pos < 0 ? 0u : (pos == ch.i_new ? (unsigned)B : (unsigned)(Bpad / 16)); };
+            auto blocks_of = [&](int pos) { return pos < 0 ? 0u : (ch.i_new < 0 ? (unsigned)(Bpad / 4) : (pos == ch.i_new ? (unsigned)B : (unsigned)(Bpad / 16))); };
             h->cone_done_total[0] += blocks_of(ch.coh0) + (ch.coh1 != ch.coh0 ? blocks_of(ch.coh1) : 0u);
             ch.done_sig = h->d_sig + LOOP_SIG_LEVEL0; ch.done_val = h->cone_done_val; ch.done_count = h->d_cone_count; ch.done_target = h->cone_done_total[0];
         }
@@ -1294,6 +1296,9 @@ int decode_loop(oph_handle* h, int t_end, int stop_mode) {
     a.p = h->d_p; a.ends = h->d_ends; a.t_ends = h->d_tends;
     a.Qhist = h->Qhist; a.align = h->align; a.Yout = h->Yout; a.ldy = h->ldy; a.Ytm = h->Ytm;
     a.sig = h->d_sig; a.sig_base = h->sig_base;
+    static const bool qw_in_loop = !getenv("OPH_NO_LOOP_QW");
+    h->qw_from_loop = qw_in_loop && h->cone_head_ok && !h->fixed_att && h->QWhist != nullptr && h->audiodec[0].cin == 2 * m.d && (m.d % 16) == 0;
+    a.QW = h->qw_from_loop ? h->QWhist : nullptr; a.attn_slices = round_up(h->audiodec[0].N, 16) / 16;
     void* dp = nullptr;
     if (hipHostGetDevicePointer(&dp, (void*)h->host_prog, 0) != hipSuccess) { h->fail("pinned progress words are not mapped"); return OPH_ERR_DEVICE; }
     a.host_progress = (volatile int*)dp;
@@ -1541,6 +1546,7 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
         hipStreamSynchronize(h->sdec);
         h->run_epoch = 0;
     }
+    h->qw_from_loop = false;
     bool loop_mode = h->use_loop && !h->fixed_att && !h->capturing && t_begin == 0 && t_end >= 1;
     if (loop_mode) {
         // every workgroup of the loop kernel must be resident at once (its row groups meet at the per-step cone signal):

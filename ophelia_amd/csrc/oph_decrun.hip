@@ -372,7 +372,8 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
     constexpr int PF = (RUN_KMAX / 16 + R - 1) / R;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* part = smem;                          // [R waves][16 columns][RQ quads][4 rows] K-split partial sums
-    float* xs = smem + R * 16 * RQ * 4;          // [R][ldxs]
+    float* partq = smem + R * 16 * RQ * 4;       // the same for the Q half of the attention layer's contraction (QW)
+    float* xs = smem + 2 * R * 16 * RQ * 4;      // [R][ldxs]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = blockIdx.x, n0 = g * 16, row0 = blockIdx.y * R, grow = row0 + w;
@@ -655,11 +656,14 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
             // ---- 5. R x 16 slice on the 4x4x1 MFMA, K split round-robin over the R waves; every LDS read of the layer is
             //         issued before the first MFMA, two accumulators per row quad
             if (cols) {
-                f32x4 acc[RQ][2];
+                f32x4 acc[RQ][2], accq[RQ];
 #pragma unroll
-                for (int rq = 0; rq < RQ; ++rq) { acc[rq][0] = zero4; acc[rq][1] = zero4; }
+                for (int rq = 0; rq < RQ; ++rq) { acc[rq][0] = zero4; acc[rq][1] = zero4; accq[rq] = zero4; }
                 const float* xa = xs + mq * ldxs + mkk * 4;
                 const int nch = Ktot >> 4;
+                // attention layer: its operand is [context | Q]; the chunks of the Q half also go to their own accumulator
+                const bool want_qw = is_attn && a.QW != nullptr;
+                const int qch0 = want_qw ? (cin >> 4) : 0x7fffffff;
                 f32x4 xf[PF][RQ];
 #pragma unroll
                 for (int i = 0; i < PF; ++i) {
@@ -670,12 +674,19 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
 #pragma unroll
                 for (int i = 0; i < PF; ++i) {
                     if (w + R * i < nch) {
+                        if (w + R * i >= qch0) {
 #pragma unroll
-                        for (int rq = 0; rq < RQ; ++rq) {
-                            acc[rq][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xf[i][rq][0], bfrag[i][0], acc[rq][0], 0, 0, 0);
-                            acc[rq][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xf[i][rq][1], bfrag[i][1], acc[rq][1], 0, 0, 0);
-                            acc[rq][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xf[i][rq][2], bfrag[i][2], acc[rq][0], 0, 0, 0);
-                            acc[rq][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xf[i][rq][3], bfrag[i][3], acc[rq][1], 0, 0, 0);
+                            for (int rq = 0; rq < RQ; ++rq)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) accq[rq] = __builtin_amdgcn_mfma_f32_4x4x1f32(xf[i][rq][e], bfrag[i][e], accq[rq], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int rq = 0; rq < RQ; ++rq) {
+                                acc[rq][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xf[i][rq][0], bfrag[i][0], acc[rq][0], 0, 0, 0);
+                                acc[rq][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xf[i][rq][1], bfrag[i][1], acc[rq][1], 0, 0, 0);
+                                acc[rq][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xf[i][rq][2], bfrag[i][2], acc[rq][0], 0, 0, 0);
+                                acc[rq][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xf[i][rq][3], bfrag[i][3], acc[rq][1], 0, 0, 0);
+                            }
                         }
                     }
                 }
@@ -683,7 +694,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
                 // registers, and k-lane 0 alone writes (the reducer then reads R values per output, not 4 R)
 #pragma unroll
                 for (int rq = 0; rq < RQ; ++rq) {
-                    f32x4 v = acc[rq][0] + acc[rq][1];
+                    f32x4 v = (acc[rq][0] + acc[rq][1]) + accq[rq];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float y = v[e];
@@ -692,6 +703,17 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
                         v[e] = y;
                     }
                     if (mkk == 0) *(f32x4*)(part + ((w * 16 + mcol) * RQ + rq) * 4) = v;      // [row i] of (quad rq, column mcol)
+                    if (want_qw) {
+                        f32x4 q = accq[rq];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float y = q[e];
+                            y += dpp_mov<0x124>(y);
+                            y += dpp_mov<0x128>(y);
+                            q[e] = y;
+                        }
+                        if (mkk == 0) *(f32x4*)(partq + ((w * 16 + mcol) * RQ + rq) * 4) = q;
+                    }
                 }
             }
             LOOP_STAMP(7);
@@ -711,16 +733,25 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
                 for (int ww = 0; ww < R; ww += 2) v += pv[ww] + pv[ww + 1];
                 granule_store(a.gbuf + ((size_t)l * Bpad + row0 + row) * RUN_GCOLS + n0 + col,
                               a.epoch0 + (unsigned)(t * LOOP_MAX_LAYERS + l + 1), v);
+                if (is_attn && a.QW != nullptr) {
+                    // QW[t] = Q[t] . Wq + bias for the cone head's cache (written through: the cone kernels read it after their acquire)
+                    const float* pq = partq + (col * RQ + (row >> 2)) * 4 + (row & 3);
+                    float vq = bias_cur;
+#pragma unroll
+                    for (int ww = 0; ww < R; ww += 2) vq += pq[ww * 16 * RQ * 4] + pq[(ww + 1) * 16 * RQ * 4];
+                    if (row0 + row < a.B && n0 + col < cin)
+                        __hip_atomic_store(a.QW + ((size_t)t * Bpad + row0 + row) * cin + n0 + col, vq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             LOOP_STAMP(5);
-            if (is_attn && g == 0) {
+            if (is_attn && (a.QW != nullptr ? cols : g == 0)) {
                 // release the cone of step t+1 on the side stream: Q[t] and prev_max are written through; once every
                 // row group has arrived, one lane raises the word the stream's wait-value operation polls
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (tid == 0) {
                     const int old = atomicAdd(a.ctl + 3, 1);
-                    if (old + 1 == (Bpad / R) * (t + 1)) {
+                    if (old + 1 == (Bpad / R) * (a.QW != nullptr ? a.attn_slices : 1) * (t + 1)) {
                         __hip_atomic_fetch_max(a.sig, a.sig_base + (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         __hip_atomic_store((int*)a.host_progress, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         if (a.sigdbg && t + 1 < a.max_T) a.sigdbg[(t + 1) * 8 + 0] = wall_clock64();
@@ -797,7 +828,7 @@ void launch_sig_set(unsigned* sig, unsigned value, int nwords, long long* stamp,
 template <int R>
 static void launch_dec_loop_t(const LoopArgs& a, int col_slices, int kmax, hipStream_t s) {
     static thread_local std::map<int, size_t> done;
-    const size_t lds_bytes = (size_t)(R * 16 * (R / 4) * 4 + R * (kmax + 16)) * 4;
+    const size_t lds_bytes = (size_t)(2 * R * 16 * (R / 4) * 4 + R * (kmax + 16)) * 4;
     int dev = 0;
     (void)hipGetDevice(&dev);
     size_t& d = done[dev];
@@ -811,7 +842,7 @@ void launch_dec_loop(const LoopArgs& a, int col_slices, int rows_per_group, int 
 // workgroups of dec_loop that fit on one CU at once (the loop kernel needs ALL of its workgroups resident)
 template <int R>
 static int blocks_per_cu_t(int kmax) {
-    const size_t lds_bytes = (size_t)(R * 16 * (R / 4) * 4 + R * (kmax + 16)) * 4;
+    const size_t lds_bytes = (size_t)(2 * R * 16 * (R / 4) * 4 + R * (kmax + 16)) * 4;
     (void)hipFuncSetAttribute((const void*)dec_loop<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)dec_loop<R>, 64 * R, lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }

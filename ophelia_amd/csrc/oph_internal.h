@@ -259,6 +259,9 @@ struct LoopArgs {
     int nlayers; int B; int Bpad; int t_end; int stop_mode;
     int attn_layer;                     // index of the RUN_ATTN layer
     const unsigned* L;                  // device memory, [nlayers][LOOP_DESC_STRIDE] packed descriptors
+    float* QW; int attn_slices;         // if non-null: the attention layer also emits QW[t] = Q[t] . Wq + bias (the Q half of its own contraction,
+                                        // kept in a second accumulator) for cone_head's cache; attn_slices = its column slices (all of them then
+                                        // arrive before the cone of step t+1 is released)
     int* ctl;                           // [0] n_ended  [1] stop_after  [2] error  [3] attention arrivals
     const int* spk_ids;
     unsigned long long* gbuf;           // granules [LOOP_MAX_LAYERS][Bpad][RUN_GCOLS]

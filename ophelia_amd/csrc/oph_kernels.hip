@@ -1431,10 +1431,13 @@ static __device__ __forceinline__ void cone_head_row(const ConeHeadArgs& a, int 
 __global__ __launch_bounds__(1024) void cone_head(ConeHeadArgs a) {
     __shared__ float ps[16][256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const bool newest = (int)blockIdx.x < a.B;
+    const bool newest = a.i_new >= 0 && (int)blockIdx.x < a.B;
     int pos_b;                              // position index this workgroup's rows belong to (one position: Bpad % 16 == 0)
+    // i_new < 0: every position's Q . Wq row is already cached (dec_loop's attention layer emits it): no special workgroups
+    const int nb_new = a.i_new >= 0 ? a.B : 0;
+    const int RB = blockDim.x >> 6;          // rows per workgroup: 16, or 4 when no workgroup has a Q . Wq row to compute (quicker to start)
     if (newest) pos_b = a.i_new;
-    else { pos_b = ((int)blockIdx.x - a.B) * 16 / a.Bpad; if (pos_b >= a.i_new) ++pos_b; }
+    else { pos_b = ((int)blockIdx.x - nb_new) * RB / a.Bpad; if (a.i_new >= 0 && pos_b >= a.i_new) ++pos_b; }
     if (a.wait_sig) {
         if (threadIdx.x == 0) {
             long long t0 = 0;
@@ -1488,9 +1491,9 @@ __global__ __launch_bounds__(1024) void cone_head(ConeHeadArgs a) {
             }
         }
     } else if (live) {
-        const int rl = ((int)blockIdx.x - a.B) * 16 + w;          // row among the positions other than the newest
+        const int rl = ((int)blockIdx.x - nb_new) * RB + w;       // row among the positions other than the newest
         int i = rl / a.Bpad; const int b = rl - i * a.Bpad;
-        if (i >= a.i_new) ++i;
+        if (a.i_new >= 0 && i >= a.i_new) ++i;
         if (i < a.npos && b < a.B) {
             const int tq = a.j - a.off[i];
             if (tq >= 0) {
@@ -1510,6 +1513,7 @@ __global__ __launch_bounds__(1024) void cone_head(ConeHeadArgs a) {
     }
 }
 void launch_cone_head(const ConeHeadArgs& a, hipStream_t s) {
+    if (a.i_new < 0) { hipLaunchKernelGGL(cone_head, dim3((a.npos * a.Bpad + 3) / 4), dim3(256), 0, s, a); return; }
     const int others = (a.npos - 1) * a.Bpad;
     hipLaunchKernelGGL(cone_head, dim3(a.B + (others + 15) / 16), dim3(1024), 0, s, a);
 }
