@@ -660,6 +660,8 @@ void launch_conv_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {     // needs a.
 //   conv : y = act(LN(h))                                     (modules.py:137-139)
 //   hc   : g = sigmoid(LN1(h[:C])), u = LN2(h[C:]), y = g*u + (1-g)*x   (modules.py:194-203)
 // =====================================================================================
+// (hardware exp / rcp / rsq forms, ~1 ulp each: the IEEE expansions made the 1024-channel rows instruction-bound -- 45 % of
+//  the wave cycles issuing, profiles/r02_ssrn_pmc.sh)
 template <int NV>
 __device__ __forceinline__ void ln_vec(f32x4 (&x)[NV], int C, int lane, const float* gam, const float* bet, int nonorm) {
     float s = 0.f;
@@ -678,7 +680,7 @@ __device__ __forceinline__ void ln_vec(f32x4 (&x)[NV], int C, int lane, const fl
             q += dlt * dlt;
         }
     const float var = wave_sum(q) / (float)C;
-    const float rstd = nonorm ? 1.0f : 1.0f / sqrtf(var + LN_EPS);
+    const float rstd = nonorm ? 1.0f : fast_rsqrt(var + LN_EPS);
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const int c = (v * 64 + lane) * 4;
@@ -739,7 +741,7 @@ __device__ __forceinline__ void ln_rows_body(const EpiArgs& a) {
                 const f32x4 xv = *(const f32x4*)(xr + c);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float gte = sigmoidf_(x[v][e]);
+                    const float gte = fast_sigmoid(x[v][e]);
                     x[v][e] = gte * u[v][e] + (1.0f - gte) * xv[e];
                 }
             }
@@ -751,13 +753,13 @@ __device__ __forceinline__ void ln_rows_body(const EpiArgs& a) {
             for (int e = 0; e < 4; ++e) {
                 const int c = (v * 64 + lane) * 4 + e;
                 const float gt = c < C ? lg[c] : 0.f;
-                x[v][e] = a.act == ACT_SIGMOID ? sigmoidf_(gt * x[v][e]) : gt * apply_act(x[v][e], a.act);
+                x[v][e] = a.act == ACT_SIGMOID ? fast_sigmoid(gt * x[v][e]) : gt * fast_act(x[v][e], a.act);
             }
     } else {
 #pragma unroll
         for (int v = 0; v < NV; ++v)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[v][e] = apply_act(x[v][e], a.act);
+            for (int e = 0; e < 4; ++e) x[v][e] = fast_act(x[v][e], a.act);
     }
     float* y = a.Y + (size_t)m * a.ldy;
     const bool vec_ok = (a.ldy & 3) == 0;
