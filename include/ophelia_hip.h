@@ -21,6 +21,7 @@
 #ifndef OPHELIA_HIP_H
 #define OPHELIA_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -103,13 +104,35 @@ int oph_finalize_weights(oph_handle* h);   /* repack to kernel layout + upload *
  *        *steps_run = number of decoder steps executed.  Frames after the break
  *        step stay 0, as in the reference.
  * oph_ssrn          replaces one sess.run(g.Z) of synth_mel2mag()  synthesize.py:250-260
- *     Y (B,T,n_mels) -> Z (B, r*T, full_dim)      (chunking stays in the caller)   */
+ *     Y (B,T,n_mels) -> Z (B, r*T, full_dim)      (chunking stays in the caller)
+ *
+ * Residency between the three calls.  The reference hands K,V and Y back to Python and feeds them in again
+ * (synthesize.py:172, 256); the results of each call also stay in HBM, and a NULL input means "what the previous call on
+ * this handle left there":
+ *     oph_text2mel(K = NULL, V = NULL, ...)  decodes from the K,V of the last oph_encode_text (same B);
+ *     oph_ssrn(Y = NULL, B, T = max_T, Z)    continues from the mel frames of the last oph_text2mel /
+ *                                            oph_text2mel_durations (same B).  While that decode ran, SSRN was already
+ *                                            evaluated over the frames that were final (oph_set_streaming), so this call
+ *                                            computes the tail and copies Z out.
+ * Non-NULL inputs are uploaded and used as they are; results are identical either way.
+ * Batches larger than 16 utterances are decoded in tiles of 16, the tiles that stop early resumed to the batch's stop step
+ * (the reference's break couples the whole batch, synthesize.py:225-228).                                           */
 int oph_encode_text(oph_handle* h, const int32_t* L, const int32_t* spk, int B,
                     float* K, float* V);
 int oph_text2mel(oph_handle* h, const float* K, const float* V, const int32_t* ends,
                  const int32_t* spk, int B, int stop_mode,
                  float* Y, int32_t* t_ends, float* alignments, int32_t* steps_run);
 int oph_ssrn(oph_handle* h, const float* Y, int B, int T, float* Z);
+/* oph_ssrn_logits   the same with the fetch surface's second tensor: Z = g.Z and Z_logits = g.Z_logits
+ *     (networks.py:527-534: the last conv1d's LayerNorm rows before squash_output_ssrn's sigmoid), both (B, r*T, full_dim). */
+int oph_ssrn_logits(oph_handle* h, const float* Y, int B, int T, float* Z, float* Z_logits);
+/* Speculative SSRN during oph_text2mel (default on): chunks of mel frames go through SSRN on their own CU partition as
+ * soon as the decoder has produced them (SSRN's receptive field is +-9 mel frames), for oph_ssrn(Y = NULL) to pick up. */
+int oph_set_streaming(oph_handle* h, int on);
+/* What the pipeline did since oph_create, out[0..n): [0] TextEnc evaluations, [1] runs whose K,V had been pre-encoded under
+ * the previous decode, [2] SSRN chunks launched while a decode was running, [3] whole-decode launches, [4] fall-backs from the
+ * whole-decode launch to two launches per step, [5] tiles resumed to their batch's stop step. */
+int oph_get_counters(oph_handle* h, int64_t* out, int n);
 /* oph_text2mel_graph  replaces ONE sess.run([g.Y, g.max_attentions, g.alignments], feed) of the reference's loop
  *     (synthesize.py:172,181-183) and serves as the fetch surface for the graph tensors of architectures.py:188-239:
  *     K,V (B,max_N,d), mels (B,max_T,n_mels) = the frames generated so far, prev_max (B) = the fed
@@ -136,11 +159,27 @@ int oph_text2mel_durations(oph_handle* h, const float* K, const float* V, const 
  * oph_stage_text copies L / ends / spk into HBM.  oph_run_resident runs
  * encode_text -> decode loop -> (optionally) SSRN entirely on the device, leaving
  * K,V,Y,alignments,Z in HBM; oph_fetch_* copy results out afterwards.
+ *   run_ssrn: 0 Text2Mel only; 1 SSRN too (streamed under the decode, tail joined); 2 pipelined batches: the SSRN tail
+ *   of this batch overlaps the next call (oph_synchronize / oph_fetch_* / oph_timer_stop join it).
+ * oph_stage_text_next stages the text of the FOLLOWING batch (second text slot, same B).  While the staged batch decodes,
+ *   the TextEnc of that next text runs on the SSRN partition; the run after it switches over and starts decoding at
+ *   once.  Called after the staged batch has run, it first makes the previously staged next text current, so a caller
+ *   with a different text per batch (synthesize.py:477-482) alternates
+ *       oph_stage_text(t0); oph_stage_text_next(t1);  loop { run; oph_stage_text_next(t[i+2]); }
+ * oph_run_host is the whole path host -> host in one call (the reference's timed region, synthesize.py:553-576, for the
+ *   staged text): every result is copied into the caller's buffer (NULL = not wanted) as it becomes final, Z chunk by chunk
+ *   while the decode runs.  Buffers from oph_host_alloc (pinned) make those copies asynchronous.
  * oph_decode_steps continues the decode loop of the staged batch over steps
  * [t_begin, t_end) (multi-GPU global-stop fix-up).                  */
 int oph_stage_text(oph_handle* h, const int32_t* L, const int32_t* ends,
                    const int32_t* spk, int B);
+int oph_stage_text_next(oph_handle* h, const int32_t* L, const int32_t* ends,
+                        const int32_t* spk, int B);
 int oph_run_resident(oph_handle* h, int stop_mode, int run_ssrn, int32_t* steps_run);
+int oph_run_host(oph_handle* h, int stop_mode, float* K, float* V, float* Y, int32_t* t_ends,
+                 float* alignments, float* Z, int32_t* steps_run);
+int oph_host_alloc(size_t bytes, void** out);     /* pinned host memory for result buffers */
+int oph_host_free(void* p);
 int oph_decode_steps(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* steps_run);
 int oph_run_ssrn_resident(oph_handle* h);
 int oph_fetch_kv(oph_handle* h, float* K, float* V);

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libophelia_hip.so")
-SOURCES = ["oph_kernels.hip", "oph_decrun.hip", "oph_cone.hip", "oph_api.hip"]
+SOURCES = ["oph_kernels.hip", "oph_decrun.hip", "oph_api.hip"]
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
@@ -53,6 +53,13 @@ SIGNATURES = {
     "oph_text2mel_graph": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, C.c_int,
                                      c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p]),
     "oph_stage_text": (C.c_int, [C.c_void_p, c_i32p, c_i32p, c_i32p, C.c_int]),
+    "oph_stage_text_next": (C.c_int, [C.c_void_p, c_i32p, c_i32p, c_i32p, C.c_int]),
+    "oph_run_host": (C.c_int, [C.c_void_p, C.c_int, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_i32p]),
+    "oph_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "oph_host_free": (C.c_int, [C.c_void_p]),
+    "oph_ssrn_logits": (C.c_int, [C.c_void_p, c_f32p, C.c_int, C.c_int, c_f32p, c_f32p]),
+    "oph_set_streaming": (C.c_int, [C.c_void_p, C.c_int]),
+    "oph_get_counters": (C.c_int, [C.c_void_p, c_i64p, C.c_int]),
     "oph_run_resident": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_i32p]),
     "oph_decode_steps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_i32p]),
     "oph_run_ssrn_resident": (C.c_int, [C.c_void_p]),

@@ -80,12 +80,15 @@ class SSRNGraph(Graph):
 class Session(object):
     """Stands in for tf.Session(): owns the device engine and the variable store."""
 
-    def __init__(self, hp, device=0):
+    def __init__(self, hp, device=0, engine=None):
+        """engine: an existing Engine (weights loaded) to run on instead of creating one -- one GPU should carry ONE
+        handle: each owns three CU-masked streams, and more than three of those alive time-slice."""
         self.hp = hp
-        self.engine = Engine(hp, device=device)
+        self._own = engine is None
+        self.engine = Engine(hp, device=device) if engine is None else engine
         self.device = device
         self._pending = {}
-        self._ready = False
+        self._ready = engine is not None
 
     def __enter__(self):
         return self
@@ -94,7 +97,8 @@ class Session(object):
         self.close()
 
     def close(self):
-        self.engine.close()
+        if self._own:
+            self.engine.close()
 
     def inventory(self, scope=None):
         return [(n, s) for n, s in self.engine.inventory() if scope is None or n.startswith(scope)]
@@ -132,11 +136,11 @@ class Session(object):
         if isinstance(g, SSRNGraph):
             if "mels" not in fed:
                 raise ValueError("SSRN graph: feed g.mels")
-            Z = eng.ssrn(fed["mels"])
-            vals = {"Z": Z}
             if any(t.name == "Z_logits" for t in fl):
-                with np.errstate(divide="ignore"):
-                    vals["Z_logits"] = (np.log(Z) - np.log1p(-Z)).astype(np.float32)      # inverse of the squash sigmoid
+                Z, Zl = eng.ssrn_logits(fed["mels"])         # the device's own pre-squash rows (networks.py:527-534)
+                vals = {"Z": Z, "Z_logits": Zl}
+            else:
+                vals = {"Z": eng.ssrn(fed["mels"])}
         elif "L" in fed and all(t.name in ("K", "V") for t in fl):
             K, V = eng.encode_text(fed["L"], fed.get("speakers"))
             self._last_L = np.asarray(fed["L"])

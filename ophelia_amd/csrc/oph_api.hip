@@ -65,9 +65,7 @@ struct Layer {
     float *Wt = nullptr, *bias = nullptr;       // conv / hc ; convT: even phase (taps x[t], x[t-1])
     float *Wt2 = nullptr;                        // convT odd phase (tap x[t])
     float *Wkn = nullptr; int ldn = 0;           // k=1 layers with N<=256: [kc][ldn] n-contiguous copy for row_chain
-    void *W1 = nullptr, *W2 = nullptr, *W3 = nullptr;   // AudioDec highway layers: Wt as three bf16 terms (conv_gemm_bf16x6, the cone's many-row levels)
     void *Wh = nullptr, *Wl = nullptr, *Wh2 = nullptr, *Wl2 = nullptr;   // SSRN layers: Wt / Wt2 split into hi + lo bf16 planes (conv_gemm_bf16x3)
-    float *Wt_cone = nullptr, *bias_cone = nullptr;   // AudioDec highway layers: columns interleaved 32 H1 | 32 H2 per 64-column tile (oph_cone.hip)
     float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
 };
 
@@ -82,45 +80,84 @@ struct ProfClass {
     double ms = 0;
 };
 constexpr int CONE_KSPLIT = 4;   // split-K of the latency-bound decoder-cone GEMMs (partials summed by ln_rows); buffers are sized for it
-// per-layer choice: many-row layers have enough tiles to fill the cone's CUs with less splitting (fewer partials to write
-// and re-read); OPH_CONE_KSPLIT="big,small" overrides (each 1..4) for experiments
-static int cone_ksplit(int M) {
-    static int big = -1, small_ = -1;
-    if (big < 0) {
-        big = 3; small_ = CONE_KSPLIT;        // measured (profiles/r02): 4,4 31.7 ms | 3,4 30.1 | 2,4 31.1 | 1,4 33.8 | 2,2 33.1 per batch
-        if (const char* e = getenv("OPH_CONE_KSPLIT")) { int a_ = 0, b_ = 0; if (sscanf(e, "%d,%d", &a_, &b_) == 2 && a_ >= 1 && a_ <= CONE_KSPLIT && b_ >= 1 && b_ <= CONE_KSPLIT) { big = a_; small_ = b_; } }
+
+// The OPH_* environment switches (debugging / measurement knobs, README.md lists them), read ONCE per handle in
+// oph_create -- nothing on a launch path calls getenv.
+struct Options {
+    int decode = 0;                  // OPH_DECODE = loop (0, default where possible) | runs (1: two launches per step) | layers (2: one launch per layer)
+    int run_rows = 8;                // OPH_RUN_ROWS: utterance rows per workgroup of dec_loop (8 or 4)
+    // split-K of the cone GEMMs: many-row levels have enough tiles to fill the cone's CUs with less splitting (fewer partials
+    // to write and re-read).  OPH_CONE_KSPLIT="big,small", each 1..4; measured (profiles/r02): 3,4 best
+    int ksplit_big = 3, ksplit_small = CONE_KSPLIT;
+    int fc_rows = -1, fc_insplit = 2;   // OPH_CONE_FC_ROWS (cone levels of at most this many rows run as cone_fc16), OPH_CONE_FC_INSPLIT
+    int lookahead = 8;               // OPH_LOOP_LOOKAHEAD: cones the host may queue ahead of the loop kernel's progress
+    int loop_dbg = 0;                // OPH_LOOP_DBG: ablation bits of dec_loop (results are wrong when set, except 16)
+    int cu_dec = 0, cu_cone = 0;     // OPH_CU_SPLIT="chain,cone" CUs of the three partitions (rest: SSRN)
+    bool no_cu_mask = false, ssrn_all = false, cone_all = false;      // OPH_NO_CU_MASK, OPH_SSRN_ALL, OPH_CONE_ALL
+    bool no_cone_head = false, no_loop_qw = false, no_preencode = false, no_stream_ssrn = false;
+    bool cone_bf16 = false;          // OPH_CONE_BF16X3: the two many-row cone contractions on the split-bf16 kernel (opt-in experiment)
+    bool ssrn_fp32 = false;          // OPH_SSRN_FP32
+    bool skip_cone = false;          // OPH_SKIP_CONE: timing experiments only, results are wrong
+    bool stream_value = false;       // OPH_STREAM_VALUE: per-step launch paths chain their two streams with stream value operations
+    bool run_stamps = false;         // OPH_RUN_STAMPS: clock stamps of the decode kernels' phases (printed under OPH_TRACE)
+    int ssrn_chunk = 40;             // OPH_SSRN_CHUNK: mel frames per streamed SSRN chunk (0 = SSRN only after the decode)
+    void read() {
+        auto flag = [](const char* n) { return getenv(n) != nullptr; };
+        auto num = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
+        if (const char* m = getenv("OPH_DECODE")) decode = !strcmp(m, "runs") ? 1 : (!strcmp(m, "layers") ? 2 : 0);
+        if (flag("OPH_NO_DECRUN")) decode = 2;
+        else if (flag("OPH_NO_DECLOOP") && decode == 0) decode = 1;
+        run_rows = num("OPH_RUN_ROWS", 8) == 4 ? 4 : 8;
+        if (const char* e = getenv("OPH_CONE_KSPLIT")) { int a_ = 0, b_ = 0; if (sscanf(e, "%d,%d", &a_, &b_) == 2 && a_ >= 1 && a_ <= CONE_KSPLIT && b_ >= 1 && b_ <= CONE_KSPLIT) { ksplit_big = a_; ksplit_small = b_; } }
+        fc_rows = num("OPH_CONE_FC_ROWS", -1); fc_insplit = std::max(1, num("OPH_CONE_FC_INSPLIT", 2));
+        lookahead = num("OPH_LOOP_LOOKAHEAD", 8); loop_dbg = num("OPH_LOOP_DBG", 0);
+        if (const char* sp = getenv("OPH_CU_SPLIT")) { int a_ = 0, b_ = 0; if (sscanf(sp, "%d,%d", &a_, &b_) == 2 && a_ > 0 && b_ > 0) { cu_dec = a_; cu_cone = b_; } }
+        no_cu_mask = flag("OPH_NO_CU_MASK"); ssrn_all = flag("OPH_SSRN_ALL"); cone_all = flag("OPH_CONE_ALL");
+        no_cone_head = flag("OPH_NO_CONE_HEAD"); no_loop_qw = flag("OPH_NO_LOOP_QW"); no_preencode = flag("OPH_NO_PREENCODE");
+        no_stream_ssrn = flag("OPH_NO_STREAM_SSRN");
+        cone_bf16 = flag("OPH_CONE_BF16X3"); ssrn_fp32 = flag("OPH_SSRN_FP32"); skip_cone = flag("OPH_SKIP_CONE");
+        { const char* sv = getenv("OPH_STREAM_VALUE"); stream_value = sv && atoi(sv) != 0; }
+        run_stamps = flag("OPH_RUN_STAMPS");
+        ssrn_chunk = std::max(0, num("OPH_SSRN_CHUNK", 40));
     }
-    return M >= 512 ? big : small_;
-}
-enum { PC_GEMM = 0, PC_GEMM64, PC_GEMM_BF16, PC_LN, PC_DEC, PC_ROWCHAIN, PC_ATTN_ROWS, PC_MISC, PC_DECRUN, PC_DECLOOP, PC_CONEHEAD, PC_GEMM_X6, PC_CONE, PC_CONE1, PC_CONE2, PC_CONE3, PC_CONE4, PC_CONE5, PC_CONE6, PC_COUNT };   // PC_CONE + i: i-th fused cone layer of a step   // PC_GEMM = the <128,128> instance
+    int cone_ksplit(int M) const { return M >= 512 ? ksplit_big : ksplit_small; }
+};
+enum { PC_GEMM = 0, PC_GEMM64, PC_GEMM_BF16, PC_LN, PC_DEC, PC_ROWCHAIN, PC_ATTN_ROWS, PC_MISC, PC_DECRUN, PC_DECLOOP, PC_CONEHEAD, PC_COUNT };   // PC_GEMM = the <128,128> instance
 
 }  // namespace
 
+// Decode state of one 16-utterance tile that has to survive between decode calls on the same utterances (a batch of
+// more than 16 utterances decodes tile by tile; oph_decode_steps resumes tiles at the step they stopped).  Everything a
+// step only uses as scratch (raw rows, cone buffers, granules) is shared by the tiles and lives in the handle.
+struct Tile {
+    int *d_p = nullptr, *d_ctl = nullptr, *d_ptab = nullptr;    // prev_max ping-pong [2][16]; ctl[0]=n_ended ctl[1]=stop_after ctl[2]=error ctl[3]=attention arrivals
+    float *Ytm = nullptr, *Qhist = nullptr, *VW = nullptr, *QWhist = nullptr;
+    std::vector<float*> ae_hist;            // AudioEnc per-highway-layer input history
+    unsigned* d_loop_layers = nullptr;      // dec_loop's packed layer descriptors (they hold this tile's history pointers)
+    int steps = 0;                          // decoder steps executed so far on this tile's utterances
+    int ssrn_done = 0;                      // mel frames whose SSRN output is up to date (streamed SSRN)
+};
+
 struct oph_handle {
     oph_dims dm{};
+    Options opt;
     int device = 0;
     hipStream_t stream = nullptr;      // API stream (unmasked): TextEnc / SSRN, timers, copies
     hipStream_t sdec = nullptr;        // decode critical path: CU-masked to a private slice of every XCD
+    hipStream_t scone = nullptr;       // side stream: AudioDec history cone, overlapped with the AudioEnc chain
+    hipStream_t sssrn = nullptr;       // SSRN partition: streamed SSRN chunks of the running decode, pipelined SSRN tails, the next batch's TextEnc
+    hipStream_t scopy = nullptr;       // copies only (unmasked): results leave for the host while the decode runs
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    hipStream_t sssrn = nullptr;       // pipelined SSRN: own CU partition, overlaps the NEXT batch's decode
-    hipEvent_t ev_dec_done = nullptr, ev_ssrn_done[2] = {nullptr, nullptr};
+    hipEvent_t ev_dec_done = nullptr, ev_ssrn_done[2] = {nullptr, nullptr}, ev_copy = nullptr, ev_chunk = nullptr;
     bool ssrn_inflight[2] = {false, false};
-    float *Yout2[2] = {nullptr, nullptr}, *Z2[2] = {nullptr, nullptr};
     int buf = 0; bool pipelined = false;
     uint32_t m_cone[16] = {0}, m_conep[16] = {0}, m_ssrn[16] = {0}; int mask_words = 0;   // CU partitions (0 words = no masking)
-    // captured decode loop (all max_T steps, both streams) per stop_mode; replayed by hipGraphLaunch
-    hipGraphExec_t dec_graph[2] = {nullptr, nullptr};
-    int dec_graph_B[2] = {0, 0};
-    bool capturing = false;
     int ssrn_prec = 1;                 // SSRN contractions: 1 = split-bf16 x3 (fp32 accumulate), 0 = exact fp32 MFMA
-    bool use_graph = true;
-    hipStream_t scone = nullptr;       // side stream in use: AudioDec history cone, overlapped with the AudioEnc chain
     hipEvent_t ev_attn = nullptr, ev_cone = nullptr;
     // The two per-step cross-stream dependencies (cone(t+1) after row_chain B(t); AudioDec(t) after cone(t)) as stream
     // write-value / wait-value operations on two device words instead of event record / wait pairs: an event operation
     // interleaved with launches costs the host ~15 us and the device ~10 us on this runtime, a stream-value operation
     // ~4 us / ~2 us (profiles/launch_rate_probe.hip).  Values grow monotonically: sig_base + step.
-    int* d_ptab = nullptr;              // FixedAttention: key index per (t, b), time-major [max_T][Bpad], -1 = no key
     bool fixed_att = false;             // the current decode uses d_ptab instead of the attention softmax
     uint32_t* d_sig = nullptr;          // [0] attention of step t done (written on sdec), [16] cone of step t done (scone), [LOOP_SIG_LEVEL0 + 16 k] cone level k done
     uint32_t sig_base = 0;
@@ -128,13 +165,14 @@ struct oph_handle {
     bool can_sigval = false;            // stream value operations work on this device
     // persistent runs of decoder layers (oph_decrun.hip): two launches per step instead of nineteen
     bool use_run = false;               // this configuration takes the dec_run path
-    unsigned long long* d_gbuf = nullptr;   // hand-off granules [RUN_MAX_LAYERS][Bpad][RUN_GCOLS]
-    uint32_t run_epoch = 0;             // advanced by RUN_MAX_LAYERS per launch: a tag value is never reused
+    unsigned long long* d_gbuf = nullptr;   // hand-off granules [LOOP_MAX_LAYERS][16][RUN_GCOLS]
+    uint32_t run_epoch = 0;             // advanced per launch: a tag value is never reused
     long long* d_sigdbg = nullptr;      // OPH_RUN_STAMPS diagnostics: [max_T][8] stamps of the cross-stream signals
     long long* d_stamps = nullptr;      // OPH_RUN_STAMPS diagnostics: [2 launches][32 slices][LOOP_MAX_LAYERS][8]
     // whole-decode persistent launch (dec_loop): static layer descriptions in device memory, progress words in pinned host memory
     bool use_loop = false;
-    unsigned* d_loop_layers = nullptr;  // packed descriptors [nlayers][LOOP_DESC_STRIDE]
+    std::vector<LoopLayer> loop_proto;  // the decode's layers with pre-swizzled weights; per tile only the history pointers differ
+    std::vector<float*> loop_lnp;
     int loop_nlayers = 0, loop_attn = 0, loop_slices = 0, loop_kmax = 0;
     volatile int* host_prog = nullptr;  // [0] last step whose attention is done  [1] stop step or INT_MAX
     int ndec_cus = 0;                   // CUs the critical stream may use (its CU mask, or the whole chip)
@@ -155,19 +193,36 @@ struct oph_handle {
     // batched workspaces
     int capB = 0;
     float *actA = nullptr, *actB = nullptr, *raw = nullptr;   // workspace of the API stream (TextEnc, host-buffer SSRN)
-    float *actA2 = nullptr, *actB2 = nullptr, *raw2 = nullptr; // workspace of the pipelined SSRN stream
+    float *actA2 = nullptr, *actB2 = nullptr, *raw2 = nullptr; // workspace of the SSRN-partition stream
     size_t act_elems = 0, raw_elems = 0;
-    // staged batch / resident state
-    int B = 0, Bpad = 0;
-    int *d_L = nullptr, *d_ends = nullptr, *d_spk = nullptr, *d_p = nullptr, *d_tends = nullptr, *d_ctl = nullptr;  // ctl[0]=n_ended ctl[1]=stop_after
+    long long* d_amax = nullptr;        // oph_text2mel_graph: argmax per (utterance, frame)
+    // ---- the staged batch: nB utterances, resident in HBM, utterance-major.  Text is double-buffered so that the NEXT
+    // batch can be staged (oph_stage_text_next) and pre-encoded while this one decodes.
+    int nB = 0, nBpad = 0;
+    int *bL[2] = {nullptr, nullptr}, *bEnds[2] = {nullptr, nullptr}, *bSpk[2] = {nullptr, nullptr}; int txt = 0;     // bX[txt]: current text
+    int next_B = 0; bool next_staged = false;      // bX[txt ^ 1] holds a staged next batch of next_B utterances
+    bool txt_ran = false;               // the current text has been through a run (a staged next text may take its place)
+    bool kv_pre = false;                // bKV[kv_cur] already holds the current text's K,V (pre-encoded while the previous batch decoded)
+    long long n_textenc = 0, n_preenc_used = 0, n_chunks_streamed = 0, n_loop_decodes = 0, n_loop_fallbacks = 0, n_tile_resumes = 0;   // oph_get_counters
+    int* bTends = nullptr;
+    float* bKV[2] = {nullptr, nullptr}; int kv_cur = 0;      // K | V rows [nB][max_N][2d]; the other buffer receives the next batch's pre-encode
+    float *bYout[2] = {nullptr, nullptr}, *bZ[2] = {nullptr, nullptr}, *bAlign = nullptr;      // Y / Z ping-pong over pipelined batches
+    hipEvent_t ev_preenc = nullptr; bool preenc_valid = false;     // bKV[kv_cur ^ 1] holds (or will hold, after ev_preenc) the K,V of the staged next text
+    bool want_preenc = false;           // set around a decode: queue the next batch's TextEnc once the loop kernel is launched
+    // residency of the three session calls (oph_encode_text -> oph_text2mel -> oph_ssrn): a NULL K/V (Y) argument means "what
+    // the previous call left in HBM"
+    bool kv_resident = false, y_resident = false;
+    bool spec_ssrn = true;              // oph_text2mel streams SSRN over the frames it has produced (consumed by oph_ssrn(Y = NULL))
+    float* z_host = nullptr;            // host destination the streamed SSRN chunks are copied to as they complete (or null)
+    // ---- decode tiles: utterances [16 j, 16 j + 16) of the batch; `tile` is the one the views below point into
+    std::vector<Tile> tiles; int tile = 0;
+    int B = 0, Bpad = 0;                // the CURRENT tile: utterances, rows (16)
+    int *d_L = nullptr, *d_ends = nullptr, *d_spk = nullptr, *d_p = nullptr, *d_tends = nullptr, *d_ctl = nullptr, *d_ptab = nullptr;
     float *KV = nullptr, *Yout = nullptr, *Ytm = nullptr, *align = nullptr, *Z = nullptr;
-    // pipelined batches: TextEnc of the NEXT batch runs ahead on the SSRN partition while this batch decodes
-    float* KV2[2] = {nullptr, nullptr}; int kv_cur = 0;
-    bool want_preenc = false;           // set around a pipelined decode: queue the next batch's TextEnc once the loop kernel is launched
-    hipEvent_t ev_preenc = nullptr; bool preenc_valid = false; uint64_t preenc_epoch = 0, stage_epoch = 0;
     float *Qhist = nullptr, *Rrow = nullptr;
-    std::vector<float*> ae_hist, ae_raw;          // AudioEnc per-layer input history / raw outputs
-    std::vector<float*> ad_raw, ad_xrow;          // AudioDec row chain
+    unsigned* d_loop_layers = nullptr;
+    std::vector<float*> ae_hist, ae_raw;          // AudioEnc per-layer input history (tile) / raw outputs (scratch)
+    std::vector<float*> ad_raw, ad_xrow;          // AudioDec row chain (scratch)
     // AudioDec history cone
     int n_hc_dec = 0, dec_pre = 0;                // #hc layers, #k=1 layers before them
     std::vector<std::vector<int>> Hset;           // Hset[h] sorted offsets (>=1) at which hc layer h's INPUT is needed
@@ -175,19 +230,13 @@ struct oph_handle {
     std::vector<FcTables> fc_tab;                 // per hc layer: cone_fc16's index tables (kernel arguments)
     bool cone_bf16 = false;                      // OPH_CONE_BF16X3 experiment
     bool qw_from_loop = false;                   // this decode's QW cache is filled by the loop kernel (cone_head computes nothing)
-    bool cone_x6 = false;                        // many-row cone levels on conv_gemm_bf16x6
-    float* coneRawC = nullptr;                    // raw buffer of the second cone stream
-    hipStream_t scone2 = nullptr; hipEvent_t ev_cone2 = nullptr; int cone_split_at = 0;    // OPH_CONE_SPLIT=k: cone levels from layer k on run on their own stream
     float* coneRawB = nullptr;                    // second raw buffer: consecutive cone_fc16 launches ping-pong
     int cone_fc_rows = 64;                        // cone levels with at most this many output rows run as cone_fc16 (0: never)
     int* d_off0 = nullptr;                        // Hset[0] on device
-    std::vector<float*> cone[2];                  // cone[t&1][h]: [|Hset[h]|][Bpad][256], ping-pong over steps
-    bool cone_fused = false;                      // cone layers as fused GEMM + LayerNorm launches (oph_cone.hip)
+    std::vector<float*> cone[2];                  // cone[t&1][h]: [|Hset[h]|][16][256], ping-pong over steps
     // cone head in one launch (cone_head): V . Wc per batch, Q . Wq + bias per position
     bool cone_head_ok = false;
     float *Wt_c = nullptr, *VW = nullptr, *QWhist = nullptr; int kc_c = 0, ldvw = 0;
-    unsigned long long* d_cone_stats = nullptr;   // row-statistics granules of the fused cone layers
-    uint32_t cone_epoch = 0;
     // dec_loop mode: the cone waits / signals inside its own first / last launch
     bool cone_inline_sig = false; uint32_t cone_wait_val = 0, cone_done_val = 0, cone_done_total[LOOP_MAX_LEVELS] = {0};     // per cone level: arrivals so far
     unsigned* d_cone_count = nullptr;
@@ -218,7 +267,7 @@ struct oph_handle {
     }
     // ---- profiling brackets
     void pbegin(int cls) {
-        if (!prof_on(cls) || capturing || g_group_cls == cls) return;
+        if (!prof_on(cls) || g_group_cls == cls) return;
         ProfClass& pc = prof[cls];
         if (pc.used == pc.ev.size()) {
             hipEvent_t a, b;
@@ -233,7 +282,7 @@ struct oph_handle {
     void gbegin(int cls) { pbegin(cls); g_group_cls = cls; }
     void gend(int cls) {
         g_group_cls = -1;
-        if (!prof_on(cls) || capturing) return;
+        if (!prof_on(cls)) return;
         ProfClass& pc = prof[cls];
         hipEventRecord(pc.ev[pc.used].second, g_cur);
         pc.used++;
@@ -243,7 +292,7 @@ struct oph_handle {
         pc.launches++;
         pc.bytes += bytes;
         pc.flops += flops;
-        if (!prof_on(cls) || capturing || g_group_cls == cls) return;
+        if (!prof_on(cls) || g_group_cls == cls) return;
         hipEventRecord(pc.ev[pc.used].second, g_cur);
         pc.used++;
     }
@@ -495,31 +544,11 @@ int pack_layer(oph_handle* h, Layer& l) {
     return (l.Wt && l.bias && l.g1 && l.b1) ? 0 : -1;
 }
 
-// AudioDec highway layer for the fused cone kernel (oph_cone.hip): column n' of tile j = n'/32 is H1 channel 16j + i
-// for i = n'%32 < 16, H2 channel 16j + i - 16 otherwise, so that one 32-column tile holds both halves of its channels.
-int pack_cone_layer(oph_handle* h, Layer& l) {
-    const std::vector<float>& k = *getw(h, l.scope + "/conv1d/kernel");      // (size, cin, 2C)
-    const std::vector<float>& b = *getw(h, l.scope + "/conv1d/bias");
-    const int C = l.cout, N = 2 * C;
-    std::vector<float> w((size_t)l.Nalloc * l.size * l.kc, 0.f), bb((size_t)l.Nalloc, 0.f);
-    for (int np = 0; np < N; ++np) {
-        const int j = np / 32, i = np % 32;
-        const int n = i < 16 ? 16 * j + i : C + 16 * j + (i - 16);
-        bb[np] = b[n];
-        for (int t = 0; t < l.size; ++t)
-            for (int c = 0; c < l.cin; ++c) w[(size_t)np * l.size * l.kc + (size_t)t * l.kc + c] = k[((size_t)t * l.cin + c) * N + n];
-    }
-    l.Wt_cone = upload(h, w);
-    l.bias_cone = upload(h, bb);
-    return (l.Wt_cone && l.bias_cone) ? 0 : -1;
-}
-
 // ------------------------------------------------------------------ launch wrappers with accounting
-void run_gemm(oph_handle* h, const GemmArgs& a, int cin_true, int prec = 0) {       // prec: 0 fp32 MFMA, 1 split-bf16 x3, 2 split-bf16 x6 (fp32-equivalent)
-    const int cls = prec == 2 ? PC_GEMM_X6 : (prec ? PC_GEMM_BF16 : (conv_gemm_tile_m(a.M, a.N) == 128 ? PC_GEMM : PC_GEMM64));
+void run_gemm(oph_handle* h, const GemmArgs& a, int cin_true, int prec = 0) {       // prec: 0 fp32 MFMA, 1 split-bf16 x3
+    const int cls = prec ? PC_GEMM_BF16 : (conv_gemm_tile_m(a.M, a.N) == 128 ? PC_GEMM : PC_GEMM64);
     h->pbegin(cls);
-    if (prec == 2) launch_conv_gemm_bf16x6(a, g_cur);
-    else if (prec) launch_conv_gemm_bf16x3(a, g_cur);
+    if (prec) launch_conv_gemm_bf16x3(a, g_cur);
     else launch_conv_gemm(a, g_cur);
     const double K = (double)a.ntaps * cin_true;
     h->pend(cls, ((double)a.M * cin_true + (double)a.M * a.N + (double)a.N * K) * 4.0, 2.0 * a.M * a.N * K);
@@ -541,8 +570,16 @@ void run_dec(oph_handle* h, const DecArgs& a, const Layer& l) {
 // Runs `layers` over dense rows (B utterances x T frames).  in: [B*T][ld_in] padded rows.
 // final_out/final_ld: where the LAST layer's epilogue writes (e.g. Z with ld = full_dim).
 // Returns pointer to the final activation rows and their ld via *out_ld; rows via *out_rows.
+struct BatchedIO {
+    const int* spk = nullptr;        // speaker id per utterance of THIS batch of rows (LCC gates, appended embeddings); null: the staged batch's
+    // row mapping of the LAST layer's output (streamed SSRN chunks): its M rows are [B][out_T]; row (b, u) with
+    // keep_lo <= u < keep_hi is stored at output row b * out_bs + out_t0 + u, the others are not stored.  out_T == 0: dense.
+    int out_T = 0, keep_lo = 0, keep_hi = 0; long long out_bs = 0; int out_t0 = 0;
+    float* final_logits = nullptr;   // also store the last layer's PRE-activation rows here (same mapping and row stride)
+};
 float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, int ld_in, int B, int T, int wsi, int prec,
-                   float* final_out, int final_ld, int final_pad, int* out_ld, long long* out_rows) {
+                   float* final_out, int final_ld, int final_pad, int* out_ld, long long* out_rows, const BatchedIO& io = BatchedIO()) {
+    const int* spk_ids = io.spk ? io.spk : h->bSpk[h->txt];
     float* x = in;
     int ldx = ld_in;
     int Tcur = T;
@@ -563,11 +600,12 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
         EpiArgs e{};
         e.g1 = l.g1; e.b1 = l.b1; e.g2 = l.g2; e.b2 = l.b2; e.act = l.act; e.Y = y; e.ldy = ldy; e.ypad = ypad;
         e.H = wsraw; e.stop_after = nullptr; e.nonorm = !l.ln;
-        e.lcc = l.lcc_gate; e.lcc_ids = h->d_spk; e.lcc_T = Tcur;
+        e.lcc = l.lcc_gate; e.lcc_ids = spk_ids; e.lcc_T = Tcur;
+        if (last && final_out && io.out_T > 0) { e.out_T = io.out_T; e.keep_lo = io.keep_lo; e.keep_hi = io.keep_hi; e.out_bs = io.out_bs; e.out_t0 = io.out_t0; }
         if (!last && layers[li + 1].ccat > 0) {       // the next layer's input = [this output | speaker embedding]
             const Layer& nx = layers[li + 1];
             e.spk_table = nx.cat_table ? nx.cat_table : h->emb_spk;      // AudioDec 'audio_decoder_input': embed_2
-            e.spk_ids = h->d_spk; e.spk_dim = nx.ccat; e.spk_T = Tcur;
+            e.spk_ids = spk_ids; e.spk_dim = nx.ccat; e.spk_T = Tcur;
             e.ldy = e.ypad = nx.kc;
         }
         if (l.kind == K_CONVT) {
@@ -594,6 +632,11 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
             if (l.kind == K_HC) { e.mode = PRE_HC; e.Xres = x; e.ldres = ldx; }
             else e.mode = PRE_CONV;
             run_epi(h, e);
+            if (last && io.final_logits && l.kind == K_CONV) {      // the fetch surface's g.Z_logits / g.Y_logits: the same rows before the squash
+                EpiArgs el = e;
+                el.act = ACT_NONE; el.Y = io.final_logits;
+                run_epi(h, el);
+            }
         }
         x = y; ldx = e.ldy;
         flip ^= 1;
@@ -629,52 +672,66 @@ int idx_of(const std::vector<int>& v, int x) {
     return (it != v.end() && *it == x) ? (int)(it - v.begin()) : -1;
 }
 
+constexpr int TILE = 16;       // utterances per decode tile = rows of every decode kernel's row block
+
+// Point the handle's working views at tile j of the staged batch: utterances [16 j, 16 j + B_j).
+void select_tile(oph_handle* h, int j) {
+    const oph_dims& m = h->dm;
+    Tile& t = h->tiles[j];
+    const size_t r0 = (size_t)j * TILE;
+    h->tile = j;
+    h->B = std::min(TILE, h->nB - j * TILE); h->Bpad = TILE;
+    h->d_L = h->bL[h->txt] + r0 * m.max_N; h->d_ends = h->bEnds[h->txt] + r0; h->d_spk = h->bSpk[h->txt] + r0; h->d_tends = h->bTends + r0;
+    h->KV = h->bKV[h->kv_cur] + r0 * m.max_N * 2 * m.d;
+    h->Yout = h->bYout[h->buf] + r0 * m.max_T * h->ldy;
+    h->Z = h->bZ[h->buf] + r0 * m.max_T * m.r * m.full_dim;
+    h->align = h->bAlign + r0 * m.max_N * m.max_T;
+    h->d_p = t.d_p; h->d_ctl = t.d_ctl; h->d_ptab = t.d_ptab;
+    h->Ytm = t.Ytm; h->Qhist = t.Qhist; h->VW = t.VW; h->QWhist = t.QWhist; h->ae_hist = t.ae_hist;
+    h->d_loop_layers = t.d_loop_layers;
+}
+
 int ensure_decode_state(oph_handle* h, int B) {
-    const int Bpad = round_up(B, 16);
-    if (h->Bpad == Bpad && h->KV) { h->B = B; return 0; }
-    if (h->KV) {
+    const int nBpad = round_up(B, TILE);
+    if (h->nBpad == nBpad && h->bKV[0]) { h->nB = B; select_tile(h, 0); return 0; }
+    if (h->bKV[0]) {
         // a different number of 16-row tiles: release the per-batch state and the workspaces and rebuild them
-        for (hipStream_t st : {h->stream, h->sdec, h->scone, h->sssrn}) if (st) hipStreamSynchronize(st);
+        for (hipStream_t st : {h->stream, h->sdec, h->scone, h->sssrn, h->scopy}) if (st) hipStreamSynchronize(st);
         for (size_t i = h->n_weight_allocs; i < h->allocs.size(); ++i) hipFree(h->allocs[i]);
         h->allocs.resize(h->n_weight_allocs);
-        h->ae_hist.clear(); h->ae_raw.clear(); h->ad_raw.clear(); h->ad_xrow.clear();
+        h->ae_hist.clear(); h->ae_raw.clear(); h->ad_raw.clear(); h->ad_xrow.clear(); h->tiles.clear(); h->loop_proto.clear(); h->loop_lnp.clear();
         h->cone[0].clear(); h->cone[1].clear(); h->d_tab.clear(); h->d_need.clear(); h->d_res.clear(); h->fc_tab.clear(); h->Hset.clear();
-        for (auto& ge : h->dec_graph) if (ge) { hipGraphExecDestroy(ge); ge = nullptr; }
-        h->KV = nullptr; h->KV2[0] = h->KV2[1] = nullptr; h->preenc_valid = false; h->capB = 0; h->actA = h->actB = h->raw = h->actA2 = h->actB2 = h->raw2 = nullptr;
+        h->bKV[0] = h->bKV[1] = nullptr; h->preenc_valid = false; h->next_staged = false; h->kv_resident = h->y_resident = false;
+        h->capB = 0; h->actA = h->actB = h->raw = h->actA2 = h->actB2 = h->raw2 = nullptr;
         h->d_loop_layers = nullptr;
         h->pipelined = false; h->buf = 0; h->ssrn_inflight[0] = h->ssrn_inflight[1] = false;
     }
     const oph_dims& m = h->dm;
-    const int d = m.d;
-    h->B = B; h->Bpad = Bpad;
+    const int d = m.d, Bpad = TILE, ntiles = nBpad / TILE;
+    h->nB = B; h->nBpad = nBpad;
     h->ldy = round_up(m.n_mels, 32);
-    h->d_L = h->dalloc<int>((size_t)Bpad * m.max_N);
-    h->d_ends = h->dalloc<int>(Bpad);
-    h->d_spk = h->dalloc<int>(Bpad);
-    h->d_p = h->dalloc<int>(2 * Bpad);
-    h->d_tends = h->dalloc<int>(Bpad);
-    h->d_ctl = h->dalloc<int>(4);
-    h->d_ptab = h->dalloc<int>((size_t)m.max_T * Bpad);
+    // ---- batch-level buffers (utterance-major)
+    for (int i = 0; i < 2; ++i) {
+        h->bL[i] = h->dalloc<int>((size_t)nBpad * m.max_N);
+        h->bEnds[i] = h->dalloc<int>(nBpad);
+        h->bSpk[i] = h->dalloc<int>(nBpad);
+        h->bKV[i] = h->dalloc<float>((size_t)nBpad * m.max_N * 2 * d);
+        h->bYout[i] = h->dalloc<float>((size_t)nBpad * m.max_T * h->ldy);
+        h->bZ[i] = h->dalloc<float>((size_t)nBpad * m.max_T * m.r * m.full_dim);
+    }
+    h->txt = 0; h->kv_cur = 0; h->preenc_valid = false; h->next_staged = false;
+    h->bTends = h->dalloc<int>(nBpad);
+    h->bAlign = h->dalloc<float>((size_t)nBpad * m.max_N * m.max_T);
+    h->d_amax = h->dalloc<long long>((size_t)nBpad * m.max_T);
+    // ---- scratch shared by the tiles
     h->d_gbuf = h->dalloc<unsigned long long>((size_t)LOOP_MAX_LAYERS * Bpad * RUN_GCOLS);
     h->run_epoch = 0;
-    if (getenv("OPH_RUN_STAMPS")) {
+    if (h->opt.run_stamps) {
         h->d_stamps = h->dalloc<long long>((size_t)2 * 32 * LOOP_MAX_LAYERS * 8);
         h->d_sigdbg = h->dalloc<long long>((size_t)m.max_T * 8);
     }
-    for (int i = 0; i < 2; ++i) h->KV2[i] = h->dalloc<float>((size_t)Bpad * m.max_N * 2 * d);
-    h->kv_cur = 0; h->KV = h->KV2[0]; h->preenc_valid = false;
-    for (int i = 0; i < 2; ++i) h->Yout2[i] = h->dalloc<float>((size_t)Bpad * m.max_T * h->ldy);
-    h->Yout = h->Yout2[0];
-    h->Ytm = h->dalloc<float>((size_t)(m.max_T + 1) * Bpad * h->ldy);
-    h->align = h->dalloc<float>((size_t)Bpad * m.max_N * m.max_T);
-    for (int i = 0; i < 2; ++i) h->Z2[i] = h->dalloc<float>((size_t)Bpad * m.max_T * m.r * m.full_dim);
-    h->Z = h->Z2[0];
-    h->Qhist = h->dalloc<float>((size_t)m.max_T * Bpad * d);
     h->Rrow = h->dalloc<float>((size_t)Bpad * 2 * d);
-    for (const Layer& l : h->audioenc) {
-        h->ae_hist.push_back(l.kind == K_HC ? h->dalloc<float>((size_t)m.max_T * Bpad * l.kc) : nullptr);
-        h->ae_raw.push_back(h->dalloc<float>((size_t)Bpad * l.Nalloc));
-    }
+    for (const Layer& l : h->audioenc) h->ae_raw.push_back(h->dalloc<float>((size_t)Bpad * l.Nalloc));
     for (const Layer& l : h->audiodec) {
         h->ad_raw.push_back(h->dalloc<float>((size_t)Bpad * l.Nalloc));
         h->ad_xrow.push_back(l.kind == K_HC ? h->dalloc<float>((size_t)Bpad * l.kc) : nullptr);
@@ -750,28 +807,34 @@ int ensure_decode_state(oph_handle* h, int B) {
     h->coneR = h->dalloc<float>(maxrows * Bpad * 2 * d);
     h->coneRaw = h->dalloc<float>((size_t)CONE_KSPLIT * maxrows * Bpad * (size_t)round_up(2 * d, 128));
     h->coneRawB = h->dalloc<float>((size_t)maxrows * Bpad * (size_t)round_up(2 * d, 128));
-    h->coneRawC = h->dalloc<float>((size_t)CONE_KSPLIT * maxrows * Bpad * (size_t)round_up(2 * d, 128));
     h->coneTmp = h->dalloc<float>(maxrows * Bpad * (size_t)ld_cat);
-    h->d_cone_stats = h->dalloc<unsigned long long>(((maxrows * Bpad + 31) / 32) * 16 * 64 * 4);
     h->d_cone_count = h->dalloc<unsigned>(LOOP_MAX_LEVELS); for (uint32_t& v : h->cone_done_total) v = 0;
-    if (h->cone_head_ok) {
-        h->VW = h->dalloc<float>((size_t)Bpad * m.max_N * h->ldvw);
-        h->QWhist = h->dalloc<float>((size_t)m.max_T * Bpad * d);
+    // ---- per-tile state
+    h->tiles.assign(ntiles, Tile());
+    for (Tile& t : h->tiles) {
+        t.d_p = h->dalloc<int>(2 * Bpad);
+        t.d_ctl = h->dalloc<int>(4);
+        t.d_ptab = h->dalloc<int>((size_t)m.max_T * Bpad);
+        t.Ytm = h->dalloc<float>((size_t)(m.max_T + 1) * Bpad * h->ldy);
+        t.Qhist = h->dalloc<float>((size_t)m.max_T * Bpad * d);
+        for (const Layer& l : h->audioenc) t.ae_hist.push_back(l.kind == K_HC ? h->dalloc<float>((size_t)m.max_T * Bpad * l.kc) : nullptr);
+        if (h->cone_head_ok) {
+            t.VW = h->dalloc<float>((size_t)Bpad * m.max_N * h->ldvw);
+            t.QWhist = h->dalloc<float>((size_t)m.max_T * Bpad * d);
+        }
+        if (!t.d_p || !t.d_ctl || !t.d_ptab || !t.Ytm || !t.Qhist || (h->cone_head_ok && !t.QWhist)) { h->fail("out of device memory for decode state"); return OPH_ERR_DEVICE; }
     }
-    h->cone_epoch = 0;
     hipStreamSynchronize(h->stream);
-    if (!h->coneTmp || !h->Z2[1] || !h->Yout2[1]) { h->fail("out of device memory for decode state"); return OPH_ERR_DEVICE; }
+    if (!h->coneTmp || !h->bZ[1] || !h->bYout[1] || !h->bAlign || !h->d_amax) { h->fail("out of device memory for decode state"); return OPH_ERR_DEVICE; }
+    select_tile(h, 0);
     return ensure_batched_capacity(h, B);
 }
 
-// reset per-utterance decode state (synthesize.py:157-166)
+// reset the CURRENT tile's decode state (synthesize.py:157-166)
 void reset_decode(oph_handle* h) {
     const oph_dims& m = h->dm;
-    if (h->pipelined) {       // ping-pong Y/Z so that SSRN of the previous batch can still read its Y
-        h->buf ^= 1;
-        h->Yout = h->Yout2[h->buf]; h->Z = h->Z2[h->buf];
-        if (h->ssrn_inflight[h->buf]) { hipStreamWaitEvent(h->stream, h->ev_ssrn_done[h->buf], 0); h->ssrn_inflight[h->buf] = false; }
-    }
+    Tile& tl = h->tiles[h->tile];
+    tl.steps = 0; tl.ssrn_done = 0;
     hipMemsetAsync(h->d_p, 0, 2 * h->Bpad * 4, h->stream);
     hipMemsetAsync(h->Yout, 0, (size_t)h->Bpad * m.max_T * h->ldy * 4, h->stream);
     hipMemsetAsync(h->Ytm, 0, (size_t)(m.max_T + 1) * h->Bpad * h->ldy * 4, h->stream);
@@ -780,7 +843,7 @@ void reset_decode(oph_handle* h) {
     const int ctl[4] = {0, INT_MAX, 0, 0};
     hipMemcpyAsync(h->d_ctl, ctl, sizeof ctl, hipMemcpyHostToDevice, h->stream);
     if (h->cone_head_ok) {
-        // V . Wc for every text position of the batch (one small GEMM; the cone head adds prob-weighted rows of it)
+        // V . Wc for every text position of the tile (one small GEMM; the cone head adds prob-weighted rows of it)
         GemmArgs g{};
         g.X = h->KV + m.d; g.ldx = 2 * m.d; g.Wt = h->Wt_c; g.ldw = h->kc_c; g.bias = h->d_zeros; g.H = h->VW; g.ldh = h->ldvw;
         g.M = h->B * m.max_N; g.N = m.d; g.kc = h->kc_c; g.ntaps = 1; g.mode = 0; g.T = g.M; g.off[0] = 0;
@@ -790,6 +853,14 @@ void reset_decode(oph_handle* h) {
         g_cur = saved;
     }
     hipStreamSynchronize(h->stream);
+}
+// a new batch starts decoding: in pipelined mode Y / Z ping-pong, so that the SSRN of the previous batch can still read its Y
+void begin_batch(oph_handle* h) {
+    if (h->pipelined) {
+        h->buf ^= 1;
+        if (h->ssrn_inflight[h->buf]) { hipStreamWaitEvent(h->stream, h->ev_ssrn_done[h->buf], 0); h->ssrn_inflight[h->buf] = false; }
+    }
+    h->y_resident = false;
 }
 
 // AudioDec history cone for step t under the mask p_t (= max_attentions of step t-1).
@@ -857,52 +928,6 @@ void launch_cone(oph_handle* h, int t) {
     launch_attn_rows(ar, g_cur);
     h->pend(PC_ATTN_ROWS, (double)n0 * B * 3.0 * d * 4.0, (double)n0 * B * 4.0 * m.attention_win_size * d);
     }
-    if (h->cone_fused) {
-        // every cone layer = ONE launch: conv GEMM with LayerNorm (+ gate + residual) in the epilogue (oph_cone.hip)
-        int fused_idx = 0;
-        auto run_fused = [&](ConeGemmArgs& c, const Layer& l, int cls_rows) {
-            const int cls = PC_CONE + std::min(fused_idx++, 6);
-            c.stats = h->d_cone_stats; c.epoch = ++h->cone_epoch;
-            c.stop_after = stop_after; c.t = t; c.err = h->d_ctl + 2;
-            c.kc = l.kc; c.ntaps = l.ntaps; c.nonorm = !l.ln;
-            h->pbegin(cls);
-            launch_cone_gemm(c, c.M <= 256 ? 1 : 0, g_cur);
-            const double K = (double)l.ntaps * l.cin;
-            h->pend(cls, ((double)c.M * (K / l.ntaps) + (double)c.M * l.cout + (double)l.N * K) * 4.0, 2.0 * c.M * l.N * K);
-            (void)cls_rows;
-        };
-        const float* x = h->coneR; int ldx = 2 * d;
-        if (pre_first == 1 && pre > 1) { x = h->coneTmp; ldx = h->audiodec[1].kc; }
-        for (int k = pre_first; k < pre; ++k) {
-            const Layer& l = h->audiodec[k];
-            ConeGemmArgs c{};
-            c.X = x; c.ldx = ldx; c.Wt = l.Wt; c.ldw = l.kc; c.bias = l.bias; c.M = n0 * Bpad; c.NT = (l.N + 31) / 32; c.dense = 1; c.Bpad = Bpad;
-            c.hc = 0; c.C = l.cout; c.g1 = l.g1; c.b1 = l.b1; c.act = l.act;
-            const bool spk_next = (k + 1 < pre) && h->audiodec[k + 1].ccat > 0;
-            if (spk_next) {
-                const Layer& nx = h->audiodec[k + 1];
-                c.Y = h->coneTmp; c.ldy = nx.kc; c.spk_table = h->emb_spk; c.spk_ids = h->d_spk; c.spk_dim = nx.ccat;
-                x = h->coneTmp; ldx = nx.kc;
-            } else {
-                c.Y = cone[0]; c.ldy = h->audiodec[pre].kc;
-                x = cone[0]; ldx = c.ldy;
-            }
-            run_fused(c, l, 0);
-        }
-        for (int k = 0; k + 1 < nh; ++k) {
-            const Layer& l = h->audiodec[pre + k];
-            const int n_out = (int)h->Hset[k + 1].size();
-            ConeGemmArgs c{};
-            c.X = cone[k]; c.ldx = l.kc; c.Wt = l.Wt_cone; c.ldw = 3 * l.kc; c.bias = l.bias_cone; c.M = n_out * Bpad; c.NT = (l.N + 31) / 32;
-            c.dense = 0; c.Bpad = Bpad; c.n_out = n_out; c.j = t; c.tab = h->d_tab[k]; c.need = h->d_need[k];
-            c.hc = 1; c.C = l.cout; c.g1 = l.g1; c.b1 = l.b1; c.g2 = l.g2; c.b2 = l.b2;
-            c.Xres = cone[k]; c.ldres = l.kc; c.restab = h->d_res[k];
-            c.Y = cone[k + 1]; c.ldy = h->audiodec[pre + k + 1].kc;
-            run_fused(c, l, 0);
-        }
-        g_cur = saved;
-        return;
-    }
     // k=1 layers before the highway stack, on all Hset[0] positions
     const float* x = h->coneR; int ldx = 2 * d;
     if (pre_first == 1 && pre > 1) { x = h->coneTmp; ldx = h->audiodec[1].kc; }
@@ -912,7 +937,7 @@ void launch_cone(oph_handle* h, int t) {
         g.X = x; g.ldx = ldx; g.Wt = l.Wt; g.ldw = l.kc; g.bias = l.bias; g.H = h->coneRaw; g.ldh = l.Nalloc;
         g.M = n0 * Bpad; g.N = l.N; g.kc = l.kc; g.ntaps = 1; g.mode = 0; g.T = g.M; g.off[0] = 0;
         g.stop_after = stop_after; g.t = t;
-        g.ksplit = cone_ksplit(g.M); g.split_stride = (long long)g.M * l.Nalloc;
+        g.ksplit = h->opt.cone_ksplit(g.M); g.split_stride = (long long)g.M * l.Nalloc;
         run_gemm(h, g, l.cin);
         EpiArgs e{};
         e.nsplit = g.ksplit; e.split_stride = g.split_stride;
@@ -935,9 +960,8 @@ void launch_cone(oph_handle* h, int t) {
     }
     // Small levels (few output rows) as ONE launch each: the previous layer's LayerNorm / gate as the prologue of this
     // layer's contraction (cone_fc16) instead of ln_rows + a split-K GEMM.  From the first such level to the end.
-    static const int fc_rows_env = getenv("OPH_CONE_FC_ROWS") ? atoi(getenv("OPH_CONE_FC_ROWS")) : -1;
-    const int fc_rows = fc_rows_env >= 0 ? fc_rows_env : h->cone_fc_rows;
-    static const int fc_in_split = getenv("OPH_CONE_FC_INSPLIT") ? std::max(1, atoi(getenv("OPH_CONE_FC_INSPLIT"))) : 2;
+    const int fc_rows = h->opt.fc_rows >= 0 ? h->opt.fc_rows : h->cone_fc_rows;
+    const int fc_in_split = h->opt.fc_insplit;
     int fc_from = nh;             // first layer index evaluated by cone_fc16
     for (int k = nh - 2; k >= 1; --k) {
         const Layer& l = h->audiodec[pre + k]; const Layer& lp = h->audiodec[pre + k - 1];
@@ -947,14 +971,10 @@ void launch_cone(oph_handle* h, int t) {
         fc_from = k;
     }
     float* raw_in = h->coneRaw; int raw_split = 1; long long raw_stride = 0;
-    // two-stream cone (dec_loop mode, OPH_CONE_SPLIT=ks): layers ks.. run on a second stream; the level ks they gather is
-    // written through completely by its producer (coh_all), whose completion word the first launch there waits for
-    const int ks_split = (h->cone_inline_sig && h->scone2 && h->cone_split_at >= 1 && h->cone_split_at < fc_from && h->cone_split_at + 1 < nh) ? h->cone_split_at : 0;
     for (int k = 0; k + 1 < nh; ++k) {
         const Layer& l = h->audiodec[pre + k];
         const int n_out = (int)h->Hset[k + 1].size();
-        if (ks_split && k == ks_split) g_cur = h->scone2;
-        float* const raw_gemm = (ks_split && k >= ks_split) ? h->coneRawC : h->coneRaw;
+        float* const raw_gemm = h->coneRaw;
         if (k >= fc_from) {
             const Layer& lp = h->audiodec[pre + k - 1];
             ConeFcArgs c{};
@@ -984,13 +1004,11 @@ void launch_cone(oph_handle* h, int t) {
             g.X = cone[k]; g.ldx = l.kc; g.Wt = l.Wt; g.ldw = 3 * l.kc; g.bias = l.bias; g.H = raw_gemm; g.ldh = l.Nalloc;
             g.M = n_out * Bpad; g.N = l.N; g.kc = l.kc; g.ntaps = 3; g.mode = 1; g.Bpad = Bpad; g.n_out = n_out; g.j = t;
             g.tab = h->d_tab[k]; g.need = h->d_need[k]; g.stop_after = stop_after; g.t = t;
-            if (ks_split && k == ks_split) { g.wait_sig = h->d_sig + LOOP_SIG_LEVEL0 + 16 * k; g.wait_val = h->cone_done_val; g.wait_err = h->d_ctl + 2; }
-            g.ksplit = cone_ksplit(g.M);
+            g.ksplit = h->opt.cone_ksplit(g.M);
             if (k + 1 >= fc_from && k + 2 < nh) g.ksplit = std::min(g.ksplit, fc_in_split);     // its consumer is a cone_fc16: fewer partials to sum there
             g.split_stride = (long long)g.M * l.Nalloc;
-            g.Wh = l.Wh; g.Wl = l.Wl; g.W1 = l.W1; g.W2 = l.W2; g.W3 = l.W3;
-            static const int x6_rows = getenv("OPH_CONE_X6_ROWS") ? atoi(getenv("OPH_CONE_X6_ROWS")) : 512;
-            run_gemm(h, g, l.cin, (h->cone_bf16 && l.Wh && g.M >= 512) ? 1 : ((h->cone_x6 && l.W1 && g.M >= x6_rows && g.N % 64 == 0 && g.kc % 32 == 0) ? 2 : 0));
+            g.Wh = l.Wh; g.Wl = l.Wl;
+            run_gemm(h, g, l.cin, (h->cone_bf16 && l.Wh && g.M >= 512) ? 1 : 0);
             raw_in = raw_gemm; raw_split = g.ksplit; raw_stride = g.split_stride;
         }
         if (k + 1 >= fc_from && k + 2 < nh) continue;       // the next level's cone_fc16 normalises these rows itself
@@ -1003,12 +1021,6 @@ void launch_cone(oph_handle* h, int t) {
         const Layer& nx = h->audiodec[pre + k + 1];
         e.Y = cone[k + 1]; e.ldy = nx.kc; e.ypad = nx.kc; e.stop_after = stop_after; e.t = t;
         level_done(k + 1, e.done_sig, e.done_val, e.done_count, e.done_target, e.coh0, e.coh1);
-        if (ks_split && k + 1 == ks_split && e.done_sig) {       // this level feeds the other stream: every row write-through, every workgroup arrives
-            e.coh_all = 1;
-            const unsigned counted = (unsigned)((e.coh0 >= 0) + (e.coh1 >= 0 && e.coh1 != e.coh0)) * (unsigned)(Bpad / 4);
-            h->cone_done_total[k + 1] += (unsigned)((e.M + 3) / 4) - counted;
-            e.done_target = h->cone_done_total[k + 1];
-        }
         run_epi(h, e);
     }
     g_cur = saved;
@@ -1086,8 +1098,7 @@ void run_launch(oph_handle* h, RunArgs& a) {
     a.epoch0 = h->run_epoch;
     h->run_epoch += RUN_MAX_LAYERS;
     h->pbegin(PC_DECRUN);
-    static const int rows_per_group = getenv("OPH_RUN_ROWS") ? atoi(getenv("OPH_RUN_ROWS")) : 4;
-    launch_dec_run(a, slices, rows_per_group, kmax, g_cur);
+    launch_dec_run(a, slices, 4, kmax, g_cur);
     h->pend(PC_DECRUN, bytes, flops);
 }
 // First launch of step t: S[t] -> AudioEnc (k=1 head, highway layers with cached dilated taps) -> attention row t
@@ -1155,7 +1166,8 @@ void run_decoder_half(oph_handle* h, int t, int stop_mode) {
 // whether this handle's configuration can take the persistent-run path
 bool run_supported(const oph_handle* h) {
     const oph_dims& m = h->dm;
-    if (getenv("OPH_NO_DECRUN")) return false;
+    if (h->opt.decode == 2) return false;
+    if (h->n_hc_dec > LOOP_MAX_LEVELS || h->n_hc_dec >= 15) return false;      // one completion word per cone level; 4-bit level fields in the packed descriptors
     if (m.flags & (OPH_FLAG_LCC | OPH_FLAG_NO_MONOTONIC)) return false;       // variants served by the per-layer kernels
     if ((int)h->audioenc.size() + h->dec_pre > RUN_MAX_LAYERS || (int)h->audiodec.size() - h->dec_pre + 1 > RUN_MAX_LAYERS) return false;
     for (const auto* net : {&h->audioenc, &h->audiodec})
@@ -1165,14 +1177,15 @@ bool run_supported(const oph_handle* h) {
     return true;
 }
 
-int run_encode_into(oph_handle* h, float* KVdst, hipStream_t stream, int wsi);      // defined with the batched networks below
-static bool skip_cone_env() { static const bool v = getenv("OPH_SKIP_CONE") != nullptr; return v; }
+int run_encode_into(oph_handle* h, const int* dL, const int* dSpk, int B, float* KVdst, hipStream_t stream, int wsi);      // defined with the batched networks below
+int ssrn_stream_chunks(oph_handle* h, int frames_ready, bool final);                                                          // streamed SSRN of the current tile
 
 // ---------------------------------------------------------------- whole-decode launch (dec_loop)
 // Static layer table of a decode: AudioEnc (layer 0 consumes the previous step's last AudioDec layer) -> attention +
-// AudioDec input convs -> AudioDec highway layers (taps from the cone ping-pong buffers) -> k=1 tail.
-int build_loop_layers(oph_handle* h) {
-    const oph_dims& m = h->dm;
+// AudioDec input convs -> AudioDec highway layers (taps from the cone ping-pong buffers) -> k=1 tail.  Built once per
+// decode state: the weights in the loop kernel's fragment order and the prologue's LayerNorm parameters are shared by the
+// tiles; build_loop_layers() then packs one descriptor table per tile (the history pointers differ).
+int build_loop_proto(oph_handle* h) {
     const int pre = h->dec_pre, nh = h->n_hc_dec;
     std::vector<LoopLayer> v;
     auto from = [&](const Layer& l, const Layer* prev) {
@@ -1186,7 +1199,7 @@ int build_loop_layers(oph_handle* h) {
         const Layer& l = h->audioenc[li];
         LoopLayer q = from(l, li ? &h->audioenc[li - 1] : &h->audiodec.back());
         if (li == 0) q.act = ACT_SIGMOID;                 // squash_output_t2m (networks.py:430-431): x = mel frame t-1
-        if (l.kind == K_HC) { q.tapkind = 1; q.hist = h->ae_hist[li]; q.off0 = -l.off[0]; q.off1 = -l.off[1]; }
+        if (l.kind == K_HC) { q.tapkind = 1; q.off0 = -l.off[0]; q.off1 = -l.off[1]; q.idx0 = (int)li; }     // idx0: which history (per tile)
         v.push_back(q);
     }
     h->loop_attn = (int)v.size();
@@ -1201,6 +1214,7 @@ int build_loop_layers(oph_handle* h) {
             q.idx0 = idx_of(h->Hset[k], q.off0); q.idx1 = idx_of(h->Hset[k], q.off1);
             q.cone0 = h->cone[0][k]; q.cone1 = h->cone[1][k];
             if (q.idx0 < 0 || q.idx1 < 0) { h->fail("internal: cone tap not in the position set"); return OPH_ERR_STATE; }
+            if (q.level1 > LOOP_MAX_LEVELS || q.level1 > 15) { h->fail("internal: too many cone levels for the loop kernel"); return OPH_ERR_STATE; }
         }
         v.push_back(q);
     }
@@ -1208,10 +1222,10 @@ int build_loop_layers(oph_handle* h) {
     h->loop_nlayers = (int)v.size();
     h->loop_slices = 1; h->loop_kmax = 32;
     for (const LoopLayer& q : v) { h->loop_slices = std::max(h->loop_slices, round_up(q.N, 16) / 16); h->loop_kmax = std::max(h->loop_kmax, q.ntaps * q.kc); }
-    if (const char* rr = getenv("OPH_RUN_ROWS")) h->loop_rows = atoi(rr) == 4 ? 4 : 8;
+    h->loop_rows = h->opt.run_rows;
     const int R = h->loop_rows, PF = (768 / 16 + R - 1) / R;       // as dec_loop<R> (RUN_KMAX = 768)
     if (h->loop_kmax > 768) { h->fail("internal: layer K exceeds the loop kernel's"); return OPH_ERR_STATE; }
-    std::vector<unsigned> words(v.size() * LOOP_DESC_STRIDE, 0u);
+    h->loop_lnp.assign(v.size(), nullptr);
     for (size_t i = 0; i < v.size(); ++i) {
         LoopLayer& q = v[i];
         // The weights in the order the loop kernel's lanes hold them: [column slice g][wave w][chunk i][lane][4] with
@@ -1239,21 +1253,35 @@ int build_loop_layers(oph_handle* h) {
             if (hipMemcpy(dsw, Ws.data(), Ws.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { h->fail("weight upload failed"); return OPH_ERR_DEVICE; }
             q.Wt = dsw;
         }
-        unsigned* w = &words[i * LOOP_DESC_STRIDE];
-        const int ls = round_up(std::max(q.cin, 4), 4);
-        float* lnp = nullptr;
         if (q.g1) {       // the prologue's LayerNorm parameters side by side: one pointer instead of four
-            lnp = h->dalloc<float>((size_t)4 * ls);
+            const int ls = round_up(std::max(q.cin, 4), 4);
+            float* lnp = h->dalloc<float>((size_t)4 * ls);
             if (!lnp) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
             hipMemset(lnp, 0, (size_t)4 * ls * sizeof(float));
             const float* src[4] = {q.g1, q.b1, q.g2, q.b2};
             for (int k = 0; k < 4; ++k)
                 if (src[k] && hipMemcpy(lnp + (size_t)k * ls, src[k], (size_t)q.cin * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess) { h->fail("descriptor upload failed"); return OPH_ERR_DEVICE; }
+            h->loop_lnp[i] = lnp;
         }
+    }
+    h->loop_proto = v;
+    return OPH_OK;
+}
+// descriptor table of the CURRENT tile
+int build_loop_layers(oph_handle* h) {
+    if (h->loop_proto.empty()) { const int rc = build_loop_proto(h); if (rc) return rc; }
+    const std::vector<LoopLayer>& v = h->loop_proto;
+    std::vector<unsigned> words(v.size() * LOOP_DESC_STRIDE, 0u);
+    for (size_t i = 0; i < v.size(); ++i) {
+        LoopLayer q = v[i];
+        if (q.tapkind == 1) { q.hist = h->ae_hist[q.idx0]; q.idx0 = 0; }
+        unsigned* w = &words[i * LOOP_DESC_STRIDE];
+        const int ls = round_up(std::max(q.cin, 4), 4);
         auto put = [&](int at, const void* ptr) { const uint64_t u = (uint64_t)(uintptr_t)ptr; w[at] = (unsigned)u; w[at + 1] = (unsigned)(u >> 32); };
-        put(0, q.Wt); put(2, q.bias); put(4, lnp); put(6, q.cat_table); put(8, q.hist); put(10, q.cone0); put(12, q.cone1);
+        put(0, q.Wt); put(2, q.bias); put(4, h->loop_lnp[i]); put(6, q.cat_table); put(8, q.hist); put(10, q.cone0); put(12, q.cone1);
         const LoopLayer& nx = v[(i + 1) % v.size()];
-        if (q.cin > 0xffff || q.kc > 0xffff || q.N > 0xffff || q.ldw > 0xffff || q.ccat > 0xffff || q.off0 > 0xffff || q.off1 > 0xffff || q.idx0 > 0xffff || q.idx1 > 0xffff || q.off0 < 0 || q.off1 < 0) {
+        if (q.cin > 0xffff || q.kc > 0xffff || q.N > 0xffff || q.ldw > 0xffff || q.ccat > 0xffff || q.off0 > 0xffff || q.off1 > 0xffff || q.idx0 > 0xffff || q.idx1 > 0xffff || q.off0 < 0 || q.off1 < 0 ||
+            q.level1 > 15 || nx.level1 > 15 || q.pre > 15 || q.act > 15 || q.ntaps > 3 || q.tapkind > 3) {
             h->fail("internal: layer geometry does not fit the packed descriptor"); return OPH_ERR_STATE;
         }
         w[14] = (unsigned)q.pre | (unsigned)q.act << 4 | (unsigned)(q.nonorm ? 1 : 0) << 8 | (unsigned)q.ntaps << 12 | (unsigned)q.tapkind << 16 | (unsigned)nx.pre << 20 |
@@ -1264,19 +1292,19 @@ int build_loop_layers(oph_handle* h) {
         w[18] = (unsigned)q.off0 | (unsigned)q.off1 << 16;
         w[19] = (unsigned)q.idx0 | (unsigned)q.idx1 << 16;
     }
-    h->d_loop_layers = h->dalloc<unsigned>(words.size());
-    if (!h->d_loop_layers) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
-    if (hipMemcpy(h->d_loop_layers, words.data(), words.size() * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) { h->fail("descriptor upload failed"); return OPH_ERR_DEVICE; }
-    (void)m;
+    unsigned* dl = h->dalloc<unsigned>(words.size());
+    if (!dl) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
+    if (hipMemcpy(dl, words.data(), words.size() * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) { h->fail("descriptor upload failed"); return OPH_ERR_DEVICE; }
+    h->tiles[h->tile].d_loop_layers = h->d_loop_layers = dl;
     return OPH_OK;
 }
 
-// The decode loop as ONE launch on the critical stream + the per-step cones on the side stream, chained by two device
-// words (stream wait-value / write-value on the side stream, in-kernel atomics on the other end).  t_end steps from 0.
+// The decode loop as ONE launch on the critical stream + the per-step cones on the side stream, chained by device words
+// (in-kernel waits and signals on both ends).  t_end steps from 0.
 int decode_loop(oph_handle* h, int t_end, int stop_mode) {
     const oph_dims& m = h->dm;
     if (!h->d_loop_layers) { const int rc = build_loop_layers(h); if (rc) return rc; }
-    static const int lookahead = getenv("OPH_LOOP_LOOKAHEAD") ? atoi(getenv("OPH_LOOP_LOOKAHEAD")) : 8;
+    const int lookahead = h->opt.lookahead;
     h->host_prog[0] = -1; h->host_prog[1] = INT_MAX;
     if ((uint64_t)h->run_epoch + (uint64_t)(m.max_T + 1) * LOOP_MAX_LAYERS > 0xF0000000ull) {     // tag wrap guard
         for (hipStream_t st : {h->sdec, h->scone}) hipStreamSynchronize(st);
@@ -1296,40 +1324,34 @@ int decode_loop(oph_handle* h, int t_end, int stop_mode) {
     a.p = h->d_p; a.ends = h->d_ends; a.t_ends = h->d_tends;
     a.Qhist = h->Qhist; a.align = h->align; a.Yout = h->Yout; a.ldy = h->ldy; a.Ytm = h->Ytm;
     a.sig = h->d_sig; a.sig_base = h->sig_base;
-    static const bool qw_in_loop = !getenv("OPH_NO_LOOP_QW");
-    h->qw_from_loop = qw_in_loop && h->cone_head_ok && !h->fixed_att && h->QWhist != nullptr && h->audiodec[0].cin == 2 * m.d && (m.d % 16) == 0;
+    h->qw_from_loop = !h->opt.no_loop_qw && h->cone_head_ok && !h->fixed_att && h->QWhist != nullptr && h->audiodec[0].cin == 2 * m.d && (m.d % 16) == 0;
     a.QW = h->qw_from_loop ? h->QWhist : nullptr; a.attn_slices = round_up(h->audiodec[0].N, 16) / 16;
     void* dp = nullptr;
     if (hipHostGetDevicePointer(&dp, (void*)h->host_prog, 0) != hipSuccess) { h->fail("pinned progress words are not mapped"); return OPH_ERR_DEVICE; }
     a.host_progress = (volatile int*)dp;
-    static const int dbg = getenv("OPH_LOOP_DBG") ? atoi(getenv("OPH_LOOP_DBG")) : 0;
+    const int dbg = h->opt.loop_dbg;
     a.dbg = dbg;
     a.sigdbg = h->d_sigdbg;
     hipStreamWaitEvent(h->scone, h->ev_in, 0);
-    if (h->scone2) hipStreamWaitEvent(h->scone2, h->ev_in, 0);
     g_cur = h->sdec;
     double bytes = 0, flops = 0;
-    {
-        const size_t nl = (size_t)h->audioenc.size() + h->audiodec.size();
-        size_t i = 0;
-        for (const auto* net : {&h->audioenc, &h->audiodec})
-            for (const Layer& l : *net) { const double K = (double)l.ntaps * l.cin; bytes += ((double)l.N * K + (double)h->B * (K + l.N)) * 4.0; flops += 2.0 * h->B * l.N * K; ++i; }
-        (void)nl; (void)i;
-    }
+    for (const auto* net : {&h->audioenc, &h->audiodec})
+        for (const Layer& l : *net) { const double K = (double)l.ntaps * l.cin; bytes += ((double)l.N * K + (double)h->B * (K + l.N)) * 4.0; flops += 2.0 * h->B * l.N * K; }
     if (h->d_sigdbg) hipMemsetAsync(h->d_sigdbg, 0, (size_t)m.max_T * 8 * sizeof(long long), h->sdec);
     h->pbegin(PC_DECLOOP);
     launch_dec_loop(a, h->loop_slices, h->loop_rows, h->loop_kmax, h->sdec);
     h->pend(PC_DECLOOP, bytes * t_end, flops * t_end);
-    if (h->want_preenc) {
-        // the staged text's K,V for the NEXT call, into the other KV buffer, on the SSRN stream (own CU partition, own
-        // workspace; in stream order behind the previous batch's SSRN and ahead of this batch's)
-        if (run_encode_into(h, h->KV2[h->kv_cur ^ 1], h->sssrn, 1) == OPH_OK && hipEventRecord(h->ev_preenc, h->sssrn) == hipSuccess) {
-            h->preenc_valid = true; h->preenc_epoch = h->stage_epoch;
-        }
+    if (h->want_preenc && h->next_staged && !h->preenc_valid) {
+        // K,V of the NEXT batch's staged text into the other KV buffer, on the SSRN partition (own workspace; in stream order
+        // behind the previous batch's SSRN and ahead of this batch's chunks)
+        if (run_encode_into(h, h->bL[h->txt ^ 1], h->bSpk[h->txt ^ 1], h->next_B, h->bKV[h->kv_cur ^ 1], h->sssrn, 1) == OPH_OK &&
+            hipEventRecord(h->ev_preenc, h->sssrn) == hipSuccess)
+            h->preenc_valid = true;
     }
-    // side stream: cone(t) after the attention of step t-1, then the word the loop kernel polls before AudioDec(t)
+    // side stream: cone(t) after the attention of step t-1; its launches wait for / raise the device words themselves
     g_cur = h->scone;
     const auto t_host0 = std::chrono::steady_clock::now();
+    const bool stream_ssrn = h->spec_ssrn && h->opt.ssrn_chunk > 0 && !h->opt.no_stream_ssrn;
     for (int t = 1; t < t_end && !(dbg & 32); ++t) {
         // bounded run-ahead, so that an early stop leaves at most `lookahead` queued cones (they early-out on the device)
         auto t_wait0 = std::chrono::steady_clock::now();
@@ -1341,24 +1363,13 @@ int decode_loop(oph_handle* h, int t_end, int stop_mode) {
         }
         const int stopped_at = h->host_prog[1];
         if (stopped_at != INT_MAX && t > stopped_at + 1) break;       // step stop+1 still runs (stores off) and polls its cone
-        static const bool sig_kernels = getenv("OPH_LOOP_SIG_KERNELS") != nullptr;    // separate wait / set launches (2 x ~6 us per step)
-        if (!sig_kernels && !h->cone_fused && !skip_cone_env()) {
+        if (!h->opt.skip_cone) {
             h->cone_inline_sig = true; h->cone_wait_val = h->sig_base + (uint32_t)t; h->cone_done_val = h->sig_base + (uint32_t)t;
             launch_cone(h, t);
             h->cone_inline_sig = false;
-            continue;
         }
-        static const bool stream_ops = getenv("OPH_LOOP_STREAM_OPS") != nullptr;      // the slow flavour, kept for the record
-        if (stream_ops) hipStreamWaitValue32(h->scone, h->d_sig, h->sig_base + (uint32_t)t, hipStreamWaitValueGte, 0xffffffffu);
-        else launch_sig_wait(h->d_sig, h->sig_base + (uint32_t)t, h->d_ctl + 2, h->d_sigdbg ? h->d_sigdbg + (size_t)t * 8 : nullptr, h->scone);
-        static const bool skip_cone = getenv("OPH_SKIP_CONE") != nullptr;      // timing experiments only: results are wrong
-        if (!skip_cone) launch_cone(h, t);
-        if (stream_ops) { for (int k = 0; k < h->n_hc_dec; ++k) hipStreamWriteValue32(h->scone, h->d_sig + LOOP_SIG_LEVEL0 + 16 * k, h->sig_base + (uint32_t)t, 0); }
-        else launch_sig_set(h->d_sig + LOOP_SIG_LEVEL0, h->sig_base + (uint32_t)t, h->n_hc_dec, h->d_sigdbg ? h->d_sigdbg + (size_t)t * 8 : nullptr, h->scone);
-    }
-    if (h->scone2) {      // the second cone stream joins the first: every later wait on scone covers both
-        hipEventRecord(h->ev_cone2, h->scone2);
-        hipStreamWaitEvent(h->scone, h->ev_cone2, 0);
+        // SSRN over the mel frames that are final: the attention of step p is done => frames < p are stored (write-through)
+        if (stream_ssrn && stopped_at == INT_MAX) { const int rc = ssrn_stream_chunks(h, h->host_prog[0], false); if (rc) return rc; g_cur = h->scone; }
     }
     if (g_trace) {
         const double enq = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_host0).count() * 1e3;
@@ -1438,7 +1449,7 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode) {
     }
     }   // !run
     // cone(t) (launched during step t-1, or by decode_range for the first step) must have landed
-    const bool sv = h->use_sigval && !h->capturing;
+    const bool sv = h->use_sigval;
     {
         HostTimer ht(0, g_trace);
         if (t >= 1) {
@@ -1458,8 +1469,7 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode) {
                 hipStreamWaitEvent(h->scone, h->ev_attn, 0);
             }
         }
-        static const bool skip_cone = getenv("OPH_SKIP_CONE") != nullptr;      // timing experiments only: results are wrong
-        if (!skip_cone) { HostTimer ht(1, g_trace); launch_cone(h, t + 1); }
+        if (!h->opt.skip_cone) { HostTimer ht(1, g_trace); launch_cone(h, t + 1); }
         {
             HostTimer ht(0, g_trace);
             if (sv) hipStreamWriteValue32(h->scone, h->d_sig + 16, h->sig_base + (uint32_t)t + 1, 0);
@@ -1502,8 +1512,23 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode) {
     }
 }
 
+// After a failed whole-decode launch (a hand-off timed out: its workgroups were not co-resident, or the cone never got
+// CUs) the cross-stream words and counters are out of step: bring them back to a quiet state so that the handle stays usable.
+void recover_loop_state(oph_handle* h) {
+    for (hipStream_t st : {h->sdec, h->scone, h->sssrn, h->stream}) if (st) hipStreamSynchronize(st);
+    (void)hipGetLastError();
+    hipMemsetAsync(h->d_sig, 0, LOOP_SIG_WORDS * sizeof(uint32_t), h->stream);
+    hipMemsetAsync(h->d_cone_count, 0, LOOP_MAX_LEVELS * sizeof(unsigned), h->stream);
+    hipMemsetAsync(h->d_gbuf, 0, (size_t)LOOP_MAX_LAYERS * h->Bpad * RUN_GCOLS * 8, h->stream);
+    hipStreamSynchronize(h->stream);
+    for (uint32_t& v : h->cone_done_total) v = 0;
+    h->sig_base = 0; h->run_epoch = 0;
+}
+
+// Steps [t_begin, t_end) of the CURRENT tile.  *steps_run = steps executed so far (stop step + 1 after an early stop).
 int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* steps_run) {
     const oph_dims& m = h->dm;
+    Tile& tl = h->tiles[h->tile];
     t_end = std::min(t_end, (int)m.max_T);
     int ctl[4] = {0, INT_MAX, 0, 0};
     int last = t_begin;
@@ -1511,35 +1536,6 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
     hipEventRecord(h->ev_in, h->stream);
     hipStreamWaitEvent(h->sdec, h->ev_in, 0);
     g_cur = h->sdec;
-    // ---- whole-loop hipGraph: a step is ~39 launches on two streams; enqueued eagerly the host
-    // (~5 us per launch) is slower than the device (profiles/r01 trace: the critical stream idles
-    // while the host enqueues the cone).  Capture all max_T steps once per (stop_mode, B) and replay.
-    // After the stop step every node early-outs on the device, so outputs are identical.
-    // (the persistent-run path stamps a fresh epoch into every launch: a replayed graph would reuse old ones)
-    const bool graphable = h->use_graph && !h->use_run && h->profiling != 1 && !h->fixed_att && t_begin == 0 && t_end == m.max_T && stop_mode >= 0 && stop_mode <= 1;
-    if (graphable) {
-        hipGraphExec_t& ge = h->dec_graph[stop_mode];
-        if (ge && h->dec_graph_B[stop_mode] != h->B) { hipGraphExecDestroy(ge); ge = nullptr; }
-        if (!ge) {
-            hipGraph_t g = nullptr;
-            bool ok = hipStreamBeginCapture(h->sdec, hipStreamCaptureModeRelaxed) == hipSuccess;
-            if (ok) {
-                h->capturing = true;
-                for (int t = 0; t < t_end; ++t) decode_step(h, t, t_end, stop_mode);
-                h->capturing = false;
-                ok = hipStreamEndCapture(h->sdec, &g) == hipSuccess && g != nullptr;
-            }
-            if (ok) ok = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess;
-            if (g) hipGraphDestroy(g);
-            if (!ok) { ge = nullptr; h->use_graph = false; (void)hipGetLastError(); }
-            else h->dec_graph_B[stop_mode] = h->B;
-        }
-        if (ge) {
-            HIPCHK(h, hipGraphLaunch(ge, h->sdec));
-            last = t_end;
-            t_begin = t_end;      // skip the eager loop below
-        }
-    }
     if (h->use_run && h->run_epoch > 0xF0000000u) {      // tag wrap guard (once per ~10^5 batches): start over from zeroed granules
         for (hipStream_t st : {h->sdec, h->scone}) hipStreamSynchronize(st);
         hipMemsetAsync(h->d_gbuf, 0, (size_t)LOOP_MAX_LAYERS * h->Bpad * RUN_GCOLS * 8, h->sdec);
@@ -1547,16 +1543,12 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
         h->run_epoch = 0;
     }
     h->qw_from_loop = false;
-    bool loop_mode = h->use_loop && !h->fixed_att && !h->capturing && t_begin == 0 && t_end >= 1;
+    bool loop_mode = h->use_loop && !h->fixed_att && t_begin == 0 && t_end >= 1;
     if (loop_mode) {
-        // every workgroup of the loop kernel must be resident at once (its row groups meet at the per-step cone signal):
-        // larger batches than the critical stream's CUs can hold take the two-launches-per-step path
+        // every workgroup of the loop kernel must be resident at once on the critical stream's own CUs (the cone needs the
+        // others): without that partition, or when the tile's workgroups do not fit it, take the two-launches-per-step path
         if (!h->d_loop_layers) { const int rc = build_loop_layers(h); if (rc) return rc; }
-        if (h->loop_capacity < 0) {
-            int ncu = h->ndec_cus;
-            if (ncu <= 0) { hipDeviceProp_t prop; ncu = hipGetDeviceProperties(&prop, h->device) == hipSuccess ? prop.multiProcessorCount : 0; }
-            h->loop_capacity = dec_loop_blocks_per_cu(h->loop_rows, h->loop_kmax) * ncu;
-        }
+        if (h->loop_capacity < 0) h->loop_capacity = h->mask_words > 0 ? dec_loop_blocks_per_cu(h->loop_rows, h->loop_kmax) * h->ndec_cus : 0;
         if (h->loop_slices * (h->Bpad / h->loop_rows) > h->loop_capacity) loop_mode = false;
     }
     if (h->use_sigval || loop_mode) {
@@ -1585,7 +1577,8 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
     int rc_loop = OPH_OK;
     const auto tq0 = std::chrono::steady_clock::now();
     if (loop_mode) {
-        if ((rc_loop = decode_loop(h, t_end, stop_mode)) != OPH_OK) return rc_loop;
+        h->n_loop_decodes++;
+        if ((rc_loop = decode_loop(h, t_end, stop_mode)) != OPH_OK) { recover_loop_state(h); return rc_loop; }
         last = t_end;
         t_begin = t_end;          // skip the per-step loop below
     }
@@ -1655,43 +1648,200 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
     hipEventRecord(h->ev_out, h->scone);
     hipStreamWaitEvent(h->stream, h->ev_out, 0);
     g_cur = h->stream;
-    if (steps_run || stop_mode == OPH_STOP_REFERENCE || h->use_run) {
+    const bool need_ctl = steps_run || stop_mode == OPH_STOP_REFERENCE || h->use_run;
+    if (need_ctl) {
         HIPCHK(h, hipMemcpyAsync(ctl, h->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (ctl[2] != 0) { h->fail(ctl[2] == 4 ? "cone layer: the row-statistics hand-off timed out" : ctl[2] == 3 ? "decoder loop: the side stream never saw the attention signal (time-out)" : ctl[2] == 2 ? "decoder loop: the side stream's cone never signalled (time-out)" : "decoder run: a workgroup hand-off timed out (workgroups of one run were not co-resident)"); return OPH_ERR_DEVICE; }
+        if (ctl[2] != 0) {
+            h->fail(ctl[2] == 3 ? "decoder loop: the side stream never saw the attention signal (time-out)" : ctl[2] == 2 ? "decoder loop: the side stream's cone never signalled (time-out)" : "decoder run: a workgroup hand-off timed out (workgroups of one run were not co-resident)");
+            recover_loop_state(h);
+            return OPH_ERR_DEVICE;
+        }
+        if (ctl[1] != INT_MAX) {
+            // The reference leaves alignment columns after the break step at zero (synthesize.py:204-228).  With several row
+            // groups a fast group of the loop kernel may have attended step stop+1 before the slowest one set the stop word
+            // (about one step of skew, rare): clear those columns.  (A later resume rewrites the ones it decodes.)
+            const int c0 = ctl[1] + 1;
+            if (c0 < m.max_T)
+                HIPCHK(h, hipMemset2DAsync(h->align + c0, (size_t)m.max_T * 4, 0, (size_t)(m.max_T - c0) * 4, (size_t)h->B * m.max_N, h->stream));
+        }
     }
-    if (steps_run) *steps_run = ctl[1] != INT_MAX ? ctl[1] + 1 : last;
+    const int steps = (need_ctl && ctl[1] != INT_MAX) ? ctl[1] + 1 : last;
+    tl.steps = steps;
+    if (steps_run) *steps_run = steps;
     HIPCHK(h, hipGetLastError());
     return OPH_OK;
 }
 
-// TextEnc (networks.py:121-212) of the staged text into `KVdst` on `stream` with workspace set `wsi`
-int run_encode_into(oph_handle* h, float* KVdst, hipStream_t stream, int wsi) {
+// All tiles of the staged batch from step 0.  The reference's break couples the whole batch (synthesize.py:225-228: the
+// loop ends after the step at which the LAST utterance has ended): every tile decodes to its own stop, then the tiles
+// that stopped earlier resume to the batch's stop step -- the same fix-up the utterance shards of a multi-GPU run get.
+int decode_batch(oph_handle* h, int t_end, int stop_mode, int32_t* steps_run) {
+    const int ntiles = (h->nB + TILE - 1) / TILE;
+    int batch_steps = 0;
+    bool retried = false;
+    for (int j = 0; j < ntiles; ++j) {
+        select_tile(h, j);
+        reset_decode(h);
+        int32_t st = 0;
+        int rc = decode_range(h, 0, t_end, stop_mode, &st);
+        if (rc == OPH_ERR_DEVICE && h->use_loop && !retried) {
+            // the whole-decode launch could not run here (e.g. another process holds CUs of its partition): fall back to the
+            // two-launches-per-step path for the rest of this handle's life and redo the tile
+            TRACE("whole-decode launch failed (%s): falling back to two launches per step", h->err.c_str());
+            h->use_loop = false; retried = true; h->n_loop_fallbacks++;
+            reset_decode(h);
+            rc = decode_range(h, 0, t_end, stop_mode, &st);
+        }
+        if (rc) return rc;
+        batch_steps = std::max(batch_steps, (int)st);
+    }
+    if (stop_mode == OPH_STOP_REFERENCE && ntiles > 1)
+        for (int j = 0; j < ntiles; ++j) {
+            if (h->tiles[j].steps >= batch_steps) continue;
+            select_tile(h, j);
+            const int ctl1 = INT_MAX;
+            HIPCHK(h, hipMemcpyAsync(h->d_ctl + 1, &ctl1, 4, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            const int rc = decode_range(h, h->tiles[j].steps, batch_steps, OPH_STOP_NEVER, nullptr);
+            if (rc) return rc;
+            h->n_tile_resumes++;
+            h->tiles[j].steps = batch_steps;
+        }
+    select_tile(h, 0);
+    if (steps_run) *steps_run = batch_steps;
+    return OPH_OK;
+}
+
+// TextEnc (networks.py:121-212) of B staged utterances (ids dL, speakers dSpk) into `KVdst` on `stream` with workspace set `wsi`
+int run_encode_into(oph_handle* h, const int* dL, const int* dSpk, int B, float* KVdst, hipStream_t stream, int wsi) {
     const oph_dims& m = h->dm;
     hipStream_t saved = g_cur;
     g_cur = stream;
-    const int B = h->B;
+    h->n_textenc++;
     float* ws = wsi ? h->actA2 : h->actA;
     // embed_1 (modules.py:15-44) -> rows [B*max_N][e]
     const Layer& first = h->textenc[0];
     const int ld0 = first.kc;                     // round_up(e [+ speaker embedding], 32)
     h->pbegin(PC_MISC);
-    launch_embed(h->d_L, (long long)B * m.max_N, h->emb_text, m.e, ws, ld0, stream);
+    launch_embed(dL, (long long)B * m.max_N, h->emb_text, m.e, ws, ld0, stream);
     h->pend(PC_MISC, (double)B * m.max_N * m.e * 4.0, 0);
     if (first.cat_table)                          // 'text_encoder_input': [embed(L) | embed(speaker)]  networks.py:138-144
-        launch_spk_append_rows(ws, ld0, (long long)B * m.max_N, m.max_N, m.e, first.cat_table, h->d_spk, first.ccat, stream);
+        launch_spk_append_rows(ws, ld0, (long long)B * m.max_N, m.max_N, m.e, first.cat_table, dSpk, first.ccat, stream);
     // last highway layer writes K|V rows straight into the resident KV buffer [B][N][2d]
-    run_batched(h, h->textenc, ws, ld0, B, m.max_N, wsi, 0, KVdst, 2 * m.d, 2 * m.d, nullptr, nullptr);
+    BatchedIO io{};
+    io.spk = dSpk;
+    run_batched(h, h->textenc, ws, ld0, B, m.max_N, wsi, 0, KVdst, 2 * m.d, 2 * m.d, nullptr, nullptr, io);
     g_cur = saved;
     HIPCHK(h, hipGetLastError());
     return OPH_OK;
 }
-int run_encode(oph_handle* h) { return run_encode_into(h, h->KV, h->stream, 0); }
+// the whole staged batch, on the API stream
+int run_encode(oph_handle* h) { return run_encode_into(h, h->bL[h->txt], h->bSpk[h->txt], h->nB, h->bKV[h->kv_cur], h->stream, 0); }
 
-int run_ssrn_on(oph_handle* h, const float* Yrows, int ldy, int B, int T, float* Zout, int wsi = 0) {
+int run_ssrn_on(oph_handle* h, const float* Yrows, int ldy, int B, int T, float* Zout, int wsi = 0, float* Zlogits = nullptr) {
     const oph_dims& m = h->dm;
-    run_batched(h, h->ssrn, const_cast<float*>(Yrows), ldy, B, T, wsi, h->ssrn_prec, Zout, m.full_dim, m.full_dim, nullptr, nullptr);
+    BatchedIO io{};
+    io.final_logits = Zlogits;
+    run_batched(h, h->ssrn, const_cast<float*>(Yrows), ldy, B, T, wsi, h->ssrn_prec, Zout, m.full_dim, m.full_dim, nullptr, nullptr, io);
     HIPCHK(h, hipGetLastError());
+    return OPH_OK;
+}
+
+// ---------------------------------------------------------------- streamed SSRN
+// SSRN (networks.py:437-537) is not causal, but its receptive field is short: output rows of mel frame f depend on mel
+// frames [f - SSRN_BACK, f + SSRN_AHEAD) only (HC r1, r3 at T; D_4; HC r1, r3 at 2T; D_7; HC r1, r3 at 4T; HC_11, HC_12 r1:
+// back 1+3 + ceil((1 + 1+3 + ceil((1 + 1+3+1+1) / 2)) / 2) = 9, ahead 1+3 + (1+3 + (1+3+1+1+1)/2)/2 = 7.x -> 8).
+// So the rows of frames [a, b) can be computed from frames [a - 9, b + 8) as soon as those exist, while the decoder
+// is still producing later frames: the chunk is run as a dense batch over the extended range (values near the range's
+// ends are wrong and are not stored; at the true sequence ends the range is clamped and SAME padding applies as in the
+// one-shot run).  Every output element is the same dot product in the same order as in the one-shot run: bitwise equal.
+// The margins are derived from the layer list (ssrn_margins) rather than hard-coded.
+void ssrn_margins(const oph_handle* h, int* back, int* ahead) {
+    // walk the layers from the output back to the input: an output row u needs input rows [u - lo, u + hi]
+    int lo = 0, hi = 0;
+    for (size_t i = h->ssrn.size(); i-- > 0;) {
+        const Layer& l = h->ssrn[i];
+        if (l.kind == K_CONVT) { lo = (lo + 1) / 2 + 1; hi = (hi + 1) / 2; }     // out[2t] reads x[t], x[t-1]; out[2t+1] reads x[t]
+        else if (l.size == 3) { lo += l.rate; hi += l.rate; }
+    }
+    *back = lo + 1; *ahead = hi + 1;     // lj_tutorial: 9 + 1 and 8 + 1 (one frame of slack each side)
+}
+
+// Z rows of mel frames [a, b) of the CURRENT tile, from its resident Yout, on stream `st` with workspace `wsi`.
+int run_ssrn_chunk(oph_handle* h, int a, int b, hipStream_t st, int wsi) {
+    const oph_dims& m = h->dm;
+    int back = 0, ahead = 0;
+    ssrn_margins(h, &back, &ahead);
+    const int lo = std::max(0, a - back), hi = std::min((int)m.max_T, b + ahead), Tc = hi - lo;
+    hipStream_t saved = g_cur;
+    g_cur = st;
+    float* ws = wsi ? h->actB2 : h->actB;
+    // the chunk's input frames as a dense [B][Tc] batch
+    launch_copy_rows_strided(h->Yout + (size_t)lo * h->ldy, (long long)m.max_T * h->ldy, h->ldy, ws, h->B, Tc, h->ldy, st);
+    BatchedIO io{};
+    io.out_T = Tc * m.r; io.keep_lo = (a - lo) * m.r; io.keep_hi = (b - lo) * m.r;
+    io.out_bs = (long long)m.max_T * m.r; io.out_t0 = lo * m.r;
+    run_batched(h, h->ssrn, ws, h->ldy, h->B, Tc, wsi, h->ssrn_prec, h->Z, m.full_dim, m.full_dim, nullptr, nullptr, io);
+    g_cur = saved;
+    if (h->z_host) {
+        // the chunk's rows leave for the host on the copy stream while the decode goes on
+        HIPCHK(h, hipEventRecord(h->ev_chunk, st));
+        HIPCHK(h, hipStreamWaitEvent(h->scopy, h->ev_chunk, 0));
+        const size_t rowb = (size_t)m.full_dim * 4, pitch = (size_t)m.max_T * m.r * rowb, r0 = (size_t)h->tile * TILE;
+        HIPCHK(h, hipMemcpy2DAsync((char*)h->z_host + r0 * pitch + (size_t)a * m.r * rowb, pitch, (const char*)h->Z + (size_t)a * m.r * rowb, pitch,
+                                   (size_t)(b - a) * m.r * rowb, (size_t)h->B, hipMemcpyDeviceToHost, h->scopy));
+    }
+    HIPCHK(h, hipGetLastError());
+    return OPH_OK;
+}
+
+// Launch the chunks of the current tile whose input frames exist: `frames_ready` = mel frames stored so far.  Chunks of
+// opt.ssrn_chunk frames on the SSRN partition while the decode runs; final: everything that is left (the decode is over).
+int ssrn_stream_chunks(oph_handle* h, int frames_ready, bool final) {
+    const oph_dims& m = h->dm;
+    Tile& tl = h->tiles[h->tile];
+    int back = 0, ahead = 0;
+    ssrn_margins(h, &back, &ahead);
+    const int ch = h->opt.ssrn_chunk;
+    while (tl.ssrn_done < m.max_T) {
+        int a = tl.ssrn_done, b;
+        if (final) b = m.max_T;
+        else {
+            b = a + ch;
+            if (b + ahead > frames_ready || b >= m.max_T) break;     // (the last frames always belong to the final chunk)
+        }
+        // while the decode runs: the SSRN partition; afterwards, not pipelined: the whole chip through the API stream (which
+        // the decode streams have joined)
+        const bool side = !final || h->pipelined;
+        const int rc = run_ssrn_chunk(h, a, b, side ? h->sssrn : h->stream, side ? 1 : 0);
+        if (rc) return rc;
+        if (!final) h->n_chunks_streamed++;
+        tl.ssrn_done = b;
+    }
+    return OPH_OK;
+}
+// SSRN of every tile brought up to date (what streaming has not covered yet); the API stream has joined the decode.
+int finish_ssrn(oph_handle* h) {
+    const int ntiles = (h->nB + TILE - 1) / TILE;
+    if (h->pipelined) {      // the tails run on the SSRN partition behind this batch's decode, under the next batch's
+        HIPCHK(h, hipEventRecord(h->ev_dec_done, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->sssrn, h->ev_dec_done, 0));
+    }
+    for (int j = 0; j < ntiles; ++j) {
+        select_tile(h, j);
+        const int rc = ssrn_stream_chunks(h, h->dm.max_T, true);
+        if (rc) return rc;
+    }
+    select_tile(h, 0);
+    if (h->pipelined) {
+        HIPCHK(h, hipEventRecord(h->ev_ssrn_done[h->buf], h->sssrn));
+        h->ssrn_inflight[h->buf] = true;
+    } else {
+        // chunks streamed during the decode ran on the SSRN partition: the API stream waits for them
+        HIPCHK(h, hipEventRecord(h->ev_ssrn_done[h->buf], h->sssrn));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_ssrn_done[h->buf], 0));
+    }
     return OPH_OK;
 }
 
@@ -1729,11 +1879,12 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
     oph_handle* h = new oph_handle();
     h->dm = m;
     h->device = device;
-    static const char* names[PC_COUNT] = {"conv_gemm_f32<128,128>", "conv_gemm_f32<64,64>", "conv_gemm_bf16x3", "ln_rows", "dec_layer16", "row_chain", "attn_rows", "misc", "dec_run", "dec_loop", "cone_head", "conv_gemm_bf16x6", "cone_gemm_ln[0]", "cone_gemm_ln[1]", "cone_gemm_ln[2]", "cone_gemm_ln[3]", "cone_gemm_ln[4]", "cone_gemm_ln[5]", "cone_gemm_ln[6]"};
+    h->opt.read();
+    static const char* names[PC_COUNT] = {"conv_gemm_f32<128,128>", "conv_gemm_f32<64,64>", "conv_gemm_bf16x3", "ln_rows", "dec_layer16", "row_chain", "attn_rows", "misc", "dec_run", "dec_loop", "cone_head"};
     for (int i = 0; i < PC_COUNT; ++i) h->prof[i].name = names[i];
-    // CU partition for the decode loop (MI355X: 256 CUs, mask bit i -> XCD i%8): the ~25 dependent
-    // tiny launches of a step get a private slice of 8 CUs in every XCD so the concurrently running
-    // history-cone GEMMs (the other 24 CUs per XCD) cannot delay their dispatch.
+    // CU partition for the decode loop (MI355X: 256 CUs, mask bit i -> XCD i%8): the dependent layers of a step get a
+    // private slice of 8 CUs in every XCD so the concurrently running history-cone GEMMs (the next 16 CUs per XCD) and the
+    // SSRN partition (the last 8 per XCD) cannot delay them.
     {
         hipDeviceProp_t prop;
         uint32_t m_dec[16] = {0};
@@ -1742,39 +1893,31 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) ncu = prop.multiProcessorCount;
         const int words = (ncu + 31) / 32;
         int ndec = ncu / 4, nconep = ncu / 2;               // 64 | 128 | 64 of 256 CUs (sweep in DESIGN.md)
-        if (const char* sp = getenv("OPH_CU_SPLIT")) { int a_ = 0, b_ = 0; if (sscanf(sp, "%d,%d", &a_, &b_) == 2 && a_ > 0 && b_ > 0 && a_ + b_ < ncu) { ndec = a_; nconep = b_; } }
-        const bool ssrn_all = getenv("OPH_SSRN_ALL") != nullptr;     // experiment: SSRN may use every CU outside the chain's partition
-        const bool cone_all = getenv("OPH_CONE_ALL") != nullptr;     // experiment: the cone may also use the SSRN partition
-        if (ncu >= 64 && words <= 16 && !getenv("OPH_NO_CU_MASK")) {
+        if (h->opt.cu_dec > 0 && h->opt.cu_cone > 0 && h->opt.cu_dec + h->opt.cu_cone < ncu) { ndec = h->opt.cu_dec; nconep = h->opt.cu_cone; }
+        if (ncu >= 64 && words <= 16 && !h->opt.no_cu_mask) {
             for (int i = 0; i < ncu; ++i) {
                 const uint32_t bit = 1u << (i % 32);
                 if (i < ndec) m_dec[i / 32] |= bit;
                 else {
                     m_cone[i / 32] |= bit;
                     (i < ndec + nconep ? m_conep : m_ssrn)[i / 32] |= bit;
-                    if (cone_all) m_conep[i / 32] |= bit;
-                    if (ssrn_all) m_ssrn[i / 32] |= bit;
+                    if (h->opt.cone_all) m_conep[i / 32] |= bit;
+                    if (h->opt.ssrn_all) m_ssrn[i / 32] |= bit;
                 }
             }
-            // CU-masked queues are a scarce resource: with four alive the queues get time-sliced and even
-            // sequential batches run 2x slower (measured); never keep more than three (see set_pipelined()).
-            // (and re-creating masked streams after destroying one hung hipStreamSynchronize), so exactly three
-            // are created here, once: critical chain | cone | SSRN partitions.
+            // CU-masked queues are a scarce resource: with four alive the queues get time-sliced and even sequential batches
+            // run 2x slower (measured), and re-creating masked streams after destroying one hung hipStreamSynchronize: exactly
+            // three are created here, once: critical chain | cone | SSRN partitions.  All three or none.
             h->mask_words = words;
             if (hipExtStreamCreateWithCUMask(&h->sdec, words, m_dec) != hipSuccess) { h->sdec = nullptr; h->mask_words = 0; }
-            h->ndec_cus = h->sdec ? ndec : ncu;
-            if (h->mask_words && hipExtStreamCreateWithCUMask(&h->scone, words, m_conep) != hipSuccess) h->scone = nullptr;
-            if (h->mask_words && hipExtStreamCreateWithCUMask(&h->sssrn, words, m_ssrn) != hipSuccess) h->sssrn = nullptr;
-            if (const char* cs = getenv("OPH_CONE_SPLIT")) {       // experiment: a FOURTH masked stream (same CUs as the cone) for the cone's tail
-                h->cone_split_at = atoi(cs);
-                if (getenv("OPH_CONE_SPLIT_PLAIN")) { if (hipStreamCreateWithFlags(&h->scone2, hipStreamNonBlocking) != hipSuccess) { h->scone2 = nullptr; h->cone_split_at = 0; } }      // unmasked: any CU
-                else if (h->cone_split_at > 0 && h->mask_words && hipExtStreamCreateWithCUMask(&h->scone2, words, m_conep) != hipSuccess) { h->scone2 = nullptr; h->cone_split_at = 0; }
-                if (h->scone2 && hipEventCreateWithFlags(&h->ev_cone2, hipEventDisableTiming) != hipSuccess) { h->cone_split_at = 0; }
-            }
-        }
+            if (h->mask_words && hipExtStreamCreateWithCUMask(&h->scone, words, m_conep) != hipSuccess) { h->scone = nullptr; h->mask_words = 0; }
+            if (h->mask_words && hipExtStreamCreateWithCUMask(&h->sssrn, words, m_ssrn) != hipSuccess) { h->sssrn = nullptr; h->mask_words = 0; }
+            h->ndec_cus = h->mask_words ? ndec : ncu;
+        } else h->ndec_cus = ncu;
         (void)hipGetLastError();
     }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->scopy, hipStreamNonBlocking) != hipSuccess ||
         (!h->sdec && hipStreamCreateWithFlags(&h->sdec, hipStreamNonBlocking) != hipSuccess) ||
         (!h->scone && hipStreamCreateWithFlags(&h->scone, hipStreamNonBlocking) != hipSuccess) ||
         (!h->sssrn && hipStreamCreateWithFlags(&h->sssrn, hipStreamNonBlocking) != hipSuccess) ||
@@ -1783,6 +1926,8 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
         hipEventCreateWithFlags(&h->ev_ssrn_done[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_preenc, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_chunk, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_attn, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_cone, hipEventDisableTiming) != hipSuccess ||
@@ -1794,24 +1939,22 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
     g_cur = h->stream;
     {
         int can = 0;
-        // Stream write/wait-value operations on two device words.  The whole-decode launch (dec_loop) needs them for its
-        // side stream.  For the per-step launch path they are opt-in (OPH_STREAM_VALUE=1): under rocprofv3 --pmc, which
-        // serialises dispatches across queues, a wait-value packet never sees the value the other queue would write and
-        // the run deadlocks; events are understood by the profiler.
-        const char* sv = getenv("OPH_STREAM_VALUE");
+        // Device words for the cross-stream dependencies.  The whole-decode launch (dec_loop) polls / raises them in-kernel.
+        // For the per-step launch paths, stream write/wait-value operations on them are opt-in (OPH_STREAM_VALUE=1): under
+        // rocprofv3 --pmc, which serialises dispatches across queues, a wait-value packet never sees the value the other queue
+        // would write and the run deadlocks; events are understood by the profiler.
+        h->d_sig = h->dalloc<uint32_t>(LOOP_SIG_WORDS);
         if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) == hipSuccess && can) {
-            h->d_sig = h->dalloc<uint32_t>(LOOP_SIG_WORDS);
             h->can_sigval = h->d_sig != nullptr && hipStreamWriteValue32(h->stream, h->d_sig, 0, 0) == hipSuccess &&
                             hipStreamSynchronize(h->stream) == hipSuccess;
-            h->use_sigval = h->can_sigval && sv && atoi(sv) != 0;
+            h->use_sigval = h->can_sigval && h->opt.stream_value;
         }
         (void)hipGetLastError();
         void* hp_ = nullptr;
         if (hipHostMalloc(&hp_, 64, hipHostMallocMapped) == hipSuccess) { h->host_prog = (volatile int*)hp_; h->host_prog[0] = -1; h->host_prog[1] = INT_MAX; }
         (void)hipGetLastError();
     }
-    h->ssrn_prec = getenv("OPH_SSRN_FP32") ? 0 : 1;
-    h->use_graph = getenv("OPH_USE_GRAPH") != nullptr;
+    h->ssrn_prec = h->opt.ssrn_fp32 ? 0 : 1;
     build_networks(h);
     *out = h;
     return OPH_OK;
@@ -1821,21 +1964,32 @@ int oph_destroy(oph_handle* h) {
     if (!h) return OPH_OK;
     hipSetDevice(h->device);
     TRACE("destroy: sync streams");
-    for (hipStream_t st : {h->stream, h->sdec, h->scone, h->sssrn}) if (st) hipStreamSynchronize(st);
-    TRACE("destroy: graphs/events");
-    for (auto& ge : h->dec_graph) if (ge) hipGraphExecDestroy(ge);
+    for (hipStream_t st : {h->stream, h->sdec, h->scone, h->sssrn, h->scopy}) if (st) hipStreamSynchronize(st);
     for (auto& pc : h->prof)
         for (auto& e : pc.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    for (hipEvent_t e : {h->ev0, h->ev1, h->ev_attn, h->ev_cone, h->ev_in, h->ev_out, h->ev_dec_done, h->ev_ssrn_done[0], h->ev_ssrn_done[1], h->ev_preenc})
+    for (hipEvent_t e : {h->ev0, h->ev1, h->ev_attn, h->ev_cone, h->ev_in, h->ev_out, h->ev_dec_done, h->ev_ssrn_done[0], h->ev_ssrn_done[1], h->ev_preenc, h->ev_copy, h->ev_chunk})
         if (e) hipEventDestroy(e);
     TRACE("destroy: free");
     for (void* p : h->allocs) hipFree(p);
     if (h->host_prog) hipHostFree((void*)h->host_prog);
     TRACE("destroy: streams");
-    for (hipStream_t st : {h->scone2, h->scone, h->sssrn, h->sdec, h->stream}) if (st) { TRACE("  destroy stream %p", (void*)st); hipStreamDestroy(st); }
+    for (hipStream_t st : {h->scone, h->sssrn, h->sdec, h->scopy, h->stream}) if (st) { TRACE("  destroy stream %p", (void*)st); hipStreamDestroy(st); }
     TRACE("destroy: done");
     delete h;
     return OPH_OK;
+}
+
+// Pinned host memory for result buffers: device-to-host copies into it are true DMA (they overlap the running decode and
+// reach the link's rate); any other host pointer is accepted everywhere too, at the cost of staged, blocking copies.
+int oph_host_alloc(size_t bytes, void** out) {
+    if (!out) return OPH_ERR_INVALID;
+    *out = nullptr;
+    if (hipHostMalloc(out, std::max<size_t>(bytes, 1), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return OPH_ERR_DEVICE; }
+    return OPH_OK;
+}
+int oph_host_free(void* p) {
+    if (!p) return OPH_OK;
+    return hipHostFree(p) == hipSuccess ? OPH_OK : OPH_ERR_DEVICE;
 }
 
 int oph_num_weights(const oph_handle* h) { return h ? (int)h->inventory.size() : OPH_ERR_INVALID; }
@@ -1895,19 +2049,9 @@ int oph_finalize_weights(oph_handle* h) {
         if (l.Wt && !split(l.Wt, (size_t)l.Nalloc * taps * l.kc, l.Wh, l.Wl)) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
         if (l.Wt2 && !split(l.Wt2, (size_t)l.Nalloc * l.kc, l.Wh2, l.Wl2)) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
     }
-    // the cone's many-row levels: fp32-equivalent contraction on the bf16 MFMA (three-term split, six products)
-    h->cone_x6 = getenv("OPH_CONE_X6") != nullptr && !getenv("OPH_NO_CONE_X6");      // opt-in: measured slower than the fp32 MFMA kernel
-    if (h->cone_x6)
-        for (int k = 0; k + 1 < h->n_hc_dec; ++k) {
-            Layer& l = h->audiodec[h->dec_pre + k];
-            const size_t n = (size_t)l.Nalloc * l.ntaps * l.kc;
-            l.W1 = h->dalloc<unsigned short>(n); l.W2 = h->dalloc<unsigned short>(n); l.W3 = h->dalloc<unsigned short>(n);
-            if (!l.W1 || !l.W2 || !l.W3) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
-            launch_split_bf16_3(l.Wt, l.W1, l.W2, l.W3, n, h->stream);
-        }
     // experiment (OPH_CONE_BF16X3=1, off by default): the two many-row cone contractions on the split-bf16 kernel as well.
     // Text2Mel is otherwise exact fp32 because its outputs feed the attention argmax; DESIGN.md records what this buys.
-    h->cone_bf16 = getenv("OPH_CONE_BF16X3") != nullptr;
+    h->cone_bf16 = h->opt.cone_bf16;
     if (h->cone_bf16)
         for (int k = 0; k + 1 < h->n_hc_dec; ++k) {
             Layer& l = h->audiodec[h->dec_pre + k];
@@ -1917,12 +2061,7 @@ int oph_finalize_weights(oph_handle* h) {
             launch_split_bf16(l.Wt, l.Wh, l.Wl, n, h->stream);
         }
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    // fused cone layers: every AudioDec highway layer but the last is re-evaluated over history positions
-    h->cone_fused = getenv("OPH_CONE_FUSED") && !getenv("OPH_NO_CONE_FUSED") && !(h->dm.flags & OPH_FLAG_LCC) && h->dm.d % 16 == 0;
-    if (h->cone_fused)
-        for (int k = 0; k + 1 < h->n_hc_dec; ++k)
-            if (pack_cone_layer(h, h->audiodec[h->dec_pre + k]) != 0) { h->fail("out of device memory packing the cone weights"); return OPH_ERR_DEVICE; }
-    h->cone_head_ok = !getenv("OPH_NO_CONE_HEAD") && !(h->dm.flags & OPH_FLAG_NO_MONOTONIC) && h->audiodec[0].Wkn != nullptr && h->dm.d <= 256 && (h->dm.d % 4) == 0;
+    h->cone_head_ok = !h->opt.no_cone_head && !(h->dm.flags & OPH_FLAG_NO_MONOTONIC) && h->audiodec[0].Wkn != nullptr && h->dm.d <= 256 && (h->dm.d % 4) == 0;
     if (h->cone_head_ok) {
         // Wc = the rows of AudioDec C_1's kernel (1, 2d, d) that multiply the attention context (R' = [ctx | Q], networks.py:316-319)
         const Layer& c1 = h->audiodec[0];
@@ -1942,10 +2081,10 @@ int oph_finalize_weights(oph_handle* h) {
     h->hostw.clear();
     h->n_weight_allocs = h->allocs.size();
     h->use_run = run_supported(h);
-    // OPH_DECODE = loop (default where possible) | runs (two launches per step) | layers (one launch per layer, round 1)
-    const char* mode = getenv("OPH_DECODE");
-    if (mode && !strcmp(mode, "layers")) h->use_run = false;
-    h->use_loop = h->use_run && h->can_sigval && h->host_prog && !(mode && !strcmp(mode, "runs")) && !getenv("OPH_NO_DECLOOP");
+    // OPH_DECODE = loop (default where possible) | runs (two launches per step) | layers (one launch per layer, round 1).
+    // The whole-decode launch needs its own CU partition (all its workgroups resident while the cone runs beside it) and
+    // the mapped progress words.
+    h->use_loop = h->use_run && h->opt.decode == 0 && h->d_sig && h->host_prog && h->mask_words > 0;
     h->finalized = true;
     return OPH_OK;
 }
@@ -1957,96 +2096,143 @@ static int check_ready(oph_handle* h, int B) {
     if (hipSetDevice(h->device) != hipSuccess) { h->fail("hipSetDevice failed"); return OPH_ERR_DEVICE; }
     return OPH_OK;
 }
-
-int oph_stage_text(oph_handle* h, const int32_t* L, const int32_t* ends, const int32_t* spk, int B) {
-    int rc = check_ready(h, B);
-    if (rc) return rc;
+static bool model_is_multispeaker(const oph_handle* h) {
+    return h->dm.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_TOWARDS_END | OPH_FLAG_LCC | OPH_FLAG_SPK_AUDIO_ENCODER_INPUT);
+}
+static int check_text(oph_handle* h, const int32_t* L, const int32_t* ends, const int32_t* spk, int B) {
     if (!L || !ends) { h->fail("null argument"); return OPH_ERR_INVALID; }
-    const bool ms = h->dm.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_TOWARDS_END | OPH_FLAG_LCC | OPH_FLAG_SPK_AUDIO_ENCODER_INPUT);
+    const bool ms = model_is_multispeaker(h);
     if (ms && !spk) { h->fail("multispeaker model needs speaker ids"); return OPH_ERR_INVALID; }
     const oph_dims& m = h->dm;
     for (long long i = 0; i < (long long)B * m.max_N; ++i)
         if (L[i] < 0 || L[i] >= m.vocab) { h->fail("text id %d out of range at %lld", L[i], i); return OPH_ERR_INVALID; }
     if (ms) for (int b = 0; b < B; ++b) if (spk[b] < 0 || spk[b] >= m.nspeakers) { h->fail("speaker id out of range"); return OPH_ERR_INVALID; }
-    if ((rc = ensure_decode_state(h, B))) return rc;
-    HIPCHK(h, hipMemcpyAsync(h->d_L, L, (size_t)B * m.max_N * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_ends, ends, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
-    if (ms) HIPCHK(h, hipMemcpyAsync(h->d_spk, spk, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    return OPH_OK;
+}
+// text of a batch into text buffer `slot`
+static int upload_text(oph_handle* h, int slot, const int32_t* L, const int32_t* ends, const int32_t* spk, int B) {
+    const oph_dims& m = h->dm;
+    HIPCHK(h, hipMemcpyAsync(h->bL[slot], L, (size_t)B * m.max_N * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->bEnds[slot], ends, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    if (model_is_multispeaker(h)) HIPCHK(h, hipMemcpyAsync(h->bSpk[slot], spk, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->stage_epoch++;                     // a pre-encoded K,V of the previous text no longer applies
+    return OPH_OK;
+}
+
+int oph_stage_text(oph_handle* h, const int32_t* L, const int32_t* ends, const int32_t* spk, int B) {
+    int rc = check_ready(h, B);
+    if (rc) return rc;
+    if ((rc = check_text(h, L, ends, spk, B))) return rc;
+    if ((rc = ensure_decode_state(h, B))) return rc;
+    if (h->preenc_valid) { HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_preenc, 0)); HIPCHK(h, hipStreamSynchronize(h->stream)); }    // a running pre-encode still reads the other slot
+    h->preenc_valid = false; h->next_staged = false;      // a directly staged text supersedes a staged "next" one
+    h->kv_resident = false; h->y_resident = false; h->txt_ran = false; h->kv_pre = false;
+    if ((rc = upload_text(h, h->txt, L, ends, spk, B))) return rc;
+    select_tile(h, 0);
+    return OPH_OK;
+}
+
+// make the staged "next" text the current one (its K,V may already be there: pre-encoded under the previous decode)
+static int advance_text(oph_handle* h) {
+    if (!h->next_staged || !h->txt_ran) return OPH_OK;
+    h->txt ^= 1; h->next_staged = false; h->txt_ran = false; h->kv_pre = false;
+    h->kv_resident = false; h->y_resident = false;
+    if (h->preenc_valid) {
+        h->kv_cur ^= 1; h->preenc_valid = false; h->kv_pre = true;
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_preenc, 0));
+    }
+    select_tile(h, 0);
+    return OPH_OK;
+}
+
+// The text of the batch AFTER the staged one, into the second text slot (same batch size: the tiles and buffers are
+// shared).  While the staged batch decodes (oph_run_resident / oph_run_host) its TextEnc runs on the SSRN partition; the
+// run after that switches to it and starts decoding at once.  If the staged batch has already run, this call makes the
+// previously staged next text current first and then stages the new one behind it, so a caller simply alternates
+//     oph_stage_text(t0); oph_stage_text_next(t1);  loop { run(); oph_stage_text_next(t_{i+2}); }
+int oph_stage_text_next(oph_handle* h, const int32_t* L, const int32_t* ends, const int32_t* spk, int B) {
+    int rc = check_ready(h, B);
+    if (rc) return rc;
+    if (!h->bKV[0]) { h->fail("stage a first batch with oph_stage_text"); return OPH_ERR_STATE; }
+    if (B != h->nB) { h->fail("the next batch must have the staged batch's size (%d)", h->nB); return OPH_ERR_INVALID; }
+    if ((rc = check_text(h, L, ends, spk, B))) return rc;
+    if ((rc = advance_text(h))) return rc;
+    if (h->next_staged) { h->fail("a next batch is already staged and the current one has not run yet"); return OPH_ERR_STATE; }
+    if ((rc = upload_text(h, h->txt ^ 1, L, ends, spk, B))) return rc;
+    h->next_staged = true; h->next_B = B;
     return OPH_OK;
 }
 
 int oph_decode_steps(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* steps_run) {
-    if (!h || !h->KV) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
+    if (!h || !h->bKV[0]) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
-    if (t_begin == 0) reset_decode(h);
-    else {   // resume (multi-GPU global stop): clear the local stop so later steps execute
+    if (t_begin == 0) { begin_batch(h); return decode_batch(h, t_end, stop_mode, steps_run); }
+    // resume (multi-GPU global stop): every tile continues from the step the batch stopped at; clear the local stops
+    const int ntiles = (h->nB + TILE - 1) / TILE;
+    int last = t_begin;
+    int back = 0, ahead = 0;
+    ssrn_margins(h, &back, &ahead);
+    for (int j = 0; j < ntiles; ++j) {
+        select_tile(h, j);
+        if (h->tiles[j].steps != t_begin) { h->fail("resume at step %d, but tile %d stands at step %d", t_begin, j, h->tiles[j].steps); return OPH_ERR_STATE; }
         const int ctl1 = INT_MAX;
         HIPCHK(h, hipMemcpyAsync(h->d_ctl + 1, &ctl1, 4, hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->tiles[j].ssrn_done = std::min(h->tiles[j].ssrn_done, std::max(0, t_begin - ahead));      // frames >= t_begin change: SSRN rows that saw them are stale
+        int32_t st = 0;
+        const int rc = decode_range(h, t_begin, t_end, stop_mode, &st);
+        if (rc) return rc;
+        last = std::max(last, (int)st);
     }
-    return decode_range(h, t_begin, t_end, stop_mode, steps_run);
-}
-
-int oph_run_ssrn_resident(oph_handle* h) {
-    if (!h || !h->KV) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
-    HIPCHK(h, hipSetDevice(h->device));
-    g_cur = h->stream;
-    return run_ssrn_on(h, h->Yout, h->ldy, h->B, h->dm.max_T, h->Z);
-}
-
-// Switch between sequential batches (SSRN on the whole chip, joined) and pipelined batches (SSRN on its
-// own CU partition, overlapping the next batch).
-static int set_pipelined(oph_handle* h, bool pipe) {
-    if (pipe == h->pipelined) return OPH_OK;
-    for (hipStream_t st : {h->stream, h->sdec, h->scone, h->sssrn}) HIPCHK(h, hipStreamSynchronize(st));
-    if (!pipe) { h->buf = 0; h->Yout = h->Yout2[0]; h->Z = h->Z2[0]; }
-    h->pipelined = pipe;
-    h->ssrn_inflight[0] = h->ssrn_inflight[1] = false;
+    select_tile(h, 0);
+    if (steps_run) *steps_run = last;
     return OPH_OK;
 }
 
-int oph_run_resident(oph_handle* h, int stop_mode, int run_ssrn, int32_t* steps_run) {
-    if (!h || !h->KV) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
+// Switch between sequential batches (everything joined when a call returns) and pipelined batches (the SSRN tail of a
+// batch stays on the SSRN partition and overlaps the next batch).
+static int set_pipelined(oph_handle* h, bool pipe) {
+    if (pipe == h->pipelined) return OPH_OK;
+    for (hipStream_t st : {h->stream, h->sdec, h->scone, h->sssrn, h->scopy}) HIPCHK(h, hipStreamSynchronize(st));
+    if (!pipe) h->buf = 0;
+    h->pipelined = pipe;
+    h->ssrn_inflight[0] = h->ssrn_inflight[1] = false;
+    select_tile(h, h->tile);
+    return OPH_OK;
+}
+
+int oph_run_ssrn_resident(oph_handle* h) {
+    if (!h || !h->bKV[0]) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
-    // run_ssrn == 2: pipelined batches -- SSRN of THIS batch is queued on its own CU partition and is not
-    // joined here, so the next call's TextEnc + decode overlap it (Y/Z ping-pong, separate workspace);
-    // oph_synchronize / oph_fetch_* / oph_timer_stop join it.
+    g_cur = h->stream;
+    return finish_ssrn(h);
+}
+
+int oph_run_resident(oph_handle* h, int stop_mode, int run_ssrn, int32_t* steps_run) {
+    if (!h || !h->bKV[0]) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
+    HIPCHK(h, hipSetDevice(h->device));
+    // run_ssrn: 0 = Text2Mel only; 1 = SSRN too, joined when the call returns; 2 = pipelined batches -- the SSRN tail of
+    // THIS batch (what its streamed chunks have not covered when the decode ends) stays queued on the SSRN partition and
+    // overlaps the next call's decode (Y/Z ping-pong); oph_synchronize / oph_fetch_* / oph_timer_stop join it.
     const bool pipe = run_ssrn == 2;
-    TRACE("run_resident pipe=%d", (int)pipe);
     int rc = set_pipelined(h, pipe);
     if (rc) return rc;
-    TRACE("mode set; encode");
     g_cur = h->stream;
-    static const bool no_preenc = getenv("OPH_NO_PREENCODE") != nullptr;
-    if (pipe && h->preenc_valid && h->preenc_epoch == h->stage_epoch) {
-        // K,V of the staged text were computed ahead (on the SSRN partition, during the previous batch's decode)
-        h->kv_cur ^= 1; h->KV = h->KV2[h->kv_cur];
-        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_preenc, 0));
-    } else {
-        if (h->preenc_valid) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_preenc, 0));    // a stale pre-encode still owns its buffers
-        if ((rc = run_encode(h))) return rc;
-    }
-    h->preenc_valid = false;
-    TRACE("encode queued; reset");
-    reset_decode(h);
-    TRACE("reset done; decode");
-    h->want_preenc = pipe && !no_preenc && h->ev_preenc != nullptr;
-    rc = decode_range(h, 0, h->dm.max_T, stop_mode, steps_run);
-    h->want_preenc = false;
+    if ((rc = advance_text(h))) return rc;       // the current text has run: a text staged with oph_stage_text_next takes its place
+    begin_batch(h);
+    select_tile(h, 0);
+    if (h->kv_pre) h->n_preenc_used++;
+    else if ((rc = run_encode(h))) return rc;
+    h->kv_pre = false; h->txt_ran = true;
+    h->kv_resident = true;
+    h->want_preenc = !h->opt.no_preencode;
+    const bool spec_saved = h->spec_ssrn;
+    h->spec_ssrn = run_ssrn != 0;
+    rc = decode_batch(h, h->dm.max_T, stop_mode, steps_run);
+    h->want_preenc = false; h->spec_ssrn = spec_saved;
     if (rc) return rc;
-    TRACE("decode done");
-    if (pipe) {
-        HIPCHK(h, hipEventRecord(h->ev_dec_done, h->stream));
-        HIPCHK(h, hipStreamWaitEvent(h->sssrn, h->ev_dec_done, 0));
-        g_cur = h->sssrn;
-        rc = run_ssrn_on(h, h->Yout, h->ldy, h->B, h->dm.max_T, h->Z, 1);
-        g_cur = h->stream;
-        HIPCHK(h, hipEventRecord(h->ev_ssrn_done[h->buf], h->sssrn));
-        h->ssrn_inflight[h->buf] = true;
-        TRACE("ssrn queued");
-    } else if (run_ssrn) rc = oph_run_ssrn_resident(h);
+    h->y_resident = true;
+    if (run_ssrn) rc = finish_ssrn(h);
     return rc;
 }
 
@@ -2055,53 +2241,119 @@ int oph_set_ssrn_precision(oph_handle* h, int mode) {
     h->ssrn_prec = mode;
     return OPH_OK;
 }
+// what the pipeline actually did since the handle was created (tests and bench.py assert on these):
+// [0] TextEnc evaluations  [1] runs that found their K,V pre-encoded  [2] SSRN chunks launched while a decode was running
+// [3] whole-decode launches  [4] fallbacks from the whole-decode launch to two launches per step  [5] tiles resumed to the batch's stop step
+int oph_get_counters(oph_handle* h, int64_t* out, int n) {
+    if (!h || !out) return OPH_ERR_INVALID;
+    const long long v[6] = {h->n_textenc, h->n_preenc_used, h->n_chunks_streamed, h->n_loop_decodes, h->n_loop_fallbacks, h->n_tile_resumes};
+    for (int i = 0; i < n && i < 6; ++i) out[i] = v[i];
+    return OPH_OK;
+}
+int oph_set_streaming(oph_handle* h, int on) {
+    if (!h) return OPH_ERR_INVALID;
+    h->spec_ssrn = on != 0;
+    return OPH_OK;
+}
 
 int oph_synchronize(oph_handle* h) {
     if (!h) return OPH_ERR_INVALID;
     if (h->sssrn) HIPCHK(h, hipStreamSynchronize(h->sssrn));
+    if (h->scopy) HIPCHK(h, hipStreamSynchronize(h->scopy));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     return OPH_OK;
 }
 
 int oph_fetch_kv(oph_handle* h, float* K, float* V) {
-    if (!h || !h->KV) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
+    if (!h || !h->bKV[0]) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
     const oph_dims& m = h->dm;
-    const size_t rows = (size_t)h->B * m.max_N, w = (size_t)m.d * 4;
-    if (K) HIPCHK(h, hipMemcpy2DAsync(K, w, h->KV, 2 * w, w, rows, hipMemcpyDeviceToHost, h->stream));
-    if (V) HIPCHK(h, hipMemcpy2DAsync(V, w, h->KV + m.d, 2 * w, w, rows, hipMemcpyDeviceToHost, h->stream));
+    const size_t rows = (size_t)h->nB * m.max_N, w = (size_t)m.d * 4;
+    const float* kv = h->bKV[h->kv_cur];
+    if (K) HIPCHK(h, hipMemcpy2DAsync(K, w, kv, 2 * w, w, rows, hipMemcpyDeviceToHost, h->stream));
+    if (V) HIPCHK(h, hipMemcpy2DAsync(V, w, kv + m.d, 2 * w, w, rows, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return OPH_OK;
 }
 
 int oph_fetch_mel(oph_handle* h, float* Y, int32_t* t_ends, float* alignments) {
-    if (!h || !h->KV) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
+    if (!h || !h->bKV[0]) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
     const oph_dims& m = h->dm;
-    if (Y) HIPCHK(h, hipMemcpy2DAsync(Y, (size_t)m.n_mels * 4, h->Yout, (size_t)h->ldy * 4, (size_t)m.n_mels * 4,
-                                      (size_t)h->B * m.max_T, hipMemcpyDeviceToHost, h->stream));
-    if (t_ends) HIPCHK(h, hipMemcpyAsync(t_ends, h->d_tends, (size_t)h->B * 4, hipMemcpyDeviceToHost, h->stream));
-    if (alignments) HIPCHK(h, hipMemcpyAsync(alignments, h->align, (size_t)h->B * m.max_N * m.max_T * 4, hipMemcpyDeviceToHost, h->stream));
+    if (Y) HIPCHK(h, hipMemcpy2DAsync(Y, (size_t)m.n_mels * 4, h->bYout[h->buf], (size_t)h->ldy * 4, (size_t)m.n_mels * 4,
+                                      (size_t)h->nB * m.max_T, hipMemcpyDeviceToHost, h->stream));
+    if (t_ends) HIPCHK(h, hipMemcpyAsync(t_ends, h->bTends, (size_t)h->nB * 4, hipMemcpyDeviceToHost, h->stream));
+    if (alignments) HIPCHK(h, hipMemcpyAsync(alignments, h->bAlign, (size_t)h->nB * m.max_N * m.max_T * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return OPH_OK;
 }
 
 int oph_fetch_mag(oph_handle* h, float* Z) {
-    if (!h || !h->KV || !Z) { if (h) h->fail("no staged batch / null"); return OPH_ERR_STATE; }
+    if (!h || !h->bKV[0] || !Z) { if (h) h->fail("no staged batch / null"); return OPH_ERR_STATE; }
     if (h->sssrn) HIPCHK(h, hipStreamSynchronize(h->sssrn));
     const oph_dims& m = h->dm;
-    HIPCHK(h, hipMemcpyAsync(Z, h->Z, (size_t)h->B * m.max_T * m.r * m.full_dim * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(Z, h->bZ[h->buf], (size_t)h->nB * m.max_T * m.r * m.full_dim * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return OPH_OK;
 }
 
 int oph_device_mag(oph_handle* h, const float** d_mag, int64_t* utt_stride, int32_t* B) {
-    if (!h || !h->KV || !h->Z || !d_mag) { if (h) h->fail("no staged batch / null"); return OPH_ERR_STATE; }
+    if (!h || !h->bKV[0] || !d_mag) { if (h) h->fail("no staged batch / null"); return OPH_ERR_STATE; }
     if (h->sssrn) HIPCHK(h, hipStreamSynchronize(h->sssrn));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const oph_dims& m = h->dm;
-    *d_mag = h->Z;
+    *d_mag = h->bZ[h->buf];
     if (utt_stride) *utt_stride = (int64_t)m.max_T * m.r * m.full_dim;
-    if (B) *B = h->B;
+    if (B) *B = h->nB;
+    return OPH_OK;
+}
+
+// One whole batch host -> host: the staged text (oph_stage_text, or the one staged with oph_stage_text_next during the
+// previous call) through TextEnc, decode and SSRN, with every result copied into the caller's buffers (any of them may be
+// NULL) as it becomes final -- SSRN rows chunk by chunk and Y / alignments at the end of the decode, on the copy stream, under
+// the work that is still running.  Pinned buffers (oph_host_alloc) make those copies asynchronous DMA.  What the
+// reference's two clocks bracket (synthesize.py:553-576).
+int oph_run_host(oph_handle* h, int stop_mode, float* K, float* V, float* Y, int32_t* t_ends, float* alignments, float* Z, int32_t* steps_run) {
+    if (!h || !h->bKV[0]) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = set_pipelined(h, false);
+    if (rc) return rc;
+    const oph_dims& m = h->dm;
+    g_cur = h->stream;
+    if ((rc = advance_text(h))) return rc;
+    begin_batch(h);
+    select_tile(h, 0);
+    if (h->kv_pre) h->n_preenc_used++;
+    else if ((rc = run_encode(h))) return rc;
+    h->kv_pre = false; h->txt_ran = true;
+    h->kv_resident = true;
+    if (K || V) {       // K,V leave on the copy stream while the decode starts
+        HIPCHK(h, hipEventRecord(h->ev_copy, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->scopy, h->ev_copy, 0));
+        const size_t rows = (size_t)h->nB * m.max_N, w = (size_t)m.d * 4;
+        const float* kv = h->bKV[h->kv_cur];
+        if (K) HIPCHK(h, hipMemcpy2DAsync(K, w, kv, 2 * w, w, rows, hipMemcpyDeviceToHost, h->scopy));
+        if (V) HIPCHK(h, hipMemcpy2DAsync(V, w, kv + m.d, 2 * w, w, rows, hipMemcpyDeviceToHost, h->scopy));
+    }
+    h->want_preenc = !h->opt.no_preencode;
+    const bool spec_saved = h->spec_ssrn;
+    h->spec_ssrn = Z != nullptr;
+    h->z_host = Z;
+    rc = decode_batch(h, m.max_T, stop_mode, steps_run);
+    h->want_preenc = false; h->spec_ssrn = spec_saved;
+    if (rc) { h->z_host = nullptr; return rc; }
+    h->y_resident = true;
+    // Y, t_ends, alignments: final now (the API stream has joined the decode streams)
+    HIPCHK(h, hipEventRecord(h->ev_copy, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->scopy, h->ev_copy, 0));
+    if (Y) HIPCHK(h, hipMemcpy2DAsync(Y, (size_t)m.n_mels * 4, h->bYout[h->buf], (size_t)h->ldy * 4, (size_t)m.n_mels * 4, (size_t)h->nB * m.max_T, hipMemcpyDeviceToHost, h->scopy));
+    if (t_ends) HIPCHK(h, hipMemcpyAsync(t_ends, h->bTends, (size_t)h->nB * 4, hipMemcpyDeviceToHost, h->scopy));
+    if (alignments) HIPCHK(h, hipMemcpyAsync(alignments, h->bAlign, (size_t)h->nB * m.max_N * m.max_T * 4, hipMemcpyDeviceToHost, h->scopy));
+    if (Z) rc = finish_ssrn(h);
+    h->z_host = nullptr;
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->sssrn));
+    HIPCHK(h, hipStreamSynchronize(h->scopy));
     return OPH_OK;
 }
 
@@ -2113,30 +2365,48 @@ int oph_encode_text(oph_handle* h, const int32_t* L, const int32_t* spk, int B, 
     // ends are not needed by TextEnc; stage zeros (get_text_lengths stays with the caller, synthesize.py:556)
     std::vector<int32_t> ends(B, 0), spk0(B, 0);
     if ((rc = oph_stage_text(h, L, ends.data(), spk ? spk : spk0.data(), B))) return rc;
+    g_cur = h->stream;
     if ((rc = run_encode(h))) return rc;
+    h->kv_resident = true;          // oph_text2mel(K = NULL, V = NULL) decodes from these
     return oph_fetch_kv(h, K, V);
+}
+
+// shared front of the two decode entry points: K,V (or the resident ones), ends / speakers of the batch
+static int stage_decode_inputs(oph_handle* h, const float* K, const float* V, bool need_k, const int32_t* ends, const int32_t* spk, int B) {
+    int rc;
+    const bool ms = h->dm.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_LCC | OPH_FLAG_SPK_AUDIO_ENCODER_INPUT);
+    if (ms && !spk) { h->fail("multispeaker model needs speaker ids"); return OPH_ERR_INVALID; }
+    const oph_dims& m = h->dm;
+    if (!K && !V) {
+        if (!h->kv_resident || B != h->nB) { h->fail("K = V = NULL asks for the K,V oph_encode_text left in HBM, but there are none for a batch of %d", B); return OPH_ERR_STATE; }
+    } else {
+        if ((need_k && !K) || !V) { h->fail("null argument"); return OPH_ERR_INVALID; }
+        if ((rc = ensure_decode_state(h, B))) return rc;
+        const size_t rows = (size_t)B * m.max_N, w = (size_t)m.d * 4;
+        float* kv = h->bKV[h->kv_cur];
+        if (K) HIPCHK(h, hipMemcpy2DAsync(kv, 2 * w, K, w, w, rows, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpy2DAsync(kv + m.d, 2 * w, V, w, w, rows, hipMemcpyHostToDevice, h->stream));
+        h->kv_resident = false;
+    }
+    if (ends) HIPCHK(h, hipMemcpyAsync(h->bEnds[h->txt], ends, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    if (ms) {
+        for (int b = 0; b < B; ++b) if (spk[b] < 0 || spk[b] >= m.nspeakers) { h->fail("speaker id out of range"); return OPH_ERR_INVALID; }
+        HIPCHK(h, hipMemcpyAsync(h->bSpk[h->txt], spk, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return OPH_OK;
 }
 
 int oph_text2mel(oph_handle* h, const float* K, const float* V, const int32_t* ends, const int32_t* spk, int B,
                  int stop_mode, float* Y, int32_t* t_ends, float* alignments, int32_t* steps_run) {
     int rc = check_ready(h, B);
     if (rc) return rc;
-    if (!K || !V || !ends) { h->fail("null argument"); return OPH_ERR_INVALID; }
-    const bool ms = h->dm.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_LCC | OPH_FLAG_SPK_AUDIO_ENCODER_INPUT);
-    if (ms && !spk) { h->fail("multispeaker model needs speaker ids"); return OPH_ERR_INVALID; }
-    if ((rc = ensure_decode_state(h, B))) return rc;
-    const oph_dims& m = h->dm;
-    const size_t rows = (size_t)B * m.max_N, w = (size_t)m.d * 4;
-    HIPCHK(h, hipMemcpy2DAsync(h->KV, 2 * w, K, w, w, rows, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpy2DAsync(h->KV + m.d, 2 * w, V, w, w, rows, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_ends, ends, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
-    if (ms) {
-        for (int b = 0; b < B; ++b) if (spk[b] < 0 || spk[b] >= m.nspeakers) { h->fail("speaker id out of range"); return OPH_ERR_INVALID; }
-        HIPCHK(h, hipMemcpyAsync(h->d_spk, spk, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
-    }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    reset_decode(h);
-    if ((rc = decode_range(h, 0, m.max_T, stop_mode, steps_run))) return rc;
+    if (!ends) { h->fail("null argument"); return OPH_ERR_INVALID; }
+    if ((rc = set_pipelined(h, false))) return rc;
+    if ((rc = stage_decode_inputs(h, K, V, true, ends, spk, B))) return rc;
+    begin_batch(h);
+    if ((rc = decode_batch(h, h->dm.max_T, stop_mode, steps_run))) return rc;
+    h->y_resident = true;           // oph_ssrn(Y = NULL) continues from here
     return oph_fetch_mel(h, Y, t_ends, alignments);
 }
 
@@ -2144,14 +2414,13 @@ int oph_text2mel_durations(oph_handle* h, const float* K, const float* V, const 
                            int B, int n_steps, float* Y, int32_t* t_ends, float* alignments, int32_t* steps_run) {
     int rc = check_ready(h, B);
     if (rc) return rc;
-    if (!V || !durations) { h->fail("null argument"); return OPH_ERR_INVALID; }
-    const bool ms = h->dm.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_LCC | OPH_FLAG_SPK_AUDIO_ENCODER_INPUT);
-    if (ms && !spk) { h->fail("multispeaker model needs speaker ids"); return OPH_ERR_INVALID; }
-    if ((rc = ensure_decode_state(h, B))) return rc;
+    if (!durations) { h->fail("null argument"); return OPH_ERR_INVALID; }
+    if ((rc = set_pipelined(h, false))) return rc;
+    if ((rc = stage_decode_inputs(h, K, V, false, nullptr, spk, B))) return rc;
     const oph_dims& m = h->dm;
-    const int Bpad = h->Bpad;
+    const int ntiles = (B + TILE - 1) / TILE;
     // selection matrix -> key index per (t, b); only hard 0/1 rows (what data_load.py:243-251 produces) are supported
-    std::vector<int> ptab((size_t)m.max_T * Bpad, -1);
+    std::vector<std::vector<int>> ptab(ntiles, std::vector<int>((size_t)m.max_T * TILE, -1));
     std::vector<int32_t> tends(B, 0);
     for (int b = 0; b < B; ++b)
         for (int t = 0; t < m.max_T; ++t) {
@@ -2162,7 +2431,7 @@ int oph_text2mel_durations(oph_handle* h, const float* K, const float* V, const 
                 if (row[n] != 1.0f || key >= 0) { h->fail("durations row (b=%d, t=%d) is not a 0/1 selection of at most one key", b, t); return OPH_ERR_UNSUPPORTED; }
                 key = n;
             }
-            if (key >= 0) { ptab[(size_t)t * Bpad + b] = key; tends[b]++; }
+            if (key >= 0) { ptab[b / TILE][(size_t)t * TILE + b % TILE] = key; tends[b]++; }
         }
     int steps = n_steps;
     if (steps <= 0) {
@@ -2171,20 +2440,15 @@ int oph_text2mel_durations(oph_handle* h, const float* K, const float* V, const 
         steps = std::min((int)m.max_T, mx + 1);          // synthesize.py:211-216: the step at which j >= max(t_ends) still runs
     }
     steps = std::min(steps, (int)m.max_T);
-    const size_t rows = (size_t)B * m.max_N, w = (size_t)m.d * 4;
-    if (K) HIPCHK(h, hipMemcpy2DAsync(h->KV, 2 * w, K, w, w, rows, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpy2DAsync(h->KV + m.d, 2 * w, V, w, w, rows, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_ptab, ptab.data(), ptab.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    if (ms) {
-        for (int b = 0; b < B; ++b) if (spk[b] < 0 || spk[b] >= m.nspeakers) { h->fail("speaker id out of range"); return OPH_ERR_INVALID; }
-        HIPCHK(h, hipMemcpyAsync(h->d_spk, spk, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
-    }
+    for (int j = 0; j < ntiles; ++j)
+        HIPCHK(h, hipMemcpyAsync(h->tiles[j].d_ptab, ptab[j].data(), ptab[j].size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    reset_decode(h);
+    begin_batch(h);
     h->fixed_att = true;
-    rc = decode_range(h, 0, steps, OPH_STOP_NEVER, nullptr);
+    rc = decode_batch(h, steps, OPH_STOP_NEVER, nullptr);
     h->fixed_att = false;
     if (rc) return rc;
+    h->y_resident = true;
     if ((rc = oph_fetch_mel(h, Y, nullptr, alignments))) return rc;
     if (t_ends) std::copy(tends.begin(), tends.end(), t_ends);
     if (steps_run) *steps_run = steps;
@@ -2203,22 +2467,16 @@ int oph_text2mel_graph(oph_handle* h, const float* K, const float* V, const floa
     if (rc) return rc;
     if (!K || !V || !mels || !prev_max) { h->fail("null argument"); return OPH_ERR_INVALID; }
     const oph_dims& m = h->dm;
-    const bool ms = m.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_LCC | OPH_FLAG_SPK_AUDIO_ENCODER_INPUT);
-    if (ms && !spk) { h->fail("multispeaker model needs speaker ids"); return OPH_ERR_INVALID; }
     if ((m.flags & OPH_FLAG_NO_MONOTONIC) && !ends) { h->fail("turn_off_monotonic_for_synthesis needs the text lengths"); return OPH_ERR_INVALID; }
     for (int b = 0; b < B; ++b) if (prev_max[b] < 0 || prev_max[b] >= m.max_N) { h->fail("prev_max_attentions out of range"); return OPH_ERR_INVALID; }
-    if ((rc = ensure_decode_state(h, B))) return rc;
+    if ((rc = set_pipelined(h, false))) return rc;
+    if ((rc = stage_decode_inputs(h, K, V, true, ends, spk, B))) return rc;
+    h->y_resident = false;
     g_cur = h->stream;
     const int T = m.max_T, d = m.d, ldy = h->ldy;
-    const size_t rows = (size_t)B * m.max_N, w = (size_t)d * 4;
-    HIPCHK(h, hipMemcpy2DAsync(h->KV, 2 * w, K, w, w, rows, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpy2DAsync(h->KV + d, 2 * w, V, w, w, rows, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_p, prev_max, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
-    if (ends) HIPCHK(h, hipMemcpyAsync(h->d_ends, ends, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
-    if (ms) {
-        for (int b = 0; b < B; ++b) if (spk[b] < 0 || spk[b] >= m.nspeakers) { h->fail("speaker id out of range"); return OPH_ERR_INVALID; }
-        HIPCHK(h, hipMemcpyAsync(h->d_spk, spk, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
-    }
+    // the fed prev_max_attentions of all utterances: one int per utterance, batch order (bTends doubles as the feed buffer)
+    int* d_pm = h->bTends;
+    HIPCHK(h, hipMemcpyAsync(d_pm, prev_max, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
     // S = concat(zeros, mels[:, :-1])  (architectures.py:191), rows padded to the first layer's K
     std::vector<float> S((size_t)B * T * ldy, 0.f);
     for (int b = 0; b < B; ++b)
@@ -2229,57 +2487,80 @@ int oph_text2mel_graph(oph_handle* h, const float* K, const float* V, const floa
     float* dQ = run_batched(h, h->audioenc, h->actA, ldy, B, T, 0, 0, nullptr, 0, 0, &ldq, nullptr);
     // attention over all positions, one mask per utterance; R' rows go to the workspace the encoder did not end in
     float* dR = dQ == h->actA ? h->actB : h->actA;
-    long long* d_amax = nullptr;
-    HIPCHK(h, hipMalloc((void**)&d_amax, (size_t)B * T * 8));
-    HIPCHK(h, hipMemsetAsync(h->align, 0, (size_t)h->Bpad * m.max_N * T * 4, h->stream));
+    const float* kv = h->bKV[h->kv_cur];
+    HIPCHK(h, hipMemsetAsync(h->bAlign, 0, (size_t)h->nBpad * m.max_N * T * 4, h->stream));
     AttnRowsArgs a{};
-    a.mode = 1; a.Q = dQ; a.ldq = ldq; a.K = h->KV; a.V = h->KV + d; a.ldkv = 2 * d; a.N = m.max_N; a.d = d; a.win = m.attention_win_size;
-    a.p = h->d_p; a.B = B; a.Bpad = h->Bpad; a.nrows = B * T; a.T = T; a.R = dR; a.ldr = 2 * d; a.align = h->align; a.amax = d_amax;
-    if (m.flags & OPH_FLAG_NO_MONOTONIC) a.ends = h->d_ends;
+    a.mode = 1; a.Q = dQ; a.ldq = ldq; a.K = kv; a.V = kv + d; a.ldkv = 2 * d; a.N = m.max_N; a.d = d; a.win = m.attention_win_size;
+    a.p = d_pm; a.B = B; a.Bpad = h->nBpad; a.nrows = B * T; a.T = T; a.R = dR; a.ldr = 2 * d; a.align = h->bAlign; a.amax = h->d_amax;
+    if (m.flags & OPH_FLAG_NO_MONOTONIC) a.ends = h->bEnds[h->txt];
     launch_attn_rows(a, h->stream);
-    std::vector<float> hQ, hR;
-    if (Q) HIPCHK(h, hipMemcpy2DAsync(Q, w, dQ, (size_t)ldq * 4, w, (size_t)B * T, hipMemcpyDeviceToHost, h->stream));
+    if (Q) HIPCHK(h, hipMemcpy2DAsync(Q, (size_t)d * 4, dQ, (size_t)ldq * 4, (size_t)d * 4, (size_t)B * T, hipMemcpyDeviceToHost, h->stream));
     if (R) HIPCHK(h, hipMemcpyAsync(R, dR, (size_t)B * T * 2 * d * 4, hipMemcpyDeviceToHost, h->stream));
-    if (alignments) HIPCHK(h, hipMemcpyAsync(alignments, h->align, (size_t)B * m.max_N * T * 4, hipMemcpyDeviceToHost, h->stream));
+    if (alignments) HIPCHK(h, hipMemcpyAsync(alignments, h->bAlign, (size_t)B * m.max_N * T * 4, hipMemcpyDeviceToHost, h->stream));
     std::vector<long long> amax((size_t)B * T);
-    HIPCHK(h, hipMemcpyAsync(amax.data(), d_amax, amax.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(amax.data(), h->d_amax, amax.size() * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));     // Q may live in the buffer the decoder overwrites next
+    // AudioDec; its last layer's LayerNorm rows are stored twice: squashed (g.Y) and as they are (g.Y_logits)
     int ldl = 0;
-    float* dL = run_batched(h, h->audiodec, dR, 2 * d, B, T, 0, 0, nullptr, 0, 0, &ldl, nullptr);
-    std::vector<float> logits((size_t)B * T * m.n_mels);
-    HIPCHK(h, hipMemcpy2DAsync(logits.data(), (size_t)m.n_mels * 4, dL, (size_t)ldl * 4, (size_t)m.n_mels * 4, (size_t)B * T, hipMemcpyDeviceToHost, h->stream));
+    BatchedIO io{};
+    float* dlogits = h->raw;         // free once the last layer's epilogues have run (they read it row by row: use the far end)
+    const int ldn = round_up(m.n_mels, 32);
+    dlogits = h->raw + (h->raw_elems - (size_t)B * T * ldn);
+    io.final_logits = dlogits;
+    std::vector<Layer> dec = h->audiodec;
+    dec.back().act = ACT_SIGMOID;                   // squash_output_t2m (networks.py:430-431)
+    float* dY = run_batched(h, dec, dR, 2 * d, B, T, 0, 0, nullptr, 0, 0, &ldl, nullptr, io);
+    if (Y) HIPCHK(h, hipMemcpy2DAsync(Y, (size_t)m.n_mels * 4, dY, (size_t)ldl * 4, (size_t)m.n_mels * 4, (size_t)B * T, hipMemcpyDeviceToHost, h->stream));
+    if (Y_logits) HIPCHK(h, hipMemcpy2DAsync(Y_logits, (size_t)m.n_mels * 4, dlogits, (size_t)ldl * 4, (size_t)m.n_mels * 4, (size_t)B * T, hipMemcpyDeviceToHost, h->stream));
     hipError_t e = hipStreamSynchronize(h->stream);
-    hipFree(d_amax);
     if (e != hipSuccess || (e = hipGetLastError()) != hipSuccess) { h->fail("graph evaluation failed: %s", hipGetErrorString(e)); return OPH_ERR_DEVICE; }
     if (max_attentions) for (size_t i = 0; i < amax.size(); ++i) max_attentions[i] = (int32_t)amax[i];
-    if (Y_logits) std::copy(logits.begin(), logits.end(), Y_logits);
-    if (Y) for (size_t i = 0; i < logits.size(); ++i) Y[i] = 1.0f / (1.0f + expf(-logits[i]));     // squash_output_t2m (networks.py:430-431)
+    // bTends was borrowed for the fed prev_max: put the "not ended" state back
+    launch_fill_int(h->bTends, m.max_T, h->nBpad, h->stream);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return OPH_OK;
 }
 
-int oph_ssrn(oph_handle* h, const float* Y, int B, int T, float* Z) {
+// oph_ssrn / oph_ssrn_logits.  Y == NULL: the mel frames the last decode call left in HBM (B and T must be that batch's);
+// whatever its streamed SSRN has not covered yet is computed now.
+static int ssrn_common(oph_handle* h, const float* Y, int B, int T, float* Z, float* Z_logits) {
     int rc = check_ready(h, B);
     if (rc) return rc;
-    if (!Y || !Z || T < 1) { h->fail("bad argument"); return OPH_ERR_INVALID; }
+    if (!Z || T < 1) { h->fail("bad argument"); return OPH_ERR_INVALID; }
     const oph_dims& m = h->dm;
     if (T > m.max_T) { h->fail("T=%d exceeds max_T=%d", T, m.max_T); return OPH_ERR_INVALID; }
+    if (!Y && !Z_logits) {
+        if (!h->y_resident || B != h->nB || T != m.max_T) { h->fail("Y = NULL asks for the mel frames the last decode left in HBM, but there are none for B=%d, T=%d", B, T); return OPH_ERR_STATE; }
+        g_cur = h->stream;
+        if ((rc = finish_ssrn(h))) return rc;
+        return oph_fetch_mag(h, Z);
+    }
+    if (!Y) { h->fail("the logits fetch needs the mel frames as an argument"); return OPH_ERR_INVALID; }
     if ((rc = ensure_batched_capacity(h, B))) return rc;
     g_cur = h->stream;
     const int ldy = round_up(m.n_mels, 32);
-    float* dY = nullptr; float* dZ = nullptr;
+    float* dY = nullptr; float* dZ = nullptr; float* dZl = nullptr;
     const size_t zn = (size_t)B * T * m.r * m.full_dim;
     HIPCHK(h, hipMalloc((void**)&dY, (size_t)B * T * m.n_mels * 4));
-    if (hipMalloc((void**)&dZ, zn * 4) != hipSuccess) { hipFree(dY); (void)hipGetLastError(); h->fail("out of device memory for the SSRN output"); return OPH_ERR_DEVICE; }
+    if (hipMalloc((void**)&dZ, zn * 4) != hipSuccess || (Z_logits && hipMalloc((void**)&dZl, zn * 4) != hipSuccess)) {
+        hipFree(dY); if (dZ) hipFree(dZ); (void)hipGetLastError(); h->fail("out of device memory for the SSRN output"); return OPH_ERR_DEVICE;
+    }
     hipError_t e = hipMemcpyAsync(dY, Y, (size_t)B * T * m.n_mels * 4, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) {
         launch_pad_rows(dY, m.n_mels, h->actB, ldy, (long long)B * T, m.n_mels, h->stream);
-        rc = run_ssrn_on(h, h->actB, ldy, B, T, dZ);
+        rc = run_ssrn_on(h, h->actB, ldy, B, T, dZ, 0, dZl);
         e = hipMemcpyAsync(Z, dZ, zn * 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess && Z_logits) e = hipMemcpyAsync(Z_logits, dZl, zn * 4, hipMemcpyDeviceToHost, h->stream);
     }
     const hipError_t es = hipStreamSynchronize(h->stream);
-    hipFree(dY); hipFree(dZ);
+    hipFree(dY); hipFree(dZ); if (dZl) hipFree(dZl);
     if (e != hipSuccess || es != hipSuccess) { h->fail("ssrn failed: %s", hipGetErrorString(e != hipSuccess ? e : es)); return OPH_ERR_DEVICE; }
     return rc;
+}
+int oph_ssrn(oph_handle* h, const float* Y, int B, int T, float* Z) { return ssrn_common(h, Y, B, T, Z, nullptr); }
+int oph_ssrn_logits(oph_handle* h, const float* Y, int B, int T, float* Z, float* Z_logits) {
+    if (h && !Z_logits) { h->fail("null argument"); return OPH_ERR_INVALID; }
+    return ssrn_common(h, Y, B, T, Z, Z_logits);
 }
 
 // ---- measurement ----------------------------------------------------------------------------

@@ -560,7 +560,8 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
             if (first && t >= 1) {
                 // x is mel frame t-1 -> Y[b][t-1] and the decoder input S[t] (synthesize.py:204-209)
                 if (g == 0 && grow < a.B && t - 1 <= stop_v && c < a.ldy) {
-                    *(f32x4*)(a.Yout + ((size_t)grow * a.max_T + (t - 1)) * a.ldy + c) = x;
+                    // written through: SSRN chunks on another stream read the frames while this launch is still running
+                    st_coherent(a.Yout + ((size_t)grow * a.max_T + (t - 1)) * a.ldy + c, x);
                     *(f32x4*)(a.Ytm + ((size_t)t * Bpad + grow) * a.ldy + c) = x;
                 }
             }
@@ -797,33 +798,6 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
     if (g == 0 && blockIdx.y == 0 && tid == 0)
         __hip_atomic_fetch_max(a.sig, a.sig_base + (unsigned)a.max_T + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-
-// Side-stream ends of the two dependencies of dec_loop, as one-wave kernels in stream order instead of
-// hipStreamWaitValue32 / hipStreamWriteValue32: measured on this runtime, a wait-value + write-value pair on an otherwise
-// idle stream turns around in ~150 us (profiles/r02 ablations: with every phase of the loop kernel switched off a step
-// still took 150 us, all of it waiting here), a spinning kernel and a storing kernel in ~5 us.
-__global__ void sig_wait_kernel(const unsigned* sig, unsigned want, int* err, long long* stamp) {
-    long long t0 = 0;
-    for (int it = 0; (int)(__hip_atomic_load(sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0; ++it) {
-        __builtin_amdgcn_s_sleep(4);
-        if ((it & 255) == 255) {
-            const long long now = wall_clock64();
-            if (t0 == 0) t0 = now;
-            if (now - t0 > RUN_TIMEOUT_TICKS || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                __hip_atomic_store(err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return;
-            }
-        }
-    }
-    (void)stamp;
-}
-__global__ void sig_set_kernel(unsigned* sig, unsigned value, int nwords, long long* stamp) {
-    // the kernels before this one in the stream have completed (their stores are written back at kernel end)
-    if ((int)threadIdx.x < nwords) __hip_atomic_fetch_max(sig + 16 * threadIdx.x, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (stamp && threadIdx.x == 0) stamp[7] = wall_clock64();
-}
-void launch_sig_wait(const unsigned* sig, unsigned want, int* err, long long* stamp, hipStream_t s) { hipLaunchKernelGGL(sig_wait_kernel, dim3(1), dim3(64), 0, s, sig, want, err, stamp); }
-void launch_sig_set(unsigned* sig, unsigned value, int nwords, long long* stamp, hipStream_t s) { hipLaunchKernelGGL(sig_set_kernel, dim3(1), dim3(64), 0, s, sig, value, nwords, stamp); }
 
 template <int R>
 static void launch_dec_loop_t(const LoopArgs& a, int col_slices, int kmax, hipStream_t s) {

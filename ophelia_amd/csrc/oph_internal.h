@@ -32,13 +32,9 @@ struct GemmArgs {
     const int* need;                // table: [ntaps][n_out] source valid iff j >= need
     const int* stop_after; int t;   // early-out when t > *stop_after (decode loop); stop_after may be null
     int ksplit; long long split_stride;  // split-K over K-steps: grid.y = ksplit, partial s written at H + s*split_stride (bias in split 0)
-    const unsigned* wait_sig; unsigned wait_val; int* wait_err;     // optional: spin until *wait_sig >= wait_val before the first read (a producer on another stream)
     // conv_gemm_bf16x3 only: Wt split once into hi = bf16(w), lo = bf16(w - hi), same [Nalloc][ntaps*kc] layout (2-byte elements)
     const void* Wh; const void* Wl;
-    const void* W1; const void* W2; const void* W3;       // conv_gemm_bf16x6: Wt as three bf16 terms w = w1 + w2 + w3 (24 significant bits: exact)
 };
-void launch_conv_gemm_bf16x6(const GemmArgs& a, hipStream_t s);       // table rows, split-K; fp32-equivalent (see oph_kernels.hip)
-void launch_split_bf16_3(const float* w, void* p1, void* p2, void* p3, size_t n, hipStream_t s);
 void launch_conv_gemm_pair(const GemmArgs& a0, const GemmArgs& a1, int prec, hipStream_t s);   // two contractions (same M, N, no split-K) in one launch
 void launch_split_bf16(const float* w, void* hi, void* lo, size_t n, hipStream_t s);      // hi/lo planes of n floats
 
@@ -57,6 +53,9 @@ struct EpiArgs {
     const float* spk_table; const int* spk_ids; int spk_dim; int spk_T; // utterance of row m: spk_T>0 ? m / spk_T : m % Bpad
     const int* stop_after; int t;
     int nonorm;                     // hp.norm None: the "LayerNorm" is the identity (mean 0, rstd 1; gamma/beta = 1/0 buffers)
+    // optional output row mapping (streamed SSRN chunks): the M rows are [B][out_T]; row (b, u) with keep_lo <= u < keep_hi is
+    // stored at output row b * out_bs + out_t0 + u, the others are skipped.  out_T == 0: row m -> output row m
+    int out_T; int keep_lo, keep_hi; long long out_bs; int out_t0;
     // learned channel contributions (modules.py:78-88): per-speaker channel gate sigmoid(lcc_embed[spk]) stored as a
     // table [nspeakers][C]; conv: y = gate * act(LN(h)) (a final squash sigmoid comes after the gate); hc: H2 *= gate
     const float* lcc; const int* lcc_ids; int lcc_T;   // utterance of row m: lcc_T > 0 ? m / lcc_T : m % Bpad
@@ -65,8 +64,6 @@ struct EpiArgs {
     // workgroup holding such rows waits for its stores, adds 1 to *done_count, and the one that makes it done_target
     // raises *done_sig to done_val
     unsigned* done_sig; unsigned done_val; unsigned* done_count; unsigned done_target; int coh0, coh1;
-    int coh_all;                    // every row is stored write-through and every workgroup arrives: consumers on ANOTHER stream may
-                                    // then read the level with plain loads once the word is up (two-stream cone)
 };
 
 // ---- fused M=16 decode layer (prologue = previous layer's LN/gate, then 16xK . KxN slice)
@@ -280,28 +277,6 @@ struct LoopArgs {
 };
 void launch_dec_loop(const LoopArgs& a, int col_slices, int rows_per_group, int kmax, hipStream_t s);   // rows_per_group 4 or 8
 int dec_loop_blocks_per_cu(int rows_per_group, int kmax);
-void launch_sig_wait(const unsigned* sig, unsigned want, int* err, long long* stamp, hipStream_t s);     // one wave spins until *sig >= want
-void launch_sig_set(unsigned* sig, unsigned value, int nwords, long long* stamp, hipStream_t s);      // words sig[16 i], i < nwords                     // *sig = max(*sig, value)
-
-// ---- one AudioDec cone layer as one launch: conv GEMM + LayerNorm (+ gate + residual) epilogue (oph_cone.hip)
-struct ConeGemmArgs {
-    const float* X; int ldx;            // input rows
-    const float* Wt; int ldw;           // packed weights [Nalloc][ntaps*kc]; highway layers: columns interleaved 16 H1 | 16 H2 per tile
-    const float* bias;                  // in the same column order
-    int M, NT, kc, ntaps;               // output rows; 32-column tiles; per-tap K; taps
-    int dense;                          // 1: source row = output row (k=1 layers); 0: table-mapped rows (highway layers)
-    int Bpad, n_out, j; const int* tab; const int* need;      // as GemmArgs mode 1
-    int hc;                             // 1 highway layer, 0 conv layer
-    int C;                              // output channels
-    const float *g1, *b1, *g2, *b2; int act; int nonorm;
-    const float* Xres; int ldres; const int* restab;           // highway residual rows: restab[m / Bpad] * Bpad + m % Bpad
-    float* Y; int ldy;                  // output rows
-    const float* spk_table; const int* spk_ids; int spk_dim;   // conv layer: speaker embedding appended after the C channels
-    unsigned long long* stats; unsigned epoch;                 // row-statistics granules [row block][NT][64][4]
-    const int* stop_after; int t; int* err;
-};
-void launch_cone_gemm(const ConeGemmArgs& a, int small_rows, hipStream_t s);  // small_rows: 32-row tiles (few-row layers), else 64-row tiles
-int cone_gemm_tile_cols();
 
 // launchers (oph_kernels.hip)
 void launch_row_chain(const RowChainArgs& a, hipStream_t s);
@@ -313,6 +288,7 @@ void launch_dec_layer(const DecArgs& a, int Npad16, hipStream_t s);
 void launch_attn_rows(const AttnRowsArgs& a, hipStream_t s);
 void launch_embed(const int* ids, long long n, const float* table, int units, float* out, int ldo, hipStream_t s);
 void launch_pad_rows(const float* src, int lds_, float* dst, int ldd, long long rows, int C, hipStream_t s);
+void launch_copy_rows_strided(const float* src, long long src_bs, int ld, float* dst, int B, int T, int C, hipStream_t s);   // dst[b*T + t][:C] = src[b*src_bs + t*ld ..]
 void launch_fill_int(int* p, int v, int n, hipStream_t s);
 void launch_spk_append_rows(float* out, int ldo, long long rows, int T, int col0, const float* table, const int* ids, int dim, hipStream_t s);
 

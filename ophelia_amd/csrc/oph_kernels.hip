@@ -27,24 +27,6 @@ namespace oph {
 // =====================================================================================
 template <int BM, int BN>
 static __device__ __forceinline__ void conv_gemm_f32_body(const GemmArgs& a) {
-    if (a.wait_sig) {       // the rows this launch gathers are produced by a launch on another stream (two-stream cone)
-        if (threadIdx.x == 0) {
-            long long t0 = 0;
-            for (int it = 0; (int)(__hip_atomic_load(a.wait_sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.wait_val) < 0; ++it) {
-                __builtin_amdgcn_s_sleep(8);
-                if ((it & 255) == 255) {
-                    const long long now = wall_clock64();
-                    if (t0 == 0) t0 = now;
-                    if (now - t0 > 200000000LL || __hip_atomic_load(a.wait_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                        __hip_atomic_store(a.wait_err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-    }
     if (stopped(a.stop_after, a.t)) return;
     constexpr int BK = 32, LD = 36;
     constexpr int AR = BM / 32, BR = BN / 32;     // float4 staging loads per thread
@@ -459,178 +441,6 @@ void launch_conv_gemm_pair(const GemmArgs& a0, const GemmArgs& a1, int prec, hip
     if (conv_gemm_tile_m(a0.M, a0.N) == 128) launch_conv_gemm_pair_t<128, 128>(a0, a1, prec, s);
     else launch_conv_gemm_pair_t<64, 64>(a0, a1, prec, s);
 }
-// =====================================================================================
-// conv_gemm_bf16x6: fp32-EQUIVALENT contraction on the bf16 MFMA, for the decoder cone's many-row levels (table rows,
-// split-K).  Every fp32 operand is written as three bf16 terms x = x1 + x2 + x3 (8 + 8 + 8 significant bits: the sum
-// reproduces x to 2^-24 |x|, i.e. exactly up to fp32's own rounding), and the product keeps the six term pairs whose
-// weight is >= 2^-16:   x.w = x1w1 + (x1w2 + x2w1) + (x1w3 + x2w2 + x3w1)  [dropped: <= 3 * 2^-24 |x.w|].
-// Each bf16 x bf16 product is exact in the fp32 accumulator, so the result differs from an fp32 MFMA contraction by
-// accumulation order and a few ulp per product -- the same class of difference as between the fp32 decode flavours
-// (tests/test_gpu_decode_modes.py).  Six MFMAs at 16x the fp32 rate: 2.7x less MFMA time than conv_gemm_f32, which is
-// MFMA-pipe-bound on these levels (profiles/r02_cone_pmc.sh: pipe 63 % busy, 58 % of wave cycles stalled on issue).
-// The small-weight pairs go to their own accumulator (added last).  Weights pre-split at load; their planes arrive by
-// global_load_lds (3-slot ring); activations are split while staged.  64x64 tiles, 4 waves of 32x32.
-// =====================================================================================
-__device__ __forceinline__ void split_bf16_3(const f32x4& x, bf16x4& p1, bf16x4& p2, bf16x4& p3) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const __bf16 h1 = (__bf16)x[e];
-        const float r1 = x[e] - (float)h1;
-        const __bf16 h2 = (__bf16)r1;
-        p1[e] = h1; p2[e] = h2; p3[e] = (__bf16)(r1 - (float)h2);
-    }
-}
-__global__ void split_bf16_3_kernel(const float* w, __bf16* p1, __bf16* p2, __bf16* p3, size_t n) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) {
-        const float x = w[i]; const __bf16 h1 = (__bf16)x; const float r1 = x - (float)h1; const __bf16 h2 = (__bf16)r1;
-        p1[i] = h1; p2[i] = h2; p3[i] = (__bf16)(r1 - (float)h2);
-    }
-}
-void launch_split_bf16_3(const float* w, void* p1, void* p2, void* p3, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(split_bf16_3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, (__bf16*)p1, (__bf16*)p2, (__bf16*)p3, n);
-}
-
-__global__ __launch_bounds__(256, 2) void conv_gemm_bf16x6(GemmArgs a) {
-    if (stopped(a.stop_after, a.t)) return;
-    constexpr int BM = 64, BN = 64, BK = 32, LDH = 32, AR = BM / 32, NP = 3;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __bf16* Ap = (__bf16*)smem;                    // [NP][2][BM*LDH]
-    __bf16* Bp = Ap + NP * 2 * BM * LDH;           // [NP][3][BN*LDH]
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
-    const int ntiles = MT * NT;
-    int id;
-    {
-        const int bid = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    constexpr int GM = 8;
-    const int width = GM * NT, g = id / width, first_m = g * GM;
-    const int gsz = min(MT - first_m, GM);
-    const int tm = first_m + (id % width) % gsz, tn = (id % width) / gsz;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int lrow = tid >> 3, kq = tid & 7;
-    int srow[3][AR];                               // source row per tap (-1 = zeros)
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-        const int m = m0 + lrow + 32 * i;
-#pragma unroll
-        for (int tap = 0; tap < 3; ++tap) {
-            srow[tap][i] = -1;
-            if (m < a.M && tap < a.ntaps) {
-                if (a.mode == 1) {
-                    const int ip = m / a.Bpad, b = m - ip * a.Bpad;
-                    if (a.j >= a.need[tap * a.n_out + ip]) srow[tap][i] = a.tab[tap * a.n_out + ip] * a.Bpad + b;
-                } else {
-                    const int t = m % a.T, tt = t + a.off[tap];
-                    if (tt >= 0 && tt < a.T) srow[tap][i] = m + a.off[tap];
-                }
-            }
-        }
-    }
-    const int kpt = a.kc / BK, nk_all = a.ntaps * kpt;
-    const int ksplit = a.ksplit > 1 ? a.ksplit : 1, split = blockIdx.y;
-    const int ks0 = split * nk_all / ksplit, nk = (split + 1) * nk_all / ksplit - ks0;
-    const __bf16* Wp[NP] = {(const __bf16*)a.W1, (const __bf16*)a.W2, (const __bf16*)a.W3};
-    f32x4 ra0[AR], ra1[AR];
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    auto dma_b = [&](int sl) {                     // the three weight planes of K-step sl -> ring slot sl % 3
-        const int s = ks0 + sl;
-        const int tap = s / kpt, kb = (s - tap * kpt) * BK, slot = sl % 3;
-        const int row = tid >> 2, pos = tid & 3;   // BN * 4 = 256 chunks: one per thread and plane
-        const size_t o = (size_t)(n0 + row) * a.ldw + tap * a.kc + kb + ((pos ^ ((row >> 2) & 3)) << 3);
-        const int base = slot * BN * LDH + (w * 64) * 8;
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wp[p] + o),
-                                             (__attribute__((address_space(3))) void*)(Bp + p * 3 * BN * LDH + base), 16, 0, 0);
-    };
-    auto load_global = [&](int sl, f32x4 (&ra)[AR]) {
-        const int s = ks0 + sl;
-        const int tap = s / kpt, ko = (s - tap * kpt) * BK + kq * 4;
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            const int src = tap == 0 ? srow[0][i] : (tap == 1 ? srow[1][i] : srow[2][i]);
-            ra[i] = src >= 0 ? *(const f32x4*)(a.X + (size_t)src * a.ldx + ko) : zero4;
-        }
-    };
-    auto store_lds = [&](int buf, const f32x4 (&ra)[AR]) {
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            bf16x4 p1, p2, p3;
-            split_bf16_3(ra[i], p1, p2, p3);
-            const int o = buf * BM * LDH + (lrow + 32 * i) * LDH + (((kq >> 1) ^ ((lrow >> 2) & 3)) << 3) + ((kq & 1) << 2);
-            *(bf16x4*)(Ap + o) = p1;
-            *(bf16x4*)(Ap + 2 * BM * LDH + o) = p2;
-            *(bf16x4*)(Ap + 4 * BM * LDH + o) = p3;
-        }
-    };
-    f32x16 accS, accM;                             // small-weight pairs / the rest
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { accS[e] = 0.f; accM[e] = 0.f; }
-    const int wr = w >> 1, wc = w & 1, r32 = lane & 31, kh = lane >> 5;
-    auto compute = [&](int buf, int bslot) {
-        const int ao = buf * BM * LDH + (wr * 32 + r32) * LDH;
-        const int bo = bslot * BN * LDH + (wc * 32 + r32) * LDH;
-        const int swr = (r32 >> 2) & 3;
-#pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
-            const int ch = ((kc * 2 + kh) ^ swr) << 3;
-            bf16x8 x1 = *(const bf16x8*)(Ap + ao + ch), x2 = *(const bf16x8*)(Ap + 2 * BM * LDH + ao + ch), x3 = *(const bf16x8*)(Ap + 4 * BM * LDH + ao + ch);
-            bf16x8 w1 = *(const bf16x8*)(Bp + bo + ch), w2 = *(const bf16x8*)(Bp + 3 * BN * LDH + bo + ch), w3 = *(const bf16x8*)(Bp + 6 * BN * LDH + bo + ch);
-            accS = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, w1, accS, 0, 0, 0);
-            accM = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, w1, accM, 0, 0, 0);
-            accS = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, w2, accS, 0, 0, 0);
-            accM = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w2, accM, 0, 0, 0);
-            accS = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w3, accS, 0, 0, 0);
-            accM = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w1, accM, 0, 0, 0);
-        }
-    };
-    auto wait_older = [&](bool issued_now) {
-        if (issued_now) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AR + NP) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    load_global(0, ra0);
-    dma_b(0);
-    if (nk > 1) { load_global(1, ra1); dma_b(1); }
-    store_lds(0, ra0);
-    wait_older(nk > 1);
-    __syncthreads();
-    for (int s = 0; s < nk; s += 2) {
-        if (s + 2 < nk) { load_global(s + 2, ra0); dma_b(s + 2); }
-        compute(0, s % 3);
-        if (s + 1 < nk) store_lds(1, ra1);
-        wait_older(s + 2 < nk);
-        __syncthreads();
-        if (s + 1 >= nk) break;
-        if (s + 3 < nk) { load_global(s + 3, ra1); dma_b(s + 3); }
-        compute(1, (s + 1) % 3);
-        if (s + 2 < nk) store_lds(0, ra0);
-        wait_older(s + 3 < nk);
-        __syncthreads();
-    }
-    {
-        const int col = n0 + wc * 32 + r32;
-        const float bv = split == 0 ? a.bias[col] : 0.f;
-        float* Hs = a.H + (size_t)split * a.split_stride;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = m0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-            if (row < a.M) Hs[(size_t)row * a.ldh + col] = (accM[e] + accS[e]) + bv;
-        }
-    }
-}
-void launch_conv_gemm_bf16x6(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set[64] = {false};
-    const size_t lds = (size_t)(3 * 2 * 64 * 32 + 3 * 3 * 64 * 32) * 2;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!attr_set[dev & 63]) { (void)hipFuncSetAttribute((const void*)conv_gemm_bf16x6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set[dev & 63] = true; }
-    const int MT = (a.M + 63) / 64, NT = (a.N + 63) / 64;
-    hipLaunchKernelGGL(conv_gemm_bf16x6, dim3(MT * NT, a.ksplit > 1 ? a.ksplit : 1), dim3(256), lds, s, a);
-}
-
 template <int BM, int BN>
 static void launch_conv_gemm_bf16x3_t(const GemmArgs& a, hipStream_t s) {
     static bool attr_set[64] = {false};
@@ -698,6 +508,12 @@ __device__ __forceinline__ void ln_rows_body(const EpiArgs& a) {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= a.M) return;
+    size_t orow = (size_t)m;               // output row
+    if (a.out_T > 0) {
+        const int b = m / a.out_T, u = m - b * a.out_T;
+        if (u < a.keep_lo || u >= a.keep_hi) return;         // a margin row of a streamed chunk: its value is not valid
+        orow = (size_t)b * (size_t)a.out_bs + (size_t)(a.out_t0 + u);
+    }
     const int C = a.C;
     const float* h = a.H + (size_t)m * a.ldh;
     f32x4 x[NV];
@@ -761,10 +577,10 @@ __device__ __forceinline__ void ln_rows_body(const EpiArgs& a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) x[v][e] = fast_act(x[v][e], a.act);
     }
-    float* y = a.Y + (size_t)m * a.ldy;
+    float* y = a.Y + orow * a.ldy;
     const bool vec_ok = (a.ldy & 3) == 0;
     const int pos = a.done_sig ? m / a.Bpad : -1;
-    const bool coh = a.done_sig && (a.coh_all || pos == a.coh0 || pos == a.coh1);      // rows a running dec_loop (or another stream) reads
+    const bool coh = a.done_sig && (pos == a.coh0 || pos == a.coh1);      // rows a running dec_loop reads
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const int c = (v * 64 + lane) * 4;
@@ -792,7 +608,7 @@ template <int NV>
 __global__ __launch_bounds__(256) void ln_rows(EpiArgs a) {
     ln_rows_body<NV>(a);
     const int pos_b = a.done_sig ? (int)(blockIdx.x * 4) / a.Bpad : -1;       // Bpad % 4 == 0: a workgroup's 4 rows share a position
-    if (a.done_sig && (a.coh_all || pos_b == a.coh0 || pos_b == a.coh1)) {
+    if (a.done_sig && (pos_b == a.coh0 || pos_b == a.coh1)) {
         // this launch writes a level of a cone: once the tap rows have left (write-through stores, no fence), one lane
         // raises the word the decoder loop kernel polls for that level (instead of a signalling kernel behind the cone)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1838,6 +1654,17 @@ __global__ void pad_rows_k(const float* src, int lds_, float* dst, int ldd, long
     const long long r = i / ldd;
     const int c = (int)(i - r * ldd);
     dst[i] = c < C ? src[r * lds_ + c] : 0.f;
+}
+__global__ void copy_rows_strided_k(const float* src, long long src_bs, int ld, float* dst, int B, int T, int C4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * T * C4) return;
+    const int c = (int)(i % C4); const long long r = i / C4; const int t = (int)(r % T), b = (int)(r / T);
+    *(f32x4*)(dst + r * ld + 4 * c) = *(const f32x4*)(src + b * src_bs + (long long)t * ld + 4 * c);
+}
+// a [B][T] window of time-strided rows as one dense batch (ld = row stride of both, C a multiple of 4)
+void launch_copy_rows_strided(const float* src, long long src_bs, int ld, float* dst, int B, int T, int C, hipStream_t s) {
+    const long long n = (long long)B * T * (C / 4);
+    hipLaunchKernelGGL(copy_rows_strided_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, src_bs, ld, dst, B, T, C / 4);
 }
 void launch_pad_rows(const float* src, int lds_, float* dst, int ldd, long long rows, int C, hipStream_t s) {
     const long long tot = rows * ldd;

@@ -2,10 +2,65 @@
 role of the reference's (graph, session) pair (synthesize.py:511-537): built from `hp`,
 loaded with variables by TF name, then driven through encode_text / text2mel / ssrn."""
 import ctypes as C
+import weakref
 
 import numpy as np
 
 from . import _lib
+
+
+class _PinnedBlock(object):
+    """One pinned host buffer (oph_host_alloc) exposed through the array interface; it goes back to the pool when the
+    last array viewing it is collected."""
+
+    def __init__(self, pool, ptr, nbytes):
+        self.pool, self.ptr, self.nbytes = pool, ptr, nbytes
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            self.pool._release(self.nbytes, self.ptr)
+        except Exception:
+            pass
+
+
+class PinnedPool(object):
+    """Result arrays in pinned host memory: device-to-host copies into them are asynchronous DMA at the link's rate (a
+    pageable NumPy array is copied through a bounce buffer, several times slower for the 52 MB of a batch's magnitudes).
+    Buffers are recycled by size; at most `keep` idle ones per size stay allocated."""
+
+    def __init__(self, keep=3):
+        self.keep = keep
+        self.idle = {}
+
+    def empty(self, shape, dtype=np.float32):
+        dtype = np.dtype(dtype)
+        nbytes = max(1, int(np.prod(shape)) * dtype.itemsize)
+        lst = self.idle.get(nbytes)
+        if lst:
+            ptr = lst.pop()
+        else:
+            out = C.c_void_p()
+            if _lib.load().oph_host_alloc(nbytes, C.byref(out)) != 0 or not out.value:
+                return np.empty(shape, dtype)            # no pinned memory left: an ordinary array works everywhere, slower
+            ptr = out.value
+        block = _PinnedBlock(self, ptr, nbytes)
+        return np.asarray(block)[:int(np.prod(shape)) * dtype.itemsize].view(dtype).reshape(shape)
+
+    def _release(self, nbytes, ptr):
+        lst = self.idle.setdefault(nbytes, [])
+        if len(lst) < self.keep:
+            lst.append(ptr)
+        else:
+            _lib.load().oph_host_free(ptr)
+
+    def drain(self):
+        for lst in self.idle.values():
+            while lst:
+                _lib.load().oph_host_free(lst.pop())
+
+
+PINNED = PinnedPool()
 
 
 def dims_from_hp(hp, max_N=None, max_T=None):
@@ -60,6 +115,28 @@ class Engine(object):
                                                     _lib.FLAG_SPK_TEXT_ENCODER_TOWARDS_END | _lib.FLAG_LCC |
                                                     _lib.FLAG_SPK_AUDIO_ENCODER_INPUT))
         self.B = 0
+        self._kv_token = None          # (K, V) arrays of the last encode_text whose values are still in HBM
+        self._y_token = None           # Y array of the last decode whose values are still in HBM
+
+    # Residency between the three session calls (include/ophelia_hip.h): the arrays a call returns are read-only and the
+    # engine remembers them; handing the very same (still read-only) arrays to the next call skips the upload -- K,V never
+    # leave HBM, SSRN has been streaming over Y while the decoder ran.  Any other array (a copy, a modified or a made-writeable
+    # one) is uploaded and used as it is.
+    @staticmethod
+    def _seal(a):
+        a.flags.writeable = False
+        return a
+
+    def _is_resident(self, token, *arrays):
+        if token is None or len(token) != len(arrays):
+            return False
+        for ref, a in zip(token, arrays):
+            if ref() is not a or a.flags.writeable:
+                return False
+        return True
+
+    def is_resident_mel(self, Y):
+        return isinstance(Y, np.ndarray) and self._is_resident(self._y_token, Y)
 
     # -- plumbing
     def _chk(self, rc):
@@ -110,25 +187,37 @@ class Engine(object):
         L = np.ascontiguousarray(L, dtype=np.int32)
         B, N = L.shape
         assert N == self.dims.max_N, (N, self.dims.max_N)
-        K = np.empty((B, N, self.dims.d), np.float32)
-        V = np.empty_like(K)
+        K = PINNED.empty((B, N, self.dims.d))
+        V = PINNED.empty((B, N, self.dims.d))
         s, sp = self._spk(speaker_data, B)
+        self._kv_token = self._y_token = None
         self._chk(self.lib.oph_encode_text(self._h, _lib.iptr(L), sp, B, _lib.fptr(K), _lib.fptr(V)))
+        self._seal(K), self._seal(V)
+        self._kv_token = (weakref.ref(K), weakref.ref(V))
+        self.B = B
         return K, V
 
     def text2mel(self, K, V, ends, speaker_data=None, stop_mode=_lib.STOP_REFERENCE):
-        K = np.ascontiguousarray(K, dtype=np.float32)
-        V = np.ascontiguousarray(V, dtype=np.float32)
+        resident = isinstance(K, np.ndarray) and isinstance(V, np.ndarray) and self._is_resident(self._kv_token, K, V)
+        if not resident:
+            K = np.ascontiguousarray(K, dtype=np.float32)
+            V = np.ascontiguousarray(V, dtype=np.float32)
         B = K.shape[0]
         assert K.shape == V.shape == (B, self.dims.max_N, self.dims.d)
         ends = np.ascontiguousarray(ends, dtype=np.int32)
-        Y = np.empty((B, self.dims.max_T, self.dims.n_mels), np.float32)
+        Y = PINNED.empty((B, self.dims.max_T, self.dims.n_mels))
         t_ends = np.empty((B,), np.int32)
-        al = np.empty((B, self.dims.max_N, self.dims.max_T), np.float32)
+        al = PINNED.empty((B, self.dims.max_N, self.dims.max_T))
         steps = C.c_int32()
         s, sp = self._spk(speaker_data, B)
-        self._chk(self.lib.oph_text2mel(self._h, _lib.fptr(K), _lib.fptr(V), _lib.iptr(ends), sp, B, int(stop_mode),
+        self._y_token = None
+        if not resident:
+            self._kv_token = None
+        self._chk(self.lib.oph_text2mel(self._h, None if resident else _lib.fptr(K), None if resident else _lib.fptr(V),
+                                        _lib.iptr(ends), sp, B, int(stop_mode),
                                         _lib.fptr(Y), _lib.iptr(t_ends), _lib.fptr(al), C.byref(steps)))
+        self._y_token = (weakref.ref(self._seal(Y)),)
+        self.B = B
         return Y, t_ends, al, steps.value
 
     def text2mel_durations(self, K, V, durations, speaker_data=None, n_steps=0):
@@ -145,13 +234,16 @@ class Engine(object):
             Kp = _lib.fptr(K)
         D = np.ascontiguousarray(durations, dtype=np.float32)
         assert D.shape == (B, self.dims.max_T, self.dims.max_N), D.shape
-        Y = np.empty((B, self.dims.max_T, self.dims.n_mels), np.float32)
+        Y = PINNED.empty((B, self.dims.max_T, self.dims.n_mels))
         t_ends = np.empty((B,), np.int32)
-        al = np.empty((B, self.dims.max_N, self.dims.max_T), np.float32)
+        al = PINNED.empty((B, self.dims.max_N, self.dims.max_T))
         steps = C.c_int32()
         s, sp = self._spk(speaker_data, B)
+        self._kv_token = self._y_token = None
         self._chk(self.lib.oph_text2mel_durations(self._h, Kp, _lib.fptr(V), _lib.fptr(D), sp, B, int(n_steps),
                                                   _lib.fptr(Y), _lib.iptr(t_ends), _lib.fptr(al), C.byref(steps)))
+        self._y_token = (weakref.ref(self._seal(Y)),)
+        self.B = B
         return Y, t_ends, al, steps.value
 
     def text2mel_graph(self, K, V, mels, prev_max_attentions, ends=None, speaker_data=None):
@@ -175,18 +267,44 @@ class Engine(object):
                    Y_logits=np.empty((B, d.max_T, d.n_mels), np.float32), Y=np.empty((B, d.max_T, d.n_mels), np.float32),
                    alignments=np.empty((B, d.max_N, d.max_T), np.float32), max_attentions=np.empty((B, d.max_T), np.int32))
         s, sp = self._spk(speaker_data, B)
+        self._kv_token = self._y_token = None
         self._chk(self.lib.oph_text2mel_graph(self._h, _lib.fptr(K), _lib.fptr(V), _lib.fptr(mels), _lib.iptr(pm), ep, sp, B,
                                               _lib.fptr(out["Q"]), _lib.fptr(out["R"]), _lib.fptr(out["Y_logits"]),
                                               _lib.fptr(out["Y"]), _lib.fptr(out["alignments"]), _lib.iptr(out["max_attentions"])))
         return out
 
     def ssrn(self, Y):
+        resident = self.is_resident_mel(Y)
+        if not resident:
+            Y = np.ascontiguousarray(Y, dtype=np.float32)
+        B, T, nm = Y.shape
+        assert nm == self.dims.n_mels
+        Z = PINNED.empty((B, T * self.dims.r, self.dims.full_dim))
+        if not resident:
+            self._kv_token = self._y_token = None        # the batch workspaces are reused
+        self._chk(self.lib.oph_ssrn(self._h, None if resident else _lib.fptr(Y), B, T, _lib.fptr(Z)))
+        return Z
+
+    def ssrn_logits(self, Y):
+        """(Z, Z_logits) = the SSRN graph's two fetchable tensors (networks.py:527-534)."""
         Y = np.ascontiguousarray(Y, dtype=np.float32)
         B, T, nm = Y.shape
         assert nm == self.dims.n_mels
-        Z = np.empty((B, T * self.dims.r, self.dims.full_dim), np.float32)
-        self._chk(self.lib.oph_ssrn(self._h, _lib.fptr(Y), B, T, _lib.fptr(Z)))
-        return Z
+        Z = PINNED.empty((B, T * self.dims.r, self.dims.full_dim))
+        Zl = PINNED.empty((B, T * self.dims.r, self.dims.full_dim))
+        self._kv_token = self._y_token = None
+        self._chk(self.lib.oph_ssrn_logits(self._h, _lib.fptr(Y), B, T, _lib.fptr(Z), _lib.fptr(Zl)))
+        return Z, Zl
+
+    def counters(self):
+        """What the pipeline did since the handle was created (oph_get_counters)."""
+        v = (C.c_int64 * 6)()
+        self._chk(self.lib.oph_get_counters(self._h, v, 6))
+        return dict(zip(("textenc", "preenc_used", "chunks_streamed", "loop_decodes", "loop_fallbacks", "tile_resumes"), [int(x) for x in v]))
+
+    def set_streaming(self, on=True):
+        """SSRN over the frames a running decode has already produced (default on); off: SSRN only when asked for."""
+        self._chk(self.lib.oph_set_streaming(self._h, int(bool(on))))
 
     # -- device-resident pipeline
     def stage_text(self, L, ends, speaker_data=None):
@@ -194,14 +312,40 @@ class Engine(object):
         ends = np.ascontiguousarray(ends, dtype=np.int32)
         B = L.shape[0]
         s, sp = self._spk(speaker_data, B)
+        self._kv_token = self._y_token = None
         self._chk(self.lib.oph_stage_text(self._h, _lib.iptr(L), _lib.iptr(ends), sp, B))
         self.B = B
+
+    def stage_text_next(self, L, ends, speaker_data=None):
+        """The text of the batch after the staged / running one (second text slot): the next run_resident / run_host
+        switches to it, and the decode before that pre-encodes it on the SSRN partition."""
+        L = np.ascontiguousarray(L, dtype=np.int32)
+        ends = np.ascontiguousarray(ends, dtype=np.int32)
+        s, sp = self._spk(speaker_data, L.shape[0])
+        self._chk(self.lib.oph_stage_text_next(self._h, _lib.iptr(L), _lib.iptr(ends), sp, L.shape[0]))
+
+    def run_host(self, stop_mode=_lib.STOP_REFERENCE, want_kv=False):
+        """The staged batch host -> host in one call (oph_run_host): returns a dict with Y, t_ends, alignments, Z, steps
+        (and K, V if asked for) in pinned arrays; the copies run under the decode."""
+        d, B = self.dims, self.B
+        out = dict(Y=PINNED.empty((B, d.max_T, d.n_mels)), t_ends=PINNED.empty((B,), np.int32),
+                   alignments=PINNED.empty((B, d.max_N, d.max_T)), Z=PINNED.empty((B, d.max_T * d.r, d.full_dim)))
+        if want_kv:
+            out["K"], out["V"] = PINNED.empty((B, d.max_N, d.d)), PINNED.empty((B, d.max_N, d.d))
+        steps = C.c_int32()
+        self._kv_token = self._y_token = None
+        self._chk(self.lib.oph_run_host(self._h, int(stop_mode), _lib.fptr(out["K"]) if want_kv else None,
+                                        _lib.fptr(out["V"]) if want_kv else None, _lib.fptr(out["Y"]), _lib.iptr(out["t_ends"]),
+                                        _lib.fptr(out["alignments"]), _lib.fptr(out["Z"]), C.byref(steps)))
+        out["steps"] = steps.value
+        return out
 
     def run_resident(self, stop_mode=_lib.STOP_NEVER, run_ssrn=True, pipelined=False):
         """encode -> decode -> SSRN on the staged batch, everything staying in HBM.  pipelined=True queues
         this batch's SSRN on its own CU partition without joining it, so the next call overlaps it."""
         steps = C.c_int32()
         mode = 2 if (run_ssrn and pipelined) else int(bool(run_ssrn))
+        self._kv_token = self._y_token = None
         self._chk(self.lib.oph_run_resident(self._h, int(stop_mode), mode, C.byref(steps)))
         return steps.value
 
@@ -220,14 +364,15 @@ class Engine(object):
         return K, V
 
     def fetch_mel(self):
-        Y = np.empty((self.B, self.dims.max_T, self.dims.n_mels), np.float32)
+        Y = PINNED.empty((self.B, self.dims.max_T, self.dims.n_mels))
         t_ends = np.empty((self.B,), np.int32)
-        al = np.empty((self.B, self.dims.max_N, self.dims.max_T), np.float32)
+        al = PINNED.empty((self.B, self.dims.max_N, self.dims.max_T))
         self._chk(self.lib.oph_fetch_mel(self._h, _lib.fptr(Y), _lib.iptr(t_ends), _lib.fptr(al)))
+        self._y_token = (weakref.ref(self._seal(Y)),)       # these ARE the frames in HBM: ssrn(Y) may continue from them
         return Y, t_ends, al
 
     def fetch_mag(self):
-        Z = np.empty((self.B, self.dims.max_T * self.dims.r, self.dims.full_dim), np.float32)
+        Z = PINNED.empty((self.B, self.dims.max_T * self.dims.r, self.dims.full_dim))
         self._chk(self.lib.oph_fetch_mag(self._h, _lib.fptr(Z)))
         return Z
 

@@ -91,7 +91,10 @@ def synth_codedtext2mel(hp, K, V, ends, g, sess, speaker_data=None, duration_dat
         Y, t_ends, alignments, _ = eng.text2mel_durations(K, V, duration_data, speaker_data, n_steps=n_steps)
         return (Y, [int(t) for t in t_ends], alignments)
     if not dist_on:
-        Y, t_ends, alignments, _ = eng.text2mel(K, V, ends, speaker_data, _lib.STOP_REFERENCE)
+        # hp.synth_stop_mode (this package's extension, default 0 = the reference's break rule): 1 = fixed length, every
+        # utterance runs max_T steps -- the configuration bench.py quotes its metric on
+        stop_mode = int(getattr(hp, "synth_stop_mode", _lib.STOP_REFERENCE))
+        Y, t_ends, alignments, _ = eng.text2mel(K, V, ends, speaker_data, stop_mode)
         return (Y, [int(t) for t in t_ends], alignments)
     # sharded batch: reproduce the batch-coupled break (synthesize.py:225-228) across ranks
     state = {}
@@ -121,12 +124,17 @@ def synth_text2mel(hp, L, g, sess, speaker_data=None, duration_data=None, labels
 
 
 def synth_mel2mag(hp, Y, g, sess, batchsize=128):
+    eng = sess.ensure_ready()
+    if getattr(eng, "is_resident_mel", lambda y: False)(Y):
+        # the very array synth_codedtext2mel returned: its frames are still in HBM and SSRN has been running over them
+        # while the decoder produced the later ones.  (The reference splits into chunks of `batchsize` utterances only to
+        # bound TF's memory; utterances are independent, the result is the same array.)
+        return eng.ssrn(Y)
     if batchsize > 0:
         nbatches = max(1, len(Y) // batchsize)       # the reference's Python-2 integer division
         batches = np.array_split(Y, nbatches)
     else:
         batches = [Y]
-    eng = sess.ensure_ready()
     return np.concatenate([eng.ssrn(Y_batch) for Y_batch in batches])
 
 

@@ -1,0 +1,35 @@
+"""bench.py's multi-rank form on the one GPU of the test box: `python bench.py --gpus 2` spawns its two ranks, which share
+GPU 0 (OPH_BENCH_SHARED_GPU=1: gloo instead of RCCL, which refuses two ranks per device).  What must hold on a real node
+too: the line reports both ranks, their per-rank step times, whole-job frames, and which cross-stream flavour ran."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_on_one_gpu():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OPH_STREAM_VALUE"):
+        env.pop(k, None)
+    env["OPH_BENCH_SHARED_GPU"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-extra-legs", "--no-cpu-baseline", "--no-vocoder", "--no-profile"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                     # rank 0 alone prints
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert len(out["rank_ms_per_step"]) == 2 and all(ms > 0 for ms in out["rank_ms_per_step"])
+    assert out["ms_per_step"] >= max(out["rank_ms_per_step"]) * 0.999          # the line is the MAX over ranks
+    cfg = out["config"]
+    assert cfg["global_utterances"] == 32 and cfg["frames_per_step"] == 32 * 200
+    assert abs(out["value"] - cfg["frames_per_step"] / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+    assert cfg["cross_stream_sync"] == "stream value operations"           # multi-rank runs select OPH_STREAM_VALUE
+    assert "all ranks on one GPU" in cfg["parallelism"]

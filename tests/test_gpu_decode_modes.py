@@ -1,6 +1,6 @@
 """Every decode flavour of the library must produce the same utterances: the whole-decode launch (default), two launches per
-step, one launch per layer, and the cone variants (no cone head, no fused small levels, fused cone GEMM).  The switches are
-read once per process, so each flavour runs in its own interpreter on the same seeded model and text; the parent compares
+step, one launch per layer, and the cone variants (no cone head, no fused small levels).  The switches are read when a
+handle is created; each flavour runs in its own interpreter on the same seeded model and text; the parent compares
 the mel frames, alignments, stop steps and the attention trace -- with the default flavour and with the oracle."""
 import json
 import os
@@ -29,7 +29,10 @@ K, V = eng.encode_text(L)
 Y, t_ends, al, steps = eng.text2mel(K, V, ends, stop_mode=stop_mode)
 Y2, t2, al2, steps2 = eng.text2mel(K, V, ends, stop_mode=stop_mode)         # a second decode on the same handle: state fully reset
 assert steps2 == steps and np.array_equal(Y2, Y) and np.array_equal(al2, al), "second decode differs from the first"
-np.savez(sys.argv[2], Y=Y, al=al, t_ends=np.asarray(t_ends), steps=steps, K=K, V=V, ends=ends)
+Z = eng.ssrn(Y2)                 # the resident frames: SSRN streamed under the decode (or not: loop_nostream, runs, layers)
+Z1 = eng.ssrn(np.array(Y2))      # a copy: uploaded, SSRN in one piece
+assert np.array_equal(Z, Z1), "streamed SSRN differs from the one-shot evaluation"
+np.savez(sys.argv[2], Y=Y, al=al, t_ends=np.asarray(t_ends), steps=steps, K=K, V=V, ends=ends, Zsum=Z.sum(axis=(1, 2)))
 eng.close()
 """
 
@@ -41,8 +44,7 @@ FLAVOURS = {
     "loop_nohead": {"OPH_NO_CONE_HEAD": "1"},
     "loop_nofc": {"OPH_CONE_FC_ROWS": "0"},
     "loop_fc256": {"OPH_CONE_FC_ROWS": "256", "OPH_CONE_FC_INSPLIT": "1"},
-    "loop_fusedcone": {"OPH_CONE_FUSED": "1"},
-    "loop_x6": {"OPH_CONE_X6": "1"},
+    "loop_nostream": {"OPH_NO_STREAM_SSRN": "1"},
     "loop_conebf16": {"OPH_CONE_BF16X3": "1"},
 }
 
@@ -54,7 +56,7 @@ TOL = {"loop_conebf16": 3e-4}
 def _run(tmp_path, name, env_extra, max_T, B, stop_mode):
     out = str(tmp_path / (name + ".npz"))
     env = dict(os.environ)
-    for k in ("OPH_DECODE", "OPH_RUN_ROWS", "OPH_NO_CONE_HEAD", "OPH_CONE_FC_ROWS", "OPH_CONE_FC_INSPLIT", "OPH_CONE_FUSED", "OPH_NO_CONE_X6", "OPH_CONE_X6", "OPH_CONE_BF16X3"):
+    for k in ("OPH_DECODE", "OPH_RUN_ROWS", "OPH_NO_CONE_HEAD", "OPH_CONE_FC_ROWS", "OPH_CONE_FC_INSPLIT", "OPH_NO_STREAM_SSRN", "OPH_CONE_BF16X3"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, "-c", CHILD, ROOT, out, str(max_T), str(B), str(stop_mode)], env=env,
@@ -80,6 +82,7 @@ def test_decode_flavours_agree(tmp_path, stop_mode, max_T, B):
         print("%-16s vs loop: max-abs Y %.2e align %.2e" % (name, ey, ea))
         tol = TOL.get(name, 2e-5)
         assert ey < tol and ea < tol, name
+        assert np.allclose(got["Zsum"], ref["Zsum"], rtol=1e-4), name
     # and the default flavour against the oracle (exact incremental algorithm) on the same K, V
     sys.path.insert(0, ROOT)
     from conftest import hp_from_snapshot
