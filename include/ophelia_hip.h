@@ -131,7 +131,7 @@ int oph_ssrn_logits(oph_handle* h, const float* Y, int B, int T, float* Z, float
 int oph_set_streaming(oph_handle* h, int on);
 /* What the pipeline did since oph_create, out[0..n): [0] TextEnc evaluations, [1] runs whose K,V had been pre-encoded under
  * the previous decode, [2] SSRN chunks launched while a decode was running, [3] whole-decode launches, [4] fall-backs from the
- * whole-decode launch to two launches per step, [5] tiles resumed to their batch's stop step. */
+ * whole-decode launch to two launches per step, [5] tiles resumed to their batch's stop step, [6] persistent cone launches. */
 int oph_get_counters(oph_handle* h, int64_t* out, int n);
 /* oph_text2mel_graph  replaces ONE sess.run([g.Y, g.max_attentions, g.alignments], feed) of the reference's loop
  *     (synthesize.py:172,181-183) and serves as the fetch surface for the graph tensors of architectures.py:188-239:

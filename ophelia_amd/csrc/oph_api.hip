@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <ctime>
 #include <climits>
 #include <cstdarg>
 #include <cstdio>
@@ -66,6 +67,7 @@ struct Layer {
     float *Wt2 = nullptr;                        // convT odd phase (tap x[t])
     float *Wkn = nullptr; int ldn = 0;           // k=1 layers with N<=256: [kc][ldn] n-contiguous copy for row_chain
     void *Wh = nullptr, *Wl = nullptr, *Wh2 = nullptr, *Wl2 = nullptr;   // SSRN layers: Wt / Wt2 split into hi + lo bf16 planes (conv_gemm_bf16x3)
+    float* Wsw_cone = nullptr;                   // AudioDec highway layers: kernel in cone_loop's fragment order (oph_coneloop.hip)
     float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
 };
 
@@ -94,7 +96,7 @@ struct Options {
     int loop_dbg = 0;                // OPH_LOOP_DBG: ablation bits of dec_loop (results are wrong when set, except 16)
     int cu_dec = 0, cu_cone = 0;     // OPH_CU_SPLIT="chain,cone" CUs of the three partitions (rest: SSRN)
     bool no_cu_mask = false, ssrn_all = false, cone_all = false;      // OPH_NO_CU_MASK, OPH_SSRN_ALL, OPH_CONE_ALL
-    bool no_cone_head = false, no_loop_qw = false, no_preencode = false, no_stream_ssrn = false;
+    bool no_cone_head = false, no_loop_qw = false, no_preencode = false, no_stream_ssrn = false, no_cone_loop = false;
     bool cone_bf16 = false;          // OPH_CONE_BF16X3: the two many-row cone contractions on the split-bf16 kernel (opt-in experiment)
     bool ssrn_fp32 = false;          // OPH_SSRN_FP32
     bool skip_cone = false;          // OPH_SKIP_CONE: timing experiments only, results are wrong
@@ -114,7 +116,7 @@ struct Options {
         if (const char* sp = getenv("OPH_CU_SPLIT")) { int a_ = 0, b_ = 0; if (sscanf(sp, "%d,%d", &a_, &b_) == 2 && a_ > 0 && b_ > 0) { cu_dec = a_; cu_cone = b_; } }
         no_cu_mask = flag("OPH_NO_CU_MASK"); ssrn_all = flag("OPH_SSRN_ALL"); cone_all = flag("OPH_CONE_ALL");
         no_cone_head = flag("OPH_NO_CONE_HEAD"); no_loop_qw = flag("OPH_NO_LOOP_QW"); no_preencode = flag("OPH_NO_PREENCODE");
-        no_stream_ssrn = flag("OPH_NO_STREAM_SSRN");
+        no_stream_ssrn = flag("OPH_NO_STREAM_SSRN"); no_cone_loop = flag("OPH_NO_CONE_LOOP");
         cone_bf16 = flag("OPH_CONE_BF16X3"); ssrn_fp32 = flag("OPH_SSRN_FP32"); skip_cone = flag("OPH_SKIP_CONE");
         { const char* sv = getenv("OPH_STREAM_VALUE"); stream_value = sv && atoi(sv) != 0; }
         run_stamps = flag("OPH_RUN_STAMPS");
@@ -240,6 +242,12 @@ struct oph_handle {
     // dec_loop mode: the cone waits / signals inside its own first / last launch
     bool cone_inline_sig = false; uint32_t cone_wait_val = 0, cone_done_val = 0, cone_done_total[LOOP_MAX_LEVELS] = {0};     // per cone level: arrivals so far
     unsigned* d_cone_count = nullptr;
+    // the cone as ONE persistent launch beside dec_loop (cone_loop, oph_coneloop.hip)
+    bool cone_loop_ok = false;          // this model's geometry fits it (d = 256, no speaker concat / LCC / nonorm in AudioDec)
+    int cone_loop_wgs = -1;             // its grid: workgroups that are resident at once on the cone partition (multiple of 8; -1: not asked yet)
+    unsigned* d_cl_flags = nullptr; unsigned long long* d_cl_stats = nullptr;     // [flags | level counters], statistics granules
+    uint32_t cl_epoch = 0;
+    long long n_cone_loops = 0;
     float *coneR = nullptr, *coneRaw = nullptr, *coneTmp = nullptr;
     int ldy = 0;
     // timing
@@ -809,6 +817,13 @@ int ensure_decode_state(oph_handle* h, int B) {
     h->coneRawB = h->dalloc<float>((size_t)maxrows * Bpad * (size_t)round_up(2 * d, 128));
     h->coneTmp = h->dalloc<float>(maxrows * Bpad * (size_t)ld_cat);
     h->d_cone_count = h->dalloc<unsigned>(LOOP_MAX_LEVELS); for (uint32_t& v : h->cone_done_total) v = 0;
+    if (h->cone_loop_ok) {
+        bool fits = nh <= CL_MAX_LEVELS;
+        for (int k = 0; k < nh; ++k) fits = fits && (int)h->Hset[k].size() <= CL_MAX_POS;
+        h->d_cl_flags = fits ? h->dalloc<unsigned>((size_t)2 * CL_MAX_LEVELS * CL_MAX_POS + 2 * CL_MAX_LEVELS) : nullptr;
+        h->d_cl_stats = fits ? h->dalloc<unsigned long long>((size_t)2 * CL_MAX_LEVELS * CL_MAX_POS * 8 * 64) : nullptr;
+        h->cl_epoch = 0;
+    }
     // ---- per-tile state
     h->tiles.assign(ntiles, Tile());
     for (Tile& t : h->tiles) {
@@ -1352,7 +1367,65 @@ int decode_loop(oph_handle* h, int t_end, int stop_mode) {
     g_cur = h->scone;
     const auto t_host0 = std::chrono::steady_clock::now();
     const bool stream_ssrn = h->spec_ssrn && h->opt.ssrn_chunk > 0 && !h->opt.no_stream_ssrn;
-    for (int t = 1; t < t_end && !(dbg & 32); ++t) {
+    // ---- the cone of every step as ONE persistent launch (cone_loop) where the model fits it and its workgroups can all be resident
+    bool cone_in_loop = false;
+    if (h->cone_loop_ok && h->qw_from_loop && h->d_cl_flags && h->d_cl_stats && !h->opt.skip_cone && !(dbg & 32) && t_end > 1) {
+        if (h->cone_loop_wgs < 0) {
+            int ncu = 0;
+            for (int i = 0; i < h->mask_words; ++i) ncu += __builtin_popcount(h->m_conep[i]);
+            h->cone_loop_wgs = std::min(2, cone_loop_blocks_per_cu()) * ncu / 8 * 8;
+        }
+        cone_in_loop = h->cone_loop_wgs >= 64;
+    }
+    if (cone_in_loop) {
+        const int pre = h->dec_pre, nh = h->n_hc_dec;
+        if ((uint64_t)h->cl_epoch + (uint64_t)(m.max_T + 2) * CL_MAX_LEVELS > 0xF0000000ull) {
+            hipStreamSynchronize(h->scone);
+            hipMemsetAsync(h->d_cl_stats, 0, (size_t)2 * CL_MAX_LEVELS * CL_MAX_POS * 8 * 64 * 8, h->scone);
+            h->cl_epoch = 0;
+        }
+        ConeLoopArgs c{};
+        c.nlevels = nh; c.t_begin = 1; c.t_end = t_end; c.B = h->B; c.d = m.d;
+        c.npos0 = (int)h->Hset[0].size(); c.off0 = h->d_off0; c.rows0[0] = h->cone[0][0]; c.rows0[1] = h->cone[1][0];
+        const Layer& tl0 = h->audiodec[pre];
+        c.sig0_pos0 = idx_of(h->Hset[0], -tl0.off[0]); c.sig0_pos1 = idx_of(h->Hset[0], -tl0.off[1]);
+        c.Q = h->Qhist; c.QW = h->QWhist; c.KV = h->KV; c.VW = h->VW; c.ldvw = h->ldvw; c.N_keys = m.max_N; c.win = m.attention_win_size;
+        c.gamma0 = h->audiodec[0].g1; c.beta0 = h->audiodec[0].b1;
+        c.p = h->d_p;
+        for (int k = 1; k < nh; ++k) {
+            const Layer& l = h->audiodec[pre + k - 1];       // the highway layer that produces level k from level k-1
+            const Layer& tl = h->audiodec[pre + k];           // the chain layer whose taps read level k
+            ConeLoopLevel& L = c.L[k];
+            L.npos = (int)h->Hset[k].size(); L.Wsw = l.Wsw_cone; L.bias = l.bias; L.g1 = l.g1; L.b1 = l.b1; L.g2 = l.g2; L.b2 = l.b2;
+            L.tab = h->d_tab[k - 1]; L.need = h->d_need[k - 1];
+            L.rows[0] = h->cone[0][k]; L.rows[1] = h->cone[1][k];
+            L.sig_pos0 = idx_of(h->Hset[k], -tl.off[0]); L.sig_pos1 = idx_of(h->Hset[k], -tl.off[1]);
+        }
+        c.flags = h->d_cl_flags; c.levelcnt = h->d_cl_flags + (size_t)2 * CL_MAX_LEVELS * CL_MAX_POS; c.stats = h->d_cl_stats;
+        c.epoch0 = h->cl_epoch; h->cl_epoch += (uint32_t)(m.max_T + 2) * CL_MAX_LEVELS;
+        c.sig = h->d_sig; c.sig_base = h->sig_base; c.ctl = h->d_ctl;
+        hipMemsetAsync(h->d_cl_flags, 0, ((size_t)2 * CL_MAX_LEVELS * CL_MAX_POS + 2 * CL_MAX_LEVELS) * sizeof(unsigned), h->scone);
+        launch_cone_loop(c, h->cone_loop_wgs, h->scone);
+        h->n_cone_loops++;
+        // the host has nothing to enqueue per step: it only watches the progress word for the SSRN chunks
+        auto t_prog = std::chrono::steady_clock::now();
+        int last_prog = -2;
+        while (stream_ssrn) {
+            const int prog = h->host_prog[0], stopped_at = h->host_prog[1];
+            if (stopped_at != INT_MAX || prog >= t_end - 1) break;
+            Tile& tl = h->tiles[h->tile];
+            if (tl.ssrn_done + h->opt.ssrn_chunk >= m.max_T) break;          // only the final chunk is left
+            { const int rc = ssrn_stream_chunks(h, prog, false); if (rc) return rc; }
+            if (prog != last_prog) { last_prog = prog; t_prog = std::chrono::steady_clock::now(); }
+            else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_prog).count() > 10.0) {
+                h->fail("decode loop kernel made no progress for 10 s (step %d)", prog);
+                return OPH_ERR_DEVICE;
+            }
+            struct timespec ts = {0, 50000};         // 50 us: a chunk boundary comes every few milliseconds
+            nanosleep(&ts, nullptr);
+        }
+    }
+    for (int t = 1; t < t_end && !(dbg & 32) && !cone_in_loop; ++t) {
         // bounded run-ahead, so that an early stop leaves at most `lookahead` queued cones (they early-out on the device)
         auto t_wait0 = std::chrono::steady_clock::now();
         while (h->host_prog[0] < t - 1 - lookahead && h->host_prog[1] == INT_MAX) {
@@ -2074,6 +2147,36 @@ int oph_finalize_weights(oph_handle* h) {
         h->Wt_c = upload(h, w);
         if (!h->Wt_c) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
     }
+    // cone_loop: every AudioDec highway layer but the last is re-evaluated over history positions by resident workgroups; its
+    // kernel in the lanes' fragment order: [column group cg][wave w][k group i][lane][4] with
+    //   column = (w >> 1) * C + 32 cg + 16 (w & 1) + (lane & 15)        (wave 0,1: H1 channels of the group, wave 2,3: the same channels of H2)
+    //   k      = 192 (lane >> 4) + 4 i + e                               (k over [tap x[t-2r] | tap x[t-r] | x[t]] x 256 channels)
+    {
+        const int pre = h->dec_pre, nh = h->n_hc_dec, d = h->dm.d;
+        bool ok = !h->opt.no_cone_loop && h->cone_head_ok && pre == 1 && d == 256 && !(h->dm.flags & (OPH_FLAG_LCC | OPH_FLAG_NORM_NONE | OPH_FLAG_NO_MONOTONIC)) &&
+                  h->dm.attention_win_size <= 4 && nh >= 2 && nh <= CL_MAX_LEVELS;
+        for (int k = 0; ok && k + 1 < nh; ++k) {
+            const Layer& l = h->audiodec[pre + k];
+            ok = l.kind == K_HC && l.ntaps == 3 && l.kc == 256 && l.cout == 256 && l.cin == 256 && l.ln && !l.lcc && l.ccat == 0 && l.causal;
+        }
+        for (int k = 0; ok && k + 1 < nh; ++k) {
+            Layer& l = h->audiodec[pre + k];
+            const std::vector<float>& kr = *getw(h, l.scope + "/conv1d/kernel");      // (3, 256, 512)
+            std::vector<float> ws((size_t)8 * 4 * CL_NCH * 64 * 4);
+            for (int cg = 0; cg < 8; ++cg)
+                for (int w = 0; w < 4; ++w)
+                    for (int i = 0; i < CL_NCH; ++i)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 4; ++e) {
+                                const int col = (w >> 1) * 256 + 32 * cg + 16 * (w & 1) + (lane & 15);
+                                const int kk = 192 * (lane >> 4) + 4 * i + e, tap = kk / 256, c = kk % 256;
+                                ws[((((size_t)cg * 4 + w) * CL_NCH + i) * 64 + lane) * 4 + e] = kr[((size_t)tap * 256 + c) * 512 + col];
+                            }
+            l.Wsw_cone = upload(h, ws);
+            if (!l.Wsw_cone) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
+        }
+        h->cone_loop_ok = ok;
+    }
     h->emb_text = upload(h, h->hostw["Text2Mel/TextEnc/embed_1/lookup_table"]);
     if (h->dm.flags & OPH_FLAG_SPK_AUDIO_DECODER_INPUT) h->emb_spk = upload(h, h->hostw["Text2Mel/AudioDec/embed_2/lookup_table"]);
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -2246,8 +2349,8 @@ int oph_set_ssrn_precision(oph_handle* h, int mode) {
 // [3] whole-decode launches  [4] fallbacks from the whole-decode launch to two launches per step  [5] tiles resumed to the batch's stop step
 int oph_get_counters(oph_handle* h, int64_t* out, int n) {
     if (!h || !out) return OPH_ERR_INVALID;
-    const long long v[6] = {h->n_textenc, h->n_preenc_used, h->n_chunks_streamed, h->n_loop_decodes, h->n_loop_fallbacks, h->n_tile_resumes};
-    for (int i = 0; i < n && i < 6; ++i) out[i] = v[i];
+    const long long v[7] = {h->n_textenc, h->n_preenc_used, h->n_chunks_streamed, h->n_loop_decodes, h->n_loop_fallbacks, h->n_tile_resumes, h->n_cone_loops};
+    for (int i = 0; i < n && i < 7; ++i) out[i] = v[i];
     return OPH_OK;
 }
 int oph_set_streaming(oph_handle* h, int on) {

@@ -278,6 +278,38 @@ struct LoopArgs {
 void launch_dec_loop(const LoopArgs& a, int col_slices, int rows_per_group, int kmax, hipStream_t s);   // rows_per_group 4 or 8
 int dec_loop_blocks_per_cu(int rows_per_group, int kmax);
 
+// ---- the AudioDec history cone of every decode step in ONE persistent launch beside dec_loop (oph_coneloop.hip).
+// Level 0 = the cone head (attention rows through the cached V.Wc / Q.Wq terms + LayerNorm); level k >= 1 = highway layer k-1
+// evaluated at the positions of Hset[k], with LayerNorm x 2 + gate + mix in the same task.  Geometry: d = 256 channels,
+// 3 taps x 256 = 768 K, 16 utterance rows.
+constexpr int CL_MAX_LEVELS = 8, CL_MAX_POS = 96;
+constexpr int CL_NCH = 48;                  // 4-wide k groups per k-quarter: 768 / 4 quarters / 4
+struct ConeLoopLevel {
+    int npos;                               // positions of this level (|Hset[k]|)
+    const float* Wsw;                       // highway layer k-1's kernel in the lanes' fragment order: [8 column groups][4 waves][CL_NCH][64 lanes][4]
+    const float* bias;                      // [2 * 256]
+    const float *g1, *b1, *g2, *b2;         // LayerNorm parameters of H1 / H2
+    const int* tab; const int* need;        // [3][npos]: source position in level k-1 per tap (oldest first); valid iff t >= need
+    float* rows[2];                         // this level's rows [npos][16][256], ping-pong over the step parity
+    int sig_pos0, sig_pos1;                 // the two positions dec_loop's taps read: when both are written the level's word is raised
+};
+struct ConeLoopArgs {
+    int nlevels; int t_begin, t_end; int B; int d;
+    int npos0; const int* off0; float* rows0[2]; int sig0_pos0, sig0_pos1;        // level 0
+    const float* Q; const float* QW; const float* KV; const float* VW; int ldvw; int N_keys; int win;
+    const float* gamma0; const float* beta0;
+    const int* p;                           // prev_max double buffer [2][16]
+    ConeLoopLevel L[CL_MAX_LEVELS];         // [1 .. nlevels)
+    unsigned* flags;                        // [2 parities][CL_MAX_LEVELS][CL_MAX_POS] tasks completed per (level, position); zero at launch
+    unsigned* levelcnt;                     // [2][CL_MAX_LEVELS] arrivals of the tap positions; zero at launch
+    unsigned long long* stats;              // granules [2][CL_MAX_LEVELS][CL_MAX_POS][8][64]
+    unsigned epoch0;                        // statistics tag of (step t, level k) = epoch0 + t * CL_MAX_LEVELS + k, never reused
+    unsigned* sig; unsigned sig_base;       // as LoopArgs
+    int* ctl;                               // [1] stop step  [2] error
+};
+void launch_cone_loop(const ConeLoopArgs& a, int nwg, hipStream_t s);     // nwg: multiple of 8, all resident
+int cone_loop_blocks_per_cu();
+
 // launchers (oph_kernels.hip)
 void launch_row_chain(const RowChainArgs& a, hipStream_t s);
 void launch_conv_gemm(const GemmArgs& a, hipStream_t s);

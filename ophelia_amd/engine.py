@@ -298,9 +298,10 @@ class Engine(object):
 
     def counters(self):
         """What the pipeline did since the handle was created (oph_get_counters)."""
-        v = (C.c_int64 * 6)()
-        self._chk(self.lib.oph_get_counters(self._h, v, 6))
-        return dict(zip(("textenc", "preenc_used", "chunks_streamed", "loop_decodes", "loop_fallbacks", "tile_resumes"), [int(x) for x in v]))
+        v = (C.c_int64 * 7)()
+        self._chk(self.lib.oph_get_counters(self._h, v, 7))
+        return dict(zip(("textenc", "preenc_used", "chunks_streamed", "loop_decodes", "loop_fallbacks", "tile_resumes", "cone_loops"),
+                        [int(x) for x in v]))
 
     def set_streaming(self, on=True):
         """SSRN over the frames a running decode has already produced (default on); off: SSRN only when asked for."""
