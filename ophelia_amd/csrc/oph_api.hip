@@ -103,6 +103,7 @@ struct Options {
     bool stream_value = false;       // OPH_STREAM_VALUE: per-step launch paths chain their two streams with stream value operations
     bool run_stamps = false;         // OPH_RUN_STAMPS: clock stamps of the decode kernels' phases (printed under OPH_TRACE)
     int ssrn_chunk = 40;             // OPH_SSRN_CHUNK: mel frames per streamed SSRN chunk (0 = SSRN only after the decode)
+    int cl_wgs_per_cu = 2, cl_dbg = 0;   // OPH_CL_WGS_PER_CU (cone_loop workgroups per CU: 1 or 2), OPH_CL_DBG
     void read() {
         auto flag = [](const char* n) { return getenv(n) != nullptr; };
         auto num = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
@@ -116,11 +117,15 @@ struct Options {
         if (const char* sp = getenv("OPH_CU_SPLIT")) { int a_ = 0, b_ = 0; if (sscanf(sp, "%d,%d", &a_, &b_) == 2 && a_ > 0 && b_ > 0) { cu_dec = a_; cu_cone = b_; } }
         no_cu_mask = flag("OPH_NO_CU_MASK"); ssrn_all = flag("OPH_SSRN_ALL"); cone_all = flag("OPH_CONE_ALL");
         no_cone_head = flag("OPH_NO_CONE_HEAD"); no_loop_qw = flag("OPH_NO_LOOP_QW"); no_preencode = flag("OPH_NO_PREENCODE");
-        no_stream_ssrn = flag("OPH_NO_STREAM_SSRN"); no_cone_loop = flag("OPH_NO_CONE_LOOP");
+        no_stream_ssrn = flag("OPH_NO_STREAM_SSRN");
+        // the cone as one persistent launch (cone_loop) is opt-in: measured 25.5-26.1 ms per batch against 25.0 ms with the nine
+        // launches per step; it frees the host thread from enqueuing, which matters with 8 ranks on one node
+        no_cone_loop = !flag("OPH_CONE_LOOP") || flag("OPH_NO_CONE_LOOP");
         cone_bf16 = flag("OPH_CONE_BF16X3"); ssrn_fp32 = flag("OPH_SSRN_FP32"); skip_cone = flag("OPH_SKIP_CONE");
         { const char* sv = getenv("OPH_STREAM_VALUE"); stream_value = sv && atoi(sv) != 0; }
         run_stamps = flag("OPH_RUN_STAMPS");
         ssrn_chunk = std::max(0, num("OPH_SSRN_CHUNK", 40));
+        cl_wgs_per_cu = num("OPH_CL_WGS_PER_CU", 2) == 1 ? 1 : 2; cl_dbg = num("OPH_CL_DBG", 0);
     }
     int cone_ksplit(int M) const { return M >= 512 ? ksplit_big : ksplit_small; }
 };
@@ -247,6 +252,7 @@ struct oph_handle {
     int cone_loop_wgs = -1;             // its grid: workgroups that are resident at once on the cone partition (multiple of 8; -1: not asked yet)
     unsigned* d_cl_flags = nullptr; unsigned long long* d_cl_stats = nullptr;     // [flags | level counters], statistics granules
     uint32_t cl_epoch = 0;
+    long long* d_cldbg = nullptr;       // OPH_RUN_STAMPS: cone_loop's per-step stamps
     long long n_cone_loops = 0;
     float *coneR = nullptr, *coneRaw = nullptr, *coneTmp = nullptr;
     int ldy = 0;
@@ -737,6 +743,7 @@ int ensure_decode_state(oph_handle* h, int B) {
     if (h->opt.run_stamps) {
         h->d_stamps = h->dalloc<long long>((size_t)2 * 32 * LOOP_MAX_LAYERS * 8);
         h->d_sigdbg = h->dalloc<long long>((size_t)m.max_T * 8);
+        h->d_cldbg = h->dalloc<long long>((size_t)(2 * m.max_T + 4) * 8 + 512);
     }
     h->Rrow = h->dalloc<float>((size_t)Bpad * 2 * d);
     for (const Layer& l : h->audioenc) h->ae_raw.push_back(h->dalloc<float>((size_t)Bpad * l.Nalloc));
@@ -820,7 +827,7 @@ int ensure_decode_state(oph_handle* h, int B) {
     if (h->cone_loop_ok) {
         bool fits = nh <= CL_MAX_LEVELS;
         for (int k = 0; k < nh; ++k) fits = fits && (int)h->Hset[k].size() <= CL_MAX_POS;
-        h->d_cl_flags = fits ? h->dalloc<unsigned>((size_t)2 * CL_MAX_LEVELS * CL_MAX_POS + 2 * CL_MAX_LEVELS) : nullptr;
+        h->d_cl_flags = fits ? h->dalloc<unsigned>((size_t)2 * CL_MAX_LEVELS * CL_MAX_POS + 2 * CL_MAX_LEVELS + 8 * 16) : nullptr;      // flags | level counters | task queues
         h->d_cl_stats = fits ? h->dalloc<unsigned long long>((size_t)2 * CL_MAX_LEVELS * CL_MAX_POS * 8 * 64) : nullptr;
         h->cl_epoch = 0;
     }
@@ -1373,7 +1380,7 @@ int decode_loop(oph_handle* h, int t_end, int stop_mode) {
         if (h->cone_loop_wgs < 0) {
             int ncu = 0;
             for (int i = 0; i < h->mask_words; ++i) ncu += __builtin_popcount(h->m_conep[i]);
-            h->cone_loop_wgs = std::min(2, cone_loop_blocks_per_cu()) * ncu / 8 * 8;
+            h->cone_loop_wgs = std::min(h->opt.cl_wgs_per_cu, cone_loop_blocks_per_cu()) * ncu / 8 * 8;
         }
         cone_in_loop = h->cone_loop_wgs >= 64;
     }
@@ -1404,7 +1411,9 @@ int decode_loop(oph_handle* h, int t_end, int stop_mode) {
         c.flags = h->d_cl_flags; c.levelcnt = h->d_cl_flags + (size_t)2 * CL_MAX_LEVELS * CL_MAX_POS; c.stats = h->d_cl_stats;
         c.epoch0 = h->cl_epoch; h->cl_epoch += (uint32_t)(m.max_T + 2) * CL_MAX_LEVELS;
         c.sig = h->d_sig; c.sig_base = h->sig_base; c.ctl = h->d_ctl;
-        hipMemsetAsync(h->d_cl_flags, 0, ((size_t)2 * CL_MAX_LEVELS * CL_MAX_POS + 2 * CL_MAX_LEVELS) * sizeof(unsigned), h->scone);
+        c.dbg = h->opt.cl_dbg;
+        if (h->d_cldbg) { c.stamps = h->d_cldbg; hipMemsetAsync(h->d_cldbg, 0, ((size_t)(2 * m.max_T + 4) * 8 + 512) * sizeof(long long), h->scone); }
+        hipMemsetAsync(h->d_cl_flags, 0, ((size_t)2 * CL_MAX_LEVELS * CL_MAX_POS + 2 * CL_MAX_LEVELS + 8 * 16) * sizeof(unsigned), h->scone);
         launch_cone_loop(c, h->cone_loop_wgs, h->scone);
         h->n_cone_loops++;
         // the host has nothing to enqueue per step: it only watches the progress word for the SSRN chunks
@@ -1688,6 +1697,31 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
                     const long long* q = &sd[(size_t)t * 8];
                     TRACE("step %d: the loop kernel spun for cone levels 0..5: %.2f %.2f %.2f %.2f %.2f %.2f us", t,
                           q[1] * 0.01, q[2] * 0.01, q[3] * 0.01, q[4] * 0.01, q[5] * 0.01, q[6] * 0.01);
+                }
+            }
+            if (loop_mode && h->d_cldbg) {
+                std::vector<long long> cd((size_t)(2 * m.max_T + 4) * 8 + 512);
+                hipMemcpy(cd.data(), h->d_cldbg, cd.size() * 8, hipMemcpyDeviceToHost);
+                {   // on which XCD did the workgroups of each column group (block % 8) run?
+                    char line[256]; int n = 0;
+                    for (int c8 = 0; c8 < 8; ++c8) {
+                        unsigned mask = 0;
+                        for (int b = c8; b < h->cone_loop_wgs && b < 512; b += 8) mask |= 1u << (unsigned)cd[(size_t)(2 * last + 4) * 8 + b];
+                        n += snprintf(line + n, sizeof line - n, " %d:0x%x", c8, mask);
+                    }
+                    TRACE("cone_loop: XCD mask per column group (block %% 8):%s", line);
+                }
+                for (int t : {50, 100, 150}) {
+                    if (t >= last) continue;
+                    const long long* q = &cd[(size_t)(last + 1 + t) * 8];
+                    if (q[0]) TRACE("cone_loop step %d, sample task (level 4): wait deps %.2f  gather %.2f  mfma %.2f  local stats %.2f  exchange %.2f  normalise %.2f  store+flag %.2f us", t,
+                                    (q[1] - q[0]) * 0.01, (q[2] - q[1]) * 0.01, (q[3] - q[2]) * 0.01, (q[4] - q[3]) * 0.01, (q[5] - q[4]) * 0.01, (q[6] - q[5]) * 0.01, (q[7] - q[6]) * 0.01);
+                }
+                for (int t : {50, 51, 100, 101, 150}) {
+                    if (t >= m.max_T) continue;
+                    const long long* q = &cd[(size_t)t * 8];
+                    if (q[0]) TRACE("cone_loop step %d: levels 0..5 written %.2f %.2f %.2f %.2f %.2f %.2f us after its release", t,
+                                    (q[1] - q[0]) * 0.01, (q[2] - q[0]) * 0.01, (q[3] - q[0]) * 0.01, (q[4] - q[0]) * 0.01, (q[5] - q[0]) * 0.01, (q[6] - q[0]) * 0.01);
                 }
             }
             if (loop_mode) {

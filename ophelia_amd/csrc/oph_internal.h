@@ -306,6 +306,8 @@ struct ConeLoopArgs {
     unsigned epoch0;                        // statistics tag of (step t, level k) = epoch0 + t * CL_MAX_LEVELS + k, never reused
     unsigned* sig; unsigned sig_base;       // as LoopArgs
     int* ctl;                               // [1] stop step  [2] error
+    long long* stamps;                      // diagnostics (OPH_RUN_STAMPS): [max_T][8] clock stamps: cone(t) released, level k's word raised; [7] = misplaced workgroups
+    int dbg;                                // 1: gather with 8-byte atomics (ld_coherent) instead of 16-byte sc1 loads
 };
 void launch_cone_loop(const ConeLoopArgs& a, int nwg, hipStream_t s);     // nwg: multiple of 8, all resident
 int cone_loop_blocks_per_cu();

@@ -45,7 +45,7 @@ FLAVOURS = {
     "loop_nofc": {"OPH_CONE_FC_ROWS": "0"},
     "loop_fc256": {"OPH_CONE_FC_ROWS": "256", "OPH_CONE_FC_INSPLIT": "1"},
     "loop_nostream": {"OPH_NO_STREAM_SSRN": "1"},
-    "loop_launchcone": {"OPH_NO_CONE_LOOP": "1"},          # the cone as per-step launches instead of the persistent cone_loop
+    "loop_coneloop": {"OPH_CONE_LOOP": "1"},               # the cone as ONE persistent task-graph launch (opt-in) instead of nine launches per step
     "loop_conebf16": {"OPH_CONE_BF16X3": "1"},
 }
 
@@ -57,7 +57,7 @@ TOL = {"loop_conebf16": 3e-4}
 def _run(tmp_path, name, env_extra, max_T, B, stop_mode):
     out = str(tmp_path / (name + ".npz"))
     env = dict(os.environ)
-    for k in ("OPH_DECODE", "OPH_RUN_ROWS", "OPH_NO_CONE_HEAD", "OPH_CONE_FC_ROWS", "OPH_CONE_FC_INSPLIT", "OPH_NO_STREAM_SSRN", "OPH_NO_CONE_LOOP", "OPH_CONE_BF16X3"):
+    for k in ("OPH_DECODE", "OPH_RUN_ROWS", "OPH_NO_CONE_HEAD", "OPH_CONE_FC_ROWS", "OPH_CONE_FC_INSPLIT", "OPH_NO_STREAM_SSRN", "OPH_CONE_LOOP", "OPH_CONE_BF16X3"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, "-c", CHILD, ROOT, out, str(max_T), str(B), str(stop_mode)], env=env,
