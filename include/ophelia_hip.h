@@ -190,10 +190,20 @@ int oph_synchronize(oph_handle* h);
  * *d_mag + b * *utt_stride floats.  Synchronises first; valid until the next run on this handle.  Lets the vocoder
  * library (ophelia_vocoder.h) consume Z without the host round trip of synthesize.py:585-617. */
 int oph_device_mag(oph_handle* h, const float** d_mag, int64_t* utt_stride, int32_t* B);
-/* SSRN contraction arithmetic: 1 (default) = each fp32 operand split into hi+lo bf16, a.b ~ ah.bh+ah.bl+al.bh on the
- * bf16 MFMA with fp32 accumulation (~1e-5 relative); 0 = exact fp32 MFMA.  Text2Mel is always exact fp32 (its
- * attention argmax feeds back into the decode). */
+/* Contraction arithmetic of the large batched contractions.  Every multiply-accumulate is fp32 x fp32 -> fp32; the choice is
+ * how the products are formed:
+ *   0  v_mfma_f32_32x32x2_f32 (fp32 operands);
+ *   2  (default) each fp32 operand split into hi + lo fp16 terms (22 of fp32's 24 significant bits), a.b ~ ah.bh + ah.bl +
+ *      al.bh on the fp16 MFMA with fp32 accumulation: 2.4e-7 relative per product, below the rounding of the fp32
+ *      accumulation itself -- measured in the same accuracy class as mode 0 (SSRN mag vs the CPU oracle 5.0e-6 vs 4.4e-6; mel
+ *      differs from the mode-0 decode by 6.7e-6, two mode-0 decode flavours among themselves by 5.6e-6; identical attention
+ *      traces), 2-3x faster;
+ *   1  the same with bf16 terms (16 bits): ~1e-5 relative per product (mag 2.9e-5); SSRN only -- Text2Mel feeds an argmax
+ *      back into itself and is only offered fp32-class arithmetic.
+ * oph_set_ssrn_precision(h, mode) = oph_set_precision(h, 0, mode).  which: 0 SSRN, 1 the two many-row levels of the
+ * AudioDec history cone, 2 TextEnc.  The decoder chain itself (dec_loop) is always mode 0. */
 int oph_set_ssrn_precision(oph_handle* h, int mode);
+int oph_set_precision(oph_handle* h, int which, int mode);
 
 /* ---- measurement helpers (HIP events on the handle's own stream) ---------------- */
 int oph_timer_start(oph_handle* h);

@@ -69,6 +69,7 @@ SIGNATURES = {
     "oph_synchronize": (C.c_int, [C.c_void_p]),
     "oph_device_mag": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i64p, c_i32p]),
     "oph_set_ssrn_precision": (C.c_int, [C.c_void_p, C.c_int]),
+    "oph_set_precision": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "oph_timer_start": (C.c_int, [C.c_void_p]),
     "oph_timer_stop": (C.c_int, [C.c_void_p, c_f32p]),
     "oph_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

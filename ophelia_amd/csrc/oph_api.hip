@@ -67,6 +67,7 @@ struct Layer {
     float *Wt2 = nullptr;                        // convT odd phase (tap x[t])
     float *Wkn = nullptr; int ldn = 0;           // k=1 layers with N<=256: [kc][ldn] n-contiguous copy for row_chain
     void *Wh = nullptr, *Wl = nullptr, *Wh2 = nullptr, *Wl2 = nullptr;   // SSRN layers: Wt / Wt2 split into hi + lo bf16 planes (conv_gemm_bf16x3)
+    void *Wh16 = nullptr, *Wl16 = nullptr, *Wh2_16 = nullptr, *Wl2_16 = nullptr;   // the same as fp16 planes (split-fp16 x3: fp32-class accuracy)
     float* Wsw_cone = nullptr;                   // AudioDec highway layers: kernel in cone_loop's fragment order (oph_coneloop.hip)
     float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
 };
@@ -81,6 +82,8 @@ struct ProfClass {
     size_t used = 0;
     double ms = 0;
 };
+constexpr int TEXTENC_PREC_DEFAULT = 2;   // TextEnc contractions when OPH_TEXTENC_PREC is not set
+constexpr int CONE_PREC_DEFAULT = 2;      // arithmetic of the cone's two many-row contractions when OPH_CONE_PREC is not set (see oph_finalize_weights)
 constexpr int CONE_KSPLIT = 4;   // split-K of the latency-bound decoder-cone GEMMs (partials summed by ln_rows); buffers are sized for it
 
 // The OPH_* environment switches (debugging / measurement knobs, README.md lists them), read ONCE per handle in
@@ -97,7 +100,9 @@ struct Options {
     int cu_dec = 0, cu_cone = 0;     // OPH_CU_SPLIT="chain,cone" CUs of the three partitions (rest: SSRN)
     bool no_cu_mask = false, ssrn_all = false, cone_all = false;      // OPH_NO_CU_MASK, OPH_SSRN_ALL, OPH_CONE_ALL
     bool no_cone_head = false, no_loop_qw = false, no_preencode = false, no_stream_ssrn = false, no_cone_loop = false;
-    bool cone_bf16 = false;          // OPH_CONE_BF16X3: the two many-row cone contractions on the split-bf16 kernel (opt-in experiment)
+    int cone_prec = -1;              // OPH_CONE_PREC: the two many-row cone contractions: 0 fp32 MFMA, 1 split-bf16 x3 (experiment), 2 split-fp16 x3; -1 = the default
+    int ssrn_prec = -1;              // OPH_SSRN_PREC: 0 fp32 MFMA, 1 split-bf16 x3, 2 split-fp16 x3; -1 = the default (OPH_SSRN_FP32 = 0)
+    int textenc_prec = -1;           // OPH_TEXTENC_PREC: 0 fp32 MFMA, 2 split-fp16 x3; -1 = the default
     bool ssrn_fp32 = false;          // OPH_SSRN_FP32
     bool skip_cone = false;          // OPH_SKIP_CONE: timing experiments only, results are wrong
     bool stream_value = false;       // OPH_STREAM_VALUE: per-step launch paths chain their two streams with stream value operations
@@ -121,7 +126,10 @@ struct Options {
         // the cone as one persistent launch (cone_loop) is opt-in: measured 25.5-26.1 ms per batch against 25.0 ms with the nine
         // launches per step; it frees the host thread from enqueuing, which matters with 8 ranks on one node
         no_cone_loop = !flag("OPH_CONE_LOOP") || flag("OPH_NO_CONE_LOOP");
-        cone_bf16 = flag("OPH_CONE_BF16X3"); ssrn_fp32 = flag("OPH_SSRN_FP32"); skip_cone = flag("OPH_SKIP_CONE");
+        ssrn_fp32 = flag("OPH_SSRN_FP32"); skip_cone = flag("OPH_SKIP_CONE");
+        cone_prec = num("OPH_CONE_PREC", flag("OPH_CONE_BF16X3") ? 1 : -1); if (cone_prec > 2) cone_prec = -1;
+        ssrn_prec = num("OPH_SSRN_PREC", ssrn_fp32 ? 0 : -1); if (ssrn_prec > 2) ssrn_prec = -1;
+        textenc_prec = num("OPH_TEXTENC_PREC", -1); if (textenc_prec != 0 && textenc_prec != 2) textenc_prec = -1;
         { const char* sv = getenv("OPH_STREAM_VALUE"); stream_value = sv && atoi(sv) != 0; }
         run_stamps = flag("OPH_RUN_STAMPS");
         ssrn_chunk = std::max(0, num("OPH_SSRN_CHUNK", 40));
@@ -159,7 +167,7 @@ struct oph_handle {
     bool ssrn_inflight[2] = {false, false};
     int buf = 0; bool pipelined = false;
     uint32_t m_cone[16] = {0}, m_conep[16] = {0}, m_ssrn[16] = {0}; int mask_words = 0;   // CU partitions (0 words = no masking)
-    int ssrn_prec = 1;                 // SSRN contractions: 1 = split-bf16 x3 (fp32 accumulate), 0 = exact fp32 MFMA
+    int ssrn_prec = 2;                 // SSRN contractions: 2 = split-fp16 x3 (fp32 accumulate, fp32-class accuracy), 1 = split-bf16 x3, 0 = fp32 MFMA
     hipEvent_t ev_attn = nullptr, ev_cone = nullptr;
     // The two per-step cross-stream dependencies (cone(t+1) after row_chain B(t); AudioDec(t) after cone(t)) as stream
     // write-value / wait-value operations on two device words instead of event record / wait pairs: an event operation
@@ -235,7 +243,8 @@ struct oph_handle {
     std::vector<std::vector<int>> Hset;           // Hset[h] sorted offsets (>=1) at which hc layer h's INPUT is needed
     std::vector<int*> d_tab, d_need, d_res;       // per hc layer h<n-1: tables for computing layer h over Hset[h+1]
     std::vector<FcTables> fc_tab;                 // per hc layer: cone_fc16's index tables (kernel arguments)
-    bool cone_bf16 = false;                      // OPH_CONE_BF16X3 experiment
+    int cone_prec = 0;                           // the two many-row cone contractions: 0 fp32 MFMA, 1 split-bf16 x3, 2 split-fp16 x3
+    int textenc_prec = 0;                        // TextEnc contractions: 0 fp32 MFMA, 2 split-fp16 x3
     bool qw_from_loop = false;                   // this decode's QW cache is filled by the loop kernel (cone_head computes nothing)
     float* coneRawB = nullptr;                    // second raw buffer: consecutive cone_fc16 launches ping-pong
     int cone_fc_rows = 64;                        // cone levels with at most this many output rows run as cone_fc16 (0: never)
@@ -559,7 +568,7 @@ int pack_layer(oph_handle* h, Layer& l) {
 }
 
 // ------------------------------------------------------------------ launch wrappers with accounting
-void run_gemm(oph_handle* h, const GemmArgs& a, int cin_true, int prec = 0) {       // prec: 0 fp32 MFMA, 1 split-bf16 x3
+void run_gemm(oph_handle* h, const GemmArgs& a, int cin_true, int prec = 0) {       // prec: 0 fp32 MFMA, 1 split-bf16 x3, 2 split-fp16 x3 (a.Wh / a.Wl / a.f16 set to match)
     const int cls = prec ? PC_GEMM_BF16 : (conv_gemm_tile_m(a.M, a.N) == 128 ? PC_GEMM : PC_GEMM64);
     h->pbegin(cls);
     if (prec) launch_conv_gemm_bf16x3(a, g_cur);
@@ -625,11 +634,12 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
         if (l.kind == K_CONVT) {
             // even rows: taps (x[t], x[t-1]); odd rows: tap x[t]; raw rows interleaved 2t / 2t+1
             g.N = l.N; g.ldh = 2 * l.Nalloc; g.M = M;
-            g.Wt = l.Wt; g.Wh = l.Wh; g.Wl = l.Wl; g.ldw = 2 * l.kc; g.ntaps = 2; g.off[0] = 0; g.off[1] = -1;
+            const bool f16 = prec == 2;
+            g.Wt = l.Wt; g.Wh = f16 ? l.Wh16 : l.Wh; g.Wl = f16 ? l.Wl16 : l.Wl; g.f16 = f16; g.ldw = 2 * l.kc; g.ntaps = 2; g.off[0] = 0; g.off[1] = -1;
             GemmArgs g2 = g;
-            g2.Wt = l.Wt2; g2.Wh = l.Wh2; g2.Wl = l.Wl2; g2.ldw = l.kc; g2.ntaps = 1; g2.off[0] = 0; g2.H = wsraw + l.Nalloc;
+            g2.Wt = l.Wt2; g2.Wh = f16 ? l.Wh2_16 : l.Wh2; g2.Wl = f16 ? l.Wl2_16 : l.Wl2; g2.ldw = l.kc; g2.ntaps = 1; g2.off[0] = 0; g2.H = wsraw + l.Nalloc;
             {   // both phases in one launch
-                const int p2 = (prec && l.Wh && l.Wh2) ? 1 : 0;
+                const int p2 = (prec && g.Wh && g2.Wh) ? prec : 0;
                 const int cls = p2 ? PC_GEMM_BF16 : (conv_gemm_tile_m(g.M, g.N) == 128 ? PC_GEMM : PC_GEMM64);
                 h->pbegin(cls);
                 launch_conv_gemm_pair(g, g2, p2, g_cur);
@@ -639,9 +649,10 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
             e.ldh = l.Nalloc; e.M = B * Tcur; e.C = l.cout; e.mode = PRE_CONV; e.act = ACT_NONE;
             run_epi(h, e);
         } else {
-            g.N = l.N; g.ldh = l.Nalloc; g.M = M; g.Wt = l.Wt; g.Wh = l.Wh; g.Wl = l.Wl; g.ldw = l.ntaps * l.kc; g.ntaps = l.ntaps;
+            const bool f16 = prec == 2;
+            g.N = l.N; g.ldh = l.Nalloc; g.M = M; g.Wt = l.Wt; g.Wh = f16 ? l.Wh16 : l.Wh; g.Wl = f16 ? l.Wl16 : l.Wl; g.f16 = f16; g.ldw = l.ntaps * l.kc; g.ntaps = l.ntaps;
             for (int t = 0; t < 3; ++t) g.off[t] = l.off[t];
-            run_gemm(h, g, l.cin, prec && l.Wh);
+            run_gemm(h, g, l.cin, g.Wh ? prec : 0);
             e.ldh = l.Nalloc; e.M = M; e.C = l.cout;
             if (l.kind == K_HC) { e.mode = PRE_HC; e.Xres = x; e.ldres = ldx; }
             else e.mode = PRE_CONV;
@@ -1029,8 +1040,9 @@ void launch_cone(oph_handle* h, int t) {
             g.ksplit = h->opt.cone_ksplit(g.M);
             if (k + 1 >= fc_from && k + 2 < nh) g.ksplit = std::min(g.ksplit, fc_in_split);     // its consumer is a cone_fc16: fewer partials to sum there
             g.split_stride = (long long)g.M * l.Nalloc;
-            g.Wh = l.Wh; g.Wl = l.Wl;
-            run_gemm(h, g, l.cin, (h->cone_bf16 && l.Wh && g.M >= 512) ? 1 : 0);
+            const int cp = (h->cone_prec && g.M >= 512) ? h->cone_prec : 0;
+            g.Wh = cp == 2 ? l.Wh16 : l.Wh; g.Wl = cp == 2 ? l.Wl16 : l.Wl; g.f16 = cp == 2;
+            run_gemm(h, g, l.cin, g.Wh ? cp : 0);
             raw_in = raw_gemm; raw_split = g.ksplit; raw_stride = g.split_stride;
         }
         if (k + 1 >= fc_from && k + 2 < nh) continue;       // the next level's cone_fc16 normalises these rows itself
@@ -1838,7 +1850,7 @@ int run_encode_into(oph_handle* h, const int* dL, const int* dSpk, int B, float*
     // last highway layer writes K|V rows straight into the resident KV buffer [B][N][2d]
     BatchedIO io{};
     io.spk = dSpk;
-    run_batched(h, h->textenc, ws, ld0, B, m.max_N, wsi, 0, KVdst, 2 * m.d, 2 * m.d, nullptr, nullptr, io);
+    run_batched(h, h->textenc, ws, ld0, B, m.max_N, wsi, h->textenc_prec, KVdst, 2 * m.d, 2 * m.d, nullptr, nullptr, io);
     g_cur = saved;
     HIPCHK(h, hipGetLastError());
     return OPH_OK;
@@ -2061,7 +2073,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
         if (hipHostMalloc(&hp_, 64, hipHostMallocMapped) == hipSuccess) { h->host_prog = (volatile int*)hp_; h->host_prog[0] = -1; h->host_prog[1] = INT_MAX; }
         (void)hipGetLastError();
     }
-    h->ssrn_prec = h->opt.ssrn_fp32 ? 0 : 1;
+    h->ssrn_prec = h->opt.ssrn_prec >= 0 ? h->opt.ssrn_prec : 2;
     build_networks(h);
     *out = h;
     return OPH_OK;
@@ -2144,29 +2156,35 @@ int oph_finalize_weights(oph_handle* h) {
     for (auto* net : {&h->textenc, &h->audioenc, &h->audiodec, &h->ssrn})
         for (Layer& l : *net)
             if (pack_layer(h, l) != 0) { h->fail("out of device memory packing %s", l.scope.c_str()); return OPH_ERR_DEVICE; }
-    // SSRN contractions run on bf16 MFMAs with every fp32 operand as hi + lo: the weights are split here, once
+    // SSRN contractions run on the 16-bit MFMAs with every fp32 operand as hi + lo: the weights are split here, once, into
+    // fp16 planes (the default arithmetic) and bf16 planes (oph_set_ssrn_precision(h, 1))
+    auto split = [&](const float* wsrc, size_t n, bool f16, void*& hi, void*& lo) {
+        hi = h->dalloc<unsigned short>(n); lo = h->dalloc<unsigned short>(n);
+        if (!hi || !lo) return false;
+        if (f16) launch_split_f16(wsrc, hi, lo, n, h->stream); else launch_split_bf16(wsrc, hi, lo, n, h->stream);
+        return true;
+    };
     for (Layer& l : h->ssrn) {
-        auto split = [&](const float* wsrc, size_t n, void*& hi, void*& lo) {
-            hi = h->dalloc<unsigned short>(n); lo = h->dalloc<unsigned short>(n);
-            if (!hi || !lo) return false;
-            launch_split_bf16(wsrc, hi, lo, n, h->stream);
-            return true;
-        };
         const size_t taps = l.kind == K_CONVT ? 2 : (size_t)l.ntaps;
-        if (l.Wt && !split(l.Wt, (size_t)l.Nalloc * taps * l.kc, l.Wh, l.Wl)) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
-        if (l.Wt2 && !split(l.Wt2, (size_t)l.Nalloc * l.kc, l.Wh2, l.Wl2)) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
+        const size_t n1 = (size_t)l.Nalloc * taps * l.kc, n2 = (size_t)l.Nalloc * l.kc;
+        if (l.Wt && (!split(l.Wt, n1, false, l.Wh, l.Wl) || !split(l.Wt, n1, true, l.Wh16, l.Wl16))) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
+        if (l.Wt2 && (!split(l.Wt2, n2, false, l.Wh2, l.Wl2) || !split(l.Wt2, n2, true, l.Wh2_16, l.Wl2_16))) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
     }
-    // experiment (OPH_CONE_BF16X3=1, off by default): the two many-row cone contractions on the split-bf16 kernel as well.
-    // Text2Mel is otherwise exact fp32 because its outputs feed the attention argmax; DESIGN.md records what this buys.
-    h->cone_bf16 = h->opt.cone_bf16;
-    if (h->cone_bf16)
-        for (int k = 0; k + 1 < h->n_hc_dec; ++k) {
-            Layer& l = h->audiodec[h->dec_pre + k];
-            const size_t n = (size_t)l.Nalloc * l.ntaps * l.kc;
-            l.Wh = h->dalloc<unsigned short>(n); l.Wl = h->dalloc<unsigned short>(n);
-            if (!l.Wh || !l.Wl) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
-            launch_split_bf16(l.Wt, l.Wh, l.Wl, n, h->stream);
-        }
+    // The two many-row levels of the AudioDec history cone (1312 and 704 rows x 768 x 512 per step) on the split contraction.
+    // Text2Mel feeds an argmax back into itself, so only fp32-class arithmetic qualifies as its default: split-fp16 x3
+    // (22 significant bits per operand; measured against the fp32 MFMA flavour in tests/test_gpu_decode_modes.py) -- the
+    // split-bf16 flavour (16 bits) stays an experiment (OPH_CONE_PREC=1).
+    h->cone_prec = h->opt.cone_prec >= 0 ? h->opt.cone_prec : CONE_PREC_DEFAULT;
+    for (int k = 0; k + 1 < h->n_hc_dec; ++k) {
+        Layer& l = h->audiodec[h->dec_pre + k];
+        const size_t n = (size_t)l.Nalloc * l.ntaps * l.kc;
+        if (!split(l.Wt, n, true, l.Wh16, l.Wl16) || (h->cone_prec == 1 && !split(l.Wt, n, false, l.Wh, l.Wl))) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
+    }
+    // TextEnc (82 GFLOP per 16-utterance batch, once per batch) on the split-fp16 contraction as well: K,V feed the attention
+    // argmax, so again only the fp32-class flavour is offered (oph_set_precision(h, 2, 0) selects the fp32 MFMA)
+    h->textenc_prec = h->opt.textenc_prec >= 0 ? h->opt.textenc_prec : TEXTENC_PREC_DEFAULT;
+    for (Layer& l : h->textenc)
+        if (!split(l.Wt, (size_t)l.Nalloc * l.ntaps * l.kc, true, l.Wh16, l.Wl16)) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->cone_head_ok = !h->opt.no_cone_head && !(h->dm.flags & OPH_FLAG_NO_MONOTONIC) && h->audiodec[0].Wkn != nullptr && h->dm.d <= 256 && (h->dm.d % 4) == 0;
     if (h->cone_head_ok) {
@@ -2374,9 +2392,22 @@ int oph_run_resident(oph_handle* h, int stop_mode, int run_ssrn, int32_t* steps_
 }
 
 int oph_set_ssrn_precision(oph_handle* h, int mode) {
-    if (!h || mode < 0 || mode > 1) return OPH_ERR_INVALID;
+    if (!h || mode < 0 || mode > 2) return OPH_ERR_INVALID;
     h->ssrn_prec = mode;
     return OPH_OK;
+}
+// which: 0 SSRN (= oph_set_ssrn_precision), 1 the cone's two many-row contractions, 2 TextEnc.  mode: 0 fp32 MFMA, 2 split-fp16 x3
+// (fp32-class), 1 split-bf16 x3 (SSRN; the cone only if the handle was created under OPH_CONE_PREC=1)
+int oph_set_precision(oph_handle* h, int which, int mode) {
+    if (!h || mode < 0 || mode > 2) return OPH_ERR_INVALID;
+    if (which == 0) { h->ssrn_prec = mode; return OPH_OK; }
+    if (which == 1) {
+        if (mode == 1 && !(h->n_hc_dec > 1 && h->audiodec[h->dec_pre].Wh)) { h->fail("the cone's bf16 planes were not built (create the handle under OPH_CONE_PREC=1)"); return OPH_ERR_STATE; }
+        h->cone_prec = mode; return OPH_OK;
+    }
+    if (which == 2 && mode != 1) { h->textenc_prec = mode; return OPH_OK; }
+    h->fail("bad precision selector");
+    return OPH_ERR_INVALID;
 }
 // what the pipeline actually did since the handle was created (tests and bench.py assert on these):
 // [0] TextEnc evaluations  [1] runs that found their K,V pre-encoded  [2] SSRN chunks launched while a decode was running
@@ -2930,18 +2961,18 @@ int oph_bench_conv1d_transpose(int device, int B, int T, int Cin, int Cout, int 
     unsigned short* dweh = c.alloc<unsigned short>(we.size()); unsigned short* dwel = c.alloc<unsigned short>(we.size());
     unsigned short* dwoh = c.alloc<unsigned short>(wo.size()); unsigned short* dwol = c.alloc<unsigned short>(wo.size());
     if (!c.ok) return OPH_ERR_DEVICE;
-    launch_split_bf16(dwe, dweh, dwel, we.size(), c.s);
-    launch_split_bf16(dwo, dwoh, dwol, wo.size(), c.s);
+    if (precision == 2) { launch_split_f16(dwe, dweh, dwel, we.size(), c.s); launch_split_f16(dwo, dwoh, dwol, wo.size(), c.s); }
+    else { launch_split_bf16(dwe, dweh, dwel, we.size(), c.s); launch_split_bf16(dwo, dwoh, dwol, wo.size(), c.s); }
     hipStreamSynchronize(c.s);
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { g_op_error = "event creation failed"; return OPH_ERR_DEVICE; }
     auto once = [&]() {
         GemmArgs g{};
         g.X = dx; g.ldx = kc; g.bias = dbias; g.ldh = 2 * Nalloc; g.M = M; g.N = Cout; g.kc = kc; g.mode = 0; g.T = T;
-        g.Wt = dwe; g.Wh = dweh; g.Wl = dwel; g.ldw = 2 * kc; g.ntaps = 2; g.off[0] = 0; g.off[1] = -1; g.H = dh;
+        g.Wt = dwe; g.Wh = dweh; g.Wl = dwel; g.f16 = precision == 2; g.ldw = 2 * kc; g.ntaps = 2; g.off[0] = 0; g.off[1] = -1; g.H = dh;
         GemmArgs g2 = g;
         g2.Wt = dwo; g2.Wh = dwoh; g2.Wl = dwol; g2.ldw = kc; g2.ntaps = 1; g2.off[0] = 0; g2.H = dh + Nalloc;
-        launch_conv_gemm_pair(g, g2, precision ? 1 : 0, c.s);
+        launch_conv_gemm_pair(g, g2, precision < 0 || precision > 2 ? 0 : precision, c.s);
         EpiArgs e{};
         e.H = dh; e.ldh = Nalloc; e.M = 2 * M; e.C = Cout; e.mode = PRE_CONV; e.act = ACT_NONE; e.g1 = dg; e.b1 = db; e.Y = dy; e.ldy = Cout; e.ypad = Cout;
         launch_epilogue(e, c.s);

@@ -201,31 +201,50 @@ void launch_conv_gemm(const GemmArgs& a, hipStream_t s) {
 // tests/test_gpu_model.py.  LDS tile = hi and lo planes [row][32 bf16 + 8 pad] (80-B rows =>
 // conflict-free ds_read_b128 of the 8-element MFMA fragments).
 // =====================================================================================
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void split_bf16(const f32x4& x, bf16x4& hi, bf16x4& lo) {
+// The two 16-bit operand formats of the split contraction.  bf16 (8 significant bits per term: hi + lo reproduce 16 bits,
+// ~1e-5 relative per product) and fp16 (11 bits per term: hi + lo reproduce 22 of fp32's 24 bits, 2.4e-7 relative per
+// product -- below the rounding of an fp32 accumulation over K >= 512 terms, i.e. the same accuracy class as the fp32 MFMA
+// kernel; the lo term of a small value falls into fp16's subnormals, whose absolute spacing 2^-24 is far below the
+// accumulator's resolution).  Both run at the same MFMA rate.  fp16's range ends at 65504: the operands here are LayerNorm
+// outputs, highway mixes of them, mel frames in [0,1] and weights -- orders of magnitude below it.
+template <bool F16> struct SplitT { typedef __bf16 T; };
+template <> struct SplitT<true> { typedef _Float16 T; };
+template <bool F16>
+__device__ __forceinline__ void split16(const f32x4& x, typename SplitT<F16>::T (&hi)[4], typename SplitT<F16>::T (&lo)[4]) {
+    typedef typename SplitT<F16>::T H;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const __bf16 h = (__bf16)x[e];
+        const H h = (H)x[e];
         hi[e] = h;
-        lo[e] = (__bf16)(x[e] - (float)h);
+        lo[e] = (H)(x[e] - (float)h);
     }
 }
 
 // The weights are split ONCE (launch_split_bf16 at load time) into hi / lo bf16 planes; only the activations are split
 // in the kernel, while they are staged.  Software pipeline as conv_gemm_f32 (prefetch distance 2): one K-step of bf16
 // MFMAs (~0.3 us for a 128x128 tile) covers nothing of an HBM round trip, two register sets in flight do.
-__global__ void split_bf16_kernel(const float* w, __bf16* hi, __bf16* lo, size_t n) {
+template <bool F16>
+__global__ void split16_kernel(const float* w, typename SplitT<F16>::T* hi, typename SplitT<F16>::T* lo, size_t n) {
+    typedef typename SplitT<F16>::T H;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) { const float x = w[i]; const __bf16 h = (__bf16)x; hi[i] = h; lo[i] = (__bf16)(x - (float)h); }
+    if (i < n) { const float x = w[i]; const H h = (H)x; hi[i] = h; lo[i] = (H)(x - (float)h); }
 }
 void launch_split_bf16(const float* w, void* hi, void* lo, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, (__bf16*)hi, (__bf16*)lo, n);
+    hipLaunchKernelGGL(split16_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, (__bf16*)hi, (__bf16*)lo, n);
+}
+void launch_split_f16(const float* w, void* hi, void* lo, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(split16_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, (_Float16*)hi, (_Float16*)lo, n);
 }
 
-template <int BM, int BN, bool TAB>      // TAB: table-mapped rows (decoder cone); a separate instance so that the dense one carries no row table
+template <bool F16, class V8>
+static __device__ __forceinline__ f32x16 mfma16(const V8& x, const V8& y, const f32x16& c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+}
+template <int BM, int BN, bool TAB, bool F16>      // TAB: table-mapped rows (decoder cone); a separate instance so that the dense one carries no row table.  F16: fp16 terms instead of bf16
 static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) {
+    typedef typename SplitT<F16>::T H16;
+    typedef H16 h16x8 __attribute__((ext_vector_type(8)));
     if (stopped(a.stop_after, a.t)) return;
     // LDS rows are 32 bf16 = four 16-byte chunks, unpadded, with the chunk index XOR-ed by (row >> 2) & 3: the 8-byte staging
     // stores of a wave (4 rows x 8 lanes per pass) then fall into four disjoint 16-bank ranges, and the 16-byte fragment reads
@@ -235,14 +254,14 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
     constexpr int AR = BM / 32, BR = BN / 32;
     constexpr int TM = BM / 64, TN = BN / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __bf16* Ah = (__bf16*)smem;                    // [2][BM*LDH]
-    __bf16* Al = Ah + 2 * BM * LDH;
+    H16* Ah = (H16*)smem;                          // [2][BM*LDH]
+    H16* Al = Ah + 2 * BM * LDH;
     // The weight planes never pass through registers: global_load_lds_dwordx4 copies 16 bytes per lane straight into LDS
     // (lane l's bytes land at the wave's base + 16 l, profiles/glds_probe.hip), two K-steps ahead, into a 3-slot ring; the
     // chunk swizzle is applied on the global side.  A: 2 buffers x 2 planes; B: 3 slots x 2 planes -- for a 128x128 tile
     // exactly half a CU's LDS, so two workgroups stay resident per CU (no source-row table in LDS for the same reason).
-    __bf16* Bh = Al + 2 * BM * LDH;                // [3][BN*LDH]
-    __bf16* Bl = Bh + 3 * BN * LDH;
+    H16* Bh = Al + 2 * BM * LDH;                   // [3][BN*LDH]
+    H16* Bl = Bh + 3 * BN * LDH;
 
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
@@ -279,7 +298,7 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
     const int kpt = a.kc / BK, nk_all = a.ntaps * kpt;
     const int ksplit = a.ksplit > 1 ? a.ksplit : 1, split = blockIdx.y;
     const int ks0 = split * nk_all / ksplit, nk = (split + 1) * nk_all / ksplit - ks0;
-    const __bf16* Wh = (const __bf16*)a.Wh; const __bf16* Wl = (const __bf16*)a.Wl;
+    const H16* Wh = (const H16*)a.Wh; const H16* Wl = (const H16*)a.Wl;
     f32x4 ra0[AR], ra1[AR];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     constexpr int NDMA = BN * 4 / 256;             // 16-byte chunks of one plane's K-step per thread
@@ -315,11 +334,12 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
     auto store_lds = [&](int buf, const f32x4 (&ra)[AR]) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            bf16x4 hi, lo;
-            split_bf16(ra[i], hi, lo);
+            H16 hi[4], lo[4];
+            split16<F16>(ra[i], hi, lo);
+            typedef H16 h16x4 __attribute__((ext_vector_type(4)));
             const int o = buf * BM * LDH + (lrow + 32 * i) * LDH + (((kq >> 1) ^ ((lrow >> 2) & 3)) << 3) + ((kq & 1) << 2);
-            *(bf16x4*)(Ah + o) = hi;
-            *(bf16x4*)(Al + o) = lo;
+            *(h16x4*)(Ah + o) = h16x4{hi[0], hi[1], hi[2], hi[3]};
+            *(h16x4*)(Al + o) = h16x4{lo[0], lo[1], lo[2], lo[3]};
         }
     };
 
@@ -339,16 +359,16 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
         const int swr = (r32 >> 2) & 3;
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
-            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+            h16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                ah[i] = *(const bf16x8*)(Ah + ao + i * 32 * LDH + (((kc * 2 + kh) ^ swr) << 3));
-                al[i] = *(const bf16x8*)(Al + ao + i * 32 * LDH + (((kc * 2 + kh) ^ swr) << 3));
+                ah[i] = *(const h16x8*)(Ah + ao + i * 32 * LDH + (((kc * 2 + kh) ^ swr) << 3));
+                al[i] = *(const h16x8*)(Al + ao + i * 32 * LDH + (((kc * 2 + kh) ^ swr) << 3));
             }
 #pragma unroll
             for (int jn = 0; jn < TN; ++jn) {
-                bh[jn] = *(const bf16x8*)(Bh + bo + jn * 32 * LDH + (((kc * 2 + kh) ^ swr) << 3));
-                bl[jn] = *(const bf16x8*)(Bl + bo + jn * 32 * LDH + (((kc * 2 + kh) ^ swr) << 3));
+                bh[jn] = *(const h16x8*)(Bh + bo + jn * 32 * LDH + (((kc * 2 + kh) ^ swr) << 3));
+                bl[jn] = *(const h16x8*)(Bl + bo + jn * 32 * LDH + (((kc * 2 + kh) ^ swr) << 3));
             }
             // product by product over all tiles: with four tiles per wave consecutive MFMAs never share an accumulator (three
             // back-to-back MFMAs on one accumulator serialise on its latency: 30 % of the wave cycles were issue stalls,
@@ -358,19 +378,19 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn) {
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[jn], acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = mfma16<F16>(al[i], bh[jn], acc[i][jn]);
                 }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn) {
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[jn], acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = mfma16<F16>(ah[i], bl[jn], acc[i][jn]);
                 }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn)
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[jn], acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = mfma16<F16>(ah[i], bh[jn], acc[i][jn]);
         }
     };
     // every VMEM operation of a step is issued before its compute; they complete in order, so "at most the operations of
@@ -413,55 +433,58 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
         }
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3(GemmArgs a) { conv_gemm_bf16x3_body<BM, BN, false>(a); }
-template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3_tab(GemmArgs a) { conv_gemm_bf16x3_body<BM, BN, true>(a); }
-template <int BM, int BN>
+template <int BM, int BN, bool F16>
+__global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3(GemmArgs a) { conv_gemm_bf16x3_body<BM, BN, false, F16>(a); }
+template <int BM, int BN, bool F16>
+__global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3_tab(GemmArgs a) { conv_gemm_bf16x3_body<BM, BN, true, F16>(a); }
+template <int BM, int BN, bool F16>
 __global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3_pair(GemmArgs a0, GemmArgs a1) {
-    if (blockIdx.z == 0) conv_gemm_bf16x3_body<BM, BN, false>(a0); else conv_gemm_bf16x3_body<BM, BN, false>(a1);
+    if (blockIdx.z == 0) conv_gemm_bf16x3_body<BM, BN, false, F16>(a0); else conv_gemm_bf16x3_body<BM, BN, false, F16>(a1);
 }
 template <int BM, int BN>
 static void launch_conv_gemm_pair_t(const GemmArgs& a0, const GemmArgs& a1, int prec, hipStream_t s) {
-    static bool attr_set[2][64] = {{false}};
+    static bool attr_set[3][64] = {{false}};
     const size_t lds = prec ? (size_t)((2 * BM + 3 * BN) * 2 * 32) * 2 : (size_t)(2 * (BM + BN) * 36) * 4 + (size_t)3 * BM * 4;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!attr_set[prec ? 1 : 0][dev & 63]) {
-        if (prec) (void)hipFuncSetAttribute((const void*)conv_gemm_bf16x3_pair<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (!attr_set[prec][dev & 63]) {
+        if (prec == 2) (void)hipFuncSetAttribute((const void*)conv_gemm_bf16x3_pair<BM, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else if (prec) (void)hipFuncSetAttribute((const void*)conv_gemm_bf16x3_pair<BM, BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         else (void)hipFuncSetAttribute((const void*)conv_gemm_f32_pair<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set[prec ? 1 : 0][dev & 63] = true;
+        attr_set[prec][dev & 63] = true;
     }
     const int MT = (a0.M + BM - 1) / BM, NT = (a0.N + BN - 1) / BN;
-    if (prec) hipLaunchKernelGGL((conv_gemm_bf16x3_pair<BM, BN>), dim3(MT * NT, 1, 2), dim3(256), lds, s, a0, a1);
+    if (prec == 2) hipLaunchKernelGGL((conv_gemm_bf16x3_pair<BM, BN, true>), dim3(MT * NT, 1, 2), dim3(256), lds, s, a0, a1);
+    else if (prec) hipLaunchKernelGGL((conv_gemm_bf16x3_pair<BM, BN, false>), dim3(MT * NT, 1, 2), dim3(256), lds, s, a0, a1);
     else hipLaunchKernelGGL((conv_gemm_f32_pair<BM, BN>), dim3(MT * NT, 1, 2), dim3(256), lds, s, a0, a1);
 }
-// same M and N, no split-K; prec != 0: split-bf16 contraction (both need Wh / Wl)
+// same M and N, no split-K; prec: 0 fp32 MFMA, 1 split-bf16 x3, 2 split-fp16 x3 (both need Wh / Wl in that format)
 void launch_conv_gemm_pair(const GemmArgs& a0, const GemmArgs& a1, int prec, hipStream_t s) {
     if (conv_gemm_tile_m(a0.M, a0.N) == 128) launch_conv_gemm_pair_t<128, 128>(a0, a1, prec, s);
     else launch_conv_gemm_pair_t<64, 64>(a0, a1, prec, s);
 }
-template <int BM, int BN>
+template <int BM, int BN, bool F16>
 static void launch_conv_gemm_bf16x3_t(const GemmArgs& a, hipStream_t s) {
     static bool attr_set[64] = {false};
     const size_t lds = (size_t)((2 * BM + 3 * BN) * 2 * 32) * 2;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr_set[dev & 63]) {
-        (void)hipFuncSetAttribute((const void*)conv_gemm_bf16x3<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)conv_gemm_bf16x3<BM, BN, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set[dev & 63] = true;
     }
     const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
     if (a.mode == 1) {
         static bool tab_set[64] = {false};
-        if (!tab_set[dev & 63]) { (void)hipFuncSetAttribute((const void*)conv_gemm_bf16x3_tab<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); tab_set[dev & 63] = true; }
-        hipLaunchKernelGGL((conv_gemm_bf16x3_tab<BM, BN>), dim3(MT * NT, a.ksplit > 1 ? a.ksplit : 1), dim3(256), lds, s, a);
+        if (!tab_set[dev & 63]) { (void)hipFuncSetAttribute((const void*)conv_gemm_bf16x3_tab<BM, BN, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); tab_set[dev & 63] = true; }
+        hipLaunchKernelGGL((conv_gemm_bf16x3_tab<BM, BN, F16>), dim3(MT * NT, a.ksplit > 1 ? a.ksplit : 1), dim3(256), lds, s, a);
     } else
-        hipLaunchKernelGGL((conv_gemm_bf16x3<BM, BN>), dim3(MT * NT, a.ksplit > 1 ? a.ksplit : 1), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((conv_gemm_bf16x3<BM, BN, F16>), dim3(MT * NT, a.ksplit > 1 ? a.ksplit : 1), dim3(256), lds, s, a);
 }
-void launch_conv_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {     // needs a.Wh / a.Wl
-    if (conv_gemm_tile_m(a.M, a.N) == 128) launch_conv_gemm_bf16x3_t<128, 128>(a, s);
-    else launch_conv_gemm_bf16x3_t<64, 64>(a, s);
+void launch_conv_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {     // needs a.Wh / a.Wl; a.f16: they are fp16 planes
+    const bool big = conv_gemm_tile_m(a.M, a.N) == 128;
+    if (a.f16) { if (big) launch_conv_gemm_bf16x3_t<128, 128, true>(a, s); else launch_conv_gemm_bf16x3_t<64, 64, true>(a, s); }
+    else { if (big) launch_conv_gemm_bf16x3_t<128, 128, false>(a, s); else launch_conv_gemm_bf16x3_t<64, 64, false>(a, s); }
 }
 
 // =====================================================================================

@@ -378,8 +378,13 @@ class Engine(object):
         return Z
 
     def set_ssrn_precision(self, mode):
-        """1 = split-bf16 x3 contractions with fp32 accumulate (default), 0 = exact fp32 MFMA."""
+        """2 = split-fp16 x3 contractions with fp32 accumulate (default, fp32-class accuracy), 1 = split-bf16 x3,
+        0 = fp32 MFMA."""
         self._chk(self.lib.oph_set_ssrn_precision(self._h, int(mode)))
+
+    def set_precision(self, which, mode):
+        """which: "ssrn" | "cone" | "textenc"; mode as set_ssrn_precision (oph_set_precision)."""
+        self._chk(self.lib.oph_set_precision(self._h, {"ssrn": 0, "cone": 1, "textenc": 2}[which], int(mode)))
 
     def synchronize(self):
         self._chk(self.lib.oph_synchronize(self._h))

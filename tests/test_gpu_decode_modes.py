@@ -46,18 +46,19 @@ FLAVOURS = {
     "loop_fc256": {"OPH_CONE_FC_ROWS": "256", "OPH_CONE_FC_INSPLIT": "1"},
     "loop_nostream": {"OPH_NO_STREAM_SSRN": "1"},
     "loop_coneloop": {"OPH_CONE_LOOP": "1"},               # the cone as ONE persistent task-graph launch (opt-in) instead of nine launches per step
-    "loop_conebf16": {"OPH_CONE_BF16X3": "1"},
+    "loop_conefp32": {"OPH_CONE_PREC": "0", "OPH_TEXTENC_PREC": "0"},      # fp32 MFMA for the cone's large levels and TextEnc (default: split-fp16 x3)
+    "loop_conebf16": {"OPH_CONE_PREC": "1"},                                # the split-bf16 experiment
 }
 
 
-# exact-fp32 flavours differ by summation order only; the split-bf16 x3 cone experiment drops terms below 2^-16
+# fp32-class flavours (fp32 MFMA, split-fp16 x3) differ at the level of summation order; the split-bf16 x3 cone experiment drops terms below 2^-16
 TOL = {"loop_conebf16": 3e-4}
 
 
 def _run(tmp_path, name, env_extra, max_T, B, stop_mode):
     out = str(tmp_path / (name + ".npz"))
     env = dict(os.environ)
-    for k in ("OPH_DECODE", "OPH_RUN_ROWS", "OPH_NO_CONE_HEAD", "OPH_CONE_FC_ROWS", "OPH_CONE_FC_INSPLIT", "OPH_NO_STREAM_SSRN", "OPH_CONE_LOOP", "OPH_CONE_BF16X3"):
+    for k in ("OPH_DECODE", "OPH_RUN_ROWS", "OPH_NO_CONE_HEAD", "OPH_CONE_FC_ROWS", "OPH_CONE_FC_INSPLIT", "OPH_NO_STREAM_SSRN", "OPH_CONE_LOOP", "OPH_CONE_BF16X3", "OPH_CONE_PREC", "OPH_TEXTENC_PREC"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, "-c", CHILD, ROOT, out, str(max_T), str(B), str(stop_mode)], env=env,

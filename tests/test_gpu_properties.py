@@ -73,4 +73,4 @@ def test_ssrn_receptive_field_locality(full):
     changed = np.where(np.abs(Z1[1] - Z0[1]).max(axis=1) > 0)[0]
     assert changed.min() == 4 * t - 30 and changed.max() == 4 * t + 36
     assert Z0.shape == (2, hp.max_T * hp.r, hp.full_dim) and (Z0 > 0).all() and (Z0 < 1).all()
-    eng.set_ssrn_precision(1)
+    eng.set_ssrn_precision(2)
