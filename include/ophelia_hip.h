@@ -129,6 +129,10 @@ int oph_ssrn_logits(oph_handle* h, const float* Y, int B, int T, float* Z, float
 /* Speculative SSRN during oph_text2mel (default on): chunks of mel frames go through SSRN on their own CU partition as
  * soon as the decoder has produced them (SSRN's receptive field is +-9 mel frames), for oph_ssrn(Y = NULL) to pick up. */
 int oph_set_streaming(oph_handle* h, int on);
+/* Host buffer (B, r*max_T, full_dim) the speculative SSRN of the NEXT oph_text2mel copies its rows to while the decoder is
+ * still running (pinned memory from oph_host_alloc makes the copies asynchronous); oph_ssrn(Y = NULL, ..., Z = that pointer)
+ * then only computes and copies the tail.  NULL clears it. */
+int oph_set_mag_destination(oph_handle* h, float* Z);
 /* What the pipeline did since oph_create, out[0..n): [0] TextEnc evaluations, [1] runs whose K,V had been pre-encoded under
  * the previous decode, [2] SSRN chunks launched while a decode was running, [3] whole-decode launches, [4] fall-backs from the
  * whole-decode launch to two launches per step, [5] tiles resumed to their batch's stop step, [6] persistent cone launches. */

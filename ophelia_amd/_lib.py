@@ -59,6 +59,7 @@ SIGNATURES = {
     "oph_host_free": (C.c_int, [C.c_void_p]),
     "oph_ssrn_logits": (C.c_int, [C.c_void_p, c_f32p, C.c_int, C.c_int, c_f32p, c_f32p]),
     "oph_set_streaming": (C.c_int, [C.c_void_p, C.c_int]),
+    "oph_set_mag_destination": (C.c_int, [C.c_void_p, c_f32p]),
     "oph_get_counters": (C.c_int, [C.c_void_p, c_i64p, C.c_int]),
     "oph_run_resident": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_i32p]),
     "oph_decode_steps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_i32p]),

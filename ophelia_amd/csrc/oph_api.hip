@@ -164,6 +164,10 @@ struct oph_handle {
     hipStream_t scopy = nullptr;       // copies only (unmasked): results leave for the host while the decode runs
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     hipEvent_t ev_dec_done = nullptr, ev_ssrn_done[2] = {nullptr, nullptr}, ev_copy = nullptr, ev_chunk = nullptr;
+    // streamed SSRN chunks are launched only while the SSRN partition keeps up: one chunk in flight, and none that could not
+    // finish before the decode does (what is left then runs on the whole chip)
+    hipEvent_t ev_cs = nullptr, ev_ce = nullptr; bool chunk_inflight = false; float chunk_ms = 0.f;
+    std::chrono::steady_clock::time_point dec_t0;
     bool ssrn_inflight[2] = {false, false};
     int buf = 0; bool pipelined = false;
     uint32_t m_cone[16] = {0}, m_conep[16] = {0}, m_ssrn[16] = {0}; int mask_words = 0;   // CU partitions (0 words = no masking)
@@ -229,6 +233,7 @@ struct oph_handle {
     bool kv_resident = false, y_resident = false;
     bool spec_ssrn = true;              // oph_text2mel streams SSRN over the frames it has produced (consumed by oph_ssrn(Y = NULL))
     float* z_host = nullptr;            // host destination the streamed SSRN chunks are copied to as they complete (or null)
+    float* z_spec = nullptr;            // oph_set_mag_destination: where oph_text2mel's speculative SSRN copies its chunks
     // ---- decode tiles: utterances [16 j, 16 j + 16) of the batch; `tile` is the one the views below point into
     std::vector<Tile> tiles; int tile = 0;
     int B = 0, Bpad = 0;                // the CURRENT tile: utterances, rows (16)
@@ -1213,6 +1218,7 @@ bool run_supported(const oph_handle* h) {
 
 int run_encode_into(oph_handle* h, const int* dL, const int* dSpk, int B, float* KVdst, hipStream_t stream, int wsi);      // defined with the batched networks below
 int ssrn_stream_chunks(oph_handle* h, int frames_ready, bool final);                                                          // streamed SSRN of the current tile
+void ssrn_margins(const oph_handle* h, int* back, int* ahead);
 
 // ---------------------------------------------------------------- whole-decode launch (dec_loop)
 // Static layer table of a decode: AudioEnc (layer 0 consumes the previous step's last AudioDec layer) -> attention +
@@ -1373,6 +1379,7 @@ int decode_loop(oph_handle* h, int t_end, int stop_mode) {
         for (const Layer& l : *net) { const double K = (double)l.ntaps * l.cin; bytes += ((double)l.N * K + (double)h->B * (K + l.N)) * 4.0; flops += 2.0 * h->B * l.N * K; }
     if (h->d_sigdbg) hipMemsetAsync(h->d_sigdbg, 0, (size_t)m.max_T * 8 * sizeof(long long), h->sdec);
     h->pbegin(PC_DECLOOP);
+    h->dec_t0 = std::chrono::steady_clock::now(); h->chunk_inflight = false;
     launch_dec_loop(a, h->loop_slices, h->loop_rows, h->loop_kmax, h->sdec);
     h->pend(PC_DECLOOP, bytes * t_end, flops * t_end);
     if (h->want_preenc && h->next_staged && !h->preenc_valid) {
@@ -1822,6 +1829,11 @@ int decode_batch(oph_handle* h, int t_end, int stop_mode, int32_t* steps_run) {
             const int ctl1 = INT_MAX;
             HIPCHK(h, hipMemcpyAsync(h->d_ctl + 1, &ctl1, 4, hipMemcpyHostToDevice, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
+            {   // frames from the tile's stop step on are about to change: SSRN rows that saw them are stale
+                int back = 0, ahead = 0;
+                ssrn_margins(h, &back, &ahead);
+                h->tiles[j].ssrn_done = std::min(h->tiles[j].ssrn_done, std::max(0, h->tiles[j].steps - ahead));
+            }
             const int rc = decode_range(h, h->tiles[j].steps, batch_steps, OPH_STOP_NEVER, nullptr);
             if (rc) return rc;
             h->n_tile_resumes++;
@@ -1929,13 +1941,27 @@ int ssrn_stream_chunks(oph_handle* h, int frames_ready, bool final) {
         else {
             b = a + ch;
             if (b + ahead > frames_ready || b >= m.max_T) break;     // (the last frames always belong to the final chunk)
+            // one chunk in flight on the partition; its measured duration tells whether another one can still finish before
+            // the decode does -- if not, those frames are cheaper in the final piece on the whole chip
+            if (h->chunk_inflight) {
+                if (hipEventQuery(h->ev_ce) != hipSuccess) { (void)hipGetLastError(); break; }
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, h->ev_cs, h->ev_ce) == hipSuccess) h->chunk_ms = ms;
+                h->chunk_inflight = false;
+            }
+            if (h->chunk_ms > 0.f && frames_ready > 8 && !h->pipelined) {
+                const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - h->dec_t0).count() * 1e3;
+                const double remaining = elapsed / frames_ready * (m.max_T - frames_ready);
+                if (h->chunk_ms > remaining) break;
+            }
         }
         // while the decode runs: the SSRN partition; afterwards, not pipelined: the whole chip through the API stream (which
         // the decode streams have joined)
         const bool side = !final || h->pipelined;
+        if (!final) hipEventRecord(h->ev_cs, h->sssrn);
         const int rc = run_ssrn_chunk(h, a, b, side ? h->sssrn : h->stream, side ? 1 : 0);
         if (rc) return rc;
-        if (!final) h->n_chunks_streamed++;
+        if (!final) { hipEventRecord(h->ev_ce, h->sssrn); h->chunk_inflight = true; h->n_chunks_streamed++; }
         tl.ssrn_done = b;
     }
     return OPH_OK;
@@ -2047,6 +2073,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
         hipEventCreateWithFlags(&h->ev_preenc, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chunk, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreate(&h->ev_cs) != hipSuccess || hipEventCreate(&h->ev_ce) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_attn, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_cone, hipEventDisableTiming) != hipSuccess ||
@@ -2086,7 +2113,7 @@ int oph_destroy(oph_handle* h) {
     for (hipStream_t st : {h->stream, h->sdec, h->scone, h->sssrn, h->scopy}) if (st) hipStreamSynchronize(st);
     for (auto& pc : h->prof)
         for (auto& e : pc.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    for (hipEvent_t e : {h->ev0, h->ev1, h->ev_attn, h->ev_cone, h->ev_in, h->ev_out, h->ev_dec_done, h->ev_ssrn_done[0], h->ev_ssrn_done[1], h->ev_preenc, h->ev_copy, h->ev_chunk})
+    for (hipEvent_t e : {h->ev0, h->ev1, h->ev_attn, h->ev_cone, h->ev_in, h->ev_out, h->ev_dec_done, h->ev_ssrn_done[0], h->ev_ssrn_done[1], h->ev_preenc, h->ev_copy, h->ev_chunk, h->ev_cs, h->ev_ce})
         if (e) hipEventDestroy(e);
     TRACE("destroy: free");
     for (void* p : h->allocs) hipFree(p);
@@ -2393,14 +2420,14 @@ int oph_run_resident(oph_handle* h, int stop_mode, int run_ssrn, int32_t* steps_
 
 int oph_set_ssrn_precision(oph_handle* h, int mode) {
     if (!h || mode < 0 || mode > 2) return OPH_ERR_INVALID;
-    h->ssrn_prec = mode;
+    h->ssrn_prec = mode; h->chunk_ms = 0.f;
     return OPH_OK;
 }
 // which: 0 SSRN (= oph_set_ssrn_precision), 1 the cone's two many-row contractions, 2 TextEnc.  mode: 0 fp32 MFMA, 2 split-fp16 x3
 // (fp32-class), 1 split-bf16 x3 (SSRN; the cone only if the handle was created under OPH_CONE_PREC=1)
 int oph_set_precision(oph_handle* h, int which, int mode) {
     if (!h || mode < 0 || mode > 2) return OPH_ERR_INVALID;
-    if (which == 0) { h->ssrn_prec = mode; return OPH_OK; }
+    if (which == 0) { h->ssrn_prec = mode; h->chunk_ms = 0.f; return OPH_OK; }
     if (which == 1) {
         if (mode == 1 && !(h->n_hc_dec > 1 && h->audiodec[h->dec_pre].Wh)) { h->fail("the cone's bf16 planes were not built (create the handle under OPH_CONE_PREC=1)"); return OPH_ERR_STATE; }
         h->cone_prec = mode; return OPH_OK;
@@ -2416,6 +2443,14 @@ int oph_get_counters(oph_handle* h, int64_t* out, int n) {
     if (!h || !out) return OPH_ERR_INVALID;
     const long long v[7] = {h->n_textenc, h->n_preenc_used, h->n_chunks_streamed, h->n_loop_decodes, h->n_loop_fallbacks, h->n_tile_resumes, h->n_cone_loops};
     for (int i = 0; i < n && i < 7; ++i) out[i] = v[i];
+    return OPH_OK;
+}
+// Where the speculative SSRN of the NEXT oph_text2mel copies its rows while the decoder is still running: a host buffer of
+// (B, r*max_T, full_dim) floats (pinned, oph_host_alloc, for the copies to be asynchronous).  oph_ssrn(Y = NULL, ..., Z = that
+// pointer) then only has the tail left to compute and copy.  NULL clears it.
+int oph_set_mag_destination(oph_handle* h, float* Z) {
+    if (!h) return OPH_ERR_INVALID;
+    h->z_spec = Z;
     return OPH_OK;
 }
 int oph_set_streaming(oph_handle* h, int on) {
@@ -2573,7 +2608,10 @@ int oph_text2mel(oph_handle* h, const float* K, const float* V, const int32_t* e
     if ((rc = set_pipelined(h, false))) return rc;
     if ((rc = stage_decode_inputs(h, K, V, true, ends, spk, B))) return rc;
     begin_batch(h);
-    if ((rc = decode_batch(h, h->dm.max_T, stop_mode, steps_run))) return rc;
+    h->z_host = h->spec_ssrn ? h->z_spec : nullptr;       // the speculative SSRN's rows leave for the host as they are produced
+    rc = decode_batch(h, h->dm.max_T, stop_mode, steps_run);
+    h->z_host = nullptr;
+    if (rc) return rc;
     h->y_resident = true;           // oph_ssrn(Y = NULL) continues from here
     return oph_fetch_mel(h, Y, t_ends, alignments);
 }
@@ -2700,6 +2738,17 @@ static int ssrn_common(oph_handle* h, const float* Y, int B, int T, float* Z, fl
     if (!Y && !Z_logits) {
         if (!h->y_resident || B != h->nB || T != m.max_T) { h->fail("Y = NULL asks for the mel frames the last decode left in HBM, but there are none for B=%d, T=%d", B, T); return OPH_ERR_STATE; }
         g_cur = h->stream;
+        if (Z == h->z_spec && Z != nullptr) {
+            // the chunks streamed during the decode are already in Z (oph_set_mag_destination): compute and copy what is left
+            h->z_host = Z;
+            rc = finish_ssrn(h);
+            h->z_host = nullptr;
+            if (rc) return rc;
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->sssrn));
+            HIPCHK(h, hipStreamSynchronize(h->scopy));
+            return OPH_OK;
+        }
         if ((rc = finish_ssrn(h))) return rc;
         return oph_fetch_mag(h, Z);
     }

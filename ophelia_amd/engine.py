@@ -117,6 +117,7 @@ class Engine(object):
         self.B = 0
         self._kv_token = None          # (K, V) arrays of the last encode_text whose values are still in HBM
         self._y_token = None           # Y array of the last decode whose values are still in HBM
+        self._z_spec = None            # pinned array the last decode's speculative SSRN has been copying its rows into
 
     # Residency between the three session calls (include/ophelia_hip.h): the arrays a call returns are read-only and the
     # engine remembers them; handing the very same (still read-only) arrays to the next call skips the upload -- K,V never
@@ -213,9 +214,17 @@ class Engine(object):
         self._y_token = None
         if not resident:
             self._kv_token = None
-        self._chk(self.lib.oph_text2mel(self._h, None if resident else _lib.fptr(K), None if resident else _lib.fptr(V),
-                                        _lib.iptr(ends), sp, B, int(stop_mode),
-                                        _lib.fptr(Y), _lib.iptr(t_ends), _lib.fptr(al), C.byref(steps)))
+        # the magnitudes this decode's speculative SSRN produces go straight into the array a following ssrn(Y) returns
+        self._z_spec = PINNED.empty((B, self.dims.max_T * self.dims.r, self.dims.full_dim))
+        self._chk(self.lib.oph_set_mag_destination(self._h, _lib.fptr(self._z_spec)))
+        try:
+            self._chk(self.lib.oph_text2mel(self._h, None if resident else _lib.fptr(K), None if resident else _lib.fptr(V),
+                                            _lib.iptr(ends), sp, B, int(stop_mode),
+                                            _lib.fptr(Y), _lib.iptr(t_ends), _lib.fptr(al), C.byref(steps)))
+        except Exception:
+            self.lib.oph_set_mag_destination(self._h, None)
+            self._z_spec = None
+            raise
         self._y_token = (weakref.ref(self._seal(Y)),)
         self.B = B
         return Y, t_ends, al, steps.value
@@ -279,10 +288,17 @@ class Engine(object):
             Y = np.ascontiguousarray(Y, dtype=np.float32)
         B, T, nm = Y.shape
         assert nm == self.dims.n_mels
-        Z = PINNED.empty((B, T * self.dims.r, self.dims.full_dim))
+        spec = getattr(self, "_z_spec", None)
+        if resident and spec is not None and spec.shape == (B, T * self.dims.r, self.dims.full_dim):
+            Z = spec                                     # most of it arrived while the decoder was running
+        else:
+            Z = PINNED.empty((B, T * self.dims.r, self.dims.full_dim))
         if not resident:
             self._kv_token = self._y_token = None        # the batch workspaces are reused
         self._chk(self.lib.oph_ssrn(self._h, None if resident else _lib.fptr(Y), B, T, _lib.fptr(Z)))
+        if Z is spec:
+            self._z_spec = None                          # handed to the caller: the next decode gets a fresh buffer
+            self.lib.oph_set_mag_destination(self._h, None)
         return Z
 
     def ssrn_logits(self, Y):
