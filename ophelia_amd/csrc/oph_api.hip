@@ -639,12 +639,13 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
         if (l.kind == K_CONVT) {
             // even rows: taps (x[t], x[t-1]); odd rows: tap x[t]; raw rows interleaved 2t / 2t+1
             g.N = l.N; g.ldh = 2 * l.Nalloc; g.M = M;
-            const bool f16 = prec == 2;
+            const bool f16 = prec >= 2;
+            g.nprod = prec == 3 ? 2 : (prec == 4 ? 1 : 3);
             g.Wt = l.Wt; g.Wh = f16 ? l.Wh16 : l.Wh; g.Wl = f16 ? l.Wl16 : l.Wl; g.f16 = f16; g.ldw = 2 * l.kc; g.ntaps = 2; g.off[0] = 0; g.off[1] = -1;
             GemmArgs g2 = g;
             g2.Wt = l.Wt2; g2.Wh = f16 ? l.Wh2_16 : l.Wh2; g2.Wl = f16 ? l.Wl2_16 : l.Wl2; g2.ldw = l.kc; g2.ntaps = 1; g2.off[0] = 0; g2.H = wsraw + l.Nalloc;
             {   // both phases in one launch
-                const int p2 = (prec && g.Wh && g2.Wh) ? prec : 0;
+                const int p2 = (prec && g.Wh && g2.Wh) ? std::min(prec, 2) : 0;
                 const int cls = p2 ? PC_GEMM_BF16 : (conv_gemm_tile_m(g.M, g.N) == 128 ? PC_GEMM : PC_GEMM64);
                 h->pbegin(cls);
                 launch_conv_gemm_pair(g, g2, p2, g_cur);
@@ -654,10 +655,11 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
             e.ldh = l.Nalloc; e.M = B * Tcur; e.C = l.cout; e.mode = PRE_CONV; e.act = ACT_NONE;
             run_epi(h, e);
         } else {
-            const bool f16 = prec == 2;
+            const bool f16 = prec >= 2;
+            g.nprod = prec == 3 ? 2 : (prec == 4 ? 1 : 3);
             g.N = l.N; g.ldh = l.Nalloc; g.M = M; g.Wt = l.Wt; g.Wh = f16 ? l.Wh16 : l.Wh; g.Wl = f16 ? l.Wl16 : l.Wl; g.f16 = f16; g.ldw = l.ntaps * l.kc; g.ntaps = l.ntaps;
             for (int t = 0; t < 3; ++t) g.off[t] = l.off[t];
-            run_gemm(h, g, l.cin, g.Wh ? prec : 0);
+            run_gemm(h, g, l.cin, g.Wh ? std::min(prec, 2) : 0);
             e.ldh = l.Nalloc; e.M = M; e.C = l.cout;
             if (l.kind == K_HC) { e.mode = PRE_HC; e.Xres = x; e.ldres = ldx; }
             else e.mode = PRE_CONV;
@@ -2419,7 +2421,7 @@ int oph_run_resident(oph_handle* h, int stop_mode, int run_ssrn, int32_t* steps_
 }
 
 int oph_set_ssrn_precision(oph_handle* h, int mode) {
-    if (!h || mode < 0 || mode > 2) return OPH_ERR_INVALID;
+    if (!h || mode < 0 || mode > 4) return OPH_ERR_INVALID;       // 3, 4: measurement only -- split-fp16 with 2 products / 1 product
     h->ssrn_prec = mode; h->chunk_ms = 0.f;
     return OPH_OK;
 }
@@ -3010,7 +3012,7 @@ int oph_bench_conv1d_transpose(int device, int B, int T, int Cin, int Cout, int 
     unsigned short* dweh = c.alloc<unsigned short>(we.size()); unsigned short* dwel = c.alloc<unsigned short>(we.size());
     unsigned short* dwoh = c.alloc<unsigned short>(wo.size()); unsigned short* dwol = c.alloc<unsigned short>(wo.size());
     if (!c.ok) return OPH_ERR_DEVICE;
-    if (precision == 2) { launch_split_f16(dwe, dweh, dwel, we.size(), c.s); launch_split_f16(dwo, dwoh, dwol, wo.size(), c.s); }
+    if (precision >= 2) { launch_split_f16(dwe, dweh, dwel, we.size(), c.s); launch_split_f16(dwo, dwoh, dwol, wo.size(), c.s); }
     else { launch_split_bf16(dwe, dweh, dwel, we.size(), c.s); launch_split_bf16(dwo, dwoh, dwol, wo.size(), c.s); }
     hipStreamSynchronize(c.s);
     hipEvent_t e0, e1;
@@ -3018,10 +3020,10 @@ int oph_bench_conv1d_transpose(int device, int B, int T, int Cin, int Cout, int 
     auto once = [&]() {
         GemmArgs g{};
         g.X = dx; g.ldx = kc; g.bias = dbias; g.ldh = 2 * Nalloc; g.M = M; g.N = Cout; g.kc = kc; g.mode = 0; g.T = T;
-        g.Wt = dwe; g.Wh = dweh; g.Wl = dwel; g.f16 = precision == 2; g.ldw = 2 * kc; g.ntaps = 2; g.off[0] = 0; g.off[1] = -1; g.H = dh;
+        g.Wt = dwe; g.Wh = dweh; g.Wl = dwel; g.f16 = precision >= 2; g.nprod = precision == 3 ? 2 : (precision == 4 ? 1 : 3); g.ldw = 2 * kc; g.ntaps = 2; g.off[0] = 0; g.off[1] = -1; g.H = dh;
         GemmArgs g2 = g;
         g2.Wt = dwo; g2.Wh = dwoh; g2.Wl = dwol; g2.ldw = kc; g2.ntaps = 1; g2.off[0] = 0; g2.H = dh + Nalloc;
-        launch_conv_gemm_pair(g, g2, precision < 0 || precision > 2 ? 0 : precision, c.s);
+        launch_conv_gemm_pair(g, g2, precision < 0 || precision > 4 ? 0 : std::min(precision, 2), c.s);
         EpiArgs e{};
         e.H = dh; e.ldh = Nalloc; e.M = 2 * M; e.C = Cout; e.mode = PRE_CONV; e.act = ACT_NONE; e.g1 = dg; e.b1 = db; e.Y = dy; e.ldy = Cout; e.ypad = Cout;
         launch_epilogue(e, c.s);

@@ -34,6 +34,7 @@ struct GemmArgs {
     int ksplit; long long split_stride;  // split-K over K-steps: grid.y = ksplit, partial s written at H + s*split_stride (bias in split 0)
     // conv_gemm_bf16x3 only: Wt split once into hi = bf16(w), lo = bf16(w - hi), same [Nalloc][ntaps*kc] layout (2-byte elements)
     const void* Wh; const void* Wl; int f16;       // f16: the planes (and the activations' split) are fp16 terms instead of bf16
+    int nprod;                      // measurement only: 0 / 3 = ah.bh + ah.bl + al.bh; 2 = ah.bh + al.bh (weights hi only); 1 = ah.bh
 };
 void launch_conv_gemm_pair(const GemmArgs& a0, const GemmArgs& a1, int prec, hipStream_t s);   // two contractions (same M, N, no split-K) in one launch
 void launch_split_bf16(const float* w, void* hi, void* lo, size_t n, hipStream_t s);      // hi/lo planes of n floats

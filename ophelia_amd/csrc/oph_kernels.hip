@@ -299,6 +299,7 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
     const int ksplit = a.ksplit > 1 ? a.ksplit : 1, split = blockIdx.y;
     const int ks0 = split * nk_all / ksplit, nk = (split + 1) * nk_all / ksplit - ks0;
     const H16* Wh = (const H16*)a.Wh; const H16* Wl = (const H16*)a.Wl;
+    const int nprod = a.nprod > 0 ? a.nprod : 3;
     f32x4 ra0[AR], ra1[AR];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     constexpr int NDMA = BN * 4 / 256;             // 16-byte chunks of one plane's K-step per thread
@@ -374,18 +375,23 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
             // back-to-back MFMAs on one accumulator serialise on its latency: 30 % of the wave cycles were issue stalls,
             // profiles/r02_ssrn_pmc.sh; own accumulators for the small terms of the single-tile instance were measured slower:
             // 168 instead of 116 registers cost it a workgroup of occupancy)
+            // (a.nprod: measurement only -- 2 drops the weights' lo term, 1 the activations' as well)
+            if (nprod >= 2) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn) {
                     acc[i][jn] = mfma16<F16>(al[i], bh[jn], acc[i][jn]);
                 }
+            }
+            if (nprod >= 3) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn) {
                     acc[i][jn] = mfma16<F16>(ah[i], bl[jn], acc[i][jn]);
                 }
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll

@@ -24,18 +24,25 @@ if sys.argv[1] == "run":
     Y, t_ends, al, steps = eng.text2mel(K, V, ends, stop_mode=1)
     Yc = np.array(Y)
     Z = {}
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3, 4):        # 3 / 4: split-fp16 with 2 products (weights hi only) / 1 product -- measurement only
         eng.set_ssrn_precision(mode)
         eng.ssrn(Yc)
         t0 = time.perf_counter()
         Z[mode] = eng.ssrn(Yc)
         print("ssrn mode %d: %.2f ms host-to-host" % (mode, (time.perf_counter() - t0) * 1e3))
-    print("SSRN vs fp32 MFMA: bf16x3 %.3e  fp16x3 %.3e (max-abs on mag)" % (np.abs(Z[1] - Z[0]).max(), np.abs(Z[2] - Z[0]).max()))
+    print("SSRN vs fp32 MFMA: bf16x3 %.3e  fp16x3 %.3e  fp16x2 %.3e  fp16x1 %.3e (max-abs on mag)" %
+          tuple(np.abs(Z[k] - Z[0]).max() for k in (1, 2, 3, 4)))
+    import ctypes as C
+    for name, T in (("D4", hp.max_T), ("D7", 2 * hp.max_T)):
+        for prec in (0, 2, 3, 4):
+            us, by, fl = C.c_double(), C.c_double(), C.c_double()
+            eng.lib.oph_bench_conv1d_transpose(0, 16, T, hp.c, hp.c, prec, 3, 20, C.byref(us), C.byref(by), C.byref(fl))
+            print("conv1d_transpose %s precision mode %d: %.1f us = %.1f %% of the HBM roofline" % (name, prec, us.value, by.value / us.value / 1e3 / 8000 * 100))
     if len(sys.argv) > 3 and sys.argv[3] == "oracle":
         from oracle import cpu_oracle
         m = cpu_oracle.CpuModel(hp, W, threads=min(cpu_oracle.usable_cores(), 32))
         Z0 = m.ssrn(Yc[:4])
-        for mode in (0, 1, 2):
+        for mode in (0, 1, 2, 3, 4):
             print("SSRN mode %d vs the CPU oracle (4 utterances): %.3e" % (mode, np.abs(Z[mode][:4] - Z0).max()))
     np.savez(sys.argv[2], Y=Y, al=al, trace=al.argmax(1))
     eng.close()
