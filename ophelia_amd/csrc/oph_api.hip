@@ -1342,12 +1342,12 @@ int build_loop_layers(oph_handle* h) {
 }
 
 // The decode loop as ONE launch on the critical stream + the per-step cones on the side stream, chained by device words
-// (in-kernel waits and signals on both ends).  t_end steps from 0.
-int decode_loop(oph_handle* h, int t_end, int stop_mode) {
+// (in-kernel waits and signals on both ends).  Steps [t_begin, t_end); t_begin > 0 continues a decode of this tile.
+int decode_loop(oph_handle* h, int t_begin, int t_end, int stop_mode) {
     const oph_dims& m = h->dm;
     if (!h->d_loop_layers) { const int rc = build_loop_layers(h); if (rc) return rc; }
     const int lookahead = h->opt.lookahead;
-    h->host_prog[0] = -1; h->host_prog[1] = INT_MAX;
+    h->host_prog[0] = t_begin - 1; h->host_prog[1] = INT_MAX;
     if ((uint64_t)h->run_epoch + (uint64_t)(m.max_T + 1) * LOOP_MAX_LAYERS > 0xF0000000ull) {     // tag wrap guard
         for (hipStream_t st : {h->sdec, h->scone}) hipStreamSynchronize(st);
         hipMemsetAsync(h->d_gbuf, 0, (size_t)LOOP_MAX_LAYERS * h->Bpad * RUN_GCOLS * 8, h->sdec);
@@ -1355,7 +1355,7 @@ int decode_loop(oph_handle* h, int t_end, int stop_mode) {
         h->run_epoch = 0;
     }
     LoopArgs a{};
-    a.nlayers = h->loop_nlayers; a.B = h->B; a.Bpad = h->Bpad; a.t_end = t_end; a.stop_mode = stop_mode; a.attn_layer = h->loop_attn;
+    a.nlayers = h->loop_nlayers; a.B = h->B; a.Bpad = h->Bpad; a.t_begin = t_begin; a.t_end = t_end; a.stop_mode = stop_mode; a.attn_layer = h->loop_attn;
     a.L = h->d_loop_layers; a.ctl = h->d_ctl;
     const bool ms = m.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_SPK_AUDIO_ENCODER_INPUT);
     a.spk_ids = ms ? h->d_spk : nullptr;
@@ -1383,7 +1383,7 @@ int decode_loop(oph_handle* h, int t_end, int stop_mode) {
     h->pbegin(PC_DECLOOP);
     h->dec_t0 = std::chrono::steady_clock::now(); h->chunk_inflight = false;
     launch_dec_loop(a, h->loop_slices, h->loop_rows, h->loop_kmax, h->sdec);
-    h->pend(PC_DECLOOP, bytes * t_end, flops * t_end);
+    h->pend(PC_DECLOOP, bytes * (t_end - t_begin), flops * (t_end - t_begin));
     if (h->want_preenc && h->next_staged && !h->preenc_valid) {
         // K,V of the NEXT batch's staged text into the other KV buffer, on the SSRN partition (own workspace; in stream order
         // behind the previous batch's SSRN and ahead of this batch's chunks)
@@ -1397,7 +1397,7 @@ int decode_loop(oph_handle* h, int t_end, int stop_mode) {
     const bool stream_ssrn = h->spec_ssrn && h->opt.ssrn_chunk > 0 && !h->opt.no_stream_ssrn;
     // ---- the cone of every step as ONE persistent launch (cone_loop) where the model fits it and its workgroups can all be resident
     bool cone_in_loop = false;
-    if (h->cone_loop_ok && h->qw_from_loop && h->d_cl_flags && h->d_cl_stats && !h->opt.skip_cone && !(dbg & 32) && t_end > 1) {
+    if (h->cone_loop_ok && h->qw_from_loop && h->d_cl_flags && h->d_cl_stats && !h->opt.skip_cone && !(dbg & 32) && t_end > 1 && t_begin == 0) {
         if (h->cone_loop_wgs < 0) {
             int ncu = 0;
             for (int i = 0; i < h->mask_words; ++i) ncu += __builtin_popcount(h->m_conep[i]);
@@ -1413,7 +1413,7 @@ int decode_loop(oph_handle* h, int t_end, int stop_mode) {
             h->cl_epoch = 0;
         }
         ConeLoopArgs c{};
-        c.nlevels = nh; c.t_begin = 1; c.t_end = t_end; c.B = h->B; c.d = m.d;
+        c.nlevels = nh; c.t_begin = std::max(1, t_begin); c.t_end = t_end; c.B = h->B; c.d = m.d;
         c.npos0 = (int)h->Hset[0].size(); c.off0 = h->d_off0; c.rows0[0] = h->cone[0][0]; c.rows0[1] = h->cone[1][0];
         const Layer& tl0 = h->audiodec[pre];
         c.sig0_pos0 = idx_of(h->Hset[0], -tl0.off[0]); c.sig0_pos1 = idx_of(h->Hset[0], -tl0.off[1]);
@@ -1455,7 +1455,7 @@ int decode_loop(oph_handle* h, int t_end, int stop_mode) {
             nanosleep(&ts, nullptr);
         }
     }
-    for (int t = 1; t < t_end && !(dbg & 32) && !cone_in_loop; ++t) {
+    for (int t = std::max(1, t_begin); t < t_end && !(dbg & 32) && !cone_in_loop; ++t) {
         // bounded run-ahead, so that an early stop leaves at most `lookahead` queued cones (they early-out on the device)
         auto t_wait0 = std::chrono::steady_clock::now();
         while (h->host_prog[0] < t - 1 - lookahead && h->host_prog[1] == INT_MAX) {
@@ -1467,7 +1467,8 @@ int decode_loop(oph_handle* h, int t_end, int stop_mode) {
         const int stopped_at = h->host_prog[1];
         if (stopped_at != INT_MAX && t > stopped_at + 1) break;       // step stop+1 still runs (stores off) and polls its cone
         if (!h->opt.skip_cone) {
-            h->cone_inline_sig = true; h->cone_wait_val = h->sig_base + (uint32_t)t; h->cone_done_val = h->sig_base + (uint32_t)t;
+            // (the first cone of a continued decode has nobody to wait for: the attention of step t_begin - 1 is long done)
+            h->cone_inline_sig = true; h->cone_wait_val = (t == t_begin) ? 0u : h->sig_base + (uint32_t)t; h->cone_done_val = h->sig_base + (uint32_t)t;
             launch_cone(h, t);
             h->cone_inline_sig = false;
         }
@@ -1646,7 +1647,7 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
         h->run_epoch = 0;
     }
     h->qw_from_loop = false;
-    bool loop_mode = h->use_loop && !h->fixed_att && t_begin == 0 && t_end >= 1;
+    bool loop_mode = h->use_loop && !h->fixed_att && t_end > t_begin;
     if (loop_mode) {
         // every workgroup of the loop kernel must be resident at once on the critical stream's own CUs (the cone needs the
         // others): without that partition, or when the tile's workgroups do not fit it, take the two-launches-per-step path
@@ -1664,7 +1665,13 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
         }
         h->sig_base += (uint32_t)m.max_T + 2;
     }
-    if (t_begin >= 1 && t_begin < t_end) {      // resuming mid-utterance: cone(t_begin) has not been launched yet
+    if (loop_mode && t_begin >= 1) {
+        // the continued launch counts its attention arrivals from zero
+        const int zero = 0;
+        HIPCHK(h, hipMemcpyAsync(h->d_ctl + 3, &zero, 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    if (!loop_mode && t_begin >= 1 && t_begin < t_end) {      // resuming mid-utterance: cone(t_begin) has not been launched yet
         if (h->use_sigval) {
             hipStreamWriteValue32(h->sdec, h->d_sig, h->sig_base + (uint32_t)t_begin, 0);
             hipStreamWaitValue32(h->scone, h->d_sig, h->sig_base + (uint32_t)t_begin, hipStreamWaitValueGte, 0xffffffffu);
@@ -1681,7 +1688,7 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
     const auto tq0 = std::chrono::steady_clock::now();
     if (loop_mode) {
         h->n_loop_decodes++;
-        if ((rc_loop = decode_loop(h, t_end, stop_mode)) != OPH_OK) { recover_loop_state(h); return rc_loop; }
+        if ((rc_loop = decode_loop(h, t_begin, t_end, stop_mode)) != OPH_OK) { recover_loop_state(h); return rc_loop; }
         last = t_end;
         t_begin = t_end;          // skip the per-step loop below
     }

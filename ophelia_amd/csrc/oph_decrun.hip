@@ -384,8 +384,10 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
     LoopDescPtr Ls = (LoopDescPtr)a.L;
     const int spk = a.spk_ids ? a.spk_ids[grow < a.B ? grow : 0] : 0;
     const int my_end = __builtin_amdgcn_readfirstlane(a.ends[grow]);
-    int my_tend = a.max_T;                       // t_ends[grow] (reset to max_T before the launch); only column slice 0 records it
-    int p = 0;                                   // prev_max of this wave's utterance: every workgroup attends for its own rows
+    // a launch may continue a decode (t_begin > 0: a tile resumed to its batch's stop step, synthesize.py:225-228): the state a
+    // step carries over is in memory -- prev_max, t_ends, the mel frame of step t_begin - 1 (Ytm), the histories
+    int my_tend = a.t_begin > 0 ? a.t_ends[grow] : a.max_T;      // t_ends[grow]; only column slice 0 records it
+    int p = a.t_begin > 0 ? a.p[(a.t_begin & 1) * Bpad + grow] : 0;   // prev_max of this wave's utterance: every workgroup attends for its own rows
     int* const stop_word = a.ctl + 1;
     int* const err = a.ctl + 2;
 
@@ -444,9 +446,9 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
     LoopDesc cur, nxt;
     desc_load(Ls, 0, cur);
     desc_pin(cur);
-    fetch_layer(cur, 0);
+    fetch_layer(cur, a.t_begin);
 
-    int t = 0;
+    int t = a.t_begin;
     for (; t < a.t_end; ++t) {
         // Early stop (synthesize.py:225-228): the step that sets the flag is >= 1 full step (tens of us) in the past when
         // it is acted on here, so every workgroup takes the same decision; step stop+1 still runs, with its stores off.
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
 #define LOOP_STAMP(K) do { if (stp && lane == 0) stp[l * 8 + (K)] = wall_clock64(); } while (0)
         const long long step_w0 = stp ? wall_clock64() : 0, step_c0 = stp ? clock64() : 0;
         for (int l = 0; l < NL; ++l) {
-            const bool first = l == 0, no_input = first && t == 0;      // S[0] = 0 (architectures.py:191)
+            const bool first = l == 0, no_input = first && t == a.t_begin;      // S[0] = 0 (architectures.py:191); a resumed launch reads S[t_begin] from Ytm
             desc_load(Ls, l + 1 < NL ? l + 1 : 0, nxt);      // in flight across the hand-off wait below
             const int pre = cur.pre(), cin = cur.cin(), nonorm = cur.nonorm(), kc = cur.kc(), ntaps = cur.ntaps();
             const bool cok = c < cin, two = pre >= RUN_HC, cols = n0 < cur.N();
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
                     for (int e = 0; e < 4; ++e) x[e] = cok ? y[e] : 0.f;
                 }
             }
-            if (no_input) x = zero4;
+            if (no_input) x = (t > 0 && c < a.ldy) ? *(const f32x4*)(a.Ytm + ((size_t)t * Bpad + grow) * a.ldy + c) : zero4;
             xprev = x;
             if (first && t >= 1) {
                 // x is mel frame t-1 -> Y[b][t-1] and the decoder input S[t] (synthesize.py:204-209)
@@ -752,7 +754,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
                 __syncthreads();
                 if (tid == 0) {
                     const int old = atomicAdd(a.ctl + 3, 1);
-                    if (old + 1 == (Bpad / R) * (a.QW != nullptr ? a.attn_slices : 1) * (t + 1)) {
+                    if (old + 1 == (Bpad / R) * (a.QW != nullptr ? a.attn_slices : 1) * (t + 1 - a.t_begin)) {
                         __hip_atomic_fetch_max(a.sig, a.sig_base + (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         __hip_atomic_store((int*)a.host_progress, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         if (a.sigdbg && t + 1 < a.max_T) a.sigdbg[(t + 1) * 8 + 0] = wall_clock64();

@@ -255,7 +255,7 @@ constexpr int LOOP_DESC_WORDS = 20, LOOP_DESC_STRIDE = 32;
 // waits for that word only -- the cone's later levels are still being computed while the chain's first tap layers run).
 constexpr int LOOP_SIG_LEVEL0 = 32, LOOP_SIG_WORDS = 256, LOOP_MAX_LEVELS = 8;
 struct LoopArgs {
-    int nlayers; int B; int Bpad; int t_end; int stop_mode;
+    int nlayers; int B; int Bpad; int t_begin, t_end; int stop_mode;      // steps [t_begin, t_end)
     int attn_layer;                     // index of the RUN_ATTN layer
     const unsigned* L;                  // device memory, [nlayers][LOOP_DESC_STRIDE] packed descriptors
     float* QW; int attn_slices;         // if non-null: the attention layer also emits QW[t] = Q[t] . Wq + bias (the Q half of its own contraction,

@@ -141,7 +141,8 @@ def test_batches_beyond_16_decode_in_tiles_with_the_batch_coupled_break(model, B
     Z = eng.ssrn(Y)
     c1 = eng.counters()
     ntiles = (B + 15) // 16
-    assert c1["loop_decodes"] - c0["loop_decodes"] == ntiles and c1["loop_fallbacks"] == c0["loop_fallbacks"]
+    # every tile, and every resumed tile, on the whole-decode launch
+    assert c1["loop_decodes"] - c0["loop_decodes"] == ntiles + (c1["tile_resumes"] - c0["tile_resumes"]) and c1["loop_fallbacks"] == c0["loop_fallbacks"]
     K0, V0 = O.encode_text(hp, W, L)
     Y0, t0, al0 = O.synth_codedtext2mel(hp, W, K0, V0, ends)          # the whole batch in one loop, as the reference runs it
     assert t_ends.tolist() == list(t0)
