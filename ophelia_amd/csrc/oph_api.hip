@@ -899,7 +899,13 @@ void begin_batch(oph_handle* h) {
     if (h->pipelined) {
         h->buf ^= 1;
         if (h->ssrn_inflight[h->buf]) { hipStreamWaitEvent(h->stream, h->ev_ssrn_done[h->buf], 0); h->ssrn_inflight[h->buf] = false; }
+    } else {
+        // speculative SSRN chunks of a previous decode nobody asked the magnitudes of may still be running (and copying into
+        // a host buffer): they read the Y / write the Z this batch is about to reuse
+        hipStreamSynchronize(h->sssrn);
+        hipStreamSynchronize(h->scopy);
     }
+    h->chunk_inflight = false;
     h->y_resident = false;
 }
 

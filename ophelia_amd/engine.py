@@ -146,8 +146,9 @@ class Engine(object):
 
     def close(self):
         if self._h:
-            self.lib.oph_destroy(self._h)
+            self.lib.oph_destroy(self._h)          # synchronises every stream first
             self._h = C.c_void_p()
+            self._z_spec = None
 
     def __del__(self):
         try:
@@ -215,6 +216,8 @@ class Engine(object):
         if not resident:
             self._kv_token = None
         # the magnitudes this decode's speculative SSRN produces go straight into the array a following ssrn(Y) returns
+        if self._z_spec is not None:          # nobody asked for the previous decode's magnitudes: let its copies finish before the buffer goes
+            self.lib.oph_synchronize(self._h)
         self._z_spec = PINNED.empty((B, self.dims.max_T * self.dims.r, self.dims.full_dim))
         self._chk(self.lib.oph_set_mag_destination(self._h, _lib.fptr(self._z_spec)))
         try:
