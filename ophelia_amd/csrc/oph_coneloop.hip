@@ -52,16 +52,6 @@ static __device__ __forceinline__ float row16_sum(float v) {      // total over 
     return v;
 }
 static __device__ __forceinline__ unsigned ld_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// 16 bytes written by another CU during this launch (write-through sc1 stores + counter): ONE 16-byte sc1 load (past the
-// CU's L1, coherent across the XCDs) instead of ld_coherent's two 8-byte atomics -- half the requests on the fabric, which
-// the latency-critical dec_loop shares (MI355X_MICROARCH.md: 8-byte accesses run at 0.54-0.70x the 16-byte rate)
-typedef int i32x4_ __attribute__((ext_vector_type(4)));
-static __device__ __forceinline__ f32x4 ld_sc1_b128(const float* base, unsigned byte_off) {
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
-    const i32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16 /* sc1 */);
-    return __builtin_bit_cast(f32x4, v);
-}
-
 // one thread spins until *p >= want (wrap-safe); false on time-out / error elsewhere
 static __device__ bool spin_ge(const unsigned* p, unsigned want, int* err, int code, int scope_system) {
     long long t0 = 0;

@@ -395,6 +395,14 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
     f32x4 bfrag[PF], tp0 = zero4, tp1 = zero4;
     bool tpok0 = false, tpok1 = false;
     float bias_v = 0.f;
+    // Early taps (kc = 256: every wave's chunk list is [tap0 x PT | tap1 x PT | current x PT]): the two older taps of a highway
+    // layer are known before the hand-off, so their rows are staged and their 2/3 of the layer's contraction runs while the
+    // sweep of the current row is still in flight -- one more barrier, overlapped with the sweep's round trip (round 3; before:
+    // all 0.97 us of MFMAs after sweep, prologue and barrier).  (Measured first: the taps requested straight in the MFMA's
+    // operand layout, no staging: 16 scattered requests per lane -- the CU's address unit made the layer 2 us longer.)
+    constexpr int PT = 16 / R;
+    f32x4 tk[8];                                 // the attention layer's K / V window rows
+    bool dt_nxt = false;                         // the layer fetch_layer() was last called for runs its taps early
     auto fetch_layer = [&](const LoopDesc& D, int t) {       // weights, bias and the two older taps of layer D at step t
         const int ntaps = D.ntaps(), kc = D.kc();
         const int nch = (ntaps * kc) >> 4;
@@ -408,6 +416,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
         // the two older taps: always requested from a valid row (clamped), masked where they are staged -- no branch, no
         // register copy between the request and its use
         const int kind = D.tapkind();
+        dt_nxt = kind != 0 && ntaps == 3 && kc == 256 && !(a.dbg & 64);
         if (kind != 0 && c < kc && !(a.dbg & 4)) {
             const int o0 = D.off0(), o1 = D.off1();
             const float* tb = kind == 1 ? (const float*)D.hist() : D.cone(t & 1);
@@ -447,6 +456,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
     desc_load(Ls, 0, cur);
     desc_pin(cur);
     fetch_layer(cur, a.t_begin);
+    bool dt_cur = dt_nxt;                        // direct taps of the layer being run
 
     int t = a.t_begin;
     for (; t < a.t_end; ++t) {
@@ -470,7 +480,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
                 level_wait(cur.next_level(), t, 0u, false);
                 desc_pin(nxt);
                 fetch_layer(nxt, l + 1 < NL ? t : t + 1);
-                cur = nxt;
+                cur = nxt; dt_cur = dt_nxt;
                 continue;
             }
 
@@ -490,14 +500,15 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
             // attention window [p, p+win): its K and V rows depend on p alone -- requested before the hand-off, not inside
             // the softmax loops (each was an exposed ~1.5 us round trip: profiles/r02 stamps, 10 us per step)
             constexpr int AW = 4;
-            f32x4 kwin[AW], vwin[AW];
+#define kwin(i) tk[(i)]
+#define vwin(i) tk[AW + (i)]
             if (is_attn) {
                 const float* KVb = a.KV + (size_t)grow * a.N_keys * 2 * cin;
 #pragma unroll
                 for (int i = 0; i < AW; ++i) {
                     const bool in = cok && i < a.win && p + i < a.N_keys;
-                    kwin[i] = in ? *(const f32x4*)(KVb + (size_t)(p + i) * 2 * cin + c) : zero4;
-                    vwin[i] = in ? *(const f32x4*)(KVb + cin + (size_t)(p + i) * 2 * cin + c) : zero4;
+                    kwin(i) = in ? *(const f32x4*)(KVb + (size_t)(p + i) * 2 * cin + c) : zero4;
+                    vwin(i) = in ? *(const f32x4*)(KVb + cin + (size_t)(p + i) * 2 * cin + c) : zero4;
                 }
             }
 
@@ -505,10 +516,62 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
             LOOP_STAMP(0);
             int passes = 0;
             f32x4 av = zero4, uv = zero4;
-            if (!no_input) {
+            f32x4 acc[RQ][2], accq[RQ];
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq) { acc[rq][0] = zero4; acc[rq][1] = zero4; accq[rq] = zero4; }
+            {
                 const int slot = first ? NL - 1 : l - 1;
                 const unsigned ep = a.epoch0 + (unsigned)((first ? t - 1 : t) * LOOP_MAX_LAYERS + slot + 1);
-                passes = sweep_row(a.gbuf + ((size_t)slot * Bpad + grow) * RUN_GCOLS, c, cok, cin + c, two, ep, lane, err, av, uv, (a.dbg & 2) != 0);
+                const u64* grow_p = a.gbuf + ((size_t)slot * Bpad + grow) * RUN_GCOLS;
+                // first pass of the hand-off sweep: requested now, looked at after the older taps' share of the contraction
+                const u64 want = (u64)ep << 32;
+                u64 ga[4], gu[4];
+                if (!no_input) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ga[e] = cok ? granule_load(grow_p + c + e) : want;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gu[e] = (cok && two) ? granule_load(grow_p + cin + c + e) : want;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (dt_cur) {
+                    // taps x[t-2r], x[t-r]: staged now (their rows arrived during the previous layer), chunks i < 2 PT of every
+                    // wave's list contracted before the sweep's answer is looked at
+                    const int ldxs_ = 3 * 256 + 16;
+                    float* xrow_ = xs + w * ldxs_;
+                    *(f32x4*)(xrow_ + c) = tpok0 ? tp0 : zero4;
+                    *(f32x4*)(xrow_ + 256 + c) = tpok1 ? tp1 : zero4;
+                    __syncthreads();
+                    if (cols) {
+                        const float* xa_ = xs + mq * ldxs_ + mkk * 4;
+                        f32x4 xt[2 * PT][RQ];
+#pragma unroll
+                        for (int i = 0; i < 2 * PT; ++i)
+#pragma unroll
+                            for (int rq = 0; rq < RQ; ++rq) xt[i][rq] = *(const f32x4*)(xa_ + rq * 4 * ldxs_ + (w + R * i) * 16);
+#pragma unroll
+                        for (int i = 0; i < 2 * PT; ++i)
+#pragma unroll
+                            for (int rq = 0; rq < RQ; ++rq) {
+                                acc[rq][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xt[i][rq][0], bfrag[i][0], acc[rq][0], 0, 0, 0);
+                                acc[rq][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xt[i][rq][1], bfrag[i][1], acc[rq][1], 0, 0, 0);
+                                acc[rq][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xt[i][rq][2], bfrag[i][2], acc[rq][0], 0, 0, 0);
+                                acc[rq][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xt[i][rq][3], bfrag[i][3], acc[rq][1], 0, 0, 0);
+                            }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!no_input) {
+                    bool ok = true;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ok = ok && (unsigned)(ga[e] >> 32) == ep && (unsigned)(gu[e] >> 32) == ep;
+                    passes = 1;
+                    if (__all(ok) || (a.dbg & 2)) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { av[e] = __uint_as_float((unsigned)ga[e]); uv[e] = __uint_as_float((unsigned)gu[e]); }
+                    } else {
+                        passes += sweep_row(grow_p, c, cok, cin + c, two, ep, lane, err, av, uv, false);
+                    }
+                }
             }
             LOOP_STAMP(1);
             if (stp && lane == 0) stp[l * 8 + 6] = passes;
@@ -581,7 +644,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
 #pragma unroll
                 for (int i = 0; i < AW; ++i) {
                     if (i < nwin) {
-                        const float sdot = wave_sum(x[0] * kwin[i][0] + x[1] * kwin[i][1] + x[2] * kwin[i][2] + x[3] * kwin[i][3]) * scale;
+                        const float sdot = wave_sum(x[0] * kwin(i)[0] + x[1] * kwin(i)[1] + x[2] * kwin(i)[2] + x[3] * kwin(i)[3]) * scale;
                         if (lane == i) scl = sdot;
                     }
                 }
@@ -605,7 +668,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
                         const float pi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, prl), i));
                         if (pi > best) { best = pi; arg = i; }       // first maximum, like tf.argmax
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) ctx[e] += pi * vwin[i][e];
+                        for (int e = 0; e < 4; ++e) ctx[e] += pi * vwin(i)[e];
                     }
                 }
                 for (int i = AW; i < nwin; ++i) {
@@ -646,7 +709,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
                     const float* tab = cur.cat_table();
                     for (int j = lane; j < ccat; j += 64) xrow[xcur + cin + j] = spk == 0 ? 0.f : tab[(size_t)spk * ccat + j];
                 }
-                if (ntaps == 3 && c < kc) {
+                if (ntaps == 3 && c < kc && !dt_cur) {
                     *(f32x4*)(xrow + c) = tpok0 ? tp0 : zero4;
                     *(f32x4*)(xrow + kc + c) = tpok1 ? tp1 : zero4;
                 }
@@ -659,24 +722,24 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
             // ---- 5. R x 16 slice on the 4x4x1 MFMA, K split round-robin over the R waves; every LDS read of the layer is
             //         issued before the first MFMA, two accumulators per row quad
             if (cols) {
-                f32x4 acc[RQ][2], accq[RQ];
-#pragma unroll
-                for (int rq = 0; rq < RQ; ++rq) { acc[rq][0] = zero4; acc[rq][1] = zero4; accq[rq] = zero4; }
                 const float* xa = xs + mq * ldxs + mkk * 4;
                 const int nch = Ktot >> 4;
                 // attention layer: its operand is [context | Q]; the chunks of the Q half also go to their own accumulator
                 const bool want_qw = is_attn && a.QW != nullptr;
                 const int qch0 = want_qw ? (cin >> 4) : 0x7fffffff;
                 f32x4 xf[PF][RQ];
+                const int i_first = dt_cur ? 2 * PT : 0;          // direct taps: chunks [0, 2 PT) are done
 #pragma unroll
                 for (int i = 0; i < PF; ++i) {
                     const int ch = min(w + R * i, nch - 1);
+                    if (i >= i_first) {
 #pragma unroll
-                    for (int rq = 0; rq < RQ; ++rq) xf[i][rq] = *(const f32x4*)(xa + rq * 4 * ldxs + ch * 16);
+                        for (int rq = 0; rq < RQ; ++rq) xf[i][rq] = *(const f32x4*)(xa + rq * 4 * ldxs + ch * 16);
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < PF; ++i) {
-                    if (w + R * i < nch) {
+                    if (i >= i_first && w + R * i < nch) {
                         if (w + R * i >= qch0) {
 #pragma unroll
                             for (int rq = 0; rq < RQ; ++rq)
@@ -761,7 +824,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
                     }
                 }
             }
-            cur = nxt;
+            cur = nxt; dt_cur = dt_nxt;
         }
         if (stp && lane == 0) {     // shader clock over this step: (c1 - c0) cycles in (w1 - w0) * 10 ns
             long long* q = stp + (LOOP_MAX_LAYERS - 1) * 8;

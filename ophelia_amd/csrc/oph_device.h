@@ -55,6 +55,15 @@ static __device__ __forceinline__ void st_coherent(float* p, const f32x4& v) {
     __hip_atomic_store((u64_*)p, (u64_)__float_as_uint(v[0]) | ((u64_)__float_as_uint(v[1]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store((u64_*)p + 1, (u64_)__float_as_uint(v[2]) | ((u64_)__float_as_uint(v[3]) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// 16 bytes written by another CU during this launch (write-through sc1 stores, then a counter / granule the reader has seen): ONE
+// 16-byte sc1 load (past the CU's L1, coherent across the XCDs) instead of ld_coherent's two 8-byte atomics -- half the requests
+// (MI355X_MICROARCH.md: 8-byte accesses run at 0.54-0.70x the 16-byte rate; 16-byte sc1 halves observed untorn)
+typedef int i32x4_ __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ f32x4 ld_sc1_b128(const float* base, unsigned byte_off) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+    const i32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16 /* sc1 */);
+    return __builtin_bit_cast(f32x4, v);
+}
 static __device__ __forceinline__ bool stopped(const int* stop_after, int t) {
     return stop_after != nullptr && t > *stop_after;
 }
