@@ -1225,7 +1225,7 @@ bool run_supported(const oph_handle* h) {
 }
 
 int run_encode_into(oph_handle* h, const int* dL, const int* dSpk, int B, float* KVdst, hipStream_t stream, int wsi);      // defined with the batched networks below
-int ssrn_stream_chunks(oph_handle* h, int frames_ready, bool final);                                                          // streamed SSRN of the current tile
+int ssrn_stream_chunks(oph_handle* h, int frames_ready, bool final, bool side_tail = false);                                  // streamed SSRN of the current tile
 void ssrn_margins(const oph_handle* h, int* back, int* ahead);
 
 // ---------------------------------------------------------------- whole-decode launch (dec_loop)
@@ -1836,6 +1836,11 @@ int decode_batch(oph_handle* h, int t_end, int stop_mode, int32_t* steps_run) {
         }
         if (rc) return rc;
         batch_steps = std::max(batch_steps, (int)st);
+        // a tile that ran to the end has all its frames: what SSRN has not covered yet goes to the SSRN partition now, under the
+        // next tile's decode (a tile that stopped early may still be resumed: its tail waits for the batch's stop step)
+        if (h->spec_ssrn && !h->opt.no_stream_ssrn && h->opt.ssrn_chunk > 0 && j + 1 < ntiles && st == t_end && t_end == h->dm.max_T &&
+            (rc = ssrn_stream_chunks(h, h->dm.max_T, true, true)))
+            return rc;
     }
     if (stop_mode == OPH_STOP_REFERENCE && ntiles > 1)
         for (int j = 0; j < ntiles; ++j) {
@@ -1944,7 +1949,7 @@ int run_ssrn_chunk(oph_handle* h, int a, int b, hipStream_t st, int wsi) {
 
 // Launch the chunks of the current tile whose input frames exist: `frames_ready` = mel frames stored so far.  Chunks of
 // opt.ssrn_chunk frames on the SSRN partition while the decode runs; final: everything that is left (the decode is over).
-int ssrn_stream_chunks(oph_handle* h, int frames_ready, bool final) {
+int ssrn_stream_chunks(oph_handle* h, int frames_ready, bool final, bool side_tail) {
     const oph_dims& m = h->dm;
     Tile& tl = h->tiles[h->tile];
     int back = 0, ahead = 0;
@@ -1972,7 +1977,7 @@ int ssrn_stream_chunks(oph_handle* h, int frames_ready, bool final) {
         }
         // while the decode runs: the SSRN partition; afterwards, not pipelined: the whole chip through the API stream (which
         // the decode streams have joined)
-        const bool side = !final || h->pipelined;
+        const bool side = !final || h->pipelined || side_tail;       // side_tail: a finished tile's last piece, under the next tile's decode
         if (!final) hipEventRecord(h->ev_cs, h->sssrn);
         const int rc = run_ssrn_chunk(h, a, b, side ? h->sssrn : h->stream, side ? 1 : 0);
         if (rc) return rc;
