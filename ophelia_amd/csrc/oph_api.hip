@@ -725,7 +725,7 @@ void select_tile(oph_handle* h, int j) {
 
 int ensure_decode_state(oph_handle* h, int B) {
     const int nBpad = round_up(B, TILE);
-    if (h->nBpad == nBpad && h->bKV[0]) { h->nB = B; select_tile(h, 0); return 0; }
+    if (h->nBpad == nBpad && h->bKV[0]) { h->nB = B; select_tile(h, 0); return ensure_batched_capacity(h, nBpad); }
     if (h->bKV[0]) {
         // a different number of 16-row tiles: release the per-batch state and the workspaces and rebuild them
         for (hipStream_t st : {h->stream, h->sdec, h->scone, h->sssrn, h->scopy}) if (st) hipStreamSynchronize(st);
@@ -867,7 +867,7 @@ int ensure_decode_state(oph_handle* h, int B) {
     hipStreamSynchronize(h->stream);
     if (!h->coneTmp || !h->bZ[1] || !h->bYout[1] || !h->bAlign || !h->d_amax) { h->fail("out of device memory for decode state"); return OPH_ERR_DEVICE; }
     select_tile(h, 0);
-    return ensure_batched_capacity(h, B);
+    return ensure_batched_capacity(h, nBpad);      // the workspaces of the batched nets, for every batch size of this tile count
 }
 
 // reset the CURRENT tile's decode state (synthesize.py:157-166)

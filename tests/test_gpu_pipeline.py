@@ -227,3 +227,28 @@ print("ok", steps, c)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code, root], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-3000:]
+
+
+def test_a_small_batch_first_then_a_full_one_on_the_same_handle(model):
+    """The batched nets' workspaces are sized when the decode state is built; a 5-utterance batch and a 16-utterance one
+    share a tile count, so the state is not rebuilt in between -- the workspaces must fit the larger one all the same
+    (regression: they were sized for the first batch, and the full batch's SSRN overran them)."""
+    from ophelia_amd.engine import Engine
+    hp, W, eng, O = model
+    L5, e5 = _texts(O, hp, 5, 61, 6, 20)
+    L16, e16 = _texts(O, hp, 16, 62, 75, 149)
+    eng.stage_text(L16, e16)
+    eng.run_resident(stop_mode=1, run_ssrn=True, pipelined=False)
+    want = eng.fetch_mel() + (eng.fetch_mag(),)
+    fresh = Engine(hp, device=0)
+    try:
+        fresh.load_weights(W)
+        K, V = fresh.encode_text(L5)
+        Y, _, _, _ = fresh.text2mel(K, V, e5)
+        fresh.ssrn(Y)
+        fresh.stage_text(L16, e16)
+        fresh.run_resident(stop_mode=1, run_ssrn=True, pipelined=False)
+        got = fresh.fetch_mel() + (fresh.fetch_mag(),)
+    finally:
+        fresh.close()
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
