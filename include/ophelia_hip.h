@@ -127,7 +127,8 @@ int oph_ssrn(oph_handle* h, const float* Y, int B, int T, float* Z);
  *     (networks.py:527-534: the last conv1d's LayerNorm rows before squash_output_ssrn's sigmoid), both (B, r*T, full_dim). */
 int oph_ssrn_logits(oph_handle* h, const float* Y, int B, int T, float* Z, float* Z_logits);
 /* Speculative SSRN during oph_text2mel (default on): chunks of mel frames go through SSRN on their own CU partition as
- * soon as the decoder has produced them (SSRN's receptive field is +-9 mel frames), for oph_ssrn(Y = NULL) to pick up. */
+ * soon as the decoder has produced them (SSRN's receptive field is +-9 mel frames), for oph_ssrn(Y = NULL) to pick up.
+ * on: 0 off, 1 on, n >= 2 on with n mel frames per chunk (default 40). */
 int oph_set_streaming(oph_handle* h, int on);
 /* Host buffer (B, r*max_T, full_dim) the speculative SSRN of the NEXT oph_text2mel copies its rows to while the decoder is
  * still running (pinned memory from oph_host_alloc makes the copies asynchronous); oph_ssrn(Y = NULL, ..., Z = that pointer)

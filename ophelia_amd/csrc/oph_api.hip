@@ -2474,8 +2474,9 @@ int oph_set_mag_destination(oph_handle* h, float* Z) {
     return OPH_OK;
 }
 int oph_set_streaming(oph_handle* h, int on) {
-    if (!h) return OPH_ERR_INVALID;
+    if (!h || on < 0) return OPH_ERR_INVALID;
     h->spec_ssrn = on != 0;
+    if (on >= 2) h->opt.ssrn_chunk = on;          // mel frames per streamed chunk (1 keeps the current size)
     return OPH_OK;
 }
 

@@ -323,8 +323,9 @@ class Engine(object):
                         [int(x) for x in v]))
 
     def set_streaming(self, on=True):
-        """SSRN over the frames a running decode has already produced (default on); off: SSRN only when asked for."""
-        self._chk(self.lib.oph_set_streaming(self._h, int(bool(on))))
+        """SSRN over the frames a running decode has already produced (default on); off: SSRN only when asked for.
+        An integer >= 2 also sets the number of mel frames per streamed chunk."""
+        self._chk(self.lib.oph_set_streaming(self._h, int(on)))
 
     # -- device-resident pipeline
     def stage_text(self, L, ends, speaker_data=None):

@@ -252,3 +252,32 @@ def test_a_small_batch_first_then_a_full_one_on_the_same_handle(model):
     finally:
         fresh.close()
     assert all(np.array_equal(a, b) for a, b in zip(got, want))
+
+
+@pytest.mark.parametrize("cfg,over,B,chunk", [("lj_tutorial.cfg", dict(max_T=97), 9, 7), ("lj_tutorial.cfg", dict(max_T=64, r=8), 16, 16),
+                                              ("vctk_01.cfg", dict(max_T=100), 8, 23)])
+def test_streamed_ssrn_for_other_geometries_and_chunk_sizes(cfg, over, B, chunk):
+    """SSRN's margins are derived from the layer list (three up-sampling stages for r = 8, odd lengths, chunk sizes that do
+    not divide them, a multispeaker model): the streamed rows equal the one-piece evaluation bit for bit."""
+    from oracle import ophelia_oracle as O
+    from ophelia_amd.engine import Engine
+    hp = hp_from_snapshot(cfg, **over)
+    W = O.random_weights(hp, 5)
+    eng = Engine(hp, device=0)
+    try:
+        eng.load_weights(W)
+        eng.set_streaming(chunk)
+        L = O.random_text(hp, B, 71, min_len=min(40, hp.max_N - 2), max_len=hp.max_N - 1)
+        ends = O.get_text_lengths(L).astype(np.int32)
+        spk = np.random.default_rng(5).integers(1, 100, size=(B, 1)) if hp.multispeaker else None
+        for prec in (0, 2):
+            eng.set_ssrn_precision(prec)
+            c0 = eng.counters()
+            K, V = eng.encode_text(L, spk)
+            Y, t_ends, al, steps = eng.text2mel(K, V, ends, spk, stop_mode=1)
+            assert eng.counters()["chunks_streamed"] - c0["chunks_streamed"] >= 1        # (one chunk in flight at a time: not every boundary is used)
+            Z = eng.ssrn(Y)
+            Z1 = eng.ssrn(np.array(Y))
+            assert Z.shape == (B, hp.max_T * hp.r, hp.full_dim) and np.array_equal(Z, Z1), prec
+    finally:
+        eng.close()
