@@ -248,6 +248,11 @@ int oph_op_hc(int device, const float* x, int B, int T, int C, int size, int rat
 int oph_op_conv1d_transpose(int device, const float* x, int B, int T, int Cin, int Cout,
                             const float* kernel, const float* bias, const float* gamma,
                             const float* beta, float* y /* (B,2T,Cout) */);
+/* The same layer through the launches the SSRN path makes at one of oph_set_precision's arithmetic codes: 0 = fp32-operand
+ * MFMA (= oph_op_conv1d_transpose), 1 = split-bf16 x3, 2 = split-fp16 x3 (both phases in one launch, then the LayerNorm rows). */
+int oph_op_conv1d_transpose_prec(int device, const float* x, int B, int T, int Cin, int Cout,
+                                 const float* kernel, const float* bias, const float* gamma,
+                                 const float* beta, int precision, float* y /* (B,2T,Cout) */);
 int oph_op_attention(int device, const float* Q, const float* K, const float* V,
                      const int32_t* prev_max, int B, int T, int N, int d, int win,
                      float* R /*(B,T,2d)*/, float* alignments /*(B,N,T)*/,

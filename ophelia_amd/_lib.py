@@ -82,6 +82,7 @@ SIGNATURES = {
     "oph_op_conv1d": (C.c_int, [C.c_int, c_f32p] + [C.c_int] * 7 + [c_f32p] * 4 + [C.c_int, c_f32p]),
     "oph_op_hc": (C.c_int, [C.c_int, c_f32p] + [C.c_int] * 6 + [c_f32p] * 7),
     "oph_op_conv1d_transpose": (C.c_int, [C.c_int, c_f32p] + [C.c_int] * 4 + [c_f32p] * 5),
+    "oph_op_conv1d_transpose_prec": (C.c_int, [C.c_int, c_f32p] + [C.c_int] * 4 + [c_f32p] * 4 + [C.c_int, c_f32p]),
     "oph_op_attention": (C.c_int, [C.c_int, c_f32p, c_f32p, c_f32p, c_i32p] + [C.c_int] * 5 + [c_f32p, c_f32p, c_i64p]),
     "oph_bench_conv1d_transpose": (C.c_int, [C.c_int] * 8 + [c_f64p, c_f64p, c_f64p]),
     "oph_op_last_error": (C.c_char_p, []),

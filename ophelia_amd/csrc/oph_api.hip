@@ -2969,6 +2969,11 @@ int oph_op_hc(int device, const float* x, int B, int T, int C, int size, int rat
 
 int oph_op_conv1d_transpose(int device, const float* x, int B, int T, int Cin, int Cout, const float* kernel,
                             const float* bias, const float* gamma, const float* beta, float* y) {
+    return oph_op_conv1d_transpose_prec(device, x, B, T, Cin, Cout, kernel, bias, gamma, beta, 0, y);
+}
+int oph_op_conv1d_transpose_prec(int device, const float* x, int B, int T, int Cin, int Cout, const float* kernel,
+                                 const float* bias, const float* gamma, const float* beta, int precision, float* y) {
+    if (precision < 0 || precision > 2) { g_op_error = "precision must be 0 (fp32 MFMA), 1 (split-bf16 x3) or 2 (split-fp16 x3)"; return OPH_ERR_INVALID; }
     OpCtx c(device);
     if (!c.ok) return OPH_ERR_DEVICE;
     if (Cout > 1280) { g_op_error = "channels out of range"; return OPH_ERR_UNSUPPORTED; }
@@ -2992,9 +2997,21 @@ int oph_op_conv1d_transpose(int device, const float* x, int B, int T, int Cin, i
     GemmArgs g{};
     g.X = dxp; g.ldx = kc; g.bias = dbias; g.ldh = 2 * Nalloc; g.M = M; g.N = Cout; g.kc = kc; g.mode = 0; g.T = T;
     g.Wt = dwe; g.ldw = 2 * kc; g.ntaps = 2; g.off[0] = 0; g.off[1] = -1; g.H = dh;
-    launch_conv_gemm(g, c.s);
-    g.Wt = dwo; g.ldw = kc; g.ntaps = 1; g.off[0] = 0; g.H = dh + Nalloc;
-    launch_conv_gemm(g, c.s);
+    GemmArgs g2 = g;
+    g2.Wt = dwo; g2.ldw = kc; g2.ntaps = 1; g2.off[0] = 0; g2.H = dh + Nalloc;
+    if (precision == 0) {
+        launch_conv_gemm(g, c.s);
+        launch_conv_gemm(g2, c.s);
+    } else {        // the SSRN path's launch for this layer: both phases in one, on the split 16-bit planes
+        unsigned short* dweh = c.alloc<unsigned short>(we.size()); unsigned short* dwel = c.alloc<unsigned short>(we.size());
+        unsigned short* dwoh = c.alloc<unsigned short>(wo.size()); unsigned short* dwol = c.alloc<unsigned short>(wo.size());
+        if (!c.ok) return OPH_ERR_DEVICE;
+        if (precision == 2) { launch_split_f16(dwe, dweh, dwel, we.size(), c.s); launch_split_f16(dwo, dwoh, dwol, wo.size(), c.s); }
+        else { launch_split_bf16(dwe, dweh, dwel, we.size(), c.s); launch_split_bf16(dwo, dwoh, dwol, wo.size(), c.s); }
+        g.Wh = dweh; g.Wl = dwel; g.f16 = precision == 2; g.nprod = 3;
+        g2.Wh = dwoh; g2.Wl = dwol; g2.f16 = g.f16; g2.nprod = 3;
+        launch_conv_gemm_pair(g, g2, precision, c.s);
+    }
     EpiArgs e{};
     e.H = dh; e.ldh = Nalloc; e.M = 2 * M; e.C = Cout; e.mode = PRE_CONV; e.act = ACT_NONE; e.g1 = dg; e.b1 = db; e.Y = dy; e.ldy = Cout; e.ypad = Cout;
     launch_epilogue(e, c.s);

@@ -70,17 +70,19 @@ def hc(inputs, W, scope="hc", size=1, rate=1, padding="SAME", device=0):
     return y
 
 
-def conv1d_transpose(inputs, W, scope="conv1d_transpose", device=0):
+def conv1d_transpose(inputs, W, scope="conv1d_transpose", device=0, precision=0):
+    """precision: the arithmetic of the contraction, as Engine.set_precision's codes -- 0 fp32-operand MFMA, 1 split-bf16 x3,
+    2 split-fp16 x3 (what the SSRN path runs by default)."""
     x = _f(inputs)
     B, T, Cin = x.shape
     k = _f(W[scope + "/conv2d_transpose/kernel"])          # (1, 3, Cout, Cin)
     assert k.shape[0] == 1 and k.shape[1] == 3 and k.shape[3] == Cin
     Cout = k.shape[2]
     y = np.empty((B, 2 * T, Cout), np.float32)
-    _chk(_lib.load().oph_op_conv1d_transpose(device, _lib.fptr(x), B, T, Cin, Cout, _lib.fptr(k),
-                                             _lib.fptr(_f(W[scope + "/conv2d_transpose/bias"])),
-                                             _lib.fptr(_f(W[scope + "/normalize/gamma"])),
-                                             _lib.fptr(_f(W[scope + "/normalize/beta"])), _lib.fptr(y)))
+    _chk(_lib.load().oph_op_conv1d_transpose_prec(device, _lib.fptr(x), B, T, Cin, Cout, _lib.fptr(k),
+                                                  _lib.fptr(_f(W[scope + "/conv2d_transpose/bias"])),
+                                                  _lib.fptr(_f(W[scope + "/normalize/gamma"])),
+                                                  _lib.fptr(_f(W[scope + "/normalize/beta"])), int(precision), _lib.fptr(y)))
     return y
 
 

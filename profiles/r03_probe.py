@@ -17,10 +17,15 @@ eng = Engine(hp, device=0)
 eng.load_weights(WT.random_weights(eng.inventory(), seed=2))
 L, ends = bench.synth_text(hp, 16, seed=3)
 eng.stage_text(L, ends)
+eng.profile_enable(2)                       # one HIP event pair per whole-decode launch
 for i in range(n):
+    eng.profile_reset()
     t0 = time.perf_counter()
     steps = eng.run_resident(stop_mode=1, run_ssrn=True, pipelined=False)
+    t1 = time.perf_counter()
     eng.synchronize()
-    print("batch %d: %d steps, %.2f ms" % (i, steps, (time.perf_counter() - t0) * 1e3), flush=True)
+    loop = next((p for p in eng.profile() if p["name"] == "dec_loop" and p["launches"] > 0), None)
+    print("batch %d: %d steps, %.2f ms (call returned after %.2f ms; dec_loop %.2f ms by HIP events)"
+          % (i, steps, (time.perf_counter() - t0) * 1e3, (t1 - t0) * 1e3, loop["total_ms"] / loop["launches"] if loop else -1), flush=True)
 print("counters", eng.counters())
 eng.close()

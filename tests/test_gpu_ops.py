@@ -82,6 +82,26 @@ def test_conv1d_transpose(B, T, C):
     assert np.abs(got - ref).max() < TOL
 
 
+@pytest.mark.parametrize("B,T,C,prec,tol", [(2, 37, 512, 2, 2e-5), (16, 200, 512, 2, 2e-5), (1, 1, 512, 2, 2e-5), (3, 50, 512, 1, 3e-4),
+                                            (2, 33, 256, 2, 2e-5)])
+def test_conv1d_transpose_split_precisions(B, T, C, prec, tol):
+    """The launches the SSRN path makes for D_4 / D_7 at the split precisions (both phases in one launch of conv_gemm_bf16x3_pair,
+    then ln_rows; ragged last tile, T = 1) against the oracle (modules.py:209-258)."""
+    from ophelia_amd import modules as M
+    x = _r(B, T, C)
+    W = {"d/conv2d_transpose/kernel": _r(1, 3, C, C, sc=(2.6 / (3 * C)) ** 0.5), "d/conv2d_transpose/bias": _r(C, sc=0.02)}
+    W.update(_ln("d/normalize", C))
+    ref = O.conv1d_transpose(x, W, "d")
+    got = M.conv1d_transpose(x, W, "d", precision=prec)
+    assert got.shape == (B, 2 * T, C)
+    assert np.abs(got - ref).max() < tol
+    # size-independent: an impulse at frame t0 touches output rows 2 t0 .. 2 t0 + 2 only (the tile and phase bookkeeping)
+    if T > 8:
+        x1 = x.copy(); x1[0, 5] += _r(C)
+        changed = np.where(np.abs(M.conv1d_transpose(x1, W, "d", precision=prec) - got).max(axis=(0, 2)) > 0)[0]
+        assert changed.tolist() == [10, 11, 12]
+
+
 def test_conv1d_transpose_linearity_and_shift():
     """size-independent properties at full SSRN size: out[2t+1] depends on x[t] only; a one-frame
     impulse touches exactly output rows 2t, 2t+1, 2t+2 (before LayerNorm: use gamma=1,beta=0 rows)."""
