@@ -187,6 +187,7 @@ struct oph_handle {
     unsigned long long* d_gbuf = nullptr;   // hand-off granules [LOOP_MAX_LAYERS][16][RUN_GCOLS]
     uint32_t run_epoch = 0;             // advanced per launch: a tag value is never reused
     long long* d_sigdbg = nullptr;      // OPH_RUN_STAMPS diagnostics: [max_T][8] stamps of the cross-stream signals
+    long long* d_lvldbg = nullptr;      // ... and [max_T][8]: when the side stream completed cone level k of step t
     long long* d_stamps = nullptr;      // OPH_RUN_STAMPS diagnostics: [2 launches][32 slices][LOOP_MAX_LAYERS][8]
     // whole-decode persistent launch (dec_loop): static layer descriptions in device memory, progress words in pinned host memory
     bool use_loop = false;
@@ -761,6 +762,8 @@ int ensure_decode_state(oph_handle* h, int B) {
     if (h->opt.run_stamps) {
         h->d_stamps = h->dalloc<long long>((size_t)2 * 32 * LOOP_MAX_LAYERS * 8);
         h->d_sigdbg = h->dalloc<long long>((size_t)m.max_T * 8);
+        h->d_lvldbg = h->dalloc<long long>((size_t)m.max_T * 8);
+        if (h->d_lvldbg) hipMemset(h->d_lvldbg, 0, (size_t)m.max_T * 8 * sizeof(long long));
         h->d_cldbg = h->dalloc<long long>((size_t)(2 * m.max_T + 4) * 8 + 512);
     }
     h->Rrow = h->dalloc<float>((size_t)Bpad * 2 * d);
@@ -936,6 +939,7 @@ void launch_cone(oph_handle* h, int t) {
     int pre_first = 0;               // first k=1 layer still to run as GEMM + LayerNorm
     const bool head = h->cone_head_ok && !h->fixed_att;
     // dec_loop mode: the launch that completes cone level `lvl` (nblocks workgroups) raises that level's word
+    auto stamp_of = [&](int lvl) -> long long* { return (h->d_lvldbg && lvl >= 0 && lvl < 8 && t < m.max_T) ? h->d_lvldbg + (size_t)t * 8 + lvl : nullptr; };
     auto level_done = [&](int lvl, unsigned*& sig, unsigned& val, unsigned*& count, unsigned& target, int& coh0, int& coh1) {
         if (!h->cone_inline_sig || lvl < 0 || lvl >= LOOP_MAX_LEVELS || lvl >= nh) return;
         const Layer& tl = h->audiodec[pre + lvl];         // the chain layer whose taps read this level (build_loop_layers)
@@ -964,6 +968,7 @@ void launch_cone(oph_handle* h, int t) {
             auto blocks_of = [&](int pos) { return pos < 0 ? 0u : (ch.i_new < 0 ? (unsigned)(Bpad / 4) : (pos == ch.i_new ? (unsigned)B : (unsigned)(Bpad / 16))); };
             h->cone_done_total[0] += blocks_of(ch.coh0) + (ch.coh1 != ch.coh0 ? blocks_of(ch.coh1) : 0u);
             ch.done_sig = h->d_sig + LOOP_SIG_LEVEL0; ch.done_val = h->cone_done_val; ch.done_count = h->d_cone_count; ch.done_target = h->cone_done_total[0];
+            ch.done_stamp = stamp_of(0);
         }
         h->pbegin(PC_CONEHEAD);
         launch_cone_head(ch, g_cur);
@@ -1001,6 +1006,7 @@ void launch_cone(oph_handle* h, int t) {
             e.Y = cone[0]; e.ldy = hc0.kc; e.ypad = hc0.kc;
             x = cone[0]; ldx = hc0.kc;
             level_done(0, e.done_sig, e.done_val, e.done_count, e.done_target, e.coh0, e.coh1);
+            if (e.done_sig) e.done_stamp = stamp_of(0);
         }
         run_epi(h, e);
     }
@@ -1039,6 +1045,7 @@ void launch_cone(oph_handle* h, int t) {
                 c.coh0 = idx_of(h->Hset[k], -tl.off[0]); c.coh1 = idx_of(h->Hset[k], -tl.off[1]);
                 h->cone_done_total[k] += (unsigned)((n_out + c.n_extra) * (Bpad / 16));
                 c.done_sig = h->d_sig + LOOP_SIG_LEVEL0 + 16 * k; c.done_val = h->cone_done_val; c.done_count = h->d_cone_count + k; c.done_target = h->cone_done_total[k];
+                c.done_stamp = stamp_of(k);
             }
             h->pbegin(PC_DEC);
             launch_cone_fc16(c, g_cur);
@@ -1068,6 +1075,7 @@ void launch_cone(oph_handle* h, int t) {
         const Layer& nx = h->audiodec[pre + k + 1];
         e.Y = cone[k + 1]; e.ldy = nx.kc; e.ypad = nx.kc; e.stop_after = stop_after; e.t = t;
         level_done(k + 1, e.done_sig, e.done_val, e.done_count, e.done_target, e.coh0, e.coh1);
+        if (e.done_sig) e.done_stamp = stamp_of(k + 1);
         run_epi(h, e);
     }
     g_cur = saved;
@@ -1731,6 +1739,21 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
                     const long long* q = &sd[(size_t)t * 8];
                     TRACE("step %d: the loop kernel spun for cone levels 0..5: %.2f %.2f %.2f %.2f %.2f %.2f us", t,
                           q[1] * 0.01, q[2] * 0.01, q[3] * 0.01, q[4] * 0.01, q[5] * 0.01, q[6] * 0.01);
+                }
+                if (h->d_lvldbg) {      // the cone of step t: release (attention of step t-1 done) -> each level complete, and the previous cone's end
+                    std::vector<long long> lv((size_t)m.max_T * 8);
+                    hipMemcpy(lv.data(), h->d_lvldbg, lv.size() * 8, hipMemcpyDeviceToHost);
+                    for (int t : {50, 51, 100, 101, 150}) {
+                        if (t >= m.max_T || t < 2) continue;
+                        const long long rel = sd[(size_t)t * 8];
+                        const long long* q = &lv[(size_t)t * 8];
+                        const long long* qp = &lv[(size_t)(t - 1) * 8];
+                        long long prev_end = 0;
+                        for (int k = 0; k < 8; ++k) prev_end = std::max(prev_end, qp[k]);
+                        TRACE("cone of step %d: levels 0..5 complete %.1f %.1f %.1f %.1f %.1f %.1f us after its release; the previous cone ended %.1f us %s it",
+                              t, (q[0] - rel) * 0.01, (q[1] - rel) * 0.01, (q[2] - rel) * 0.01, (q[3] - rel) * 0.01, (q[4] - rel) * 0.01, (q[5] - rel) * 0.01,
+                              std::fabs((double)(prev_end - rel)) * 0.01, prev_end > rel ? "AFTER" : "before");
+                    }
                 }
             }
             if (loop_mode && h->d_cldbg) {

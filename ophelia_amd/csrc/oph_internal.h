@@ -66,6 +66,7 @@ struct EpiArgs {
     // workgroup holding such rows waits for its stores, adds 1 to *done_count, and the one that makes it done_target
     // raises *done_sig to done_val
     unsigned* done_sig; unsigned done_val; unsigned* done_count; unsigned done_target; int coh0, coh1;
+    long long* done_stamp;          // diagnostics: the raising lane stores the constant clock here (or null)
 };
 
 // ---- fused M=16 decode layer (prologue = previous layer's LN/gate, then 16xK . KxN slice)
@@ -125,6 +126,7 @@ struct ConeHeadArgs {
     const int* stop_after; int t;
     const unsigned* wait_sig; unsigned wait_val; int* wait_err;
     unsigned* done_sig; unsigned done_val; unsigned* done_count; unsigned done_target; int coh0, coh1;      // as EpiArgs: cone level 0 written
+    long long* done_stamp;
 };
 void launch_cone_head(const ConeHeadArgs& a, hipStream_t s);
 
@@ -150,6 +152,7 @@ struct ConeFcArgs {
     int Bpad;
     const int* stop_after; int t;
     unsigned* done_sig; unsigned done_val; unsigned* done_count; unsigned done_target; int coh0, coh1;   // level k completion (see EpiArgs)
+    long long* done_stamp;
 };
 void launch_cone_fc16(const ConeFcArgs& a, hipStream_t s);
 

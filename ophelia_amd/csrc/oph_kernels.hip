@@ -644,7 +644,10 @@ __global__ __launch_bounds__(256) void ln_rows(EpiArgs a) {
         __syncthreads();
         if (threadIdx.x == 0) {
             const unsigned old = atomicAdd(a.done_count, 1u);
-            if (old + 1u == a.done_target) __hip_atomic_fetch_max(a.done_sig, a.done_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (old + 1u == a.done_target) {
+                __hip_atomic_fetch_max(a.done_sig, a.done_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (a.done_stamp) *a.done_stamp = wall_clock64();      // diagnostics (OPH_RUN_STAMPS): when this level was complete
+            }
         }
     }
 }
@@ -1081,7 +1084,10 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void cone_fc16(ConeFcArgs a) {
         __syncthreads();
         if (threadIdx.x == 0) {
             const unsigned old = atomicAdd(a.done_count, 1u);
-            if (old + 1u == a.done_target) __hip_atomic_fetch_max(a.done_sig, a.done_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (old + 1u == a.done_target) {
+                __hip_atomic_fetch_max(a.done_sig, a.done_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (a.done_stamp) *a.done_stamp = wall_clock64();      // diagnostics (OPH_RUN_STAMPS): when this level was complete
+            }
         }
     }
 }
@@ -1355,7 +1361,10 @@ __global__ __launch_bounds__(1024) void cone_head(ConeHeadArgs a) {
         __syncthreads();
         if (threadIdx.x == 0) {
             const unsigned old = atomicAdd(a.done_count, 1u);
-            if (old + 1u == a.done_target) __hip_atomic_fetch_max(a.done_sig, a.done_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (old + 1u == a.done_target) {
+                __hip_atomic_fetch_max(a.done_sig, a.done_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (a.done_stamp) *a.done_stamp = wall_clock64();      // diagnostics (OPH_RUN_STAMPS): when this level was complete
+            }
         }
     }
 }
