@@ -1,0 +1,138 @@
+"""Randomised call sequences through the C ABI on ONE handle: batch sizes on both sides of the 16-utterance tile (1 ... 40),
+early stops and fixed-length decodes, the three session calls with resident or re-uploaded arrays, the staged / resident
+entry points with and without a staged next text, oph_run_host, streamed and one-piece SSRN, changing chunk sizes -- in an
+order drawn from a seed.  Whatever came before on the handle, a batch must give bit for bit what the plainest sequence
+gives for it (encode_text -> text2mel on copies -> ssrn on a copy, SSRN streaming off): the handle's state machine
+(residency tokens, ping-pong buffers, staged text slots, tile bookkeeping, workspaces sized per batch) is what is under test,
+not the arithmetic -- every variant runs the same kernels on the same rows.  (A handle that had served a 7-utterance batch
+once overran its workspaces on the next full one: tests/test_gpu_pipeline.py holds that case; this test looks for its
+relatives.)"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import hp_from_snapshot
+
+pytestmark = pytest.mark.gpu
+
+BATCHES = [1, 3, 7, 8, 15, 16, 17, 20, 31, 32, 33, 40]
+
+
+@pytest.fixture(scope="module")
+def model():
+    from oracle import ophelia_oracle as O
+    from ophelia_amd.engine import Engine
+    hp = hp_from_snapshot("lj_tutorial.cfg", max_T=96)
+    W = O.random_weights(hp, 5)
+    eng = Engine(hp, device=0)
+    eng.load_weights(W)
+    yield hp, eng, O
+    eng.close()
+
+
+def _text(O, hp, B, seed, early):
+    lo, hi = (5, 18) if early else (60, 140)
+    L = O.random_text(hp, B, seed, min_len=lo, max_len=hi)
+    return L, O.get_text_lengths(L).astype(np.int32)
+
+
+def _plain(eng, L, ends, stop_mode):
+    """The plainest sequence: nothing resident, nothing streamed, nothing staged ahead."""
+    eng.set_streaming(0)
+    K, V = eng.encode_text(L)
+    K, V = np.array(K), np.array(V)
+    Y, t_ends, al, steps = eng.text2mel(K, V, ends, stop_mode=stop_mode)
+    Y, t_ends, al = np.array(Y), np.array(t_ends), np.array(al)
+    Z = np.array(eng.ssrn(np.array(Y)))
+    eng.set_streaming(1)
+    return dict(K=K, V=V, Y=Y, t_ends=t_ends, al=al, Z=Z, steps=steps)
+
+
+def _same(ref, got, what):
+    for k, v in got.items():
+        if k == "steps":
+            assert v == ref["steps"], (what, "steps", v, ref["steps"])
+        else:
+            assert np.array_equal(np.asarray(v), ref[k]), (what, k)
+
+
+# OPH_FUZZ_SEEDS / OPH_FUZZ_ITERS lengthen the search (e.g. 40 x 40 in a few minutes); the defaults keep the suite short
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OPH_FUZZ_SEEDS", "4"))))
+def test_random_call_sequences_leave_no_trace(model, seed):
+    hp, eng, O = model
+    rng = np.random.default_rng(1000 + seed)
+    refs = {}
+
+    def ref_of(B, tseed, early, stop_mode):
+        key = (B, tseed, early, stop_mode, prec[0])
+        if key not in refs:
+            L, ends = _text(O, hp, B, tseed, early)
+            refs[key] = (L, ends, _plain(eng, L, ends, stop_mode))
+        return refs[key]
+
+    prec = [2]                  # the SSRN arithmetic in force (oph_set_ssrn_precision): switched between batches as well
+
+    seen = dict(next=0, stopped=0, tiles=0)
+    for it in range(int(os.environ.get("OPH_FUZZ_ITERS", "16"))):
+        B = int(rng.choice(BATCHES))
+        early = bool(rng.integers(0, 2))
+        stop_mode = 0 if early else 1                  # the reference's break on short texts; fixed length on long ones
+        tseed = int(rng.integers(0, 3))
+        style = int(rng.integers(0, 5))
+        chunk = int(rng.choice([1, 8, 24, 40]))
+        eng.set_streaming(chunk if chunk >= 2 else 1)
+        if rng.integers(0, 4) == 0:
+            prec[0] = 2 if prec[0] == 0 else 0
+            eng.set_ssrn_precision(prec[0])
+        L, ends, ref = ref_of(B, tseed, early, stop_mode)
+        what = "it %d: B=%d early=%d style=%d chunk=%d" % (it, B, early, style, chunk)
+        seen["stopped"] += ref["steps"] < hp.max_T
+        seen["tiles"] += B > 16
+        if style == 0:                                  # the three session calls, arrays handed back untouched (resident)
+            K, V = eng.encode_text(L)
+            Y, t_ends, al, steps = eng.text2mel(K, V, ends, stop_mode=stop_mode)
+            Z = eng.ssrn(Y)
+            _same(ref, dict(K=K, V=V, Y=Y, t_ends=t_ends, al=al, Z=Z, steps=steps), what)
+        elif style == 1:                                # session calls on copies (everything uploaded again), SSRN asked twice
+            K, V = eng.encode_text(L)
+            Y, t_ends, al, steps = eng.text2mel(np.array(K), np.array(V), ends, stop_mode=stop_mode)
+            Z1 = eng.ssrn(np.array(Y))
+            Z2 = eng.ssrn(Y)
+            _same(ref, dict(Y=Y, t_ends=t_ends, al=al, Z=Z1, steps=steps), what)
+            assert np.array_equal(Z2, ref["Z"]), what
+        elif style in (2, 3):                           # staged text, resident run (2) or host -> host in one call (3)
+            eng.stage_text(L, ends)
+            nxt = None
+            if rng.integers(0, 2):                      # put some text into the second slot while this batch runs
+                nearly, nseed = bool(rng.integers(0, 2)), int(rng.integers(0, 3))       # (the two slots belong to one batch size)
+                nxt = (B, nseed, nearly, 0 if nearly else 1)
+                nref = ref_of(*nxt)                         # (its plain reference first: that is a sequence of its own on the handle)
+                eng.stage_text(L, ends)
+                nL, nends, _ = nref
+                eng.stage_text_next(nL, nends)
+                seen["next"] += 1
+            if style == 2:
+                steps = eng.run_resident(stop_mode=stop_mode, run_ssrn=True, pipelined=bool(rng.integers(0, 2)))
+                Y, t_ends, al = eng.fetch_mel()
+                Z = eng.fetch_mag()
+                _same(ref, dict(Y=Y, t_ends=t_ends, al=al, Z=Z, steps=steps), what)
+            else:
+                out = eng.run_host(stop_mode=stop_mode, want_kv=True)
+                _same(ref, dict(K=out["K"], V=out["V"], Y=out["Y"], t_ends=out["t_ends"], al=out["alignments"], Z=out["Z"],
+                                steps=out["steps"]), what)
+            if nxt is not None:                         # the staged next text is the batch of the next run on this handle
+                steps = eng.run_resident(stop_mode=nxt[3], run_ssrn=True, pipelined=False)
+                Y, t_ends, al = eng.fetch_mel()
+                _same(nref[2], dict(Y=Y, t_ends=t_ends, al=al, Z=eng.fetch_mag(), steps=steps), what + " -> staged next")
+        else:                                           # decode without SSRN, then SSRN on the resident frames, then again on a copy
+            eng.stage_text(L, ends)
+            steps = eng.run_resident(stop_mode=stop_mode, run_ssrn=False)
+            Y, t_ends, al = eng.fetch_mel()
+            Z = eng.ssrn(Y)
+            _same(ref, dict(Y=Y, t_ends=t_ends, al=al, Z=Z, steps=steps), what)
+            assert np.array_equal(eng.ssrn(np.array(Y)), ref["Z"]), what
+    eng.set_streaming(1)
+    eng.set_ssrn_precision(2)
+    eng.synchronize()
+    assert seen["next"] >= 1 and seen["stopped"] >= 2 and seen["tiles"] >= 2, seen      # the sequence did visit what it is meant to
