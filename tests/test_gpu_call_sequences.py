@@ -19,11 +19,13 @@ pytestmark = pytest.mark.gpu
 BATCHES = [1, 3, 7, 8, 15, 16, 17, 20, 31, 32, 33, 40]
 
 
-@pytest.fixture(scope="module")
-def model():
+# lj_tutorial: one speaker; vctk_01: speaker codes at the decoder input (two input convs before AudioDec's highway stack: another
+# layer table for the whole-decode launch, the speaker ids travel with every staged text)
+@pytest.fixture(scope="module", params=["lj_tutorial.cfg", "vctk_01.cfg"])
+def model(request):
     from oracle import ophelia_oracle as O
     from ophelia_amd.engine import Engine
-    hp = hp_from_snapshot("lj_tutorial.cfg", max_T=96)
+    hp = hp_from_snapshot(request.param, max_T=96)
     W = O.random_weights(hp, 5)
     eng = Engine(hp, device=0)
     eng.load_weights(W)
@@ -32,17 +34,20 @@ def model():
 
 
 def _text(O, hp, B, seed, early):
-    lo, hi = (5, 18) if early else (60, 140)
+    lo, hi = (5, 18) if early else (60, min(140, hp.max_N - 2))
     L = O.random_text(hp, B, seed, min_len=lo, max_len=hi)
-    return L, O.get_text_lengths(L).astype(np.int32)
+    spk = None
+    if getattr(hp, "multispeaker", False):
+        spk = np.random.default_rng(seed + 77).integers(1, hp.nspeakers, size=(B, 1)).astype(np.int32)
+    return L, O.get_text_lengths(L).astype(np.int32), spk
 
 
-def _plain(eng, L, ends, stop_mode):
+def _plain(eng, L, ends, spk, stop_mode):
     """The plainest sequence: nothing resident, nothing streamed, nothing staged ahead."""
     eng.set_streaming(0)
-    K, V = eng.encode_text(L)
+    K, V = eng.encode_text(L, spk)
     K, V = np.array(K), np.array(V)
-    Y, t_ends, al, steps = eng.text2mel(K, V, ends, stop_mode=stop_mode)
+    Y, t_ends, al, steps = eng.text2mel(K, V, ends, spk, stop_mode=stop_mode)
     Y, t_ends, al = np.array(Y), np.array(t_ends), np.array(al)
     Z = np.array(eng.ssrn(np.array(Y)))
     eng.set_streaming(1)
@@ -67,8 +72,8 @@ def test_random_call_sequences_leave_no_trace(model, seed):
     def ref_of(B, tseed, early, stop_mode):
         key = (B, tseed, early, stop_mode, prec[0])
         if key not in refs:
-            L, ends = _text(O, hp, B, tseed, early)
-            refs[key] = (L, ends, _plain(eng, L, ends, stop_mode))
+            L, ends, spk = _text(O, hp, B, tseed, early)
+            refs[key] = (L, ends, spk, _plain(eng, L, ends, spk, stop_mode))
         return refs[key]
 
     prec = [2]                  # the SSRN arithmetic in force (oph_set_ssrn_precision): switched between batches as well
@@ -85,32 +90,32 @@ def test_random_call_sequences_leave_no_trace(model, seed):
         if rng.integers(0, 4) == 0:
             prec[0] = 2 if prec[0] == 0 else 0
             eng.set_ssrn_precision(prec[0])
-        L, ends, ref = ref_of(B, tseed, early, stop_mode)
+        L, ends, spk, ref = ref_of(B, tseed, early, stop_mode)
         what = "it %d: B=%d early=%d style=%d chunk=%d" % (it, B, early, style, chunk)
         seen["stopped"] += ref["steps"] < hp.max_T
         seen["tiles"] += B > 16
         if style == 0:                                  # the three session calls, arrays handed back untouched (resident)
-            K, V = eng.encode_text(L)
-            Y, t_ends, al, steps = eng.text2mel(K, V, ends, stop_mode=stop_mode)
+            K, V = eng.encode_text(L, spk)
+            Y, t_ends, al, steps = eng.text2mel(K, V, ends, spk, stop_mode=stop_mode)
             Z = eng.ssrn(Y)
             _same(ref, dict(K=K, V=V, Y=Y, t_ends=t_ends, al=al, Z=Z, steps=steps), what)
         elif style == 1:                                # session calls on copies (everything uploaded again), SSRN asked twice
-            K, V = eng.encode_text(L)
-            Y, t_ends, al, steps = eng.text2mel(np.array(K), np.array(V), ends, stop_mode=stop_mode)
+            K, V = eng.encode_text(L, spk)
+            Y, t_ends, al, steps = eng.text2mel(np.array(K), np.array(V), ends, spk, stop_mode=stop_mode)
             Z1 = eng.ssrn(np.array(Y))
             Z2 = eng.ssrn(Y)
             _same(ref, dict(Y=Y, t_ends=t_ends, al=al, Z=Z1, steps=steps), what)
             assert np.array_equal(Z2, ref["Z"]), what
         elif style in (2, 3):                           # staged text, resident run (2) or host -> host in one call (3)
-            eng.stage_text(L, ends)
+            eng.stage_text(L, ends, spk)
             nxt = None
             if rng.integers(0, 2):                      # put some text into the second slot while this batch runs
                 nearly, nseed = bool(rng.integers(0, 2)), int(rng.integers(0, 3))       # (the two slots belong to one batch size)
                 nxt = (B, nseed, nearly, 0 if nearly else 1)
                 nref = ref_of(*nxt)                         # (its plain reference first: that is a sequence of its own on the handle)
-                eng.stage_text(L, ends)
-                nL, nends, _ = nref
-                eng.stage_text_next(nL, nends)
+                eng.stage_text(L, ends, spk)
+                nL, nends, nspk, _ = nref
+                eng.stage_text_next(nL, nends, nspk)
                 seen["next"] += 1
             if style == 2:
                 steps = eng.run_resident(stop_mode=stop_mode, run_ssrn=True, pipelined=bool(rng.integers(0, 2)))
@@ -124,9 +129,9 @@ def test_random_call_sequences_leave_no_trace(model, seed):
             if nxt is not None:                         # the staged next text is the batch of the next run on this handle
                 steps = eng.run_resident(stop_mode=nxt[3], run_ssrn=True, pipelined=False)
                 Y, t_ends, al = eng.fetch_mel()
-                _same(nref[2], dict(Y=Y, t_ends=t_ends, al=al, Z=eng.fetch_mag(), steps=steps), what + " -> staged next")
+                _same(nref[3], dict(Y=Y, t_ends=t_ends, al=al, Z=eng.fetch_mag(), steps=steps), what + " -> staged next")
         else:                                           # decode without SSRN, then SSRN on the resident frames, then again on a copy
-            eng.stage_text(L, ends)
+            eng.stage_text(L, ends, spk)
             steps = eng.run_resident(stop_mode=stop_mode, run_ssrn=False)
             Y, t_ends, al = eng.fetch_mel()
             Z = eng.ssrn(Y)
