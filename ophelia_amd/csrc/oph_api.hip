@@ -2324,8 +2324,15 @@ static int check_ready(oph_handle* h, int B) {
 static bool model_is_multispeaker(const oph_handle* h) {
     return h->dm.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_TOWARDS_END | OPH_FLAG_LCC | OPH_FLAG_SPK_AUDIO_ENCODER_INPUT);
 }
+// ends = get_text_lengths(L) (synthesize.py:242-247): a key position of the text, 0 ... max_N
+static int check_ends(oph_handle* h, const int32_t* ends, int B) {
+    for (int b = 0; b < B; ++b)
+        if (ends[b] < 0 || ends[b] > h->dm.max_N) { h->fail("text end %d of utterance %d is outside the text (max_N = %d)", ends[b], b, h->dm.max_N); return OPH_ERR_INVALID; }
+    return OPH_OK;
+}
 static int check_text(oph_handle* h, const int32_t* L, const int32_t* ends, const int32_t* spk, int B) {
     if (!L || !ends) { h->fail("null argument"); return OPH_ERR_INVALID; }
+    if (int rc = check_ends(h, ends, B)) return rc;
     const bool ms = model_is_multispeaker(h);
     if (ms && !spk) { h->fail("multispeaker model needs speaker ids"); return OPH_ERR_INVALID; }
     const oph_dims& m = h->dm;
@@ -2390,6 +2397,8 @@ int oph_stage_text_next(oph_handle* h, const int32_t* L, const int32_t* ends, co
 
 int oph_decode_steps(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* steps_run) {
     if (!h || !h->bKV[0]) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
+    if (stop_mode != OPH_STOP_REFERENCE && stop_mode != OPH_STOP_NEVER) { h->fail("unknown stop mode %d", stop_mode); return OPH_ERR_INVALID; }
+    if (t_begin < 0 || t_end < t_begin || t_end > h->dm.max_T) { h->fail("steps [%d, %d) are outside [0, max_T = %d]", t_begin, t_end, h->dm.max_T); return OPH_ERR_INVALID; }
     HIPCHK(h, hipSetDevice(h->device));
     if (t_begin == 0) { begin_batch(h); return decode_batch(h, t_end, stop_mode, steps_run); }
     // resume (multi-GPU global stop): every tile continues from the step the batch stopped at; clear the local stops
@@ -2435,6 +2444,8 @@ int oph_run_ssrn_resident(oph_handle* h) {
 
 int oph_run_resident(oph_handle* h, int stop_mode, int run_ssrn, int32_t* steps_run) {
     if (!h || !h->bKV[0]) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
+    if (stop_mode != OPH_STOP_REFERENCE && stop_mode != OPH_STOP_NEVER) { h->fail("unknown stop mode %d", stop_mode); return OPH_ERR_INVALID; }
+    if (run_ssrn < 0 || run_ssrn > 2) { h->fail("run_ssrn must be 0, 1 or 2"); return OPH_ERR_INVALID; }
     HIPCHK(h, hipSetDevice(h->device));
     // run_ssrn: 0 = Text2Mel only; 1 = SSRN too, joined when the call returns; 2 = pipelined batches -- the SSRN tail of
     // THIS batch (what its streamed chunks have not covered when the decode ends) stays queued on the SSRN partition and
@@ -2561,6 +2572,7 @@ int oph_device_mag(oph_handle* h, const float** d_mag, int64_t* utt_stride, int3
 // reference's two clocks bracket (synthesize.py:553-576).
 int oph_run_host(oph_handle* h, int stop_mode, float* K, float* V, float* Y, int32_t* t_ends, float* alignments, float* Z, int32_t* steps_run) {
     if (!h || !h->bKV[0]) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
+    if (stop_mode != OPH_STOP_REFERENCE && stop_mode != OPH_STOP_NEVER) { h->fail("unknown stop mode %d", stop_mode); return OPH_ERR_INVALID; }
     HIPCHK(h, hipSetDevice(h->device));
     int rc = set_pipelined(h, false);
     if (rc) return rc;
@@ -2635,7 +2647,10 @@ static int stage_decode_inputs(oph_handle* h, const float* K, const float* V, bo
         HIPCHK(h, hipMemcpy2DAsync(kv + m.d, 2 * w, V, w, w, rows, hipMemcpyHostToDevice, h->stream));
         h->kv_resident = false;
     }
-    if (ends) HIPCHK(h, hipMemcpyAsync(h->bEnds[h->txt], ends, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    if (ends) {
+        if ((rc = check_ends(h, ends, B))) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->bEnds[h->txt], ends, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    }
     if (ms) {
         for (int b = 0; b < B; ++b) if (spk[b] < 0 || spk[b] >= m.nspeakers) { h->fail("speaker id out of range"); return OPH_ERR_INVALID; }
         HIPCHK(h, hipMemcpyAsync(h->bSpk[h->txt], spk, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
@@ -2649,6 +2664,7 @@ int oph_text2mel(oph_handle* h, const float* K, const float* V, const int32_t* e
     int rc = check_ready(h, B);
     if (rc) return rc;
     if (!ends) { h->fail("null argument"); return OPH_ERR_INVALID; }
+    if (stop_mode != OPH_STOP_REFERENCE && stop_mode != OPH_STOP_NEVER) { h->fail("unknown stop mode %d", stop_mode); return OPH_ERR_INVALID; }
     if ((rc = set_pipelined(h, false))) return rc;
     if ((rc = stage_decode_inputs(h, K, V, true, ends, spk, B))) return rc;
     begin_batch(h);
