@@ -136,7 +136,9 @@ int oph_set_streaming(oph_handle* h, int on);
 int oph_set_mag_destination(oph_handle* h, float* Z);
 /* What the pipeline did since oph_create, out[0..n): [0] TextEnc evaluations, [1] runs whose K,V had been pre-encoded under
  * the previous decode, [2] SSRN chunks launched while a decode was running, [3] whole-decode launches, [4] fall-backs from the
- * whole-decode launch to two launches per step, [5] tiles resumed to their batch's stop step, [6] persistent cone launches. */
+ * whole-decode launch to two launches per step, [5] tiles resumed to their batch's stop step, [6] persistent cone launches,
+ * [7] fp16 range guard: bit 0 SSRN, bit 1 cone, bit 2 TextEnc -- a weight of that net exceeds fp16's range (|w| > 6e4), so its
+ *     split-fp16 contractions are pinned to the fp32-operand MFMA. */
 int oph_get_counters(oph_handle* h, int64_t* out, int n);
 /* oph_text2mel_graph  replaces ONE sess.run([g.Y, g.max_attentions, g.alignments], feed) of the reference's loop
  *     (synthesize.py:172,181-183) and serves as the fetch surface for the graph tensors of architectures.py:188-239:
@@ -219,6 +221,11 @@ int oph_timer_stop(oph_handle* h, float* elapsed_ms);      /* synchronises */
  * ALGORITHMIC bytes and flops of those launches (DESIGN.md gives the formulas).
  * on = 2 brackets only the whole-decode launch (dec_loop: one event pair per decode,
  * cheap enough to stay on inside a timed region); 1 = every class; 0 = off.       */
+/* Device-side witness of the whole-decode launches (dec_chain / dec_loop) since the last reset: every workgroup stores the
+ * 100 MHz constant clock (s_memrealtime) when it enters and when it leaves; per launch the library keeps the minimum of the
+ * former and the maximum of the latter.  *launches launches, *total_us = sum of (last out - first in).  Independent of HIP
+ * events and of any profiler: bench.py reports it beside the event-based average (roofline.device_clock_us). */
+int oph_loop_clock(oph_handle* h, int64_t* launches, double* total_us, int reset);
 int oph_profile_enable(oph_handle* h, int on);
 int oph_profile_reset(oph_handle* h);
 int oph_profile_count(const oph_handle* h);

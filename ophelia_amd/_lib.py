@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libophelia_hip.so")
-SOURCES = ["oph_kernels.hip", "oph_decrun.hip", "oph_coneloop.hip", "oph_api.hip"]
+SOURCES = ["oph_kernels.hip", "oph_decrun.hip", "oph_decchain.hip", "oph_coneloop.hip", "oph_api.hip"]
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
@@ -73,6 +73,7 @@ SIGNATURES = {
     "oph_set_precision": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "oph_timer_start": (C.c_int, [C.c_void_p]),
     "oph_timer_stop": (C.c_int, [C.c_void_p, c_f32p]),
+    "oph_loop_clock": (C.c_int, [C.c_void_p, c_i64p, c_f64p, C.c_int]),
     "oph_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "oph_profile_reset": (C.c_int, [C.c_void_p]),
     "oph_profile_count": (C.c_int, [C.c_void_p]),
@@ -146,7 +147,7 @@ def build(verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     inc = os.path.join(os.path.dirname(HERE), "include")
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    _hipcc_shared(LIBPATH, srcs, srcs + [os.path.join(CSRC, "oph_internal.h"), os.path.join(CSRC, "oph_device.h"), os.path.join(inc, "ophelia_hip.h")],
+    _hipcc_shared(LIBPATH, srcs, srcs + [os.path.join(CSRC, "oph_internal.h"), os.path.join(CSRC, "oph_device.h"), os.path.join(CSRC, "oph_loopdev.h"), os.path.join(inc, "ophelia_hip.h")],
                   [], verbose)
     vsrcs = [os.path.join(CSRC, s) for s in VOCODER_SOURCES]
     _hipcc_shared(VOCODER_LIBPATH, vsrcs, vsrcs + [os.path.join(inc, "ophelia_vocoder.h")],

@@ -109,6 +109,7 @@ struct Options {
     bool run_stamps = false;         // OPH_RUN_STAMPS: clock stamps of the decode kernels' phases (printed under OPH_TRACE)
     int ssrn_chunk = 40;             // OPH_SSRN_CHUNK: mel frames per streamed SSRN chunk (0 = SSRN only after the decode)
     int cl_wgs_per_cu = 2, cl_dbg = 0;   // OPH_CL_WGS_PER_CU (cone_loop workgroups per CU: 1 or 2), OPH_CL_DBG
+    bool no_chain = false;           // OPH_NO_CHAIN: the whole-decode launch as dec_loop (generic) even where dec_chain (specialised) fits
     void read() {
         auto flag = [](const char* n) { return getenv(n) != nullptr; };
         auto num = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
@@ -134,6 +135,7 @@ struct Options {
         run_stamps = flag("OPH_RUN_STAMPS");
         ssrn_chunk = std::max(0, num("OPH_SSRN_CHUNK", 40));
         cl_wgs_per_cu = num("OPH_CL_WGS_PER_CU", 2) == 1 ? 1 : 2; cl_dbg = num("OPH_CL_DBG", 0);
+        no_chain = flag("OPH_NO_CHAIN");
     }
     int cone_ksplit(int M) const { return M >= 512 ? ksplit_big : ksplit_small; }
 };
@@ -151,6 +153,8 @@ struct Tile {
     unsigned* d_loop_layers = nullptr;      // dec_loop's packed layer descriptors (they hold this tile's history pointers)
     int steps = 0;                          // decoder steps executed so far on this tile's utterances
     int ssrn_done = 0;                      // mel frames whose SSRN output is up to date (streamed SSRN)
+    int z_copied = 0;                       // mel frames whose SSRN rows have been copied to this batch's host destination (z_host);
+                                            // <= ssrn_done: chunks computed while no destination was set (a resumed decode) are not copied
 };
 
 struct oph_handle {
@@ -198,6 +202,9 @@ struct oph_handle {
     int ndec_cus = 0;                   // CUs the critical stream may use (its CU mask, or the whole chip)
     int loop_capacity = -1;             // workgroups of dec_loop that can be resident at once (-1: not yet asked)
     int loop_rows = 8;                  // rows (utterances) per workgroup of dec_loop: 8 (default) or 4 (OPH_RUN_ROWS)
+    bool chain_ok = false;              // the decode's geometry fits dec_chain (oph_decchain.hip), the specialised whole-decode launch
+    long long* d_clk = nullptr;         // device-side witness of the whole-decode launches: [2 k] first workgroup in, [2 k + 1] last workgroup out (100 MHz clock)
+    int clk_used = 0; long long clk_launches = 0; double clk_total_us = 0;     // launches not yet read back; accumulated over read-back ones
     std::string err;
     bool finalized = false;
     // expected variables (TF names) and host copies
@@ -235,6 +242,11 @@ struct oph_handle {
     bool spec_ssrn = true;              // oph_text2mel streams SSRN over the frames it has produced (consumed by oph_ssrn(Y = NULL))
     float* z_host = nullptr;            // host destination the streamed SSRN chunks are copied to as they complete (or null)
     float* z_spec = nullptr;            // oph_set_mag_destination: where oph_text2mel's speculative SSRN copies its chunks
+    unsigned long long batch_gen = 0;   // advanced by every decode that starts at step 0 (begin_batch)
+    unsigned long long z_spec_gen = 0;  // the batch whose speculative SSRN streamed into z_spec (0: none)
+    int dec_tbegin = 0, dec_tend = 0;   // step range of the running / last whole-decode launch (the chunk scheduler's time estimate)
+    bool guard_ssrn = false, guard_cone = false, guard_text = false;      // a weight of that net is outside fp16's range (|w| > 6e4: hi = inf, lo = nan): its
+                                                                          // split contractions are pinned to the fp32-operand MFMA (oph_get_counters [7])
     // ---- decode tiles: utterances [16 j, 16 j + 16) of the batch; `tile` is the one the views below point into
     std::vector<Tile> tiles; int tile = 0;
     int B = 0, Bpad = 0;                // the CURRENT tile: utterances, rows (16)
@@ -759,6 +771,7 @@ int ensure_decode_state(oph_handle* h, int B) {
     // ---- scratch shared by the tiles
     h->d_gbuf = h->dalloc<unsigned long long>((size_t)LOOP_MAX_LAYERS * Bpad * RUN_GCOLS);
     h->run_epoch = 0;
+    h->d_clk = h->dalloc<long long>((size_t)2 * 512); h->clk_used = 0;
     if (h->opt.run_stamps) {
         h->d_stamps = h->dalloc<long long>((size_t)2 * 32 * LOOP_MAX_LAYERS * 8);
         h->d_sigdbg = h->dalloc<long long>((size_t)m.max_T * 8);
@@ -877,7 +890,7 @@ int ensure_decode_state(oph_handle* h, int B) {
 void reset_decode(oph_handle* h) {
     const oph_dims& m = h->dm;
     Tile& tl = h->tiles[h->tile];
-    tl.steps = 0; tl.ssrn_done = 0;
+    tl.steps = 0; tl.ssrn_done = 0; tl.z_copied = 0;
     hipMemsetAsync(h->d_p, 0, 2 * h->Bpad * 4, h->stream);
     hipMemsetAsync(h->Yout, 0, (size_t)h->Bpad * m.max_T * h->ldy * 4, h->stream);
     hipMemsetAsync(h->Ytm, 0, (size_t)(m.max_T + 1) * h->Bpad * h->ldy * 4, h->stream);
@@ -910,6 +923,7 @@ void begin_batch(oph_handle* h) {
     }
     h->chunk_inflight = false;
     h->y_resident = false;
+    h->batch_gen++;
 }
 
 // AudioDec history cone for step t under the mask p_t (= max_attentions of step t-1).
@@ -1235,8 +1249,23 @@ bool run_supported(const oph_handle* h) {
 int run_encode_into(oph_handle* h, const int* dL, const int* dSpk, int B, float* KVdst, hipStream_t stream, int wsi);      // defined with the batched networks below
 int ssrn_stream_chunks(oph_handle* h, int frames_ready, bool final, bool side_tail = false);                                  // streamed SSRN of the current tile
 void ssrn_margins(const oph_handle* h, int* back, int* ahead);
+int copy_mag_rows(oph_handle* h, int a, int b, hipStream_t after);
 
-// ---------------------------------------------------------------- whole-decode launch (dec_loop)
+// ---------------------------------------------------------------- whole-decode launch (dec_loop / dec_chain)
+constexpr int CLK_SLOTS = 512;
+// read the finished launches' clock pairs back (the launches must be complete) and add them to the running totals
+void drain_loop_clock(oph_handle* h) {
+    if (!h->d_clk || h->clk_used == 0) return;
+    std::vector<long long> v((size_t)2 * h->clk_used);
+    if (hipMemcpy(v.data(), h->d_clk, v.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess)
+        for (int k = 0; k < h->clk_used; ++k) {
+            const unsigned long long t0 = (unsigned long long)v[2 * k], t1 = (unsigned long long)v[2 * k + 1];
+            if (t1 > t0 && t0 != ~0ull) { h->clk_launches++; h->clk_total_us += (double)(t1 - t0) * 0.01; }      // 100 MHz constant clock
+        }
+    (void)hipGetLastError();
+    h->clk_used = 0;
+}
+
 // Static layer table of a decode: AudioEnc (layer 0 consumes the previous step's last AudioDec layer) -> attention +
 // AudioDec input convs -> AudioDec highway layers (taps from the cone ping-pong buffers) -> k=1 tail.  Built once per
 // decode state: the weights in the loop kernel's fragment order and the prologue's LayerNorm parameters are shared by the
@@ -1321,6 +1350,20 @@ int build_loop_proto(oph_handle* h) {
         }
     }
     h->loop_proto = v;
+    // dec_chain (oph_decchain.hip) is dec_loop specialised for the standard geometry: 256 channels per row, 8 rows per workgroup,
+    // LayerNorm everywhere, a window of <= 4 keys, the attention layer emitting QW, k = 3 layers 3 x 256 wide, k = 1 layers <= 512 wide
+    {
+        const oph_dims& m = h->dm;
+        bool ok = !h->opt.no_chain && R == 8 && m.d == 256 && m.attention_win_size <= 4 && m.n_mels <= 256 && !(m.flags & OPH_FLAG_NORM_NONE) &&
+                  h->cone_head_ok && !h->opt.no_loop_qw && h->audiodec[0].cin == 2 * m.d;
+        for (size_t i = 0; ok && i < v.size(); ++i) {
+            const LoopLayer& q = v[i];
+            ok = !q.nonorm && q.g1 != nullptr && (i == 0 || q.cin == 256) && (q.ntaps == 3 ? (q.kc == 256 && q.ccat == 0 && q.pre != RUN_ATTN) : (q.ntaps == 1 && q.kc <= 512 && q.kc % 16 == 0)) &&
+                 (q.pre == RUN_CONV || q.pre == RUN_HC || q.pre == RUN_ATTN) && (q.pre != RUN_ATTN || (q.kc == 512 && q.ccat == 0)) && (q.ccat == 0 || (q.cat_table != nullptr && q.kc >= 256 + q.ccat)) &&
+                 (i != 0 || (q.pre == RUN_CONV && q.ccat == 0 && q.ntaps == 1));
+        }
+        h->chain_ok = ok;
+    }
     return OPH_OK;
 }
 // descriptor table of the CURRENT tile
@@ -1395,8 +1438,16 @@ int decode_loop(oph_handle* h, int t_begin, int t_end, int stop_mode) {
         for (const Layer& l : *net) { const double K = (double)l.ntaps * l.cin; bytes += ((double)l.N * K + (double)h->B * (K + l.N)) * 4.0; flops += 2.0 * h->B * l.N * K; }
     if (h->d_sigdbg) hipMemsetAsync(h->d_sigdbg, 0, (size_t)m.max_T * 8 * sizeof(long long), h->sdec);
     h->pbegin(PC_DECLOOP);
-    h->dec_t0 = std::chrono::steady_clock::now(); h->chunk_inflight = false;
-    launch_dec_loop(a, h->loop_slices, h->loop_rows, h->loop_kmax, h->sdec);
+    h->dec_t0 = std::chrono::steady_clock::now(); h->chunk_inflight = false; h->dec_tbegin = t_begin; h->dec_tend = t_end;
+    if (h->d_clk) {        // device-side witness: first workgroup in / last workgroup out of this launch, on the kernel's own clock
+        if (h->clk_used == CLK_SLOTS) { hipStreamSynchronize(h->sdec); drain_loop_clock(h); }
+        static const long long clk_init[2] = {-1LL, 0LL};
+        a.clk = h->d_clk + 2 * h->clk_used++;
+        hipMemcpyAsync(a.clk, clk_init, sizeof clk_init, hipMemcpyHostToDevice, h->sdec);
+    }
+    // the generic kernel when stamps or ablation bits other than "no side stream" are asked for (they live there)
+    if (h->chain_ok && !h->fixed_att && a.QW != nullptr && (dbg & ~32) == 0) launch_dec_chain(a, h->loop_slices, h->sdec);
+    else launch_dec_loop(a, h->loop_slices, h->loop_rows, h->loop_kmax, h->sdec);
     h->pend(PC_DECLOOP, bytes * (t_end - t_begin), flops * (t_end - t_begin));
     if (h->want_preenc && h->next_staged && !h->preenc_valid) {
         // K,V of the NEXT batch's staged text into the other KV buffer, on the SSRN partition (own workspace; in stream order
@@ -1666,7 +1717,7 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
         // every workgroup of the loop kernel must be resident at once on the critical stream's own CUs (the cone needs the
         // others): without that partition, or when the tile's workgroups do not fit it, take the two-launches-per-step path
         if (!h->d_loop_layers) { const int rc = build_loop_layers(h); if (rc) return rc; }
-        if (h->loop_capacity < 0) h->loop_capacity = h->mask_words > 0 ? dec_loop_blocks_per_cu(h->loop_rows, h->loop_kmax) * h->ndec_cus : 0;
+        if (h->loop_capacity < 0) h->loop_capacity = h->mask_words > 0 ? (h->chain_ok ? dec_chain_blocks_per_cu() : dec_loop_blocks_per_cu(h->loop_rows, h->loop_kmax)) * h->ndec_cus : 0;
         if (h->loop_slices * (h->Bpad / h->loop_rows) > h->loop_capacity) loop_mode = false;
     }
     if (h->use_sigval || loop_mode) {
@@ -1876,6 +1927,7 @@ int decode_batch(oph_handle* h, int t_end, int stop_mode, int32_t* steps_run) {
                 int back = 0, ahead = 0;
                 ssrn_margins(h, &back, &ahead);
                 h->tiles[j].ssrn_done = std::min(h->tiles[j].ssrn_done, std::max(0, h->tiles[j].steps - ahead));
+                h->tiles[j].z_copied = std::min(h->tiles[j].z_copied, h->tiles[j].ssrn_done);
             }
             const int rc = decode_range(h, h->tiles[j].steps, batch_steps, OPH_STOP_NEVER, nullptr);
             if (rc) return rc;
@@ -1942,6 +1994,18 @@ void ssrn_margins(const oph_handle* h, int* back, int* ahead) {
     *back = lo + 1; *ahead = hi + 1;     // lj_tutorial: 9 + 1 and 8 + 1 (one frame of slack each side)
 }
 
+// SSRN rows of mel frames [a, b) of the CURRENT tile -> the batch's host destination, on the copy stream, after everything queued on `after`
+int copy_mag_rows(oph_handle* h, int a, int b, hipStream_t after) {
+    if (!h->z_host || b <= a) return OPH_OK;
+    const oph_dims& m = h->dm;
+    HIPCHK(h, hipEventRecord(h->ev_chunk, after));
+    HIPCHK(h, hipStreamWaitEvent(h->scopy, h->ev_chunk, 0));
+    const size_t rowb = (size_t)m.full_dim * 4, pitch = (size_t)m.max_T * m.r * rowb, r0 = (size_t)h->tile * TILE;
+    HIPCHK(h, hipMemcpy2DAsync((char*)h->z_host + r0 * pitch + (size_t)a * m.r * rowb, pitch, (const char*)h->Z + (size_t)a * m.r * rowb, pitch,
+                               (size_t)(b - a) * m.r * rowb, (size_t)h->B, hipMemcpyDeviceToHost, h->scopy));
+    return OPH_OK;
+}
+
 // Z rows of mel frames [a, b) of the CURRENT tile, from its resident Yout, on stream `st` with workspace `wsi`.
 int run_ssrn_chunk(oph_handle* h, int a, int b, hipStream_t st, int wsi) {
     const oph_dims& m = h->dm;
@@ -1959,12 +2023,13 @@ int run_ssrn_chunk(oph_handle* h, int a, int b, hipStream_t st, int wsi) {
     run_batched(h, h->ssrn, ws, h->ldy, h->B, Tc, wsi, h->ssrn_prec, h->Z, m.full_dim, m.full_dim, nullptr, nullptr, io);
     g_cur = saved;
     if (h->z_host) {
-        // the chunk's rows leave for the host on the copy stream while the decode goes on
-        HIPCHK(h, hipEventRecord(h->ev_chunk, st));
-        HIPCHK(h, hipStreamWaitEvent(h->scopy, h->ev_chunk, 0));
-        const size_t rowb = (size_t)m.full_dim * 4, pitch = (size_t)m.max_T * m.r * rowb, r0 = (size_t)h->tile * TILE;
-        HIPCHK(h, hipMemcpy2DAsync((char*)h->z_host + r0 * pitch + (size_t)a * m.r * rowb, pitch, (const char*)h->Z + (size_t)a * m.r * rowb, pitch,
-                                   (size_t)(b - a) * m.r * rowb, (size_t)h->B, hipMemcpyDeviceToHost, h->scopy));
+        // the chunk's rows leave for the host on the copy stream while the decode goes on.  The copied frontier only moves over a
+        // contiguous range: rows computed earlier without a destination (a resumed decode) are picked up by finish_ssrn
+        Tile& tl = h->tiles[h->tile];
+        const int from = std::min(a, tl.z_copied);
+        const int rc = copy_mag_rows(h, from, b, st);
+        if (rc) return rc;
+        tl.z_copied = b;
     }
     HIPCHK(h, hipGetLastError());
     return OPH_OK;
@@ -1992,9 +2057,10 @@ int ssrn_stream_chunks(oph_handle* h, int frames_ready, bool final, bool side_ta
                 if (hipEventElapsedTime(&ms, h->ev_cs, h->ev_ce) == hipSuccess) h->chunk_ms = ms;
                 h->chunk_inflight = false;
             }
-            if (h->chunk_ms > 0.f && frames_ready > 8 && !h->pipelined) {
+            if (h->chunk_ms > 0.f && frames_ready - h->dec_tbegin > 8 && !h->pipelined) {
+                // (dec_t0 is the launch of steps [dec_tbegin, dec_tend): a resumed decode counts its own frames only)
                 const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - h->dec_t0).count() * 1e3;
-                const double remaining = elapsed / frames_ready * (m.max_T - frames_ready);
+                const double remaining = elapsed / std::max(1, frames_ready - h->dec_tbegin) * std::max(0, h->dec_tend - frames_ready);
                 if (h->chunk_ms > remaining) break;
             }
         }
@@ -2018,6 +2084,14 @@ int finish_ssrn(oph_handle* h) {
     }
     for (int j = 0; j < ntiles; ++j) {
         select_tile(h, j);
+        Tile& tl = h->tiles[j];
+        if (h->z_host && tl.z_copied < tl.ssrn_done) {
+            // rows that were computed while no host destination was set (chunks streamed under a resumed decode, oph_decode_steps):
+            // they are final, and every stream that may have produced them is ordered before the copy
+            int rc = copy_mag_rows(h, tl.z_copied, tl.ssrn_done, h->sssrn);
+            if (rc) return rc;
+            tl.z_copied = tl.ssrn_done;
+        }
         const int rc = ssrn_stream_chunks(h, h->dm.max_T, true);
         if (rc) return rc;
     }
@@ -2226,6 +2300,23 @@ int oph_finalize_weights(oph_handle* h) {
     for (auto* net : {&h->textenc, &h->audioenc, &h->audiodec, &h->ssrn})
         for (Layer& l : *net)
             if (pack_layer(h, l) != 0) { h->fail("out of device memory packing %s", l.scope.c_str()); return OPH_ERR_DEVICE; }
+    // Range guard of the fp16 split (hi = fp16(w) overflows to inf above 65504, lo = w - hi to nan): trained weights are orders of
+    // magnitude below that, but a net that has one falls back to the fp32-operand MFMA instead of propagating NaNs silently.
+    // (Small values are safe: the lo term of a tiny weight lands in fp16's subnormals, which the gfx950 MFMA does not flush.)
+    {
+        auto too_big = [&](const std::vector<Layer>& net, size_t from, size_t to) {
+            for (size_t i = from; i < to && i < net.size(); ++i) {
+                const std::vector<float>* k = getw(h, net[i].scope + (net[i].kind == K_CONVT ? "/conv2d_transpose/kernel" : "/conv1d/kernel"));
+                if (!k) continue;
+                for (float v : *k) if (!(std::fabs(v) <= 6.0e4f)) return true;
+            }
+            return false;
+        };
+        h->guard_ssrn = too_big(h->ssrn, 0, h->ssrn.size());
+        h->guard_cone = too_big(h->audiodec, (size_t)h->dec_pre, (size_t)(h->dec_pre + h->n_hc_dec));
+        h->guard_text = too_big(h->textenc, 0, h->textenc.size());
+        if (h->guard_ssrn) h->ssrn_prec = 0;
+    }
     // SSRN contractions run on the 16-bit MFMAs with every fp32 operand as hi + lo: the weights are split here, once, into
     // fp16 planes (the default arithmetic) and bf16 planes (oph_set_ssrn_precision(h, 1))
     auto split = [&](const float* wsrc, size_t n, bool f16, void*& hi, void*& lo) {
@@ -2244,7 +2335,7 @@ int oph_finalize_weights(oph_handle* h) {
     // Text2Mel feeds an argmax back into itself, so only fp32-class arithmetic qualifies as its default: split-fp16 x3
     // (22 significant bits per operand; measured against the fp32 MFMA flavour in tests/test_gpu_decode_modes.py) -- the
     // split-bf16 flavour (16 bits) stays an experiment (OPH_CONE_PREC=1).
-    h->cone_prec = h->opt.cone_prec >= 0 ? h->opt.cone_prec : CONE_PREC_DEFAULT;
+    h->cone_prec = h->guard_cone ? 0 : (h->opt.cone_prec >= 0 ? h->opt.cone_prec : CONE_PREC_DEFAULT);
     for (int k = 0; k + 1 < h->n_hc_dec; ++k) {
         Layer& l = h->audiodec[h->dec_pre + k];
         const size_t n = (size_t)l.Nalloc * l.ntaps * l.kc;
@@ -2252,7 +2343,7 @@ int oph_finalize_weights(oph_handle* h) {
     }
     // TextEnc (82 GFLOP per 16-utterance batch, once per batch) on the split-fp16 contraction as well: K,V feed the attention
     // argmax, so again only the fp32-class flavour is offered (oph_set_precision(h, 2, 0) selects the fp32 MFMA)
-    h->textenc_prec = h->opt.textenc_prec >= 0 ? h->opt.textenc_prec : TEXTENC_PREC_DEFAULT;
+    h->textenc_prec = h->guard_text ? 0 : (h->opt.textenc_prec >= 0 ? h->opt.textenc_prec : TEXTENC_PREC_DEFAULT);
     for (Layer& l : h->textenc)
         if (!split(l.Wt, (size_t)l.Nalloc * l.ntaps * l.kc, true, l.Wh16, l.Wl16)) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -2413,6 +2504,7 @@ int oph_decode_steps(oph_handle* h, int t_begin, int t_end, int stop_mode, int32
         HIPCHK(h, hipMemcpyAsync(h->d_ctl + 1, &ctl1, 4, hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         h->tiles[j].ssrn_done = std::min(h->tiles[j].ssrn_done, std::max(0, t_begin - ahead));      // frames >= t_begin change: SSRN rows that saw them are stale
+        h->tiles[j].z_copied = std::min(h->tiles[j].z_copied, h->tiles[j].ssrn_done);
         int32_t st = 0;
         const int rc = decode_range(h, t_begin, t_end, stop_mode, &st);
         if (rc) return rc;
@@ -2474,6 +2566,7 @@ int oph_run_resident(oph_handle* h, int stop_mode, int run_ssrn, int32_t* steps_
 
 int oph_set_ssrn_precision(oph_handle* h, int mode) {
     if (!h || mode < 0 || mode > 4) return OPH_ERR_INVALID;       // 3, 4: measurement only -- split-fp16 with 2 products / 1 product
+    if (h->guard_ssrn && mode != 0) { h->fail("an SSRN weight is outside fp16's range: only the fp32-operand MFMA (mode 0) is offered"); return OPH_ERR_UNSUPPORTED; }
     h->ssrn_prec = mode; h->chunk_ms = 0.f;
     return OPH_OK;
 }
@@ -2481,6 +2574,9 @@ int oph_set_ssrn_precision(oph_handle* h, int mode) {
 // (fp32-class), 1 split-bf16 x3 (SSRN; the cone only if the handle was created under OPH_CONE_PREC=1)
 int oph_set_precision(oph_handle* h, int which, int mode) {
     if (!h || mode < 0 || mode > 2) return OPH_ERR_INVALID;
+    if (mode != 0 && ((which == 0 && h->guard_ssrn) || (which == 1 && h->guard_cone) || (which == 2 && h->guard_text))) {
+        h->fail("a weight of that net is outside fp16's range: only the fp32-operand MFMA (mode 0) is offered"); return OPH_ERR_UNSUPPORTED;
+    }
     if (which == 0) { h->ssrn_prec = mode; h->chunk_ms = 0.f; return OPH_OK; }
     if (which == 1) {
         if (mode == 1 && !(h->n_hc_dec > 1 && h->audiodec[h->dec_pre].Wh)) { h->fail("the cone's bf16 planes were not built (create the handle under OPH_CONE_PREC=1)"); return OPH_ERR_STATE; }
@@ -2495,8 +2591,9 @@ int oph_set_precision(oph_handle* h, int which, int mode) {
 // [3] whole-decode launches  [4] fallbacks from the whole-decode launch to two launches per step  [5] tiles resumed to the batch's stop step
 int oph_get_counters(oph_handle* h, int64_t* out, int n) {
     if (!h || !out) return OPH_ERR_INVALID;
-    const long long v[7] = {h->n_textenc, h->n_preenc_used, h->n_chunks_streamed, h->n_loop_decodes, h->n_loop_fallbacks, h->n_tile_resumes, h->n_cone_loops};
-    for (int i = 0; i < n && i < 7; ++i) out[i] = v[i];
+    const long long v[8] = {h->n_textenc, h->n_preenc_used, h->n_chunks_streamed, h->n_loop_decodes, h->n_loop_fallbacks, h->n_tile_resumes, h->n_cone_loops,
+                            (long long)((h->guard_ssrn ? 1 : 0) | (h->guard_cone ? 2 : 0) | (h->guard_text ? 4 : 0))};
+    for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
     return OPH_OK;
 }
 // Where the speculative SSRN of the NEXT oph_text2mel copies its rows while the decoder is still running: a host buffer of
@@ -2504,7 +2601,7 @@ int oph_get_counters(oph_handle* h, int64_t* out, int n) {
 // pointer) then only has the tail left to compute and copy.  NULL clears it.
 int oph_set_mag_destination(oph_handle* h, float* Z) {
     if (!h) return OPH_ERR_INVALID;
-    h->z_spec = Z;
+    h->z_spec = Z; h->z_spec_gen = 0;
     return OPH_OK;
 }
 int oph_set_streaming(oph_handle* h, int on) {
@@ -2669,6 +2766,7 @@ int oph_text2mel(oph_handle* h, const float* K, const float* V, const int32_t* e
     if ((rc = stage_decode_inputs(h, K, V, true, ends, spk, B))) return rc;
     begin_batch(h);
     h->z_host = h->spec_ssrn ? h->z_spec : nullptr;       // the speculative SSRN's rows leave for the host as they are produced
+    h->z_spec_gen = h->z_host ? h->batch_gen : 0;         // this batch's rows are the ones in z_spec
     rc = decode_batch(h, h->dm.max_T, stop_mode, steps_run);
     h->z_host = nullptr;
     if (rc) return rc;
@@ -2798,8 +2896,9 @@ static int ssrn_common(oph_handle* h, const float* Y, int B, int T, float* Z, fl
     if (!Y && !Z_logits) {
         if (!h->y_resident || B != h->nB || T != m.max_T) { h->fail("Y = NULL asks for the mel frames the last decode left in HBM, but there are none for B=%d, T=%d", B, T); return OPH_ERR_STATE; }
         g_cur = h->stream;
-        if (Z == h->z_spec && Z != nullptr) {
-            // the chunks streamed during the decode are already in Z (oph_set_mag_destination): compute and copy what is left
+        if (Z == h->z_spec && Z != nullptr && h->z_spec_gen == h->batch_gen) {
+            // the chunks streamed during THIS batch's decode are already in Z (oph_set_mag_destination; the batch generation tells a
+            // later batch on the same handle apart): compute and copy what is left -- every row past the copied frontier
             h->z_host = Z;
             rc = finish_ssrn(h);
             h->z_host = nullptr;
@@ -2855,6 +2954,18 @@ int oph_timer_stop(oph_handle* h, float* ms) {
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipEventSynchronize(h->ev1));
     HIPCHK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return OPH_OK;
+}
+// Device-side witness of the whole-decode launches since the last reset: every workgroup stores the constant 100 MHz clock when it
+// enters (minimum kept) and when it leaves (maximum kept); *total_us = sum over launches of (last out - first in).
+int oph_loop_clock(oph_handle* h, int64_t* launches, double* total_us, int reset) {
+    if (!h) return OPH_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->sdec) HIPCHK(h, hipStreamSynchronize(h->sdec));
+    drain_loop_clock(h);
+    if (launches) *launches = h->clk_launches;
+    if (total_us) *total_us = h->clk_total_us;
+    if (reset) { h->clk_launches = 0; h->clk_total_us = 0; }
     return OPH_OK;
 }
 int oph_profile_enable(oph_handle* h, int on) { if (!h) return OPH_ERR_INVALID; h->profiling = on == 2 ? 2 : (on != 0); return OPH_OK; }

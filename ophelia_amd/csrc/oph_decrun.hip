@@ -18,57 +18,11 @@
 // R waves and the 4 k-quarters of a 16-wide chunk, partials summed in a fixed order.
 #include "oph_internal.h"
 #include "oph_device.h"
+#include "oph_loopdev.h"
 
 #include <map>
 
 namespace oph {
-
-typedef unsigned long long u64;
-constexpr int RUN_KMAX = 768;                     // largest contraction length of a layer (3 taps x 256)
-constexpr long long RUN_TIMEOUT_TICKS = 200000000LL;   // 2 s of the 100 MHz constant clock: a hand-off that takes
-                                                       // longer means a workgroup of the run never became resident
-
-static __device__ __forceinline__ u64 granule_load(const u64* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-static __device__ __forceinline__ void granule_store(u64* p, unsigned epoch, float v) {
-    __hip_atomic_store(p, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// One wave re-reads its row's granules until every tag carries this layer's epoch.  Lane l owns columns c..c+3 (and
-// c2..c2+3 of the second half when `two`).  Bounded: on a time-out (or when another wave already failed) the error word
-// is set and the run continues with whatever was read, so the launch always terminates.
-static __device__ __forceinline__ int sweep_row(const u64* row, int c, bool cok, int c2, bool two, unsigned epoch, int lane,
-                                                int* err, f32x4& av, f32x4& uv, bool once = false) {
-    long long t0 = 0;
-    const u64 want = (u64)epoch << 32;
-    for (int it = 0;; ++it) {
-        u64 ga[4], gu[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ga[e] = cok ? granule_load(row + c + e) : want;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) gu[e] = (cok && two) ? granule_load(row + c2 + e) : want;
-        bool ok = true;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ok = ok && (unsigned)(ga[e] >> 32) == epoch && (unsigned)(gu[e] >> 32) == epoch;
-        bool give_up = false;
-        if (!__all(ok) && it >= 64 && (it & 63) == 0) {
-            const long long now = wall_clock64();
-            if (t0 == 0) t0 = now;
-            give_up = now - t0 > RUN_TIMEOUT_TICKS || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-            if (give_up && lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (__all(ok) || give_up || once) {      // once: timing ablation only
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                av[e] = __uint_as_float((unsigned)ga[e]);
-                uv[e] = __uint_as_float((unsigned)gu[e]);
-            }
-            return it + 1;
-        }
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
 
 template <int R>       // rows (= waves) per workgroup
 __global__ __launch_bounds__(64 * R) void dec_run(RunArgs a) {
@@ -313,51 +267,6 @@ __global__ __launch_bounds__(64 * R) void dec_run(RunArgs a) {
 // wrote while this launch was running (cone rows): moved as two 8-byte agent-scope relaxed atomics (sc1: past the CU's
 // L1, coherent across the XCDs' L2s, write-through), never as plain accesses -- a launch-long kernel gets no cache
 // maintenance at step boundaries.
-// Packed layer descriptor (oph_internal.h: LOOP_DESC_WORDS) held in scalar registers.  desc_load only ISSUES the scalar
-// loads; desc_pin is the one place their results are waited for (an empty asm that needs every word in an SGPR) -- put
-// after a wait that is long anyway (the hand-off sweep), so that no field access later stalls on the scalar cache.
-typedef const __attribute__((address_space(4))) unsigned* LoopDescPtr;
-struct LoopDesc {
-    unsigned w[LOOP_DESC_WORDS];
-    // global address space spelled out: a pointer assembled from two words is otherwise generic (flat_load, which also
-    // ties up the LDS counter)
-    __device__ __forceinline__ const float* ptr(int i) const {
-        return (const float*)(const __attribute__((address_space(1))) float*)(((u64)w[i + 1] << 32) | (u64)w[i]);
-    }
-    __device__ __forceinline__ const float* Wt() const { return ptr(0); }
-    __device__ __forceinline__ const float* bias() const { return ptr(2); }
-    __device__ __forceinline__ const float* lnp() const { return ptr(4); }
-    __device__ __forceinline__ const float* cat_table() const { return ptr(6); }
-    __device__ __forceinline__ float* hist() const { return (float*)ptr(8); }
-    __device__ __forceinline__ const float* cone(int odd) const { return odd ? ptr(12) : ptr(10); }
-    __device__ __forceinline__ int pre() const { return w[14] & 15; }
-    __device__ __forceinline__ int act() const { return (w[14] >> 4) & 15; }
-    __device__ __forceinline__ int nonorm() const { return (w[14] >> 8) & 1; }
-    __device__ __forceinline__ int ntaps() const { return (w[14] >> 12) & 3; }
-    __device__ __forceinline__ int tapkind() const { return (w[14] >> 16) & 3; }
-    __device__ __forceinline__ int next_pre() const { return (w[14] >> 20) & 15; }
-    __device__ __forceinline__ int next_level() const { return (w[14] >> 28) & 15; }      // 1 + cone level read by the next layer's taps
-    __device__ __forceinline__ int cin() const { return w[15] & 0xffff; }
-    __device__ __forceinline__ int kc() const { return w[15] >> 16; }
-    __device__ __forceinline__ int N() const { return w[16] & 0xffff; }
-    __device__ __forceinline__ int ldw() const { return w[16] >> 16; }
-    __device__ __forceinline__ int ccat() const { return w[17] & 0xffff; }
-    __device__ __forceinline__ int ls() const { return w[17] >> 16; }
-    __device__ __forceinline__ int off0() const { return w[18] & 0xffff; }
-    __device__ __forceinline__ int off1() const { return w[18] >> 16; }
-    __device__ __forceinline__ int idx0() const { return w[19] & 0xffff; }
-    __device__ __forceinline__ int idx1() const { return w[19] >> 16; }
-};
-static __device__ __forceinline__ void desc_load(LoopDescPtr base, int l, LoopDesc& d) {
-    LoopDescPtr p = base + l * LOOP_DESC_STRIDE;
-#pragma unroll
-    for (int i = 0; i < LOOP_DESC_WORDS; ++i) d.w[i] = p[i];
-}
-static __device__ __forceinline__ void desc_pin(LoopDesc& d) {
-#pragma unroll
-    for (int i = 0; i < LOOP_DESC_WORDS; ++i) asm volatile("" : "+s"(d.w[i]));
-}
-
 // Contraction on v_mfma_f32_4x4x1_16B_f32 (16 independent 4x4 outer products per instruction, exact fp32): the 4 rows
 // of the group are the M of every block; block (cg, kk) = lanes 16cg + 4kk .. +3 owns columns 4cg..4cg+3 and k-lane kk
 // of each 16-wide chunk:  A[lane] = x[row lane&3][16 ch + 4 kk + e],  B[lane] = Wt[n0 + 4cg + (lane&3)][16 ch + 4 kk + e],
@@ -365,8 +274,9 @@ static __device__ __forceinline__ void desc_pin(LoopDesc& d) {
 // 4 reads + 16 FMAs: the contraction of a highway layer drops from ~1.0 us to ~0.25 us per wave (profiles/r02 stamps).
 // R rows per workgroup = R/4 row quads that share every weight fragment (R = 8: half the weight traffic of R = 4 per
 // row, the dominant issue cost of a highway layer -- profiles/r02 ablations).
-template <int R>
+template <int R, bool DIAG>      // DIAG: phase stamps (OPH_RUN_STAMPS) and the ablation bits of LoopArgs::dbg; the production instance carries neither
 __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
+    const int dbg = DIAG ? a.dbg : 0;
     static_assert(R == 4 || R == 8, "rows per workgroup: one or two quads of the 4x4x1 MFMA");
     constexpr int RQ = R / 4;
     constexpr int PF = (RUN_KMAX / 16 + R - 1) / R;
@@ -390,6 +300,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
     int p = a.t_begin > 0 ? a.p[(a.t_begin & 1) * Bpad + grow] : 0;   // prev_max of this wave's utterance: every workgroup attends for its own rows
     int* const stop_word = a.ctl + 1;
     int* const err = a.ctl + 2;
+    if (a.clk && tid == 0) atomicMin((unsigned long long*)a.clk, (unsigned long long)wall_clock64());      // device-side witness: first workgroup in
 
     f32x4 xprev = zero4;
     f32x4 bfrag[PF], tp0 = zero4, tp1 = zero4;
@@ -406,7 +317,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
     auto fetch_layer = [&](const LoopDesc& D, int t) {       // weights, bias and the two older taps of layer D at step t
         const int ntaps = D.ntaps(), kc = D.kc();
         const int nch = (ntaps * kc) >> 4;
-        if (n0 < D.N() && !(a.dbg & 1)) {       // chunks past the layer's K are never multiplied: load a valid address instead of branching
+        if (n0 < D.N() && !(dbg & 1)) {       // chunks past the layer's K are never multiplied: load a valid address instead of branching
             // pre-swizzled on the host (build_loop_layers): [slice g][wave w][chunk i][lane] -- 1 KB contiguous per request
             const f32x4* wsw = (const f32x4*)D.Wt() + ((size_t)(g * R + w) * PF) * 64 + lane;
 #pragma unroll
@@ -416,8 +327,8 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
         // the two older taps: always requested from a valid row (clamped), masked where they are staged -- no branch, no
         // register copy between the request and its use
         const int kind = D.tapkind();
-        dt_nxt = kind != 0 && ntaps == 3 && kc == 256 && !(a.dbg & 64);
-        if (kind != 0 && c < kc && !(a.dbg & 4)) {
+        dt_nxt = kind != 0 && ntaps == 3 && kc == 256 && !(dbg & 64);
+        if (kind != 0 && c < kc && !(dbg & 4)) {
             const int o0 = D.off0(), o1 = D.off1();
             const float* tb = kind == 1 ? (const float*)D.hist() : D.cone(t & 1);
             const int r0 = kind == 1 ? max(t - o0, 0) : D.idx0(), r1 = kind == 1 ? max(t - o1, 0) : D.idx1();
@@ -430,12 +341,12 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
     // word, raised by the launch that completes it; a layer waits only for the level it reads, so the cone's later
     // levels overlap the chain's first tap layers.  `seen` is a value requested earlier (one layer ahead).
     auto level_wait = [&](int lv1, int t, unsigned seen, bool have) {
-        if (lv1 == 0 || t < 1 || (a.dbg & 32)) return;
+        if (lv1 == 0 || t < 1 || (dbg & 32)) return;
         const unsigned* word = a.sig + LOOP_SIG_LEVEL0 + 16 * (lv1 - 1);
         const unsigned want = a.sig_base + (unsigned)t;
         if (!have) seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((int)(seen - want) >= 0) return;
-        const bool dbgw = a.sigdbg && g == 0 && blockIdx.y == 0 && w == 0 && lane == 0 && lv1 < 8;
+        const bool dbgw = DIAG && a.sigdbg && g == 0 && blockIdx.y == 0 && w == 0 && lane == 0 && lv1 < 8;
         const long long tw0 = dbgw ? wall_clock64() : 0;
         long long t0 = 0;
         for (int it = 0; (int)(seen - want) < 0; ++it) {
@@ -463,7 +374,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
         // Early stop (synthesize.py:225-228): the step that sets the flag is >= 1 full step (tens of us) in the past when
         // it is acted on here, so every workgroup takes the same decision; step stop+1 still runs, with its stores off.
         if (__hip_atomic_load(stop_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= t - 2) break;
-        long long* const stp = (a.stamps && t == a.stamp_t && w == 0 && blockIdx.y == 0) ? a.stamps + (size_t)g * LOOP_MAX_LAYERS * 8 : nullptr;
+        long long* const stp = (DIAG && a.stamps && t == a.stamp_t && w == 0 && blockIdx.y == 0) ? a.stamps + (size_t)g * LOOP_MAX_LAYERS * 8 : nullptr;
 #define LOOP_STAMP(K) do { if (stp && lane == 0) stp[l * 8 + (K)] = wall_clock64(); } while (0)
         const long long step_w0 = stp ? wall_clock64() : 0, step_c0 = stp ? clock64() : 0;
         for (int l = 0; l < NL; ++l) {
@@ -476,7 +387,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
             // A column slice beyond this layer's width (k=1 layers are 256 or n_mels wide, highway layers 512) has
             // nothing to contract here.  It needs the layer's input only as the highway residual of the next prologue --
             // which the consumer of a k=1 layer never uses -- so it sits the layer out: fewer pollers on the hand-off.
-            if (!cols && cur.next_pre() < RUN_HC && !(a.dbg & 16)) {
+            if (!cols && cur.next_pre() < RUN_HC && !(dbg & 16)) {
                 level_wait(cur.next_level(), t, 0u, false);
                 desc_pin(nxt);
                 fetch_layer(nxt, l + 1 < NL ? t : t + 1);
@@ -565,7 +476,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ok = ok && (unsigned)(ga[e] >> 32) == ep && (unsigned)(gu[e] >> 32) == ep;
                     passes = 1;
-                    if (__all(ok) || (a.dbg & 2)) {
+                    if (__all(ok) || (dbg & 2)) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { av[e] = __uint_as_float((unsigned)ga[e]); uv[e] = __uint_as_float((unsigned)gu[e]); }
                     } else {
@@ -579,7 +490,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
 
             // ---- 3. prologue math (one row per wave)
             f32x4 x = av;
-            if (pre != RUN_COPY && !(a.dbg & 8)) {
+            if (pre != RUN_COPY && !(dbg & 8)) {
                 const float invc = __builtin_amdgcn_rcpf((float)cin);
                 float s1 = av[0] + av[1] + av[2] + av[3], s2 = uv[0] + uv[1] + uv[2] + uv[3];
                 s1 = wave_sum(s1);
@@ -820,7 +731,7 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
                     if (old + 1 == (Bpad / R) * (a.QW != nullptr ? a.attn_slices : 1) * (t + 1 - a.t_begin)) {
                         __hip_atomic_fetch_max(a.sig, a.sig_base + (unsigned)t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         __hip_atomic_store((int*)a.host_progress, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        if (a.sigdbg && t + 1 < a.max_T) a.sigdbg[(t + 1) * 8 + 0] = wall_clock64();
+                        if (DIAG && a.sigdbg && t + 1 < a.max_T) a.sigdbg[(t + 1) * 8 + 0] = wall_clock64();
                     }
                 }
             }
@@ -862,29 +773,31 @@ __global__ __launch_bounds__(64 * R) void dec_loop(LoopArgs a) {
     // whatever happened, the side stream's remaining wait-value operations must not wait for steps that never ran
     if (g == 0 && blockIdx.y == 0 && tid == 0)
         __hip_atomic_fetch_max(a.sig, a.sig_base + (unsigned)a.max_T + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.clk && tid == 0) atomicMax((unsigned long long*)a.clk + 1, (unsigned long long)wall_clock64());      // device-side witness: last workgroup out
 }
 
-template <int R>
+template <int R, bool DIAG>
 static void launch_dec_loop_t(const LoopArgs& a, int col_slices, int kmax, hipStream_t s) {
     static thread_local std::map<int, size_t> done;
     const size_t lds_bytes = (size_t)(2 * R * 16 * (R / 4) * 4 + R * (kmax + 16)) * 4;
     int dev = 0;
     (void)hipGetDevice(&dev);
     size_t& d = done[dev];
-    if (d < lds_bytes) { (void)hipFuncSetAttribute((const void*)dec_loop<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); d = lds_bytes; }
-    hipLaunchKernelGGL(dec_loop<R>, dim3(col_slices, a.Bpad / R), dim3(64 * R), lds_bytes, s, a);
+    if (d < lds_bytes) { (void)hipFuncSetAttribute((const void*)dec_loop<R, DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); d = lds_bytes; }
+    hipLaunchKernelGGL((dec_loop<R, DIAG>), dim3(col_slices, a.Bpad / R), dim3(64 * R), lds_bytes, s, a);
 }
 void launch_dec_loop(const LoopArgs& a, int col_slices, int rows_per_group, int kmax, hipStream_t s) {
-    if (rows_per_group == 4) launch_dec_loop_t<4>(a, col_slices, kmax, s);
-    else launch_dec_loop_t<8>(a, col_slices, kmax, s);
+    const bool diag = a.dbg != 0 || a.stamps != nullptr || a.sigdbg != nullptr;
+    if (rows_per_group == 4) { if (diag) launch_dec_loop_t<4, true>(a, col_slices, kmax, s); else launch_dec_loop_t<4, false>(a, col_slices, kmax, s); }
+    else { if (diag) launch_dec_loop_t<8, true>(a, col_slices, kmax, s); else launch_dec_loop_t<8, false>(a, col_slices, kmax, s); }
 }
 // workgroups of dec_loop that fit on one CU at once (the loop kernel needs ALL of its workgroups resident)
 template <int R>
 static int blocks_per_cu_t(int kmax) {
     const size_t lds_bytes = (size_t)(2 * R * 16 * (R / 4) * 4 + R * (kmax + 16)) * 4;
-    (void)hipFuncSetAttribute((const void*)dec_loop<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    (void)hipFuncSetAttribute((const void*)dec_loop<R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)dec_loop<R>, 64 * R, lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)dec_loop<R, true>, 64 * R, lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return n;
 }
 int dec_loop_blocks_per_cu(int rows_per_group, int kmax) { return rows_per_group == 4 ? blocks_per_cu_t<4>(kmax) : blocks_per_cu_t<8>(kmax); }

@@ -276,12 +276,18 @@ struct LoopArgs {
     unsigned* sig; unsigned sig_base;
     volatile int* host_progress;        // pinned host words: [0] last step whose attention is done, [1] stop step (or INT_MAX)
     long long* sigdbg;                  // diagnostics: [max_T][8] clock stamps of the two signals, or null
+    long long* clk;                     // device-side witness of the launch's duration (or null): [0] = min over workgroups of the 100 MHz
+                                        // constant clock at entry, [1] = max at exit (the host sets them to ~0 / 0 before the launch)
     int dbg;                            // ablation switches for timing experiments (OPH_LOOP_DBG; results are wrong when set):
                                         // 1 no weight loads, 2 single-pass sweeps (no waiting), 4 no tap loads, 8 no prologue math,
                                         // 16 idle column slices do not sit layers out (results stay right)
 };
 void launch_dec_loop(const LoopArgs& a, int col_slices, int rows_per_group, int kmax, hipStream_t s);   // rows_per_group 4 or 8
 int dec_loop_blocks_per_cu(int rows_per_group, int kmax);
+// dec_chain (oph_decchain.hip): the same launch for the standard geometry (d = 256, 8 rows per workgroup, LayerNorm everywhere,
+// attention window <= 4, QW emitted by the attention layer), specialised per layer kind; same LoopArgs, same descriptors
+void launch_dec_chain(const LoopArgs& a, int col_slices, hipStream_t s);
+int dec_chain_blocks_per_cu();
 
 // ---- the AudioDec history cone of every decode step in ONE persistent launch beside dec_loop (oph_coneloop.hip).
 // Level 0 = the cone head (attention rows through the cached V.Wc / Q.Wq terms + LayerNorm); level k >= 1 = highway layer k-1

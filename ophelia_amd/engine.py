@@ -103,7 +103,14 @@ def dims_from_hp(hp, max_N=None, max_T=None):
 
 
 class Engine(object):
-    def __init__(self, hp, device=0, max_N=None, max_T=None):
+    """resident_results (default True, or hp.resident_results): the K, V and Y arrays a call returns are READ-ONLY views of
+    pinned memory, and handing the very same arrays to the next call skips the upload (K, V and Y never leave HBM, SSRN has been
+    streaming while the decoder ran).  The reference returns ordinary writable arrays (synthesize.py:166, 240): a caller that
+    post-processes them in place (`Y[i, t_end:] = 0`) either copies first (`np.array(Y)`: uploaded like any other array, same
+    results) or builds the engine with resident_results=False: every result is then a plain writable array and every input is
+    uploaded, exactly the reference's data flow."""
+
+    def __init__(self, hp, device=0, max_N=None, max_T=None, resident_results=None):
         self.lib = _lib.load()
         self.dims = dims_from_hp(hp, max_N, max_T)
         self.hp = hp
@@ -118,18 +125,27 @@ class Engine(object):
         self._kv_token = None          # (K, V) arrays of the last encode_text whose values are still in HBM
         self._y_token = None           # Y array of the last decode whose values are still in HBM
         self._z_spec = None            # pinned array the last decode's speculative SSRN has been copying its rows into
+        self.resident_results = bool(getattr(hp, "resident_results", True) if resident_results is None else resident_results)
 
     # Residency between the three session calls (include/ophelia_hip.h): the arrays a call returns are read-only and the
     # engine remembers them; handing the very same (still read-only) arrays to the next call skips the upload -- K,V never
     # leave HBM, SSRN has been streaming over Y while the decoder ran.  Any other array (a copy, a modified or a made-writeable
     # one) is uploaded and used as it is.
-    @staticmethod
-    def _seal(a):
-        a.flags.writeable = False
+    def _seal(self, a):
+        if self.resident_results:
+            a.flags.writeable = False
         return a
 
+    def _drop_spec(self):
+        """A different batch (or a different kind of call) starts: the magnitudes the last decode's speculative SSRN streamed to the
+        host belong to nobody any more.  Its copies must have landed before the pinned buffer goes back to the pool."""
+        if self._z_spec is not None:
+            self.lib.oph_synchronize(self._h)
+            self.lib.oph_set_mag_destination(self._h, None)
+            self._z_spec = None
+
     def _is_resident(self, token, *arrays):
-        if token is None or len(token) != len(arrays):
+        if token is None or len(token) != len(arrays) or not self.resident_results:
             return False
         for ref, a in zip(token, arrays):
             if ref() is not a or a.flags.writeable:
@@ -193,6 +209,7 @@ class Engine(object):
         V = PINNED.empty((B, N, self.dims.d))
         s, sp = self._spk(speaker_data, B)
         self._kv_token = self._y_token = None
+        self._drop_spec()
         self._chk(self.lib.oph_encode_text(self._h, _lib.iptr(L), sp, B, _lib.fptr(K), _lib.fptr(V)))
         self._seal(K), self._seal(V)
         self._kv_token = (weakref.ref(K), weakref.ref(V))
@@ -216,10 +233,10 @@ class Engine(object):
         if not resident:
             self._kv_token = None
         # the magnitudes this decode's speculative SSRN produces go straight into the array a following ssrn(Y) returns
-        if self._z_spec is not None:          # nobody asked for the previous decode's magnitudes: let its copies finish before the buffer goes
-            self.lib.oph_synchronize(self._h)
-        self._z_spec = PINNED.empty((B, self.dims.max_T * self.dims.r, self.dims.full_dim))
-        self._chk(self.lib.oph_set_mag_destination(self._h, _lib.fptr(self._z_spec)))
+        self._drop_spec()                     # nobody asked for the previous decode's magnitudes
+        if self.resident_results:
+            self._z_spec = PINNED.empty((B, self.dims.max_T * self.dims.r, self.dims.full_dim))
+            self._chk(self.lib.oph_set_mag_destination(self._h, _lib.fptr(self._z_spec)))
         try:
             self._chk(self.lib.oph_text2mel(self._h, None if resident else _lib.fptr(K), None if resident else _lib.fptr(V),
                                             _lib.iptr(ends), sp, B, int(stop_mode),
@@ -252,6 +269,7 @@ class Engine(object):
         steps = C.c_int32()
         s, sp = self._spk(speaker_data, B)
         self._kv_token = self._y_token = None
+        self._drop_spec()
         self._chk(self.lib.oph_text2mel_durations(self._h, Kp, _lib.fptr(V), _lib.fptr(D), sp, B, int(n_steps),
                                                   _lib.fptr(Y), _lib.iptr(t_ends), _lib.fptr(al), C.byref(steps)))
         self._y_token = (weakref.ref(self._seal(Y)),)
@@ -280,6 +298,7 @@ class Engine(object):
                    alignments=np.empty((B, d.max_N, d.max_T), np.float32), max_attentions=np.empty((B, d.max_T), np.int32))
         s, sp = self._spk(speaker_data, B)
         self._kv_token = self._y_token = None
+        self._drop_spec()
         self._chk(self.lib.oph_text2mel_graph(self._h, _lib.fptr(K), _lib.fptr(V), _lib.fptr(mels), _lib.iptr(pm), ep, sp, B,
                                               _lib.fptr(out["Q"]), _lib.fptr(out["R"]), _lib.fptr(out["Y_logits"]),
                                               _lib.fptr(out["Y"]), _lib.fptr(out["alignments"]), _lib.iptr(out["max_attentions"])))
@@ -298,6 +317,8 @@ class Engine(object):
             Z = PINNED.empty((B, T * self.dims.r, self.dims.full_dim))
         if not resident:
             self._kv_token = self._y_token = None        # the batch workspaces are reused
+            if Z is not spec:
+                self._drop_spec()
         self._chk(self.lib.oph_ssrn(self._h, None if resident else _lib.fptr(Y), B, T, _lib.fptr(Z)))
         if Z is spec:
             self._z_spec = None                          # handed to the caller: the next decode gets a fresh buffer
@@ -312,14 +333,15 @@ class Engine(object):
         Z = PINNED.empty((B, T * self.dims.r, self.dims.full_dim))
         Zl = PINNED.empty((B, T * self.dims.r, self.dims.full_dim))
         self._kv_token = self._y_token = None
+        self._drop_spec()
         self._chk(self.lib.oph_ssrn_logits(self._h, _lib.fptr(Y), B, T, _lib.fptr(Z), _lib.fptr(Zl)))
         return Z, Zl
 
     def counters(self):
         """What the pipeline did since the handle was created (oph_get_counters)."""
-        v = (C.c_int64 * 7)()
-        self._chk(self.lib.oph_get_counters(self._h, v, 7))
-        return dict(zip(("textenc", "preenc_used", "chunks_streamed", "loop_decodes", "loop_fallbacks", "tile_resumes", "cone_loops"),
+        v = (C.c_int64 * 8)()
+        self._chk(self.lib.oph_get_counters(self._h, v, 8))
+        return dict(zip(("textenc", "preenc_used", "chunks_streamed", "loop_decodes", "loop_fallbacks", "tile_resumes", "cone_loops", "fp16_guard"),
                         [int(x) for x in v]))
 
     def set_streaming(self, on=True):
@@ -334,6 +356,7 @@ class Engine(object):
         B = L.shape[0]
         s, sp = self._spk(speaker_data, B)
         self._kv_token = self._y_token = None
+        self._drop_spec()
         self._chk(self.lib.oph_stage_text(self._h, _lib.iptr(L), _lib.iptr(ends), sp, B))
         self.B = B
 
@@ -355,6 +378,7 @@ class Engine(object):
             out["K"], out["V"] = PINNED.empty((B, d.max_N, d.d)), PINNED.empty((B, d.max_N, d.d))
         steps = C.c_int32()
         self._kv_token = self._y_token = None
+        self._drop_spec()
         self._chk(self.lib.oph_run_host(self._h, int(stop_mode), _lib.fptr(out["K"]) if want_kv else None,
                                         _lib.fptr(out["V"]) if want_kv else None, _lib.fptr(out["Y"]), _lib.iptr(out["t_ends"]),
                                         _lib.fptr(out["alignments"]), _lib.fptr(out["Z"]), C.byref(steps)))
@@ -367,11 +391,17 @@ class Engine(object):
         steps = C.c_int32()
         mode = 2 if (run_ssrn and pipelined) else int(bool(run_ssrn))
         self._kv_token = self._y_token = None
+        self._drop_spec()
         self._chk(self.lib.oph_run_resident(self._h, int(stop_mode), mode, C.byref(steps)))
         return steps.value
 
     def decode_steps(self, t_begin, t_end, stop_mode):
         steps = C.c_int32()
+        if int(t_begin) == 0:
+            self._kv_token = self._y_token = None
+            self._drop_spec()                            # a new decode; a resume (t_begin > 0) continues the batch the magnitudes belong to
+        else:
+            self._y_token = None                         # the frames in HBM change: an earlier fetch no longer names them
         self._chk(self.lib.oph_decode_steps(self._h, int(t_begin), int(t_end), int(stop_mode), C.byref(steps)))
         return steps.value
 
@@ -417,6 +447,12 @@ class Engine(object):
         ms = C.c_float()
         self._chk(self.lib.oph_timer_stop(self._h, C.byref(ms)))
         return ms.value
+
+    def loop_clock(self, reset=False):
+        """(launches, total_us) of the whole-decode launches as the kernel itself clocked them (oph_loop_clock)."""
+        n, us = C.c_int64(), C.c_double()
+        self._chk(self.lib.oph_loop_clock(self._h, C.byref(n), C.byref(us), int(bool(reset))))
+        return n.value, us.value
 
     def profile_enable(self, on=True):
         self._chk(self.lib.oph_profile_enable(self._h, int(on)))

@@ -281,3 +281,65 @@ def test_streamed_ssrn_for_other_geometries_and_chunk_sizes(cfg, over, B, chunk)
             assert Z.shape == (B, hp.max_T * hp.r, hp.full_dim) and np.array_equal(Z, Z1), prec
     finally:
         eng.close()
+
+
+def test_resumed_decode_then_ssrn_returns_every_row(model):
+    """text2mel stops early and streams its SSRN chunks to the host; the decode is then resumed to a later
+    (global, multi-GPU) stop step -- chunks streamed during the resume have no host destination; ssrn(Y) on the fetched frames
+    must still return every magnitude row (copied frontier tracked apart from the computed one)."""
+    hp, W, eng, O = model
+    eng.set_ssrn_precision(0)
+    eng.set_streaming(8)                                   # small chunks: several are streamed during the short resume
+    try:
+        L, ends = _texts(O, hp, 9, 21, 6, 14)
+        K, V = eng.encode_text(L)
+        Y, t_ends, al, steps = eng.text2mel(K, V, ends)
+        assert steps < hp.max_T - 60
+        later = steps + 56
+        assert eng.decode_steps(steps, later, 1) == later          # the shard resumes to the batch's stop step (SURVEY 8e)
+        Y2, _, _ = eng.fetch_mel()
+        assert np.array_equal(Y2[:, :steps], Y[:, :steps]) and Y2[:, steps:later].any() and not Y2[:, later:].any()
+        Z = eng.ssrn(Y2)                                        # resident: picks up what was streamed, computes / copies the rest
+        Z1 = eng.ssrn(np.array(Y2))                             # one piece from the uploaded copy
+        assert np.array_equal(Z, Z1)
+    finally:
+        eng.set_streaming(40)
+        eng.set_ssrn_precision(2)
+
+
+def test_unfetched_magnitudes_of_an_earlier_batch_are_never_adopted(model):
+    """text2mel() whose magnitudes nobody fetched, then another batch through the resident pipeline, then
+    ssrn() on ITS fetched frames: the result must be that batch's magnitudes, not the stale streaming buffer of the first."""
+    hp, W, eng, O = model
+    La, ea = _texts(O, hp, 16, 31, 40, 100)
+    Lb, eb = _texts(O, hp, 16, 32, 40, 100)
+    K, V = eng.encode_text(La)
+    eng.text2mel(K, V, ea, stop_mode=1)                        # streams into its own pinned buffer; Z never asked for
+    eng.stage_text(Lb, eb)
+    assert eng.run_resident(stop_mode=1, run_ssrn=True, pipelined=False) == hp.max_T
+    Zb = eng.fetch_mag()
+    Y, _, _ = eng.fetch_mel()
+    Z = eng.ssrn(Y)
+    assert np.array_equal(Z, Zb)
+    assert np.array_equal(Z, eng.ssrn(np.array(Y)))
+
+
+def test_writable_results_when_residency_is_off():
+    """Engine(resident_results=False): plain writable arrays out, everything uploaded -- the reference's data flow; same numbers."""
+    from oracle import ophelia_oracle as O
+    from ophelia_amd.engine import Engine
+    hp = hp_from_snapshot("lj_tutorial.cfg", max_N=30, max_T=24)
+    W = O.random_weights(hp, 2)
+    L, ends = _texts(O, hp, 5, 41, 8, 20)
+    res = []
+    for flag in (True, False):
+        eng = Engine(hp, device=0, resident_results=flag)
+        eng.load_weights(W)
+        K, V = eng.encode_text(L)
+        Y, t_ends, al, steps = eng.text2mel(K, V, ends, stop_mode=1)
+        assert K.flags.writeable == (not flag) and Y.flags.writeable == (not flag)
+        if not flag:
+            Y[0, -1] += 0.0                                    # in-place post-processing works on the writable arrays
+        res.append((np.array(K), np.array(Y), np.array(eng.ssrn(Y))))
+        eng.close()
+    assert all(np.array_equal(a, b) for a, b in zip(res[0], res[1]))
