@@ -69,6 +69,8 @@ struct Layer {
     void *Wh = nullptr, *Wl = nullptr, *Wh2 = nullptr, *Wl2 = nullptr;   // SSRN layers: Wt / Wt2 split into hi + lo bf16 planes (conv_gemm_bf16x3)
     void *Wh16 = nullptr, *Wl16 = nullptr, *Wh2_16 = nullptr, *Wl2_16 = nullptr;   // the same as fp16 planes (split-fp16 x3: fp32-class accuracy)
     float* Wsw_cone = nullptr;                   // AudioDec highway layers: kernel in cone_loop's fragment order (oph_coneloop.hip)
+    void *Wph = nullptr, *Wpl = nullptr; float* bias_p = nullptr;   // AudioDec highway layers: kernel as fp16 planes [2C][3 kc] with the columns
+                                                                     // permuted per 64-tile to [32 H1 | the same 32 channels of H2] (hc_fused)
     float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
 };
 
@@ -109,6 +111,7 @@ struct Options {
     bool run_stamps = false;         // OPH_RUN_STAMPS: clock stamps of the decode kernels' phases (printed under OPH_TRACE)
     int ssrn_chunk = 40;             // OPH_SSRN_CHUNK: mel frames per streamed SSRN chunk (0 = SSRN only after the decode)
     int cl_wgs_per_cu = 2, cl_dbg = 0;   // OPH_CL_WGS_PER_CU (cone_loop workgroups per CU: 1 or 2), OPH_CL_DBG
+    bool no_fused_cone = false;      // OPH_NO_FUSED_CONE: the cone's levels as contraction + ln_rows launches instead of hc_fused
     bool no_chain = false;           // OPH_NO_CHAIN: the whole-decode launch as dec_loop (generic) even where dec_chain (specialised) fits
     void read() {
         auto flag = [](const char* n) { return getenv(n) != nullptr; };
@@ -135,7 +138,7 @@ struct Options {
         run_stamps = flag("OPH_RUN_STAMPS");
         ssrn_chunk = std::max(0, num("OPH_SSRN_CHUNK", 40));
         cl_wgs_per_cu = num("OPH_CL_WGS_PER_CU", 2) == 1 ? 1 : 2; cl_dbg = num("OPH_CL_DBG", 0);
-        no_chain = flag("OPH_NO_CHAIN");
+        no_chain = flag("OPH_NO_CHAIN"); no_fused_cone = flag("OPH_NO_FUSED_CONE");
     }
     int cone_ksplit(int M) const { return M >= 512 ? ksplit_big : ksplit_small; }
 };
@@ -215,8 +218,6 @@ struct oph_handle {
     float* emb_text = nullptr;       // (vocab, e)
     float* emb_spk = nullptr;        // (nspeakers, spk_emb)   AudioDec/embed_2
     float *d_ones = nullptr, *d_zeros = nullptr;   // gamma / beta stand-ins of layers without LayerNorm (hp.norm None)
-    std::vector<void*> allocs;
-    size_t n_weight_allocs = 0;       // allocs[0 .. n_weight_allocs) are the packed weights (live as long as the handle)
     // batched workspaces
     int capB = 0;
     float *actA = nullptr, *actB = nullptr, *raw = nullptr;   // workspace of the API stream (TextEnc, host-buffer SSRN)
@@ -282,6 +283,10 @@ struct oph_handle {
     long long* d_cldbg = nullptr;       // OPH_RUN_STAMPS: cone_loop's per-step stamps
     long long n_cone_loops = 0;
     float *coneR = nullptr, *coneRaw = nullptr, *coneTmp = nullptr;
+    // the cone's levels as one launch each (hc_fused): every level also as fp16 hi / lo planes, the LayerNorm exchange granules
+    bool cone_fused_ok = false;         // weights packed for it (standard geometry)
+    std::vector<void*> coneH[2], coneL[2];
+    unsigned long long* d_hcf_stats = nullptr; uint32_t hcf_epoch = 0; int hcf_capacity = -1;
     int ldy = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -297,15 +302,31 @@ struct oph_handle {
         va_end(ap);
         err = buf;
     }
+    // Device memory comes out of a few large slabs (bump allocation, zero-filled, 256-byte aligned) instead of one hipMalloc per
+    // buffer: hundreds of small allocations are backed by small page fragments, and the streaming kernels' rows then miss the TLB
+    // all the time; a slab is one large-fragment mapping.  Pool 0: the packed weights (live as long as the handle); pool 1: the
+    // per-batch-size state (released and rebuilt when the number of 16-row tiles changes).
+    struct Slab { char* base; size_t size, used; };
+    std::vector<Slab> slabs[2];
+    int pool = 0;
     template <class T>
     T* dalloc(size_t n) {
-        void* p = nullptr;
-        if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
-        hipMemsetAsync(p, 0, std::max<size_t>(n, 1) * sizeof(T), stream);
+        const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
+        std::vector<Slab>& v = slabs[pool];
+        if (v.empty() || v.back().used + bytes > v.back().size) {
+            const size_t want = std::max<size_t>(bytes, (size_t)256 << 20);
+            void* p = nullptr;
+            if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            v.push_back(Slab{(char*)p, want, 0});
+        }
+        Slab& sl = v.back();
+        void* p = sl.base + sl.used;
+        sl.used += bytes;
+        hipMemsetAsync(p, 0, bytes, stream);
         hipStreamSynchronize(stream);     // setup path only; keeps later copies on any stream ordered
-        allocs.push_back(p);
         return (T*)p;
     }
+    void free_pool(int which) { for (Slab& sl : slabs[which]) hipFree(sl.base); slabs[which].clear(); }
     // ---- profiling brackets
     void pbegin(int cls) {
         if (!prof_on(cls) || g_group_cls == cls) return;
@@ -742,10 +763,9 @@ int ensure_decode_state(oph_handle* h, int B) {
     if (h->bKV[0]) {
         // a different number of 16-row tiles: release the per-batch state and the workspaces and rebuild them
         for (hipStream_t st : {h->stream, h->sdec, h->scone, h->sssrn, h->scopy}) if (st) hipStreamSynchronize(st);
-        for (size_t i = h->n_weight_allocs; i < h->allocs.size(); ++i) hipFree(h->allocs[i]);
-        h->allocs.resize(h->n_weight_allocs);
+        h->free_pool(1);
         h->ae_hist.clear(); h->ae_raw.clear(); h->ad_raw.clear(); h->ad_xrow.clear(); h->tiles.clear(); h->loop_proto.clear(); h->loop_lnp.clear();
-        h->cone[0].clear(); h->cone[1].clear(); h->d_tab.clear(); h->d_need.clear(); h->d_res.clear(); h->fc_tab.clear(); h->Hset.clear();
+        h->cone[0].clear(); h->cone[1].clear(); for (int pp = 0; pp < 2; ++pp) { h->coneH[pp].clear(); h->coneL[pp].clear(); } h->d_tab.clear(); h->d_need.clear(); h->d_res.clear(); h->fc_tab.clear(); h->Hset.clear();
         h->bKV[0] = h->bKV[1] = nullptr; h->preenc_valid = false; h->next_staged = false; h->kv_resident = h->y_resident = false;
         h->capB = 0; h->actA = h->actB = h->raw = h->actA2 = h->actB2 = h->raw2 = nullptr;
         h->d_loop_layers = nullptr;
@@ -805,8 +825,13 @@ int ensure_decode_state(oph_handle* h, int B) {
     hipStreamSynchronize(h->stream);
     size_t maxrows = h->Hset[0].size();
     for (int k = 0; k < nh; ++k) {
-        for (int pp = 0; pp < 2; ++pp)
+        for (int pp = 0; pp < 2; ++pp) {
             h->cone[pp].push_back(h->dalloc<float>(h->Hset[k].size() * Bpad * (size_t)h->audiodec[pre + k].kc));
+            if (h->cone_fused_ok) {
+                h->coneH[pp].push_back(h->dalloc<unsigned short>(h->Hset[k].size() * Bpad * (size_t)256));
+                h->coneL[pp].push_back(h->dalloc<unsigned short>(h->Hset[k].size() * Bpad * (size_t)256));
+            }
+        }
         if (k + 1 < nh) {
             // hc layer k evaluated at output offsets Hset[k+1]: taps (oldest first) read Hset[k]
             const int r = h->audiodec[pre + k].rate, n_out = (int)h->Hset[k + 1].size();
@@ -858,6 +883,12 @@ int ensure_decode_state(oph_handle* h, int B) {
     h->coneRawB = h->dalloc<float>((size_t)maxrows * Bpad * (size_t)round_up(2 * d, 128));
     h->coneTmp = h->dalloc<float>(maxrows * Bpad * (size_t)ld_cat);
     h->d_cone_count = h->dalloc<unsigned>(LOOP_MAX_LEVELS); for (uint32_t& v : h->cone_done_total) v = 0;
+    if (h->cone_fused_ok) {
+        const size_t mt = (maxrows * Bpad + 63) / 64;
+        h->d_hcf_stats = h->dalloc<unsigned long long>((size_t)nh * mt * 2 * 2 * 32 * 8 * 2);      // one region per level: launches of two streams overlap
+        h->hcf_epoch = 0;
+        if (!h->d_hcf_stats) { h->fail("out of device memory for decode state"); return OPH_ERR_DEVICE; }
+    }
     if (h->cone_loop_ok) {
         bool fits = nh <= CL_MAX_LEVELS;
         for (int k = 0; k < nh; ++k) fits = fits && (int)h->Hset[k].size() <= CL_MAX_POS;
@@ -971,6 +1002,8 @@ void launch_cone(oph_handle* h, int t) {
         if (spk_next) { ch.Y = h->coneTmp; ch.ldy = h->audiodec[1].kc; ch.spk_table = h->emb_spk; ch.spk_ids = h->d_spk; ch.spk_dim = h->audiodec[1].ccat; }
         else { ch.Y = cone[0]; ch.ldy = h->audiodec[pre].kc; }
         ch.stop_after = stop_after; ch.t = t;
+        const bool fused = h->cone_fused_ok && !spk_next && h->cone_prec == 2 && h->hcf_capacity != 0;
+        if (fused) { ch.Yh = h->coneH[t & 1][0]; ch.Yl = h->coneL[t & 1][0]; }
         ch.wait_sig = ar.wait_sig; ch.wait_val = ar.wait_val; ch.wait_err = ar.wait_err;
         ch.npos = n0; ch.i_new = 0;
         for (int i = 1; i < n0; ++i) if (h->Hset[0][i] < h->Hset[0][ch.i_new]) ch.i_new = i;
@@ -988,6 +1021,55 @@ void launch_cone(oph_handle* h, int t) {
         launch_cone_head(ch, g_cur);
         h->pend(PC_CONEHEAD, ((double)n0 * B * (3.0 * d + 2.0 * m.attention_win_size * d) + (double)d * d) * 4.0, (double)n0 * B * 4.0 * m.attention_win_size * d + 2.0 * B * d * d);
         pre_first = 1;
+        if (fused) {
+            // levels 1 .. nh-1: one hc_fused launch each (contraction on the planes + LayerNorm x 2 + gate + mix)
+            // the 8 workgroups of a row block exchange statistics: every workgroup of a launch must be resident (the cone's launches run
+            // one after the other on their own CU partition)
+            bool fits = h->hcf_capacity != 0;
+            if (h->hcf_capacity < 0) {
+                int ncu = 0;
+                for (int i = 0; i < h->mask_words; ++i) ncu += __builtin_popcount(h->m_conep[i]);
+                if (h->mask_words == 0) { hipDeviceProp_t prop; ncu = hipGetDeviceProperties(&prop, h->device) == hipSuccess ? prop.multiProcessorCount : 0; }
+                fits = true;
+                for (int k = 0; k + 1 < nh; ++k) {
+                    const int Mk = (int)h->Hset[k + 1].size() * Bpad;
+                    fits = fits && hc_fused_grid(Mk) <= hc_fused_blocks_per_cu(Mk) * ncu;
+                }
+                h->hcf_capacity = fits ? 1 : 0;
+            }
+            if (!fits) h->hcf_capacity = 0;        // (this launch already wrote the planes; harmless) -> the unfused path from here on
+            else {
+                if (h->hcf_epoch > 0xF0000000u) {
+                    hipStreamSynchronize(h->scone);
+                    hipMemsetAsync(h->d_hcf_stats, 0, (size_t)nh * ((h->Hset[0].size() * Bpad + 63) / 64) * 2 * 2 * 32 * 8 * 2 * sizeof(unsigned long long), g_cur);
+                    h->hcf_epoch = 0;
+                }
+                for (int k = 0; k + 1 < nh; ++k) {
+                    const Layer& l = h->audiodec[pre + k];
+                    const int n_out = (int)h->Hset[k + 1].size();
+                    HcFusedArgs f{};
+                    f.Xh = h->coneH[t & 1][k]; f.Xl = h->coneL[t & 1][k]; f.in_rows = (int)h->Hset[k].size() * Bpad; f.Xres = cone[k]; f.restab = h->d_res[k];
+                    f.tab = h->d_tab[k]; f.need = h->d_need[k]; f.n_out = n_out; f.j = t; f.Bpad = Bpad; f.M = n_out * Bpad;
+                    f.Wh = l.Wph; f.Wl = l.Wpl; f.bias = l.bias_p; f.g1 = l.g1; f.b1 = l.b1; f.g2 = l.g2; f.b2 = l.b2;
+                    f.Y = cone[k + 1]; f.Yh = h->coneH[t & 1][k + 1]; f.Yl = h->coneL[t & 1][k + 1];
+                    f.stats = h->d_hcf_stats + (size_t)k * ((h->Hset[0].size() * Bpad + 63) / 64) * 2 * 2 * 32 * 8 * 2; f.epoch = ++h->hcf_epoch; f.err = h->d_ctl + 2; f.zeros = h->d_zeros;
+                    f.stop_after = stop_after; f.t = t;
+                    if (h->cone_inline_sig && k + 1 < LOOP_MAX_LEVELS) {
+                        const Layer& tl = h->audiodec[pre + k + 1];
+                        f.coh0 = idx_of(h->Hset[k + 1], -tl.off[0]); f.coh1 = idx_of(h->Hset[k + 1], -tl.off[1]);
+                        h->cone_done_total[k + 1] += (unsigned)hc_fused_holders(f.M, Bpad, f.coh0, f.coh1);
+                        f.done_sig = h->d_sig + LOOP_SIG_LEVEL0 + 16 * (k + 1); f.done_val = h->cone_done_val; f.done_count = h->d_cone_count + (k + 1); f.done_target = h->cone_done_total[k + 1];
+                        f.done_stamp = stamp_of(k + 1);
+                    }
+                    if (h->d_cldbg && t == m.max_T / 2) f.dbg = h->d_cldbg + 8 * k;
+                    h->pbegin(PC_GEMM_BF16);
+                    launch_hc_fused(f, g_cur);
+                    h->pend(PC_GEMM_BF16, ((double)f.M * 3.0 * l.cin + (double)f.M * l.cout + (double)l.N * 3.0 * l.cin) * 4.0, 2.0 * f.M * l.N * 3.0 * l.cin);
+                }
+                g_cur = saved;
+                return;
+            }
+        }
     } else {
     h->pbegin(PC_ATTN_ROWS);
     launch_attn_rows(ar, g_cur);
@@ -1807,7 +1889,16 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
                     }
                 }
             }
-            if (loop_mode && h->d_cldbg) {
+            if (loop_mode && h->d_cldbg && h->cone_fused_ok) {
+                std::vector<long long> cd(64);
+                hipMemcpy(cd.data(), h->d_cldbg, cd.size() * 8, hipMemcpyDeviceToHost);
+                for (int k = 0; k + 1 < h->n_hc_dec; ++k) {
+                    const long long* q = &cd[(size_t)8 * k];
+                    if (q[0]) TRACE("hc_fused level %d, workgroup 0: K loop %.2f  stats+publish %.2f  gather %.2f  normalise..store %.2f us", k + 1,
+                                    (q[1] - q[0]) * 0.01, (q[2] - q[1]) * 0.01, (q[3] - q[2]) * 0.01, (q[4] - q[3]) * 0.01);
+                }
+            }
+            if (loop_mode && h->d_cldbg && !h->cone_fused_ok) {
                 std::vector<long long> cd((size_t)(2 * m.max_T + 4) * 8 + 512);
                 hipMemcpy(cd.data(), h->d_cldbg, cd.size() * 8, hipMemcpyDeviceToHost);
                 {   // on which XCD did the workgroups of each column group (block % 8) run?
@@ -2233,7 +2324,7 @@ int oph_destroy(oph_handle* h) {
     for (hipEvent_t e : {h->ev0, h->ev1, h->ev_attn, h->ev_cone, h->ev_in, h->ev_out, h->ev_dec_done, h->ev_ssrn_done[0], h->ev_ssrn_done[1], h->ev_preenc, h->ev_copy, h->ev_chunk, h->ev_cs, h->ev_ce})
         if (e) hipEventDestroy(e);
     TRACE("destroy: free");
-    for (void* p : h->allocs) hipFree(p);
+    h->free_pool(0); h->free_pool(1);
     if (h->host_prog) hipHostFree((void*)h->host_prog);
     TRACE("destroy: streams");
     for (hipStream_t st : {h->scone, h->sssrn, h->sdec, h->scopy, h->stream}) if (st) { TRACE("  destroy stream %p", (void*)st); hipStreamDestroy(st); }
@@ -2390,12 +2481,42 @@ int oph_finalize_weights(oph_handle* h) {
         }
         h->cone_loop_ok = ok;
     }
+    // hc_fused: the cone's levels as one launch each.  Kernel of AudioDec highway layer k as planes with the output columns permuted
+    // per 64-tile to [32 H1 channels | the same 32 channels of H2]
+    {
+        const int pre = h->dec_pre, nh = h->n_hc_dec, d = h->dm.d;
+        bool ok = !h->opt.no_fused_cone && h->cone_head_ok && pre == 1 && d == 256 && !(h->dm.flags & (OPH_FLAG_LCC | OPH_FLAG_NORM_NONE | OPH_FLAG_NO_MONOTONIC)) &&
+                  nh >= 2 && !h->guard_cone;
+        for (int k = 0; ok && k + 1 < nh; ++k) {
+            const Layer& l = h->audiodec[pre + k];
+            ok = l.kind == K_HC && l.ntaps == 3 && l.kc == 256 && l.cout == 256 && l.cin == 256 && l.ln && !l.lcc && l.ccat == 0 && l.causal;
+        }
+        for (int k = 0; ok && k + 1 < nh; ++k) {
+            Layer& l = h->audiodec[pre + k];
+            const std::vector<float>& kr = *getw(h, l.scope + "/conv1d/kernel");      // (3, 256, 512)
+            const std::vector<float>& bs = *getw(h, l.scope + "/conv1d/bias");
+            std::vector<float> wp((size_t)512 * 768), bp(512);       // [column tile jt][K-step ks][64 columns][64 k]
+            for (int np = 0; np < 512; ++np) {
+                const int jt = np >> 6, q = np & 63, col = q < 32 ? 32 * jt + q : 256 + 32 * jt + (q - 32);
+                bp[np] = bs[col];
+                for (int tap = 0; tap < 3; ++tap)
+                    for (int c = 0; c < 256; ++c) {
+                        const int k = tap * 256 + c;
+                        wp[(((size_t)jt * 12 + (k >> 6)) * 64 + q) * 64 + (k & 63)] = kr[((size_t)tap * 256 + c) * 512 + col];
+                    }
+            }
+            float* dwp = upload(h, wp);
+            l.bias_p = upload(h, bp);
+            if (!dwp || !l.bias_p || !split(dwp, wp.size(), true, l.Wph, l.Wpl)) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
+        }
+        h->cone_fused_ok = ok;
+    }
     h->emb_text = upload(h, h->hostw["Text2Mel/TextEnc/embed_1/lookup_table"]);
     if (h->dm.flags & OPH_FLAG_SPK_AUDIO_DECODER_INPUT) h->emb_spk = upload(h, h->hostw["Text2Mel/AudioDec/embed_2/lookup_table"]);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     h->hostw.clear();
-    h->n_weight_allocs = h->allocs.size();
+    h->pool = 1;          // everything allocated from here on is per-batch-size state
     h->use_run = run_supported(h);
     // OPH_DECODE = loop (default where possible) | runs (two launches per step) | layers (one launch per layer, round 1).
     // The whole-decode launch needs its own CU partition (all its workgroups resident while the cone runs beside it) and
@@ -2519,7 +2640,7 @@ int oph_decode_steps(oph_handle* h, int t_begin, int t_end, int stop_mode, int32
 // batch stays on the SSRN partition and overlaps the next batch).
 static int set_pipelined(oph_handle* h, bool pipe) {
     if (pipe == h->pipelined) return OPH_OK;
-    for (hipStream_t st : {h->stream, h->sdec, h->scone, h->sssrn, h->scopy}) HIPCHK(h, hipStreamSynchronize(st));
+    for (hipStream_t st : {h->stream, h->sdec, h->scone, h->sssrn, h->scopy}) if (st) HIPCHK(h, hipStreamSynchronize(st));
     if (!pipe) h->buf = 0;
     h->pipelined = pipe;
     h->ssrn_inflight[0] = h->ssrn_inflight[1] = false;

@@ -122,6 +122,7 @@ struct ConeHeadArgs {
     const int* p; int B; int Bpad; int nrows; const int* off; int j;     // row i*Bpad+b <-> time j - off[i]
     int npos; int i_new;                // positions (nrows = npos * Bpad); index of the newest one (smallest offset)
     float* Y; int ldy;                  // output rows (layer input of the next cone stage)
+    void* Yh; void* Yl;                 // optional: the same rows as fp16 hi / lo planes, K-blocked [d / 64][nrows][64] (hc_fused's operand format)
     const float* spk_table; const int* spk_ids; int spk_dim;            // optional embedding appended after the d channels
     const int* stop_after; int t;
     const unsigned* wait_sig; unsigned wait_val; int* wait_err;
@@ -129,6 +130,31 @@ struct ConeHeadArgs {
     long long* done_stamp;
 };
 void launch_cone_head(const ConeHeadArgs& a, hipStream_t s);
+
+// ---- hc_fused: a level of the AudioDec history cone as ONE launch (oph_hcfused.hip): split-fp16 x3 contraction with both operands
+// as fp16 hi / lo planes through global_load_lds, then LayerNorm x 2 + gate + highway mix in the same kernel -- the 8 column tiles of
+// a 64-row block exchange per-row (mean, M2) partials as granules.  C = 256 channels, 3 taps, Bpad = 16.
+struct HcFusedArgs {
+    const void* Xh; const void* Xl; int in_rows;        // level k-1 rows as fp16 planes, K-blocked: [256 / 64][in_rows = positions * Bpad][64]
+    const float* Xres; const int* restab;               // ... and as fp32 (highway residual): row restab[ip] * Bpad + b
+    const int* tab; const int* need; int n_out; int j;  // [3][n_out] source position per tap (oldest first), valid iff j >= need
+    int Bpad; int M;                                    // M = n_out * Bpad output rows
+    const void* Wh; const void* Wl; const float* bias;  // the layer's kernel as planes [8 column tiles][12 K-steps][64 columns][64], a tile's
+                                                        // columns = [32 H1 | the same 32 channels of H2]; bias in the same column order
+    const float *g1, *b1, *g2, *b2;                     // LayerNorm parameters of H1 / H2 (channel order)
+    float* Y; void* Yh; void* Yl;                       // level k rows: fp32 [M][256] and K-blocked planes [4][M][64]
+    unsigned long long* stats; unsigned epoch;          // exchange granules [row block][2][2][32][8][2]; tag of this launch (never reused)
+    int* err; const float* zeros;
+    const int* stop_after; int t;
+    unsigned* done_sig; unsigned done_val; unsigned* done_count; unsigned done_target; int coh0, coh1;      // as EpiArgs
+    long long* done_stamp;
+    long long* dbg;                                     // diagnostics: phase stamps of workgroup 0 [8], or null
+};
+void launch_hc_fused(const HcFusedArgs& a, hipStream_t s);
+int hc_fused_grid(int M);
+int hc_fused_active(int M);
+int hc_fused_holders(int M, int Bpad, int pos, int pos2);
+int hc_fused_blocks_per_cu(int M);
 
 // ---- cone_fc16: a SMALL cone level in one launch (oph_kernels.hip).  Highway layer k of the AudioDec cone evaluated at
 // its n_out output positions, with the LayerNorm / gate / highway mix of layer k-1 (the launch ln_rows would be) as the

@@ -1272,6 +1272,15 @@ static __device__ __forceinline__ void cone_head_row(const ConeHeadArgs& a, int 
         for (int n = 0; n < 4; ++n) o[n] = h[n] * rstd * g[n] + bt[n];
         if (a.done_sig && (i == a.coh0 || i == a.coh1)) st_coherent(y + c, o);
         else *(f32x4*)(y + c) = o;
+        if (a.Yh) {
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            h4 hi, lo;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) { hi[n] = (_Float16)o[n]; lo[n] = (_Float16)(o[n] - (float)hi[n]); }
+            const size_t po = ((size_t)(c >> 6) * a.nrows + (size_t)i * a.Bpad + b) * 64 + (c & 63);
+            *(h4*)((_Float16*)a.Yh + po) = hi;
+            *(h4*)((_Float16*)a.Yl + po) = lo;
+        }
     }
     int ctot = d;
     if (a.spk_table) {
