@@ -4,9 +4,12 @@ restore_latest_model_parameters / restore_archived_model_parameters (synthesize.
 by train.py:296-305 as {logdir}-{t2m|ssrn}/model_epoch_{E}.{index,data-00000-of-00001} plus a `checkpoint`
 state file).  SURVEY.md 8f row f-1.
 
-PARITY STATUS: unpinned.  Neither TensorFlow nor a sample checkpoint exists in the reference tree or in
-this image, so this module is written from the published formats and validated only structurally
-(tests/test_tf_checkpoint.py: write -> read round trip, magic/CRC/varint/prefix-compression handling):
+PARITY STATUS: pinned against an INDEPENDENT encoder, not against TensorFlow.  Neither TensorFlow nor a sample
+checkpoint exists in the reference tree or in this image; tests/golden/make_tf_bundle.py assembles a bundle byte by byte
+from the published formats without importing this package (LevelDB table with restart points and prefix compression
+across blocks, a snappy block, two data shards, int64 global_step, Adam slots, a partitioned variable with slices, a
+float16 tensor) and tests/test_tf_bundle_fixture.py reads it back with this module; tests/test_tf_checkpoint.py adds the
+structural checks (round trip through this module's own writer, magic / CRC / varint handling):
   * `<prefix>.index` is a LevelDB-style SSTable: data blocks of prefix-compressed (shared, non_shared,
     value_len) entries with a restart array, each block followed by a 1-byte compression type
     (0 none / 1 snappy) and a masked CRC32C; then metaindex block, index block (separator key ->
@@ -15,7 +18,11 @@ this image, so this module is written from the published formats and validated o
     name holding BundleEntryProto {dtype=1, shape=2{dim=2{size=1}}, shard_id=3, offset=4, size=5,
     crc32c=6 (fixed32)}.
   * `<prefix>.data-0000S-of-0000N` holds the raw little-endian tensor bytes at [offset, offset+size).
-Only what the synthesis path needs is supported: float32/float64/int32/int64 dense tensors, no slices.
+  * a partitioned variable: its entry lists `slices` (TensorSliceProto, field 7) and owns no bytes; every slice is a second
+    entry under the key OrderedCode(0, name, rank, (start, length) per dimension) -- saved_tensor_slice_util.cc:
+    EncodeTensorNameSlice -- and is copied into its place of the full tensor here.
+float32 / float64 / int32 / int64 tensors are returned; any other dtype among the SELECTED variables is refused loudly
+(strict=False skips it), as is anything malformed.
 """
 import os
 import re
@@ -99,7 +106,7 @@ def _pb_fields(buf):
 
 
 def _parse_entry(buf):
-    e = {"dtype": 0, "shape": [], "shard_id": 0, "offset": 0, "size": 0, "crc32c": None, "slices": False}
+    e = {"dtype": 0, "shape": [], "shard_id": 0, "offset": 0, "size": 0, "crc32c": None, "slices": []}
     for f, wt, v in _pb_fields(buf):
         if f == 1: e["dtype"] = v
         elif f == 2:
@@ -113,8 +120,76 @@ def _parse_entry(buf):
         elif f == 4: e["offset"] = v
         elif f == 5: e["size"] = v
         elif f == 6: e["crc32c"] = v
-        elif f == 7: e["slices"] = True
+        elif f == 7:                                          # TensorSliceProto: repeated Extent extent = 1 {start = 1, length = 2 (oneof: absent = all)}
+            ext = []
+            for f2, _, v2 in _pb_fields(v):
+                if f2 == 1:
+                    start, length = 0, None
+                    for f3, _, v3 in _pb_fields(v2):
+                        if f3 == 1: start = v3
+                        elif f3 == 2: length = v3
+                    ext.append((start, length))
+            e["slices"].append(ext)
     return e
+
+
+# ------------------------------------------------------------------ OrderedCode keys of tensor slices (ordered_code.cc)
+def _oc_read_num(buf, pos):
+    n = buf[pos]; pos += 1
+    if n > 8:
+        raise ValueError("corrupt ordered-code number in a tensor-slice key")
+    return int.from_bytes(buf[pos:pos + n], "big"), pos + n
+
+
+def _oc_read_string(buf, pos):
+    out = bytearray()
+    while True:
+        ch = buf[pos]; pos += 1
+        if ch == 0x00:
+            nx = buf[pos]; pos += 1
+            if nx == 0x01:
+                return bytes(out), pos
+            if nx != 0xff:
+                raise ValueError("corrupt ordered-code string in a tensor-slice key")
+            out.append(0x00)
+        elif ch == 0xff:
+            nx = buf[pos]; pos += 1
+            if nx != 0x00:
+                raise ValueError("corrupt ordered-code string in a tensor-slice key")
+            out.append(0xff)
+        else:
+            out.append(ch)
+
+
+def _oc_read_signed(buf, pos):
+    first = buf[pos]
+    neg = not (first & 0x80)
+    fb = first ^ (0xff if neg else 0)
+    if fb == 0xff:
+        raise ValueError("tensor-slice key with a >= 8-byte extent: not supported")
+    ln = 7 - ((fb ^ 0xff).bit_length() - 1)              # leading one bits of fb = length of the encoding
+    x = -1 if neg else 0
+    for i in range(ln):
+        x = (x << 8) | buf[pos + i]
+    mask = ((0xff << (8 - ln)) & 0xff) << (8 * (ln - 1))  # the header bits: 0x80, 0xc000, 0xe00000, ...
+    return x ^ mask, pos + ln
+
+
+def _decode_slice_key(key):
+    """(variable name, [(start, length or None)]) of a key written by EncodeTensorNameSlice."""
+    zero, pos = _oc_read_num(key, 0)
+    if zero != 0:
+        raise ValueError("not a tensor-slice key")
+    name, pos = _oc_read_string(key, pos)
+    rank, pos = _oc_read_num(key, pos)
+    ext = []
+    for _ in range(rank):
+        start, pos = _oc_read_signed(key, pos)
+        length, pos = _oc_read_signed(key, pos)
+        ext.append((start, None if length < 0 else length))
+    if pos != len(key):
+        raise ValueError("trailing bytes in a tensor-slice key")
+    return name.decode("utf-8"), ext
 
 
 # ------------------------------------------------------------------ snappy (raw format) decompression
@@ -174,8 +249,9 @@ def _block_entries(block):
         yield key, bytes(block[pos:pos + vlen]); pos += vlen
 
 
-def read_index(prefix, verify=True):
-    """{variable name: entry dict} and the header, from <prefix>.index."""
+def read_index(prefix, verify=True, with_slices=False):
+    """{variable name: entry dict} and the header, from <prefix>.index (with_slices: also {(name, extents): entry} of the slices
+    of partitioned variables)."""
     path = prefix + ".index"
     size = os.path.getsize(path)
     with open(path, "rb") as f:
@@ -185,41 +261,75 @@ def read_index(prefix, verify=True):
             raise ValueError("%s is not a TensorFlow checkpoint index (bad magic)" % path)
         _, p = _get_varint(footer, 0); _, p = _get_varint(footer, p)        # metaindex handle
         ioff, p = _get_varint(footer, p); isz, p = _get_varint(footer, p)  # index handle
-        entries, header = {}, None
+        entries, header, pieces = {}, None, {}
         for _, handle in _block_entries(_read_block(f, ioff, isz, verify)):
             boff, q = _get_varint(handle, 0); bsz, q = _get_varint(handle, q)
             for key, val in _block_entries(_read_block(f, boff, bsz, verify)):
                 if key == b"":
                     header = {fn: v for fn, _, v in _pb_fields(val)}
+                elif key[:1] == b"\x00":                      # a slice of a partitioned variable
+                    name, ext = _decode_slice_key(key)
+                    pieces[(name, tuple(ext))] = _parse_entry(val)
                 else:
                     entries[key.decode("utf-8")] = _parse_entry(val)
-    return entries, header
+    return (entries, header, pieces) if with_slices else (entries, header)
 
 
-def read_checkpoint(prefix, scope=None, verify_data=False):
-    """{variable name: ndarray} for every dense variable under `scope` (e.g. 'Text2Mel/'), skipping optimizer
-    slots ('.../Adam', '.../Adam_1') and bookkeeping (global_step, beta*_power)."""
-    entries, header = read_index(prefix)
+def read_checkpoint(prefix, scope=None, verify_data=False, strict=True):
+    """{variable name: ndarray} for every variable under `scope` (e.g. 'Text2Mel/'), skipping optimizer slots ('.../Adam',
+    '.../Adam_1') and bookkeeping (global_step, beta*_power).  Partitioned variables are assembled from their slices.  A
+    selected variable of a dtype other than float32 / float64 / int32 / int64 raises (strict=False: it is left out)."""
+    entries, header, pieces = read_index(prefix, with_slices=True)
     nshards = (header or {}).get(1, 1) or 1
     if (header or {}).get(2, 0) != 0:
         raise ValueError("big-endian checkpoints are not supported")
     out, files = {}, {}
+
+    def payload(name, e, shape):
+        if e["dtype"] not in _DT:
+            raise ValueError("tensor %s has dtype enum %d: only float32 / float64 / int32 / int64 are supported" % (name, e["dtype"]))
+        sid = e["shard_id"]
+        if not 0 <= sid < nshards:
+            raise ValueError("tensor %s names shard %d of %d" % (name, sid, nshards))
+        if sid not in files:
+            files[sid] = open("%s.data-%05d-of-%05d" % (prefix, sid, nshards), "rb")
+        files[sid].seek(e["offset"])
+        raw = files[sid].read(e["size"])
+        want = int(np.prod(shape, dtype=np.int64)) * np.dtype(_DT[e["dtype"]]).itemsize
+        if len(raw) != e["size"] or e["size"] != want:
+            raise ValueError("tensor %s: %d bytes on disk, %d in the index, %d by its shape" % (name, len(raw), e["size"], want))
+        if verify_data and e["crc32c"] is not None and mask_crc(crc32c(raw)) != e["crc32c"]:
+            raise ValueError("tensor %s fails its CRC" % name)
+        return np.frombuffer(raw, dtype=np.dtype(_DT[e["dtype"]]).newbyteorder("<")).reshape(shape)
     try:
         for name, e in entries.items():
             if scope and not name.startswith(scope):
                 continue
             if re.search(r"(/Adam(_\d+)?$)|(^global_step$)|(beta\d_power$)", name):
                 continue
-            if e["slices"] or e["dtype"] not in _DT:
+            if e["dtype"] not in _DT:
+                if strict:
+                    raise ValueError("variable %s has dtype enum %d: only float32 / float64 / int32 / int64 are supported" % (name, e["dtype"]))
                 continue
-            sid = e["shard_id"]
-            if sid not in files:
-                files[sid] = open("%s.data-%05d-of-%05d" % (prefix, sid, nshards), "rb")
-            files[sid].seek(e["offset"])
-            raw = files[sid].read(e["size"])
-            if verify_data and e["crc32c"] is not None and mask_crc(crc32c(raw)) != e["crc32c"]:
-                raise ValueError("tensor %s fails its CRC" % name)
-            out[name] = np.frombuffer(raw, dtype=_DT[e["dtype"]]).reshape(e["shape"]).copy()
+            if not e["slices"]:
+                out[name] = payload(name, e, e["shape"]).astype(_DT[e["dtype"]])
+                continue
+            full = np.zeros(e["shape"], _DT[e["dtype"]])
+            seen = np.zeros(e["shape"], bool)
+            for ext in e["slices"]:
+                if len(ext) != len(e["shape"]):
+                    raise ValueError("variable %s: a slice of rank %d for a tensor of rank %d" % (name, len(ext), len(e["shape"])))
+                pe = pieces.get((name, tuple(ext)))
+                if pe is None:
+                    raise ValueError("variable %s: the index lists slice %s but holds no entry for it" % (name, ext))
+                idx = tuple(slice(st, None if ln is None else st + ln) for st, ln in ext)
+                if full[idx].shape != tuple(pe["shape"]):
+                    raise ValueError("variable %s: slice %s has shape %s, its entry says %s" % (name, ext, full[idx].shape, pe["shape"]))
+                full[idx] = payload("%s%s" % (name, ext), pe, pe["shape"])
+                seen[idx] = True
+            if not seen.all():
+                raise ValueError("variable %s: its slices do not cover the tensor" % name)
+            out[name] = full
     finally:
         for f in files.values():
             f.close()

@@ -72,8 +72,9 @@ def test_without_pinned_memory_an_ordinary_array_is_returned():
 
 def test_residency_needs_the_very_same_read_only_array():
     eng = E.Engine.__new__(E.Engine)      # no handle: only the residency bookkeeping is exercised
+    eng.resident_results = True
     K, V = np.zeros((2, 3)), np.ones((2, 3))
-    E.Engine._seal(K), E.Engine._seal(V)
+    eng._seal(K), eng._seal(V)
     token = (weakref.ref(K), weakref.ref(V))
     assert eng._is_resident(token, K, V)
     assert not eng._is_resident(token, K.copy(), V)          # a copy is not the resident array
@@ -81,4 +82,7 @@ def test_residency_needs_the_very_same_read_only_array():
     assert not eng._is_resident(None, K, V)
     K.flags.writeable = True                                  # made writable again: may have been modified -> upload
     assert not eng._is_resident(token, K, V)
+    eng.resident_results = False                              # residency switched off: nothing is sealed, nothing is resident
+    W = np.zeros((2, 3))
+    assert eng._seal(W).flags.writeable and not eng._is_resident((weakref.ref(W),), W)
     eng._h = None
