@@ -11,8 +11,9 @@ Same flags, same output directory naming ({sampledir|odir/cfg}/t2m{E}_ssrn{E}[_s
 same trimming rules, same {base}.wav files (16-bit PCM) from Griffin-Lim -- which runs batched on the GPU
 (ophelia_amd.vocoder) instead of on `-ncores` CPU processes -- and the same per-utterance
 "File | CDP | Ain" report.  With hp.store_synth_features the trimmed magnitudes {base}.npy are stored as in the
-reference (synthesize.py:436-437), plus {base}.mel.npy and {base}.alignment.npy; {base}.png attention plots are
-written when matplotlib is importable.  Not provided: the WORLD vocoder (external binaries).  Under torchrun (WORLD_SIZE>1) the utterances are sharded
+reference (synthesize.py:436-437); {base}.png attention plots are written when matplotlib is importable.  The default
+output set is exactly the reference's; hp.store_synth_extras (an extension, off unless a config sets it) adds
+{base}.mel.npy and {base}.alignment.npy.  Not provided: the WORLD vocoder (external binaries).  Under torchrun (WORLD_SIZE>1) the utterances are sharded
 over the GPUs of the node (ophelia_amd.parallel).
 """
 from __future__ import print_function
@@ -297,7 +298,7 @@ def synthesize(hp, speaker_id="", num_sentences=0, ncores=1, topoutdir="", t2m_e
             CDP = getCDP(trimmed_alignment)
             APin, APout = getAP(trimmed_alignment)
             print("%s | %.2f | %.2f" % (bases[i], CDP, APin))
-            if hp.store_synth_features:
+            if getattr(hp, "store_synth_extras", False):     # (extension, off by default: the reference's output set is .wav / .png / .npy)
                 np.save(os.path.join(outdir, bases[i] + ".alignment.npy"), trimmed_alignment)
 
         print("Generating wav files, will save to following dir: %s" % (outdir))
@@ -305,7 +306,7 @@ def synthesize(hp, speaker_id="", num_sentences=0, ncores=1, topoutdir="", t2m_e
         mags = [mag[:lengths[i] * hp.r, :] for i, mag in enumerate(Z)]          # trim to generated length
         synth_waves(hp, mags, [os.path.join(outdir, b + ".wav") for b in bases], device=device)
         stop_clock(t)
-        if hp.store_synth_features:
+        if getattr(hp, "store_synth_extras", False):
             for i, b in enumerate(bases):
                 np.save(os.path.join(outdir, b + ".mel.npy"), Y[i, :lengths[i], :])
     return outdir

@@ -6,7 +6,7 @@ import socket
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 from oracle import ophelia_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -16,7 +16,8 @@ def _hp(max_T=24):
     from ophelia_amd.configuration import load_config
     hp = load_config(os.path.join(GOLDEN, "cfg_unit.cfg"))
     hp.max_T = max_T
-    hp.store_synth_features = True          # keep {base}.npy / .mel.npy / .alignment.npy next to the .wav
+    hp.store_synth_features = True          # keep {base}.npy next to the .wav (synthesize.py:436-437)
+    hp.store_synth_extras = True            # ... and this package's opt-in extras: {base}.mel.npy / .alignment.npy
     return hp
 
 
@@ -229,3 +230,39 @@ def test_sharded_external_durations_run_to_the_global_longest():
     assert max(t0[:3]) + 1 < steps                       # shard 0 alone would have stopped earlier
     assert np.abs(Y0[:3, max(t0[:3]) + 1:steps]).max() > 0
     assert np.abs(Y - Y0).max() < 1e-4 and not Y[:, steps:].any()
+
+
+def test_cli_on_the_ten_line_test_transcript(tmp_path):
+    """BASELINE configs[0] (C1) as the command line runs it: `python -m ophelia_amd.synthesize -c lj_test.cfg -N 10 -odir ...` on the
+    10-line test transcript with lj_test.cfg's own dimensions (max_N 180, max_T 210), and the DEFAULT output set -- what the
+    reference leaves in {odir}/{cfg}/t2m{E}_ssrn{E}/: one .wav per utterance (synthesize.py:433-438), one attention .png when
+    matplotlib is there (:594-595), no .npy unless hp.store_synth_features (:436-437), nothing else."""
+    import json
+    import subprocess
+    import sys
+    import wave
+    snap = json.load(open(os.path.join(GOLDEN, "config_snapshot.json")))["lj_test.cfg"]
+    cfg = tmp_path / "lj_test.cfg"
+    with open(cfg, "w") as f:                               # the reference's config format: an executable Python file
+        for k, v in sorted(snap.items()):
+            f.write("%s = %r\n" % (k, v))
+        f.write("test_transcript = %r\nsampledir = %r\n" % (os.path.join(GOLDEN, "test_transcript_lj_test.csv"), str(tmp_path / "synth")))
+        for k in ("topworkdir", "voicedir", "logdir", "datadir", "waveforms", "coarse_audio_dir", "full_audio_dir", "full_mel_dir", "attention_guide_dir"):
+            f.write("%s = %r\n" % (k, str(tmp_path / "work" / k)))         # the paths the snapshot leaves out (machine-specific in the reference's file)
+        f.write("transcript = %r\n" % str(tmp_path / "work" / "transcript.csv"))
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    res = subprocess.run([sys.executable, "-m", "ophelia_amd.synthesize", "-c", str(cfg), "-N", "10", "-odir", str(tmp_path / "out"),
+                          "-random_init", "5"], env=env, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:]
+    assert "max_N=180" in res.stdout and "max_T=210" in res.stdout and "File |  CDP | Ain" in res.stdout
+    outdir = tmp_path / "out" / "lj_test" / "t2mrand_ssrnrand"
+    names = sorted(os.listdir(outdir))
+    bases = [line.split("|")[0] for line in open(os.path.join(GOLDEN, "test_transcript_lj_test.csv")) if line.strip()]
+    assert len(bases) == 10
+    assert [n for n in names if n.endswith(".wav")] == sorted(b + ".wav" for b in bases)
+    assert not [n for n in names if n.endswith(".npy")]     # lj_test.cfg does not set store_synth_features
+    assert set(os.path.splitext(n)[1] for n in names) <= {".wav", ".png"}
+    for b in bases:
+        assert ("%s | " % b) in res.stdout                  # the per-utterance CDP / Ain report line
+        with wave.open(str(outdir / (b + ".wav")), "rb") as f:
+            assert (f.getnchannels(), f.getsampwidth(), f.getframerate()) == (1, 2, snap["sr"]) and f.getnframes() > 0

@@ -97,7 +97,7 @@ def test_deemphasis_is_bit_exact_across_spans_and_slow_filters():
             assert np.array_equal(v.deemphasis(x), ref), a
 
 
-@pytest.fixture(params=[0, 1], ids=["fused", "hipfft"])
+@pytest.fixture(params=[pytest.param(0, id="fused"), pytest.param(1, id="hipfft", marks=pytest.mark.hipfft_backend)])
 def backend(request, voc):
     voc.set_backend(request.param)
     yield request.param
@@ -114,6 +114,7 @@ def test_griffin_lim_ragged_batch(voc, gl, backend, n_iter, tol):
         assert np.abs(y - ref).max() <= tol * np.abs(ref).max(), (S.shape, np.abs(y - ref).max(), np.abs(ref).max())
 
 
+@pytest.mark.hipfft_backend
 def test_backends_agree(voc):
     """fused in-LDS kernel vs hipFFT path: same arithmetic, different FFT factorisation"""
     mags = [_speechlike_mag(T, 3 * T) for T in (90, 2, 31)]
@@ -125,20 +126,25 @@ def test_backends_agree(voc):
         assert np.abs(x - y).max() <= 2e-3 * np.abs(x).max()
 
 
+BACKENDS = [pytest.param(0, id="fused"), pytest.param(1, id="hipfft", marks=pytest.mark.hipfft_backend)]
+
+
+@pytest.mark.parametrize("be", BACKENDS)
 @pytest.mark.parametrize("hop,win", [(200, 800), (256, 1024), (275, 1102), (512, 2048)])
-def test_other_stft_geometries(gl, hop, win):
+def test_other_stft_geometries(gl, hop, win, be):
     """the 16 kHz configs (hop 200 / win 800) and nancy-style (256 / 1024) share n_fft = 2048"""
     from ophelia_amd.vocoder import Vocoder
     hp = SimpleNamespace(**dict(vars(HP), hop_length=hop, win_length=win, n_iter=4))
     with Vocoder(hp, 0) as v:
         mags = [_speechlike_mag(T, T + hop) for T in (25, 6)]
-        for backend in (0, 1):
+        for backend in (be,):
             v.set_backend(backend)
             for m, w in zip(mags, v.spectrogram2wav_batch(mags)):
                 ref = gl.spectrogram2wav(hp, m)
                 assert w.shape == ref.shape and np.abs(w - ref).max() <= 2e-4 * np.abs(ref).max(), (backend, hop)
 
 
+@pytest.mark.hipfft_backend
 def test_non_2048_fft_uses_generic_path(gl):
     from ophelia_amd.vocoder import Vocoder
     hp = SimpleNamespace(**dict(vars(HP), n_fft=1024, hop_length=256, win_length=1024, n_iter=3))
@@ -159,6 +165,7 @@ def test_spectrogram2wav_matches_oracle(voc, gl):
         assert np.abs(w - ref).max() <= 2e-3 * np.abs(ref).max()
 
 
+@pytest.mark.hipfft_backend
 def test_full_size_batch_backends_agree(voc):
     """the bench workload (16 utterances x 800 frames, 50 iterations): fused kernel vs hipFFT path, every utterance"""
     mags = [_speechlike_mag(800, 1000 + b) for b in range(16)]
@@ -224,7 +231,8 @@ def test_from_engine_resident_mag(voc):
     eng.close()
 
 
-def test_random_stft_geometries(gl):
+@pytest.mark.parametrize("be", BACKENDS)
+def test_random_stft_geometries(gl, be):
     """hop / window lengths no shipped config uses (odd values, window = n_fft, hop = window, tiny hops are refused
     only when more than the supported overlap would be needed by the generic gather -- none here), ragged batches"""
     from ophelia_amd.vocoder import Vocoder
@@ -236,7 +244,7 @@ def test_random_stft_geometries(gl):
                                     power=float(rng.choice([1.0, 1.2, 1.5])), preemphasis=float(rng.choice([0.0, 0.9, 0.97]))))
         mags = [_speechlike_mag(int(T), case * 10 + int(T)) for T in rng.integers(2, 40, size=3)]
         with Vocoder(hp, 0) as v:
-            for backend in (0, 1):
+            for backend in (be,):
                 v.set_backend(backend)
                 for m, w in zip(mags, v.spectrogram2wav_batch(mags)):
                     ref = gl.spectrogram2wav(hp, m)
