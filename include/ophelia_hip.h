@@ -92,7 +92,13 @@ int oph_weight_info(const oph_handle* h, int index, char* name, int name_cap,
                     int64_t* shape /*[4]*/, int* rank);
 int oph_set_weight(oph_handle* h, const char* tf_var_name, const float* data,
                    const int64_t* shape, int rank);
-int oph_finalize_weights(oph_handle* h);   /* repack to kernel layout + upload */
+/* oph_set_weights_device: ALL variables at once from a buffer already on this handle's GPU -- float32, back to back in
+ * oph_weight_info order, n_floats in total -- instead of one oph_set_weight call per variable.  replaces: the same restore, when
+ * the weights arrive over the wire: in a multi-GPU run rank 0 loads the checkpoint and broadcasts one flat tensor (RCCL over
+ * xGMI); every rank hands its receive buffer over here, oph_finalize_weights repacks it with device kernels and
+ * nothing passes through the host.  The buffer must stay valid until oph_finalize_weights returns. */
+int oph_set_weights_device(oph_handle* h, const float* d_flat, int64_t n_floats);
+int oph_finalize_weights(oph_handle* h);   /* repack to kernel layout (device kernels) */
 
 /* ---- the three session calls of the hot path (host buffers in / out) ----------
  * oph_encode_text   replaces encode_text()          synthesize.py:232-240

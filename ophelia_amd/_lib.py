@@ -11,7 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libophelia_hip.so")
-SOURCES = ["oph_kernels.hip", "oph_decrun.hip", "oph_decchain.hip", "oph_hcfused.hip", "oph_coneloop.hip", "oph_api.hip"]
+SOURCES = ["oph_kernels.hip", "oph_decrun.hip", "oph_decchain.hip", "oph_hcfused.hip", "oph_coneloop.hip",
+           "oph_pack.hip", "oph_model.hip", "oph_nets.hip", "oph_cone.hip", "oph_decode.hip", "oph_api.hip", "oph_ops.hip"]
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
@@ -43,6 +44,7 @@ SIGNATURES = {
     "oph_num_weights": (C.c_int, [C.c_void_p]),
     "oph_weight_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, c_i64p, C.POINTER(C.c_int)]),
     "oph_set_weight": (C.c_int, [C.c_void_p, C.c_char_p, c_f32p, c_i64p, C.c_int]),
+    "oph_set_weights_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "oph_finalize_weights": (C.c_int, [C.c_void_p]),
     "oph_encode_text": (C.c_int, [C.c_void_p, c_i32p, c_i32p, C.c_int, c_f32p, c_f32p]),
     "oph_text2mel": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_i32p, c_i32p, C.c_int, C.c_int,
@@ -147,8 +149,8 @@ def build(verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     inc = os.path.join(os.path.dirname(HERE), "include")
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    _hipcc_shared(LIBPATH, srcs, srcs + [os.path.join(CSRC, "oph_internal.h"), os.path.join(CSRC, "oph_device.h"), os.path.join(CSRC, "oph_loopdev.h"), os.path.join(inc, "ophelia_hip.h")],
-                  [], verbose)
+    _hipcc_shared(LIBPATH, srcs, srcs + [os.path.join(CSRC, "oph_internal.h"), os.path.join(CSRC, "oph_device.h"), os.path.join(CSRC, "oph_loopdev.h"), os.path.join(CSRC, "oph_host.h"), os.path.join(inc, "ophelia_hip.h")],
+                  ["-fvisibility=hidden"], verbose)
     vsrcs = [os.path.join(CSRC, s) for s in VOCODER_SOURCES]
     _hipcc_shared(VOCODER_LIBPATH, vsrcs, vsrcs + [os.path.join(inc, "ophelia_vocoder.h")],
                   ["-L/opt/rocm/lib", "-lhipfft", "-Wl,-rpath,/opt/rocm/lib"], verbose)

@@ -37,6 +37,11 @@ constexpr long long HF_TIMEOUT_TICKS = 200000000LL;      // 2 s of the 100 MHz c
 // rows, sc1 loads -- so that they would overlap the next step's large levels: with a fourth queue busy beside the three CU-masked
 // ones the queues time-slice, 50 ms per decode instead of 20.4; removed.)
 __global__ __launch_bounds__(512) void hc_fused(HcFusedArgs a) {
+    // Every output row must get the SAME arithmetic whatever register or lane holds it (an utterance's result may not depend on its
+    // row of the tile: tests/test_gpu_properties.py).  With contraction left to the compiler the unrolled epilogue got v_fma for some
+    // register pairs and mul + add for others -- rows with (b & 1) ^ (b >> 3) set rounded differently (profiles/r04_alone.py).
+    // Contraction off; the fused operations are spelled out with fmaf.
+#pragma clang fp contract(off)
     constexpr int SLOTS = 2;                               // LDS buffers of the operand planes (32 KB each)
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     // A K-step is 64 wide: a row's 128 bytes of a plane are ONE cache line (32-wide steps fetched half of every line they touched:
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(512) void hc_fused(HcFusedArgs a) {
         for (int e = 0; e < 16; ++e) {
             const int row = (e & 3) + 8 * (e >> 2) + 4 * kh;
             const float mean = srow[(w * 32 + row) * 2], rstd = srow[(w * 32 + row) * 2 + 1];
-            acc[e] = (acc[e] - mean) * rstd * gamma + beta;
+            acc[e] = fmaf((acc[e] - mean) * rstd, gamma, beta);
         }
         if (wc == 1) {
 #pragma unroll
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(512) void hc_fused(HcFusedArgs a) {
                 const int rt = wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
                 const float h2 = h2s[rt * 32 + r32];
                 const float gte = fast_sigmoid(acc[e]);
-                ys[rt * 36 + r32] = gte * h2 + (1.0f - gte) * xres[e];
+                ys[rt * 36 + r32] = fmaf(gte, h2, (1.0f - gte) * xres[e]);
             }
         }
         __syncthreads();

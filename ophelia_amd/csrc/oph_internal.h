@@ -349,6 +349,15 @@ struct ConeLoopArgs {
 void launch_cone_loop(const ConeLoopArgs& a, int nwg, hipStream_t s);     // nwg: multiple of 8, all resident
 int cone_loop_blocks_per_cu();
 
+// weight repacking on the device (oph_pack.hip)
+void launch_pack_conv(const float* k, float* Wt, int size, int cin, int cout, int kc, int Nalloc, hipStream_t s);
+void launch_pack_convT(const float* kt, float* We, float* Wo, int cin, int cout, int kc, int Nalloc, hipStream_t s);
+void launch_pack_wkn(const float* k, float* Wkn, int cin, int N, int kc, int ldn, hipStream_t s);
+void launch_pack_wtc(const float* k, float* Wc, int d, int kc_c, int ldvw, hipStream_t s);
+void launch_pack_hcf(const float* kr, const float* bs, float* wp, float* bp, hipStream_t s);
+void launch_pad_copy(const float* src, float* dst, size_t n, size_t npad, int mode, int row0, hipStream_t s);
+void launch_maxabs(const float* x, size_t n, unsigned* out, hipStream_t s);
+
 // launchers (oph_kernels.hip)
 void launch_row_chain(const RowChainArgs& a, hipStream_t s);
 void launch_conv_gemm(const GemmArgs& a, hipStream_t s);

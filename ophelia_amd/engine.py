@@ -114,6 +114,7 @@ class Engine(object):
         self.lib = _lib.load()
         self.dims = dims_from_hp(hp, max_N, max_T)
         self.hp = hp
+        self.device = int(device)
         self._h = C.c_void_p()
         rc = self.lib.oph_create(C.byref(self.dims), int(device), C.byref(self._h))
         if rc != 0:
@@ -190,6 +191,12 @@ class Engine(object):
             a = np.ascontiguousarray(W[name], dtype=np.float32)
             shp = (C.c_int64 * 4)(*a.shape)
             self._chk(self.lib.oph_set_weight(self._h, name.encode(), _lib.fptr(a), shp, a.ndim))
+        self._chk(self.lib.oph_finalize_weights(self._h))
+
+    def load_weights_device(self, device_ptr, n_floats):
+        """Every variable at once from a float32 buffer on this engine's GPU (inventory order, back to back): repacked in place by
+        device kernels (oph_set_weights_device).  The buffer must stay alive until this call returns."""
+        self._chk(self.lib.oph_set_weights_device(self._h, C.c_void_p(int(device_ptr)), int(n_floats)))
         self._chk(self.lib.oph_finalize_weights(self._h))
 
     # -- the three session calls (host arrays in/out), synthesize.py:232-260

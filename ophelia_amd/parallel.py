@@ -41,6 +41,36 @@ def broadcast_weights(W, inventory, src=0, device=None):
     return W if dist.get_rank() == src else WT.unflatten(flat.cpu().numpy(), inventory)
 
 
+def load_weights_broadcast(eng, W, src=0, device=None):
+    """Start-up weight distribution of a multi-GPU run: rank `src` holds the weight dict, every rank ends up with a
+    loaded engine.  ONE flat fp32 tensor is broadcast (RCCL over xGMI when `device` is a GPU) and the receive buffer is handed to
+    the library as it is (oph_set_weights_device): the variables are repacked by device kernels, nothing goes back through the host
+    (round 3 copied the 210 MB to the host, unflattened them and re-uploaded them variable by variable on every rank).
+    Without a process group this is eng.load_weights(W)."""
+    import torch
+    from . import weights as WT
+    dist = _dist()
+    if dist is None:
+        eng.load_weights(W)
+        return
+    inventory = eng.inventory()
+    n = int(sum(int(np.prod(s)) for _, s in inventory))
+    on_gpu = torch.cuda.is_available()
+    dev = torch.device("cuda", device) if (device is not None and on_gpu) else torch.device("cpu")
+    if dist.get_rank() == src:
+        flat = torch.from_numpy(WT.flatten(W, inventory)).to(dev)
+    else:
+        flat = torch.empty(n, dtype=torch.float32, device=dev)
+    dist.broadcast(flat, src=src)
+    if on_gpu:
+        if flat.device.type != "cuda":                 # gloo process group (tests: ranks sharing one GPU): one upload of the flat tensor
+            flat = flat.to(torch.device("cuda", eng.device))
+        torch.cuda.synchronize(flat.device)
+        eng.load_weights_device(flat.data_ptr(), n)    # `flat` stays alive until the repack is done
+    else:
+        eng.load_weights(WT.unflatten(flat.numpy(), inventory))
+
+
 def global_max_int(value, device=None):
     """MAX over ranks of one integer (the global stop step)."""
     import torch

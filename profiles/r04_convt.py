@@ -1,0 +1,12 @@
+"""conv1d_transpose (SSRN D_4 / D_7) timing through oph_bench_conv1d_transpose: fp32-operand MFMA, split-bf16 (two launches) and
+split-fp16 (convt_fused: one launch)."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ophelia_amd import _lib
+lib = _lib.load()
+for name, T in (("D_4", 200), ("D_7", 400)):
+    for prec in (0, 1, 2):
+        us, by, fl = C.c_double(), C.c_double(), C.c_double()
+        rc = lib.oph_bench_conv1d_transpose(0, 16, T, 512, 512, prec, 5, 50, C.byref(us), C.byref(by), C.byref(fl))
+        print(name, "prec", prec, "rc", rc, "%.1f us  %.1f%% HBM  %.0f TFLOP/s (x%d products)" % (us.value, by.value / us.value / 1e3 / 8000 * 100, fl.value / us.value / 1e6, 1 if prec == 0 else 3), lib.oph_op_last_error().decode() if rc else "")

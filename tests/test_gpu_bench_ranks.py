@@ -33,3 +33,5 @@ def test_bench_two_ranks_on_one_gpu():
     assert abs(out["value"] - cfg["frames_per_step"] / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
     assert cfg["cross_stream_sync"] == "stream value operations"           # multi-rank runs select OPH_STREAM_VALUE
     assert "all ranks on one GPU" in cfg["parallelism"]
+    # a rank must not need a whole host core to drive its GPU: 8 of them share a node's cores
+    assert len(cfg["rank_host_cores"]) == 2 and all(0.0 < c < 0.8 for c in cfg["rank_host_cores"]), cfg["rank_host_cores"]

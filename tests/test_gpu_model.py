@@ -229,3 +229,43 @@ def test_session_run_in_the_reference_feed_fetch_style(tag):
         Zl = sess.run(g2.Z_logits, {g2.mels: Y})
         inner = (Z > 1e-6) & (Z < 1 - 1e-6)
         assert np.abs(1.0 / (1.0 + np.exp(-Zl[inner])) - Z[inner]).max() < 1e-5
+
+
+def test_weights_from_a_device_buffer_equal_weights_set_one_by_one():
+    """oph_set_weights_device (the multi-GPU start-up path: the RCCL receive buffer consumed in place, repacked by device kernels)
+    against oph_set_weight per variable: the same packed weights, hence bitwise the same outputs -- on the single-speaker config and
+    on the multispeaker one (lookup tables, speaker concat)."""
+    import torch
+    from oracle import ophelia_oracle as O
+    from ophelia_amd.engine import Engine
+    from ophelia_amd import weights as WT
+    from conftest import hp_from_snapshot
+    for cfg, over in (("lj_tutorial.cfg", dict(max_N=40, max_T=30)), ("vctk_01.cfg", dict(max_N=30, max_T=20))):
+        hp = hp_from_snapshot(cfg, **over)
+        ms = bool(getattr(hp, "multispeaker", []))
+        a = Engine(hp, device=0)
+        inv = a.inventory()
+        W = WT.random_weights(inv, seed=9)
+        a.load_weights(W)
+        b = Engine(hp, device=0)
+        flat = torch.from_numpy(WT.flatten(W, inv)).cuda()
+        torch.cuda.synchronize()
+        b.load_weights_device(flat.data_ptr(), flat.numel())
+        del flat
+        L = O.random_text(hp, 5, 3, min_len=8, max_len=over["max_N"] - 2)
+        ends = O.get_text_lengths(L)
+        spk = np.array([[3], [1], [7], [2], [5]], np.int32) if ms else None
+        outs = []
+        for eng in (a, b):
+            K, V = eng.encode_text(L, speaker_data=spk)
+            Y, t_ends, al, steps = eng.text2mel(K, V, ends, speaker_data=spk, stop_mode=1)
+            outs.append((np.array(K), np.array(V), np.array(Y), np.array(al), np.array(eng.ssrn(Y))))
+            eng.close()
+        for x, y in zip(*outs):
+            assert np.array_equal(x, y)
+    # misuse: a host pointer, a wrong size
+    c = Engine(hp, device=0)
+    host = np.zeros(16, np.float32)
+    with pytest.raises(Exception, match="needs a pointer to memory of device|flat weight buffer holds"):
+        c.load_weights_device(host.ctypes.data, 16)
+    c.close()
