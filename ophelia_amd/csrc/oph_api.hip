@@ -46,7 +46,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
     h->dm = m;
     h->device = device;
     h->opt.read();
-    static const char* names[PC_COUNT] = {"conv_gemm_f32<128,128>", "conv_gemm_f32<64,64>", "conv_gemm_bf16x3", "ln_rows", "dec_layer16", "row_chain", "attn_rows", "misc", "dec_run", "dec_loop", "cone_head"};
+    static const char* names[PC_COUNT] = {"conv_gemm_f32<128,128>", "conv_gemm_f32<64,64>", "conv_gemm_bf16x3", "ln_rows", "dec_layer16", "row_chain", "attn_rows", "misc", "dec_run", "dec_loop", "cone_head", "hc_fused"};
     for (int i = 0; i < PC_COUNT; ++i) h->prof[i].name = names[i];
     // CU partition for the decode loop (MI355X: 256 CUs, mask bit i -> XCD i%8): the dependent layers of a step get a
     // private slice of 8 CUs in every XCD so the concurrently running history-cone GEMMs (the next 16 CUs per XCD) and the
@@ -67,8 +67,6 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
                 else {
                     m_cone[i / 32] |= bit;
                     (i < ndec + nconep ? m_conep : m_ssrn)[i / 32] |= bit;
-                    if (h->opt.cone_all) m_conep[i / 32] |= bit;
-                    if (h->opt.ssrn_all) m_ssrn[i / 32] |= bit;
                 }
             }
             // CU-masked queues are a scarce resource: with four alive the queues get time-sliced and even sequential batches

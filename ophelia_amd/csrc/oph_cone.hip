@@ -86,7 +86,7 @@ void launch_cone(oph_handle* h, int t) {
             else {
                 if (h->hcf_epoch > 0xF0000000u) {
                     hipStreamSynchronize(h->scone);
-                    hipMemsetAsync(h->d_hcf_stats, 0, (size_t)nh * ((h->Hset[0].size() * Bpad + 63) / 64) * 2 * 2 * 32 * 8 * 2 * sizeof(unsigned long long), g_cur);
+                    hipMemsetAsync(h->d_hcf_stats, 0, (size_t)nh * h->hcf_stats_stride * sizeof(unsigned long long), g_cur);
                     h->hcf_epoch = 0;
                 }
                 for (int k = 0; k + 1 < nh; ++k) {
@@ -97,7 +97,7 @@ void launch_cone(oph_handle* h, int t) {
                     f.tab = h->d_tab[k]; f.need = h->d_need[k]; f.n_out = n_out; f.j = t; f.Bpad = Bpad; f.M = n_out * Bpad;
                     f.Wh = l.Wph; f.Wl = l.Wpl; f.bias = l.bias_p; f.g1 = l.g1; f.b1 = l.b1; f.g2 = l.g2; f.b2 = l.b2;
                     f.Y = cone[k + 1]; f.Yh = h->coneH[t & 1][k + 1]; f.Yl = h->coneL[t & 1][k + 1];
-                    f.stats = h->d_hcf_stats + (size_t)k * ((h->Hset[0].size() * Bpad + 63) / 64) * 2 * 2 * 32 * 8 * 2; f.epoch = ++h->hcf_epoch; f.err = h->d_ctl + 2; f.zeros = h->d_zeros;
+                    f.stats = h->d_hcf_stats + (size_t)k * h->hcf_stats_stride; f.epoch = ++h->hcf_epoch; f.err = h->d_ctl + 2; f.zeros = h->d_zeros;
                     f.stop_after = stop_after; f.t = t;
                     if (h->cone_inline_sig && k + 1 < LOOP_MAX_LEVELS) {
                         const Layer& tl = h->audiodec[pre + k + 1];
@@ -107,9 +107,9 @@ void launch_cone(oph_handle* h, int t) {
                         f.done_stamp = stamp_of(k + 1);
                     }
                     if (h->d_cldbg && t == m.max_T / 2) f.dbg = h->d_cldbg + 8 * k;
-                    h->pbegin(PC_GEMM_BF16);
+                    h->pbegin(PC_HCFUSED);
                     launch_hc_fused(f, g_cur);
-                    h->pend(PC_GEMM_BF16, ((double)f.M * 3.0 * l.cin + (double)f.M * l.cout + (double)l.N * 3.0 * l.cin) * 4.0, 2.0 * f.M * l.N * 3.0 * l.cin);
+                    h->pend(PC_HCFUSED, ((double)f.M * 3.0 * l.cin + (double)f.M * l.cout + (double)l.N * 3.0 * l.cin) * 4.0, 2.0 * f.M * l.N * 3.0 * l.cin);
                 }
                 g_cur = saved;
                 return;

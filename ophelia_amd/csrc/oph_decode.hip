@@ -153,8 +153,8 @@ int ensure_decode_state(oph_handle* h, int B) {
     h->coneTmp = h->dalloc<float>(maxrows * Bpad * (size_t)ld_cat);
     h->d_cone_count = h->dalloc<unsigned>(LOOP_MAX_LEVELS); for (uint32_t& v : h->cone_done_total) v = 0;
     if (h->cone_fused_ok) {
-        const size_t mt = (maxrows * Bpad + 63) / 64;
-        h->d_hcf_stats = h->dalloc<unsigned long long>((size_t)nh * mt * 2 * 2 * 32 * 8 * 2);      // one region per level: launches of two streams overlap
+        h->hcf_stats_stride = (size_t)((maxrows * Bpad + 63) / 64) * 2 * 2 * 32 * 8 * 2;      // granules per level: [row block][2][2][32 rows][8 tiles][2 values]
+        h->d_hcf_stats = h->dalloc<unsigned long long>((size_t)nh * h->hcf_stats_stride);
         h->hcf_epoch = 0;
         if (!h->d_hcf_stats) { h->fail("out of device memory for decode state"); return OPH_ERR_DEVICE; }
     }
@@ -944,6 +944,16 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
                     const long long* q = &cd[(size_t)8 * k];
                     if (q[0]) TRACE("hc_fused level %d, workgroup 0: K loop %.2f  stats+publish %.2f  gather %.2f  normalise..store %.2f us", k + 1,
                                     (q[1] - q[0]) * 0.01, (q[2] - q[1]) * 0.01, (q[3] - q[2]) * 0.01, (q[4] - q[3]) * 0.01);
+                }
+                if (h->d_lvldbg && m.max_T / 2 + 1 < m.max_T) {      // the launches of step max_T/2 on one time line (us after level 0 completed)
+                    std::vector<long long> lv((size_t)m.max_T * 8);
+                    hipMemcpy(lv.data(), h->d_lvldbg, lv.size() * 8, hipMemcpyDeviceToHost);
+                    const long long* q = &lv[(size_t)(m.max_T / 2) * 8];
+                    const long long z = q[0];
+                    for (int k = 0; k + 1 < h->n_hc_dec; ++k)
+                        TRACE("step %d, level %d: workgroup 0 in at %.2f, out at %.2f; level complete at %.2f us (level 0 complete = 0)", m.max_T / 2, k + 1,
+                              (cd[(size_t)8 * k] - z) * 0.01, (cd[(size_t)8 * k + 4] - z) * 0.01, (q[k + 1] - z) * 0.01);
+                    TRACE("step %d: level 0 of the next cone complete at %.2f us", m.max_T / 2, (lv[(size_t)(m.max_T / 2 + 1) * 8] - z) * 0.01);
                 }
             }
             if (loop_mode && h->d_cldbg && !h->cone_fused_ok) {

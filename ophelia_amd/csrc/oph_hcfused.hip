@@ -75,20 +75,18 @@ __global__ __launch_bounds__(512) void hc_fused(HcFusedArgs a) {
         const h16* const Xh = (const h16*)a.Xh; const h16* const Xl = (const h16*)a.Xl;
         const h16* const Wh = (const h16*)a.Wh; const h16* const Wl = (const h16*)a.Wl;
         const h16* const zrow = (const h16*)a.zeros;
-        int asrc[3][1];                                    // element offset of the source row per (tap, request), or -1 (a tap outside the utterance: zeros)
-        int gp[1];                                         // the chunk of the row this lane fetches (the swizzle, applied on the global side)
+        // element offset of the source row per tap, or -1 (a tap outside the utterance: zeros).  A request's 8 rows lie within one
+        // position (16 utterance rows), so the table entries are wave-uniform and all six loads are in flight together (as per-lane
+        // loads under their row conditions they were six dependent round trips before the first operand request)
+        const int gp = (pos ^ ((rq0 >> 1) & 7)) * 8;       // the chunk of the row this lane fetches (the swizzle, applied on the global side)
+        int asrc[3];
+        {
+            const int ipw = (m0 + 8 * w8) >> 4, ipc = min(ipw, a.n_out - 1), bq = rq0 & 15;
+            int needv[3], tabv[3];
 #pragma unroll
-        for (int i = 0; i < 1; ++i) {
-            const int r = rq0 + 8 * i, m = m0 + r;
-            gp[i] = (pos ^ ((r >> 1) & 7)) * 8;
+            for (int tap = 0; tap < 3; ++tap) { needv[tap] = a.need[tap * a.n_out + ipc]; tabv[tap] = a.tab[tap * a.n_out + ipc]; }
 #pragma unroll
-            for (int tap = 0; tap < 3; ++tap) {
-                asrc[tap][i] = -1;
-                if (m < a.M) {
-                    const int ip = m >> 4, b = m & 15;
-                    if (a.j >= a.need[tap * a.n_out + ip]) asrc[tap][i] = (a.tab[tap * a.n_out + ip] * 16 + b) * HF_BK + gp[i];
-                }
-            }
+            for (int tap = 0; tap < 3; ++tap) asrc[tap] = (ipw < a.n_out && a.j >= needv[tap]) ? (tabv[tap] * 16 + bq) * HF_BK + gp : -1;
         }
         // 32x32x16 fragment: lane l holds row (l & 31), k = 8 (l >> 5) .. +7 of the 16-wide chunk
         const int wr = w >> 1, wc = w & 1, r32 = lane & 31, kh = lane >> 5;
@@ -116,12 +114,12 @@ __global__ __launch_bounds__(512) void hc_fused(HcFusedArgs a) {
             const size_t kb = (size_t)(s & 3) * a.in_rows * HF_BK;        // planes are K-blocked: [channel / 64][row][64]
 #pragma unroll
             for (int i = 0; i < 1; ++i) {
-                const int so = tap == 0 ? asrc[0][i] : (tap == 1 ? asrc[1][i] : asrc[2][i]);
+                const int so = asrc[tap];
                 const h16* gh = so >= 0 ? Xh + so + kb : zrow;
                 const h16* gl = so >= 0 ? Xl + so + kb : zrow;
                 q.ah[i] = *(const i32x4*)gh;
                 q.al[i] = *(const i32x4*)gl;
-                const size_t bo = (((size_t)jt * (HF_K / HF_BK) + s) * HF_BN + rq0 + 8 * i) * HF_BK + gp[i];      // [column tile][K-step][64 columns][64]
+                const size_t bo = (((size_t)jt * (HF_K / HF_BK) + s) * HF_BN + rq0 + 8 * i) * HF_BK + gp;      // [column tile][K-step][64 columns][64]
                 q.bh[i] = *(const i32x4*)(Wh + bo);
                 q.bl[i] = *(const i32x4*)(Wl + bo);
             }

@@ -104,9 +104,10 @@ struct Options {
     int ksplit_big = 3, ksplit_small = CONE_KSPLIT;
     int fc_rows = -1, fc_insplit = 2;   // OPH_CONE_FC_ROWS (cone levels of at most this many rows run as cone_fc16), OPH_CONE_FC_INSPLIT
     int lookahead = 8;               // OPH_LOOP_LOOKAHEAD: cones the host may queue ahead of the loop kernel's progress
-    int loop_dbg = 0;                // OPH_LOOP_DBG: ablation bits of dec_loop (results are wrong when set, except 16)
+    int loop_dbg = 0;                // OPH_LOOP_ALONE -> 32: the whole-decode launch without its side stream (counter passes; mel unused).
+                                     // The other ablation bits of dec_loop (OPH_LOOP_DBG) exist only in -DOPH_ABLATE builds
     int cu_dec = 0, cu_cone = 0;     // OPH_CU_SPLIT="chain,cone" CUs of the three partitions (rest: SSRN)
-    bool no_cu_mask = false, ssrn_all = false, cone_all = false;      // OPH_NO_CU_MASK, OPH_SSRN_ALL, OPH_CONE_ALL
+    bool no_cu_mask = false;         // OPH_NO_CU_MASK
     bool no_cone_head = false, no_loop_qw = false, no_preencode = false, no_stream_ssrn = false, no_cone_loop = false;
     int cone_prec = -1;              // OPH_CONE_PREC: the two many-row cone contractions: 0 fp32 MFMA, 1 split-bf16 x3 (experiment), 2 split-fp16 x3; -1 = the default
     int ssrn_prec = -1;              // OPH_SSRN_PREC: 0 fp32 MFMA, 1 split-bf16 x3, 2 split-fp16 x3; -1 = the default (OPH_SSRN_FP32 = 0)
@@ -128,9 +129,13 @@ struct Options {
         run_rows = num("OPH_RUN_ROWS", 8) == 4 ? 4 : 8;
         if (const char* e = getenv("OPH_CONE_KSPLIT")) { int a_ = 0, b_ = 0; if (sscanf(e, "%d,%d", &a_, &b_) == 2 && a_ >= 1 && a_ <= CONE_KSPLIT && b_ >= 1 && b_ <= CONE_KSPLIT) { ksplit_big = a_; ksplit_small = b_; } }
         fc_rows = num("OPH_CONE_FC_ROWS", -1); fc_insplit = std::max(1, num("OPH_CONE_FC_INSPLIT", 2));
-        lookahead = num("OPH_LOOP_LOOKAHEAD", 8); loop_dbg = num("OPH_LOOP_DBG", 0);
+        lookahead = num("OPH_LOOP_LOOKAHEAD", 8);
+        loop_dbg = flag("OPH_LOOP_ALONE") ? 32 : 0;
+#ifdef OPH_ABLATE
+        loop_dbg = num("OPH_LOOP_DBG", loop_dbg);
+#endif
         if (const char* sp = getenv("OPH_CU_SPLIT")) { int a_ = 0, b_ = 0; if (sscanf(sp, "%d,%d", &a_, &b_) == 2 && a_ > 0 && b_ > 0) { cu_dec = a_; cu_cone = b_; } }
-        no_cu_mask = flag("OPH_NO_CU_MASK"); ssrn_all = flag("OPH_SSRN_ALL"); cone_all = flag("OPH_CONE_ALL");
+        no_cu_mask = flag("OPH_NO_CU_MASK");
         no_cone_head = flag("OPH_NO_CONE_HEAD"); no_loop_qw = flag("OPH_NO_LOOP_QW"); no_preencode = flag("OPH_NO_PREENCODE");
         no_stream_ssrn = flag("OPH_NO_STREAM_SSRN");
         // the cone as one persistent launch (cone_loop) is opt-in: measured 25.5-26.1 ms per batch against 25.0 ms with the nine
@@ -148,7 +153,7 @@ struct Options {
     }
     int cone_ksplit(int M) const { return M >= 512 ? ksplit_big : ksplit_small; }
 };
-enum { PC_GEMM = 0, PC_GEMM64, PC_GEMM_BF16, PC_LN, PC_DEC, PC_ROWCHAIN, PC_ATTN_ROWS, PC_MISC, PC_DECRUN, PC_DECLOOP, PC_CONEHEAD, PC_COUNT };   // PC_GEMM = the <128,128> instance
+enum { PC_GEMM = 0, PC_GEMM64, PC_GEMM_BF16, PC_LN, PC_DEC, PC_ROWCHAIN, PC_ATTN_ROWS, PC_MISC, PC_DECRUN, PC_DECLOOP, PC_CONEHEAD, PC_HCFUSED, PC_COUNT };   // PC_GEMM = the <128,128> instance
 
 
 // Decode state of one 16-utterance tile that has to survive between decode calls on the same utterances (a batch of
@@ -294,6 +299,7 @@ struct oph_handle {
     bool cone_fused_ok = false;         // weights packed for it (standard geometry)
     std::vector<void*> coneH[2], coneL[2];
     unsigned long long* d_hcf_stats = nullptr; uint32_t hcf_epoch = 0; int hcf_capacity = -1;
+    size_t hcf_stats_stride = 0;        // granules of one level's statistics region
     int ldy = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

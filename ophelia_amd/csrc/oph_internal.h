@@ -42,32 +42,42 @@ void launch_split_f16(const float* w, void* hi, void* lo, size_t n, hipStream_t 
 
 // ---- LayerNorm epilogues over raw conv rows (one wavefront per row)
 struct EpiArgs {
-    const float* H; int ldh;        // raw rows
-    int nsplit; long long split_stride;   // raw = sum of nsplit partial buffers (split-K GEMM)
-    int M; int C;                   // rows ; channels of the OUTPUT (hc: raw has 2C)
-    int mode;                       // PRE_CONV (LN + act) or PRE_HC (2xLN + gate + highway)
-    int act;
+    // (pointers and 64-bit fields first, then the 32-bit ones: 248 bytes; see HcFusedArgs)
+    const float* H;                 // raw rows
     const float *g1, *b1, *g2, *b2; // gamma/beta (conv: g1,b1 ; hc: H1 -> g1,b1, H2 -> g2,b2)
-    const float* Xres; int ldres;   // hc residual rows
-    const int* restab; int Bpad;    // if non-null: residual row = restab[m / Bpad]*Bpad + m % Bpad
-    float* Y; int ldy; int ypad;    // output rows; columns [Ctot, ypad) are zero-filled
+    const float* Xres;              // hc residual rows
+    const int* restab;              // if non-null: residual row = restab[m / Bpad]*Bpad + m % Bpad
+    float* Y;                       // output rows; columns [Ctot, ypad) are zero-filled
     // optional speaker-embedding append (AudioDec 'audio_decoder_input', networks.py:381-387)
-    const float* spk_table; const int* spk_ids; int spk_dim; int spk_T; // utterance of row m: spk_T>0 ? m / spk_T : m % Bpad
-    const int* stop_after; int t;
-    int nonorm;                     // hp.norm None: the "LayerNorm" is the identity (mean 0, rstd 1; gamma/beta = 1/0 buffers)
-    // optional output row mapping (streamed SSRN chunks): the M rows are [B][out_T]; row (b, u) with keep_lo <= u < keep_hi is
-    // stored at output row b * out_bs + out_t0 + u, the others are skipped.  out_T == 0: row m -> output row m
-    int out_T; int keep_lo, keep_hi; long long out_bs; int out_t0;
+    const float* spk_table; const int* spk_ids;
+    const int* stop_after;
     // learned channel contributions (modules.py:78-88): per-speaker channel gate sigmoid(lcc_embed[spk]) stored as a
     // table [nspeakers][C]; conv: y = gate * act(LN(h)) (a final squash sigmoid comes after the gate); hc: H2 *= gate
-    const float* lcc; const int* lcc_ids; int lcc_T;   // utterance of row m: lcc_T > 0 ? m / lcc_T : m % Bpad
+    const float* lcc; const int* lcc_ids;
     // optional completion signal (the launch that writes a cone level in dec_loop mode): the rows of positions coh0 and
     // coh1 -- the only ones the loop kernel reads as taps -- are stored write-through (8-byte sc1 stores, no fence); each
     // workgroup holding such rows waits for its stores, adds 1 to *done_count, and the one that makes it done_target
     // raises *done_sig to done_val
-    unsigned* done_sig; unsigned done_val; unsigned* done_count; unsigned done_target; int coh0, coh1;
+    unsigned* done_sig; unsigned* done_count;
     long long* done_stamp;          // diagnostics: the raising lane stores the constant clock here (or null)
+    long long split_stride;         // raw = sum of nsplit partial buffers (split-K GEMM)
+    long long out_bs;
+    int ldh, nsplit;
+    int M; int C;                   // rows ; channels of the OUTPUT (hc: raw has 2C)
+    int mode;                       // PRE_CONV (LN + act) or PRE_HC (2xLN + gate + highway)
+    int act;
+    int ldres, Bpad;
+    int ldy; int ypad;
+    int spk_dim; int spk_T;         // utterance of row m: spk_T>0 ? m / spk_T : m % Bpad
+    int t;
+    int nonorm;                     // hp.norm None: the "LayerNorm" is the identity (mean 0, rstd 1; gamma/beta = 1/0 buffers)
+    // optional output row mapping (streamed SSRN chunks): the M rows are [B][out_T]; row (b, u) with keep_lo <= u < keep_hi is
+    // stored at output row b * out_bs + out_t0 + u, the others are skipped.  out_T == 0: row m -> output row m
+    int out_T; int keep_lo, keep_hi; int out_t0;
+    int lcc_T;                      // utterance of row m: lcc_T > 0 ? m / lcc_T : m % Bpad
+    unsigned done_val, done_target; int coh0, coh1;
 };
+static_assert(sizeof(EpiArgs) <= 256, "ln_rows' kernel arguments: four 64-byte lines");
 
 // ---- fused M=16 decode layer (prologue = previous layer's LN/gate, then 16xK . KxN slice)
 struct DecArgs {
@@ -113,43 +123,58 @@ struct AttnRowsArgs {
 // new exactly once: at offset 1; the workgroups of that position compute it).  One wave per (position, utterance) row: attention window, the
 // two cached terms, LayerNorm -- instead of attn_rows + a [1344 x 512 x 256] GEMM + ln_rows every step.
 struct ConeHeadArgs {
-    const float* Q; int d;              // Qhist [max_T][Bpad][d]
-    const float* KV; int N_keys; int win;   // K | V rows [B][N][2d]
-    const float* VW; int ldvw;          // [B][N][ldvw] = V . Wc
+    // (pointers first, then the 32-bit fields, and no blockDim in the kernel -- that would append 256 bytes of implicit arguments:
+    //  252 bytes = four 64-byte lines of kernel arguments; see HcFusedArgs)
+    const float* Q;                     // Qhist [max_T][Bpad][d]
+    const float* KV;                    // K | V rows [B][N][2d]
+    const float* VW;                    // [B][N][ldvw] = V . Wc
     float* QW;                          // [max_T][Bpad][d] cache of Q . Wq + bias
-    const float* Wq; int ldn;           // [d][ldn] n-contiguous rows of the Q half of C_1's kernel
-    const float* bias; const float* gamma; const float* beta; int nonorm;
-    const int* p; int B; int Bpad; int nrows; const int* off; int j;     // row i*Bpad+b <-> time j - off[i]
-    int npos; int i_new;                // positions (nrows = npos * Bpad); index of the newest one (smallest offset)
-    float* Y; int ldy;                  // output rows (layer input of the next cone stage)
+    const float* Wq;                    // [d][ldn] n-contiguous rows of the Q half of C_1's kernel
+    const float* bias; const float* gamma; const float* beta;
+    const int* p; const int* off;       // row i*Bpad+b <-> time j - off[i]
+    float* Y;                           // output rows (layer input of the next cone stage)
     void* Yh; void* Yl;                 // optional: the same rows as fp16 hi / lo planes, K-blocked [d / 64][nrows][64] (hc_fused's operand format)
-    const float* spk_table; const int* spk_ids; int spk_dim;            // optional embedding appended after the d channels
-    const int* stop_after; int t;
-    const unsigned* wait_sig; unsigned wait_val; int* wait_err;
-    unsigned* done_sig; unsigned done_val; unsigned* done_count; unsigned done_target; int coh0, coh1;      // as EpiArgs: cone level 0 written
+    const float* spk_table; const int* spk_ids;       // optional embedding appended after the d channels
+    const int* stop_after;
+    const unsigned* wait_sig; int* wait_err;
+    unsigned* done_sig; unsigned* done_count;          // as EpiArgs: cone level 0 written
     long long* done_stamp;
+    int d, N_keys, win, ldvw, ldn, nonorm;
+    int B, Bpad, nrows, j;
+    int npos; int i_new;                // positions (nrows = npos * Bpad); index of the newest one (smallest offset)
+    int ldy, spk_dim, t;
+    unsigned wait_val, done_val, done_target; int coh0, coh1;
+    int rb;                             // rows per workgroup (= waves per workgroup), set by launch_cone_head
 };
+static_assert(sizeof(ConeHeadArgs) <= 256, "cone_head's kernel arguments: four 64-byte lines");
 void launch_cone_head(const ConeHeadArgs& a, hipStream_t s);
 
 // ---- hc_fused: a level of the AudioDec history cone as ONE launch (oph_hcfused.hip): split-fp16 x3 contraction with both operands
 // as fp16 hi / lo planes through global_load_lds, then LayerNorm x 2 + gate + highway mix in the same kernel -- the 8 column tiles of
 // a 64-row block exchange per-row (mean, M2) partials as granules.  C = 256 channels, 3 taps, Bpad = 16.
 struct HcFusedArgs {
-    const void* Xh; const void* Xl; int in_rows;        // level k-1 rows as fp16 planes, K-blocked: [256 / 64][in_rows = positions * Bpad][64]
+    // (pointers first, then the 32-bit fields: 248 bytes.  With the fields in reading order the struct was 264 bytes -- a fifth 64-byte
+    //  line of kernel arguments for every wave's scalar loads -- and every launch measured ~1 us longer, profiles/r04_ab.sh)
+    const void* Xh; const void* Xl;                     // level k-1 rows as fp16 planes, K-blocked: [256 / 64][in_rows = positions * Bpad][64]
     const float* Xres; const int* restab;               // ... and as fp32 (highway residual): row restab[ip] * Bpad + b
-    const int* tab; const int* need; int n_out; int j;  // [3][n_out] source position per tap (oldest first), valid iff j >= need
-    int Bpad; int M;                                    // M = n_out * Bpad output rows
+    const int* tab; const int* need;                    // [3][n_out] source position per tap (oldest first), valid iff j >= need
     const void* Wh; const void* Wl; const float* bias;  // the layer's kernel as planes [8 column tiles][12 K-steps][64 columns][64], a tile's
                                                         // columns = [32 H1 | the same 32 channels of H2]; bias in the same column order
     const float *g1, *b1, *g2, *b2;                     // LayerNorm parameters of H1 / H2 (channel order)
     float* Y; void* Yh; void* Yl;                       // level k rows: fp32 [M][256] and K-blocked planes [4][M][64]
-    unsigned long long* stats; unsigned epoch;          // exchange granules [row block][2][2][32][8][2]; tag of this launch (never reused)
+    unsigned long long* stats;                          // exchange granules [row block][2][2][32][8][2]
     int* err; const float* zeros;
-    const int* stop_after; int t;
-    unsigned* done_sig; unsigned done_val; unsigned* done_count; unsigned done_target; int coh0, coh1;      // as EpiArgs
+    const int* stop_after;
+    unsigned* done_sig; unsigned* done_count;           // as EpiArgs
     long long* done_stamp;
     long long* dbg;                                     // diagnostics: phase stamps of workgroup 0 [8], or null
+    int in_rows, n_out, j;
+    int Bpad, M;                                        // M = n_out * Bpad output rows
+    unsigned epoch;                                     // tag of this launch's granules (never reused)
+    int t;
+    unsigned done_val, done_target; int coh0, coh1;
 };
+static_assert(sizeof(HcFusedArgs) <= 256, "hc_fused's kernel arguments: four 64-byte lines");
 void launch_hc_fused(const HcFusedArgs& a, hipStream_t s);
 int hc_fused_grid(int M);
 int hc_fused_active(int M);

@@ -25,8 +25,12 @@ namespace oph {
 // K order inside an 8-wide chunk is permuted (lanes<32 take k..k+3, lanes>=32 take k+4..k+7,
 // MFMA e pairs k+e with k+4+e) identically for A and B, so the sum is unchanged.
 // =====================================================================================
+// the fields in which the two phases of a paired launch differ travel by value (scalars: they stay in SGPRs; a modified copy of
+// the whole GemmArgs would live in scratch memory because of its indexed off[] member)
+struct GemmAlt { const float* Wt; const void* Wh; const void* Wl; float* H; int ldw, ntaps; };
+__device__ __forceinline__ GemmAlt gemm_alt(const GemmArgs& a) { return GemmAlt{a.Wt, a.Wh, a.Wl, a.H, a.ldw, a.ntaps}; }
 template <int BM, int BN>
-static __device__ __forceinline__ void conv_gemm_f32_body(const GemmArgs& a) {
+static __device__ __forceinline__ void conv_gemm_f32_body(const GemmArgs& a, const GemmAlt ph) {
     if (stopped(a.stop_after, a.t)) return;
     constexpr int BK = 32, LD = 36;
     constexpr int AR = BM / 32, BR = BN / 32;     // float4 staging loads per thread
@@ -52,7 +56,7 @@ static __device__ __forceinline__ void conv_gemm_f32_body(const GemmArgs& a) {
     const int tm = first_m + (id % width) % gsz, tn = (id % width) / gsz;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    for (int i = tid; i < BM * a.ntaps; i += 256) {
+    for (int i = tid; i < BM * ph.ntaps; i += 256) {
         const int tap = i / BM, m = m0 + (i - tap * BM);
         int src = -1;
         if (m < a.M) {
@@ -69,7 +73,7 @@ static __device__ __forceinline__ void conv_gemm_f32_body(const GemmArgs& a) {
     __syncthreads();
 
     const int lrow = tid >> 3, kq = tid & 7;
-    const int kpt = a.kc / BK, nk_all = a.ntaps * kpt;
+    const int kpt = a.kc / BK, nk_all = ph.ntaps * kpt;
     const int ksplit = a.ksplit > 1 ? a.ksplit : 1, split = blockIdx.y;
     const int ks0 = split * nk_all / ksplit, nk = (split + 1) * nk_all / ksplit - ks0;
     // Software pipeline, prefetch distance 2: while tile s is multiplied out of LDS buffer s&1, tile s+1
@@ -89,7 +93,7 @@ static __device__ __forceinline__ void conv_gemm_f32_body(const GemmArgs& a) {
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i)
-            rb[i] = *(const f32x4*)(a.Wt + (size_t)(n0 + lrow + 32 * i) * a.ldw + tap * a.kc + ko);
+            rb[i] = *(const f32x4*)(ph.Wt + (size_t)(n0 + lrow + 32 * i) * ph.ldw + tap * a.kc + ko);
     };
     auto store_lds = [&](int buf, const f32x4 (&ra)[AR], const f32x4 (&rb)[BR]) {
 #pragma unroll
@@ -151,7 +155,7 @@ static __device__ __forceinline__ void conv_gemm_f32_body(const GemmArgs& a) {
         for (int jn = 0; jn < TN; ++jn) {
             const int col = n0 + wc * (BN / 2) + jn * 32 + r32;
             const float bv = split == 0 ? a.bias[col] : 0.f;
-            float* Hs = a.H + (size_t)split * a.split_stride;
+            float* Hs = ph.H + (size_t)split * a.split_stride;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
@@ -161,13 +165,22 @@ static __device__ __forceinline__ void conv_gemm_f32_body(const GemmArgs& a) {
 }
 
 template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void conv_gemm_f32(GemmArgs a) { conv_gemm_f32_body<BM, BN>(a); }
+__global__ __launch_bounds__(256, 2) void conv_gemm_f32(GemmArgs a) { conv_gemm_f32_body<BM, BN>(a, gemm_alt(a)); }
 // Two contractions over the same rows in ONE launch (grid.z picks): the even- and odd-phase halves of a transposed
 // convolution (modules.py:209-258) are each too small to fill the chip, and each launch has a fixed ~5 us floor.
-template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void conv_gemm_f32_pair(GemmArgs a0, GemmArgs a1) {
-    if (blockIdx.z == 0) conv_gemm_f32_body<BM, BN>(a0); else conv_gemm_f32_body<BM, BN>(a1);
+// (The second contraction travels as the handful of fields in which it differs: two whole GemmArgs were 336 bytes of kernel arguments,
+// and a launch whose arguments exceed 256 bytes measured several us slower -- see HcFusedArgs in oph_internal.h.)
+struct GemmPairArgs {
+    GemmArgs a;                                                   // phase 0
+    const float* Wt2; const void* Wh2; const void* Wl2; float* H2;      // phase 1: its kernel (fp32 / planes) and its raw rows ...
+    int ldw2, ntaps2;                                             // ... their row stride and tap count (off[0] is shared)
+};
+static_assert(sizeof(GemmPairArgs) <= 256, "kernel arguments: four 64-byte lines");
+__device__ __forceinline__ GemmAlt pair_phase(const GemmPairArgs& p) {
+    return blockIdx.z != 0 ? GemmAlt{p.Wt2, p.Wh2, p.Wl2, p.H2, p.ldw2, p.ntaps2} : gemm_alt(p.a);
 }
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_f32_pair(GemmPairArgs p) { conv_gemm_f32_body<BM, BN>(p.a, pair_phase(p)); }
 
 int conv_gemm_tile_m(int M, int N) {
     const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
@@ -242,7 +255,7 @@ static __device__ __forceinline__ f32x16 mfma16(const V8& x, const V8& y, const 
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
 }
 template <int BM, int BN, bool TAB, bool F16>      // TAB: table-mapped rows (decoder cone); a separate instance so that the dense one carries no row table.  F16: fp16 terms instead of bf16
-static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) {
+static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a, const GemmAlt ph) {
     typedef typename SplitT<F16>::T H16;
     typedef H16 h16x8 __attribute__((ext_vector_type(8)));
     if (stopped(a.stop_after, a.t)) return;
@@ -288,17 +301,17 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap) {
                 srow[tap][i] = -1;
-                if (m < a.M && tap < a.ntaps) {
+                if (m < a.M && tap < ph.ntaps) {
                     const int ip = m / a.Bpad, b = m - ip * a.Bpad;
                     if (a.j >= a.need[tap * a.n_out + ip]) srow[tap][i] = a.tab[tap * a.n_out + ip] * a.Bpad + b;
                 }
             }
         }
     }
-    const int kpt = a.kc / BK, nk_all = a.ntaps * kpt;
+    const int kpt = a.kc / BK, nk_all = ph.ntaps * kpt;
     const int ksplit = a.ksplit > 1 ? a.ksplit : 1, split = blockIdx.y;
     const int ks0 = split * nk_all / ksplit, nk = (split + 1) * nk_all / ksplit - ks0;
-    const H16* Wh = (const H16*)a.Wh; const H16* Wl = (const H16*)a.Wl;
+    const H16* Wh = (const H16*)ph.Wh; const H16* Wl = (const H16*)ph.Wl;
     const int nprod = a.nprod > 0 ? a.nprod : 3;
     f32x4 ra0[AR], ra1[AR];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -309,7 +322,7 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
 #pragma unroll
         for (int q = 0; q < NDMA; ++q) {
             const int id = q * 256 + tid, row = id >> 2, pos = id & 3;
-            const size_t o = (size_t)(n0 + row) * a.ldw + tap * a.kc + kb + ((pos ^ ((row >> 2) & 3)) << 3);
+            const size_t o = (size_t)(n0 + row) * ph.ldw + tap * a.kc + kb + ((pos ^ ((row >> 2) & 3)) << 3);
             const int base = slot * BN * LDH + (q * 256 + w * 64) * 8;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wh + o),
                                              (__attribute__((address_space(3))) void*)(Bh + base), 16, 0, 0);
@@ -430,7 +443,7 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
         for (int jn = 0; jn < TN; ++jn) {
             const int col = n0 + wc * (BN / 2) + jn * 32 + r32;
             const float bv = split == 0 ? a.bias[col] : 0.f;
-            float* Hs = a.H + (size_t)split * a.split_stride;
+            float* Hs = ph.H + (size_t)split * a.split_stride;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
@@ -440,13 +453,11 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a) 
 }
 
 template <int BM, int BN, bool F16>
-__global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3(GemmArgs a) { conv_gemm_bf16x3_body<BM, BN, false, F16>(a); }
+__global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3(GemmArgs a) { conv_gemm_bf16x3_body<BM, BN, false, F16>(a, gemm_alt(a)); }
 template <int BM, int BN, bool F16>
-__global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3_tab(GemmArgs a) { conv_gemm_bf16x3_body<BM, BN, true, F16>(a); }
+__global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3_tab(GemmArgs a) { conv_gemm_bf16x3_body<BM, BN, true, F16>(a, gemm_alt(a)); }
 template <int BM, int BN, bool F16>
-__global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3_pair(GemmArgs a0, GemmArgs a1) {
-    if (blockIdx.z == 0) conv_gemm_bf16x3_body<BM, BN, false, F16>(a0); else conv_gemm_bf16x3_body<BM, BN, false, F16>(a1);
-}
+__global__ __launch_bounds__(256, 2) void conv_gemm_bf16x3_pair(GemmPairArgs p) { conv_gemm_bf16x3_body<BM, BN, false, F16>(p.a, pair_phase(p)); }
 template <int BM, int BN>
 static void launch_conv_gemm_pair_t(const GemmArgs& a0, const GemmArgs& a1, int prec, hipStream_t s) {
     static bool attr_set[3][64] = {{false}};
@@ -460,9 +471,11 @@ static void launch_conv_gemm_pair_t(const GemmArgs& a0, const GemmArgs& a1, int 
         attr_set[prec][dev & 63] = true;
     }
     const int MT = (a0.M + BM - 1) / BM, NT = (a0.N + BN - 1) / BN;
-    if (prec == 2) hipLaunchKernelGGL((conv_gemm_bf16x3_pair<BM, BN, true>), dim3(MT * NT, 1, 2), dim3(256), lds, s, a0, a1);
-    else if (prec) hipLaunchKernelGGL((conv_gemm_bf16x3_pair<BM, BN, false>), dim3(MT * NT, 1, 2), dim3(256), lds, s, a0, a1);
-    else hipLaunchKernelGGL((conv_gemm_f32_pair<BM, BN>), dim3(MT * NT, 1, 2), dim3(256), lds, s, a0, a1);
+    GemmPairArgs p{};
+    p.a = a0; p.Wt2 = a1.Wt; p.Wh2 = a1.Wh; p.Wl2 = a1.Wl; p.H2 = a1.H; p.ldw2 = a1.ldw; p.ntaps2 = a1.ntaps;      // (everything else is shared: same rows, N, kc, off[0], stop word)
+    if (prec == 2) hipLaunchKernelGGL((conv_gemm_bf16x3_pair<BM, BN, true>), dim3(MT * NT, 1, 2), dim3(256), lds, s, p);
+    else if (prec) hipLaunchKernelGGL((conv_gemm_bf16x3_pair<BM, BN, false>), dim3(MT * NT, 1, 2), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((conv_gemm_f32_pair<BM, BN>), dim3(MT * NT, 1, 2), dim3(256), lds, s, p);
 }
 // same M and N, no split-K; prec: 0 fp32 MFMA, 1 split-bf16 x3, 2 split-fp16 x3 (both need Wh / Wl in that format)
 void launch_conv_gemm_pair(const GemmArgs& a0, const GemmArgs& a1, int prec, hipStream_t s) {
@@ -1297,7 +1310,7 @@ __global__ __launch_bounds__(1024) void cone_head(ConeHeadArgs a) {
     int pos_b;                              // position index this workgroup's rows belong to (one position: Bpad % 16 == 0)
     // i_new < 0: every position's Q . Wq row is already cached (dec_loop's attention layer emits it): no special workgroups
     const int nb_new = a.i_new >= 0 ? a.B : 0;
-    const int RB = blockDim.x >> 6;          // rows per workgroup: 16, or 4 when no workgroup has a Q . Wq row to compute (quicker to start)
+    const int RB = a.rb;                     // rows per workgroup: 16, or 4 when no workgroup has a Q . Wq row to compute (quicker to start)
     if (newest) pos_b = a.i_new;
     else { pos_b = ((int)blockIdx.x - nb_new) * RB / a.Bpad; if (a.i_new >= 0 && pos_b >= a.i_new) ++pos_b; }
     if (a.wait_sig) {
@@ -1378,9 +1391,11 @@ __global__ __launch_bounds__(1024) void cone_head(ConeHeadArgs a) {
     }
 }
 void launch_cone_head(const ConeHeadArgs& a, hipStream_t s) {
-    if (a.i_new < 0) { hipLaunchKernelGGL(cone_head, dim3((a.npos * a.Bpad + 3) / 4), dim3(256), 0, s, a); return; }
+    ConeHeadArgs c = a;
+    if (a.i_new < 0) { c.rb = 4; hipLaunchKernelGGL(cone_head, dim3((a.npos * a.Bpad + 3) / 4), dim3(256), 0, s, c); return; }
     const int others = (a.npos - 1) * a.Bpad;
-    hipLaunchKernelGGL(cone_head, dim3(a.B + (others + 15) / 16), dim3(1024), 0, s, a);
+    c.rb = 16;
+    hipLaunchKernelGGL(cone_head, dim3(a.B + (others + 15) / 16), dim3(1024), 0, s, c);
 }
 
 void launch_attn_rows(const AttnRowsArgs& a, hipStream_t s) {
@@ -1661,8 +1676,8 @@ void launch_row_chain(const RowChainArgs& a, hipStream_t s) {
 }
 
 // embed_rows: modules.py:15-44 (row 0 replaced by zeros at lookup time); pads to ldo with zeros
-__global__ void embed_rows(const int* ids, long long n, const float* table, int units, float* out, int ldo) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void embed_rows(const int* ids, long long n, const float* table, int units, float* out, int ldo) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const int per = ldo / 4;
     if (i >= n * per) return;
     const long long row = i / per;
@@ -1681,8 +1696,8 @@ void launch_embed(const int* ids, long long n, const float* table, int units, fl
 
 // spk_append_rows: out[row][col0 : col0+dim) = table[ids[row / T]] (row 0 of the table reads as zeros, modules.py:38-40)
 // -- tf.tile(speaker_codes, [1, T]) -> embed -> concat on the channel axis (networks.py:139-144)
-__global__ void spk_append_rows_k(float* out, int ldo, long long rows, int T, int col0, const float* table, const int* ids, int dim) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void spk_append_rows_k(float* out, int ldo, long long rows, int T, int col0, const float* table, const int* ids, int dim) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= rows * dim) return;
     const long long row = i / dim;
     const int c = (int)(i - row * dim);
@@ -1695,8 +1710,8 @@ void launch_spk_append_rows(float* out, int ldo, long long rows, int T, int col0
 }
 
 // pad_rows: dst[r][0:ldd) = src[r][0:C) then zeros
-__global__ void pad_rows_k(const float* src, int lds_, float* dst, int ldd, long long rows, int C) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void pad_rows_k(const float* src, int lds_, float* dst, int ldd, long long rows, int C) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= rows * ldd) return;
     const long long r = i / ldd;
     const int c = (int)(i - r * ldd);
@@ -1718,8 +1733,8 @@ void launch_pad_rows(const float* src, int lds_, float* dst, int ldd, long long 
     hipLaunchKernelGGL(pad_rows_k, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, lds_, dst, ldd, rows, C);
 }
 
-__global__ void fill_int_k(int* p, int v, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void fill_int_k(int* p, int v, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;
 }
 void launch_fill_int(int* p, int v, int n, hipStream_t s) {

@@ -1,5 +1,5 @@
-"""conv1d_transpose (SSRN D_4 / D_7) timing through oph_bench_conv1d_transpose: fp32-operand MFMA, split-bf16 (two launches) and
-split-fp16 (convt_fused: one launch)."""
+"""conv1d_transpose (SSRN D_4 / D_7) timing through oph_bench_conv1d_transpose: fp32-operand MFMA (prec 0), split-bf16 (1) and split-fp16 (2):
+even- and odd-phase contractions in one launch + LayerNorm rows."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -235,11 +235,15 @@ def test_weights_from_a_device_buffer_equal_weights_set_one_by_one():
     """oph_set_weights_device (the multi-GPU start-up path: the RCCL receive buffer consumed in place, repacked by device kernels)
     against oph_set_weight per variable: the same packed weights, hence bitwise the same outputs -- on the single-speaker config and
     on the multispeaker one (lookup tables, speaker concat)."""
-    import torch
+    import ctypes
     from oracle import ophelia_oracle as O
     from ophelia_amd.engine import Engine
     from ophelia_amd import weights as WT
     from conftest import hp_from_snapshot
+    hip = ctypes.CDLL("libamdhip64.so")          # a plain device allocation (no torch: its lazy CUDA init is not this test's subject)
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
     for cfg, over in (("lj_tutorial.cfg", dict(max_N=40, max_T=30)), ("vctk_01.cfg", dict(max_N=30, max_T=20))):
         hp = hp_from_snapshot(cfg, **over)
         ms = bool(getattr(hp, "multispeaker", []))
@@ -248,10 +252,12 @@ def test_weights_from_a_device_buffer_equal_weights_set_one_by_one():
         W = WT.random_weights(inv, seed=9)
         a.load_weights(W)
         b = Engine(hp, device=0)
-        flat = torch.from_numpy(WT.flatten(W, inv)).cuda()
-        torch.cuda.synchronize()
-        b.load_weights_device(flat.data_ptr(), flat.numel())
-        del flat
+        flat = np.ascontiguousarray(WT.flatten(W, inv), np.float32)
+        dptr = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(dptr), flat.nbytes) == 0
+        assert hip.hipMemcpy(dptr, flat.ctypes.data, flat.nbytes, 1) == 0          # hipMemcpyHostToDevice (synchronous)
+        b.load_weights_device(dptr.value, flat.size)
+        assert hip.hipFree(dptr) == 0              # the library has repacked the weights into its own memory
         L = O.random_text(hp, 5, 3, min_len=8, max_len=over["max_N"] - 2)
         ends = O.get_text_lengths(L)
         spk = np.array([[3], [1], [7], [2], [5]], np.int32) if ms else None
