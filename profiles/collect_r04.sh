@@ -4,13 +4,13 @@
 # Raw outputs go under gpurun_out/r04/ (scratch); profiles/summarize_r04.py condenses them into profiles/r04_*.
 #  A  kernel trace of the DEFAULT bench command.  rocprofv3's kernel filter (--kernel-include-regex) applies to counter collection
 #     only, so every dispatch is traced, and tracing the ~1900 cone dispatches per batch delays the cone the loop kernel waits
-#     for: the traced run is slower than the un-traced one (D).  What must agree is the rocprofv3 average of dec_loop and the
+#     for: the traced run is slower than the un-traced one (D).  What must agree is the rocprofv3 average of dec_chain and the
 #     roofline.avg_launch_us (HIP events) of the bench line THIS traced run prints (bench_traced.json).
 #  A2 the same with the cone as one persistent launch (OPH_CONE_LOOP=1): two dispatches per decode, nothing for the tracer to
-#     delay -- rocprofv3's dec_loop average, the HIP events of that run and its un-traced twin all agree (the method check).
+#     delay -- rocprofv3's dec_chain average, the HIP events of that run and its un-traced twin all agree (the method check).
 #  B  kernel trace of every kernel (sequential batches, 5 steps): per-kernel durations of the cone / SSRN / TextEnc kernels.
 #  C  counter passes.  They serialise dispatches across queues, so the whole-decode launch runs without its side stream
-#     there (OPH_BENCH_PMC=1 -> OPH_LOOP_DBG=32: its own reads and writes are unchanged) -> dec_loop's FETCH / WRITE;
+#     there (OPH_BENCH_PMC=1 -> OPH_LOOP_ALONE=1: its own reads and writes are unchanged) -> dec_chain's FETCH / WRITE;
 #     the cone's and the batched nets' kernels are counted in OPH_DECODE=runs passes (two launches per step + the cone's
 #     launches, chained by events the profiler understands): FETCH_SIZE, WRITE_SIZE (separate passes) and the SQ busy / stall
 #     counters.
