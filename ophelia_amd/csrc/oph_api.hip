@@ -426,6 +426,9 @@ int oph_run_host(oph_handle* h, int stop_mode, float* K, float* V, float* Y, int
     int rc = set_pipelined(h, false);
     if (rc) return rc;
     const oph_dims& m = h->dm;
+    using clk = std::chrono::steady_clock;
+    const clk::time_point tp0 = clk::now();
+    clk::time_point tp1 = tp0, tp2 = tp0, tp3 = tp0;
     g_cur = h->stream;
     if ((rc = advance_text(h))) return rc;
     begin_batch(h);
@@ -446,7 +449,9 @@ int oph_run_host(oph_handle* h, int stop_mode, float* K, float* V, float* Y, int
     const bool spec_saved = h->spec_ssrn;
     h->spec_ssrn = Z != nullptr;
     h->z_host = Z;
+    tp1 = clk::now();
     rc = decode_batch(h, m.max_T, stop_mode, steps_run);
+    tp2 = clk::now();
     h->want_preenc = false; h->spec_ssrn = spec_saved;
     if (rc) { h->z_host = nullptr; return rc; }
     h->y_resident = true;
@@ -459,9 +464,14 @@ int oph_run_host(oph_handle* h, int stop_mode, float* K, float* V, float* Y, int
     if (Z) rc = finish_ssrn(h);
     h->z_host = nullptr;
     if (rc) return rc;
+    tp3 = clk::now();
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipStreamSynchronize(h->sssrn));
     HIPCHK(h, hipStreamSynchronize(h->scopy));
+    if (g_trace) {
+        auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        TRACE("run_host: text / K,V %.3f ms, decode_batch %.3f ms, finish_ssrn enqueue %.3f ms, final syncs %.3f ms", ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3), ms(tp3, clk::now()));
+    }
     return OPH_OK;
 }
 
