@@ -64,6 +64,11 @@ static __device__ __forceinline__ f32x4 ld_sc1_b128(const float* base, unsigned 
     const i32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16 /* sc1 */);
     return __builtin_bit_cast(f32x4, v);
 }
+// ... and the matching 16-byte write-through store (one request per lane; consecutive lanes fill whole cache lines)
+static __device__ __forceinline__ void st_sc1_b128(float* base, unsigned byte_off, const f32x4& v) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_, v), r, (int)byte_off, 0, 16 /* sc1 */);
+}
 static __device__ __forceinline__ bool stopped(const int* stop_after, int t) {
     return stop_after != nullptr && t > *stop_after;
 }

@@ -199,27 +199,38 @@ __global__ __launch_bounds__(512) void hc_fused(HcFusedArgs a) {
         for (int e = 0; e < 16; ++e) { const float dl = acc[e] - pm[e]; pq[e] = row16(dl * dl); }
 #pragma unroll
         for (int e = 0; e < 16; ++e) pq[e] += __shfl_xor(pq[e], 16);
-        // publish: granule ((tm, wr, half wc), row, tile jt, {mean, M2}), one lane per row
+        // publish: region (tm, wr, half wc) = [tile jt][row 0..31][{mean, M2}] granules -- a tile's 32 rows are 512 contiguous bytes, written
+        // by ONE store instruction (lane (r32, kh) holds row r32 when kh == (r32 >> 2) & 1, in accumulator slot (r32 & 3) + 4 (r32 >> 3)):
+        // whole cache lines per writer.  (Laid out [row][tile] every 128-byte line collected eight 16-byte partial write-throughs
+        // from eight CUs.)
         u64_t* const sg = a.stats + ((((size_t)tm * 2 + wr) * 2 + wc) * 32) * (HF_NT * 2);
         const u64_t tag = (u64_t)a.epoch << 32;
+        {
+            const int esel = (r32 & 3) + 4 * (r32 >> 3);
+            float mv = pm[0], qv = pq[0];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = (e & 3) + 8 * (e >> 2) + 4 * kh;          // row within the wave's 32
-            if (r32 == (e & 15)) {                                     // (any one lane of the 32: the stores are spread over the lanes)
-                __hip_atomic_store(sg + ((size_t)row * HF_NT + jt) * 2, tag | (u64_t)__float_as_uint(pm[e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(sg + ((size_t)row * HF_NT + jt) * 2 + 1, tag | (u64_t)__float_as_uint(pq[e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int e = 1; e < 16; ++e) { mv = esel == e ? pm[e] : mv; qv = esel == e ? pq[e] : qv; }
+            if (kh == ((r32 >> 2) & 1)) {
+                f32x4 g;
+                g[0] = mv; g[1] = __uint_as_float(a.epoch); g[2] = qv; g[3] = __uint_as_float(a.epoch);
+                st_sc1_b128((float*)sg, (unsigned)((jt * 32 + r32) * 16), g);
             }
         }
         if (dbg) dbg[2] = wall_clock64();
-        // gather: lane l reads row (l >> 1), tiles 4 (l & 1) .. +3, both values = 8 consecutive granules; re-read until all carry the epoch
+        // gather: lane l reads row (l >> 1) of tiles 4 (l & 1) .. +3 (16 bytes each); re-read until all carry the epoch
         {
-            const u64_t* gp = sg + (size_t)lane * 8;
+            const float* gbase = (const float*)sg;
+            const unsigned goff = (unsigned)((((lane & 1) * 4) * 32 + (lane >> 1)) * 16);
             float gm[4], gq[4];
             long long t0 = 0;
             for (int it = 0;; ++it) {
                 u64_t gv[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) gv[i] = __hip_atomic_load(gp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 g = ld_sc1_b128(gbase, goff + (unsigned)i * 32 * 16);
+                    gv[2 * i] = ((u64_t)__float_as_uint(g[1]) << 32) | __float_as_uint(g[0]);
+                    gv[2 * i + 1] = ((u64_t)__float_as_uint(g[3]) << 32) | __float_as_uint(g[2]);
+                }
                 bool ok = true;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) ok = ok && (unsigned)(gv[i] >> 32) == a.epoch;
