@@ -215,7 +215,8 @@ def synthesize(hp, speaker_id="", num_sentences=0, ncores=1, topoutdir="", t2m_e
                weights=None, device=None):
     """topoutdir: store samples under here; defaults to hp.sampledir.
     t2m_epoch / ssrn_epoch: -1 = latest, else archived epoch.
-    weights: optional {TF name: array} bypassing the checkpoint lookup (tests / random-init runs)."""
+    weights: optional {TF name: array} -- or a function of the variable inventory returning one -- bypassing the checkpoint lookup
+    (tests / random-init runs)."""
     assert hp.vocoder in ["griffin_lim", "world"], "Other vocoders than griffin_lim/world not yet supported"
     _check_scope(hp)
     dist = parallel._dist()
@@ -255,6 +256,8 @@ def synthesize(hp, speaker_id="", num_sentences=0, ncores=1, topoutdir="", t2m_e
 
     with Session(hp, device=device) as sess:
         if weights is not None:
+            if callable(weights):          # weights as a function of the variable inventory (random-init runs: no probe engine needed)
+                weights = weights(sess.inventory()) if rank == 0 or world == 1 else None
             if world > 1:
                 weights = parallel.broadcast_weights(weights if rank == 0 else None, sess.inventory(), src=0, device=device)
             sess.assign(weights)
@@ -359,14 +362,24 @@ def main_work():
 
     weights = None
     if opts.random_init >= 0:
-        from .engine import Engine
         from . import weights as WT
-        probe = Engine(hp, device=int(os.environ.get("LOCAL_RANK", "0")))
-        weights = WT.random_weights(probe.inventory(), opts.random_init)
-        probe.close()
+        seed = opts.random_init
+        # (a function of the session's inventory rather than a probe engine of its own: one handle per process -- creating CU-masked
+        #  streams again after another handle's were destroyed is a pattern that has hung in the HIP runtime, oph_api.hip)
+        weights = lambda inventory: WT.random_weights(inventory, seed)
     synthesize(hp, speaker_id=opts.speaker, num_sentences=opts.num_sentences, ncores=opts.ncores,
                topoutdir=outdir, t2m_epoch=opts.t2m_epoch, ssrn_epoch=opts.ssrn_epoch, weights=weights)
 
 
+def _hang_dump():
+    """OPH_HANG_DUMP_S=n: if the process is still running after n seconds, every thread's Python stack goes to stderr and the
+    process exits (diagnostics for a stuck device call: the innermost frame names the ctypes call that does not return)."""
+    s = os.environ.get("OPH_HANG_DUMP_S")
+    if s:
+        import faulthandler
+        faulthandler.dump_traceback_later(float(s), exit=True)
+
+
 if __name__ == "__main__":
+    _hang_dump()
     main_work()

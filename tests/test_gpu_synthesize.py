@@ -250,7 +250,8 @@ def test_cli_on_the_ten_line_test_transcript(tmp_path):
         for k in ("topworkdir", "voicedir", "logdir", "datadir", "waveforms", "coarse_audio_dir", "full_audio_dir", "full_mel_dir", "attention_guide_dir"):
             f.write("%s = %r\n" % (k, str(tmp_path / "work" / k)))         # the paths the snapshot leaves out (machine-specific in the reference's file)
         f.write("transcript = %r\n" % str(tmp_path / "work" / "transcript.csv"))
-    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    # (OPH_HANG_DUMP_S: a run that is still going after 4 minutes -- it takes seconds -- prints its Python stacks and exits non-zero)
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), OPH_HANG_DUMP_S="240")
     res = subprocess.run([sys.executable, "-m", "ophelia_amd.synthesize", "-c", str(cfg), "-N", "10", "-odir", str(tmp_path / "out"),
                           "-random_init", "5"], env=env, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:]
