@@ -52,7 +52,7 @@ find $O -name "*.csv" | head -40
 cd $R && python profiles/summarize_r04.py
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
 tail -c 1200 $O/bench.json
-cp $O/bench.json profiles/r04_bench.json; cp $O/bench_traced.json profiles/r04_bench_traced.json; cp $O/bench_traced_coneloop.json profiles/r04_bench_traced_coneloop.json; cp $O/bench_coneloop.json profiles/r04_bench_coneloop.json
+cp $O/bench.json profiles/r04_bench.json;  cp $O/bench_traced.json profiles/r04_bench_traced.json; cp $O/bench_traced_coneloop.json profiles/r04_bench_traced_coneloop.json; cp $O/bench_coneloop.json profiles/r04_bench_coneloop.json
 mkdir -p $R/gpurun_out/r04_summary && cp profiles/r04_* $R/gpurun_out/r04_summary/
 tail -n 3 $O/traceA.log
 rm -rf $O/traceA $O/traceA2 $O/traceB $O/loop_fetch $O/loop_write $O/runs_fetch $O/runs_write $O/runs_sq $O/runs_lds

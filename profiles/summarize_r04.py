@@ -46,7 +46,8 @@ def durations(sub):
     dur = collections.defaultdict(list)
     path = find(sub, "kernel_trace.csv")
     if path:
-        for r in csv.DictReader(open(path)):
+        rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))       # dispatch order
+        for r in rows:
             dur[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     return dur
 
@@ -89,6 +90,30 @@ with open(os.path.join(dst, tag + "_sq_summary.csv"), "w") as fo:
         wr.writerow([k, n_disp] + ["%.0f" % m[n] for n in names] +
                     ["%.3f" % (m["SQ_WAIT_ANY"] / wc), "%.3f" % (m["SQ_WAIT_INST_ANY"] / wc), "%.3f" % (m["SQ_ACTIVE_INST_ANY"] / wc),
                      "%.3f" % (m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"] if m["SQ_LDS_IDX_ACTIVE"] else 0.0)])
+# the three witnesses of the whole-decode launch on the same runs: rocprofv3's kernel trace (all launches, and the launches of the
+# timed region = the last `steps` of them: the warm-up batches come first), the HIP events and the kernel's own clock of the bench
+# line that same traced run printed
+def witness(sub, line_file):
+    try:
+        line = json.loads(open(os.path.join(src, line_file)).read().strip().splitlines()[-1])
+    except Exception:
+        return None
+    d = [x for k, v in durations(sub).items() if k.startswith(("dec_chain", "dec_loop")) for x in v]
+    if not d:
+        return None
+    steps = int(line["steps"])
+    r = line["roofline"]
+    w = {"rocprofv3_all_launches": len(d), "rocprofv3_avg_us_all_launches": statistics.mean(d) / 1e3,
+         "rocprofv3_avg_us_timed_region": statistics.mean(d[-steps:]) / 1e3, "timed_launches": steps,
+         "hip_events_avg_us": r.get("avg_launch_us"), "device_clock_avg_us": r.get("device_clock_us")}
+    ref = w["rocprofv3_avg_us_timed_region"]
+    w["max_relative_spread"] = max(abs(w[k] - ref) / ref for k in ("hip_events_avg_us", "device_clock_avg_us") if w[k])
+    return w
+
+
+json.dump({"traced_default_run": witness("traceA", "bench_traced.json"), "traced_cone_as_one_launch": witness("traceA2", "bench_traced_coneloop.json"),
+           "note": "durations() keeps dispatch order per kernel; the bench's timed region is its last `steps` whole-decode launches"},
+          open(os.path.join(dst, tag + "_witness.json"), "w"), indent=1)
 command = open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else ""
 json.dump({"tag": tag, "command": command,
            "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)",
