@@ -35,3 +35,25 @@ def test_bench_two_ranks_on_one_gpu():
     assert "all ranks on one GPU" in cfg["parallelism"]
     # a rank must not need a whole host core to drive its GPU: 8 of them share a node's cores
     assert len(cfg["rank_host_cores"]) == 2 and all(0.0 < c < 0.8 for c in cfg["rank_host_cores"]), cfg["rank_host_cores"]
+
+
+def test_bench_line_survives_a_stuck_supplementary_leg():
+    """bench.py's watchdog: the timed region's numbers are final when it ends, so a leg after it that does not come back must not
+    cost the run its line.  OPH_BENCH_WATCHDOG_S = 0.2 makes the watchdog fire while the supplementary legs are still running:
+    ONE JSON line with the metric, the timed region's value, its roofline (HIP events and the kernel's own clock), marked incomplete."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["OPH_BENCH_WATCHDOG_S"] = "0.2"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-vocoder"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert "incomplete" in out and out["metric"].startswith("mel-frames/sec") and out["unit"] == "frames/s"
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["value"] > 0
+    assert abs(out["value"] - 16 * 200 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+    roof = out["roofline"]
+    assert roof["bound"] == "hbm" and 0 < roof["frac"] < 1 and roof["avg_launch_us"] > 0
+    assert abs(roof["device_clock_us"] - roof["avg_launch_us"]) < 0.02 * roof["avg_launch_us"]      # the two witnesses of the same launches
