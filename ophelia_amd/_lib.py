@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libophelia_hip.so")
-SOURCES = ["oph_kernels.hip", "oph_decrun.hip", "oph_decchain.hip", "oph_hcfused.hip", "oph_coneloop.hip",
+SOURCES = ["oph_kernels.hip", "oph_planegemm.hip", "oph_decrun.hip", "oph_decchain.hip", "oph_hcfused.hip", "oph_coneloop.hip",
            "oph_pack.hip", "oph_model.hip", "oph_nets.hip", "oph_cone.hip", "oph_decode.hip", "oph_api.hip", "oph_ops.hip"]
 
 c_i32p = C.POINTER(C.c_int32)

@@ -74,6 +74,7 @@ struct Layer {
     float *Wkn = nullptr; int ldn = 0;           // k=1 layers with N<=256: [kc][ldn] n-contiguous copy for row_chain
     void *Wh = nullptr, *Wl = nullptr, *Wh2 = nullptr, *Wl2 = nullptr;   // SSRN layers: Wt / Wt2 split into hi + lo bf16 planes (conv_gemm_bf16x3)
     void *Wh16 = nullptr, *Wl16 = nullptr, *Wh2_16 = nullptr, *Wl2_16 = nullptr;   // the same as fp16 planes (split-fp16 x3: fp32-class accuracy)
+    void *Wkh = nullptr, *Wkl = nullptr, *Wkh2 = nullptr, *Wkl2 = nullptr;         // the fp16 planes K-blocked [ntaps kc / 32][Nalloc][32] (plane_gemm)
     float* Wsw_cone = nullptr;                   // AudioDec highway layers: kernel in cone_loop's fragment order (oph_coneloop.hip)
     void *Wph = nullptr, *Wpl = nullptr; float* bias_p = nullptr;   // AudioDec highway layers: kernel as fp16 planes [2C][3 kc] with the columns
                                                                      // permuted per 64-tile to [32 H1 | the same 32 channels of H2] (hc_fused)
@@ -119,6 +120,7 @@ struct Options {
     int ssrn_chunk = 40;             // OPH_SSRN_CHUNK: mel frames per streamed SSRN chunk (0 = SSRN only after the decode)
     int cl_wgs_per_cu = 2, cl_dbg = 0;   // OPH_CL_WGS_PER_CU (cone_loop workgroups per CU: 1 or 2), OPH_CL_DBG
     bool no_fused_cone = false;      // OPH_NO_FUSED_CONE: the cone's levels as contraction + ln_rows launches instead of hc_fused
+    bool no_plane_gemm = false;      // OPH_NO_PLANE_GEMM: the batched nets' split-fp16 contractions on fp32 rows (conv_gemm_bf16x3) instead of planes (plane_gemm)
     bool no_chain = false;           // OPH_NO_CHAIN: the whole-decode launch as dec_loop (generic) even where dec_chain (specialised) fits
     void read() {
         auto flag = [](const char* n) { return getenv(n) != nullptr; };
@@ -149,7 +151,7 @@ struct Options {
         run_stamps = flag("OPH_RUN_STAMPS");
         ssrn_chunk = std::max(0, num("OPH_SSRN_CHUNK", 40));
         cl_wgs_per_cu = num("OPH_CL_WGS_PER_CU", 2) == 1 ? 1 : 2; cl_dbg = num("OPH_CL_DBG", 0);
-        no_chain = flag("OPH_NO_CHAIN"); no_fused_cone = flag("OPH_NO_FUSED_CONE");
+        no_chain = flag("OPH_NO_CHAIN"); no_fused_cone = flag("OPH_NO_FUSED_CONE"); no_plane_gemm = flag("OPH_NO_PLANE_GEMM");
     }
     int cone_ksplit(int M) const { return M >= 512 ? ksplit_big : ksplit_small; }
 };
@@ -235,6 +237,8 @@ struct oph_handle {
     float *actA = nullptr, *actB = nullptr, *raw = nullptr;   // workspace of the API stream (TextEnc, host-buffer SSRN)
     float *actA2 = nullptr, *actB2 = nullptr, *raw2 = nullptr; // workspace of the SSRN-partition stream
     size_t act_elems = 0, raw_elems = 0;
+    // the activation buffers once more as fp16 hi / lo planes, K-blocked [channel / 32][rows][32] (plane_gemm's operand): [workspace][A | B][hi | lo]
+    void* actP[2][2][2] = {{{nullptr, nullptr}, {nullptr, nullptr}}, {{nullptr, nullptr}, {nullptr, nullptr}}};
     long long* d_amax = nullptr;        // oph_text2mel_graph: argmax per (utterance, frame)
     // ---- the staged batch: nB utterances, resident in HBM, utterance-major.  Text is double-buffered so that the NEXT
     // batch can be staged (oph_stage_text_next) and pre-encoded while this one decodes.

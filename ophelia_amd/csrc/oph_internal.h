@@ -36,6 +36,28 @@ struct GemmArgs {
     const void* Wh; const void* Wl; int f16;       // f16: the planes (and the activations' split) are fp16 terms instead of bf16
     int nprod;                      // measurement only: 0 / 3 = ah.bh + ah.bl + al.bh; 2 = ah.bh + al.bh (weights hi only); 1 = ah.bh
 };
+// ---- the same contraction on operands that arrive as fp16 hi / lo planes (oph_planegemm.hip)
+constexpr int PLANE_GEMM_HALO = 16;             // activation rows loaded either side of a 128-row tile: the largest tap offset served
+struct PlaneGemmArgs {
+    const _Float16* Ah; const _Float16* Al;     // activation planes, K-blocked [kc / 32][M][32]
+    // weight planes, K-blocked like the activations: [ntaps kc / 32][Nalloc][32], tap-major (launch_kblock_planes; a tile's 128
+    // rows of one K block are 8 contiguous KB -- rows of a k-contiguous [Nalloc][ntaps kc] plane lie a power of two apart and
+    // land on one L2 channel).  Transposed conv: the even phase (taps x[t], x[t-1]) ...
+    const _Float16* Wh; const _Float16* Wl;
+    const _Float16* Wh2; const _Float16* Wl2;   // ... and the odd phase's planes [kc / 32][Nalloc][32]
+    const float* bias;
+    float* H;                                   // raw rows [M][ldh] (transposed conv: ldh = 2 Nalloc, row 2t at H + m ldh, row 2t + 1 at + Nalloc)
+    int M, N, kc, T;                            // rows, output channels, padded input channels (multiple of 32), rows per utterance
+    int nalloc, ldh;                            // rows of the weight planes; raw row stride
+    int ntaps, off[3];
+    int convt;
+    int dbg;                                    // measurement only: 1 = no MFMAs (operand stream alone), 2 = no operand stream (MFMAs on whatever the LDS holds)
+};
+void launch_plane_gemm(const PlaneGemmArgs& a, hipStream_t s);
+bool plane_gemm_ok(int ntaps, const int* off, int kc, bool convt);
+void launch_kblock_planes(const void* src, void* dst, int rows, int ld, hipStream_t s);      // 2-byte plane [rows][ld] -> [ld / 32][rows][32]
+void launch_rows_to_planes(const float* x, int ld, int M, int kc, void* ph, void* pl, hipStream_t s);
+
 void launch_conv_gemm_pair(const GemmArgs& a0, const GemmArgs& a1, int prec, hipStream_t s);   // two contractions (same M, N, no split-K) in one launch
 void launch_split_bf16(const float* w, void* hi, void* lo, size_t n, hipStream_t s);      // hi/lo planes of n floats
 void launch_split_f16(const float* w, void* hi, void* lo, size_t n, hipStream_t s);
@@ -58,7 +80,10 @@ struct EpiArgs {
     // coh1 -- the only ones the loop kernel reads as taps -- are stored write-through (8-byte sc1 stores, no fence); each
     // workgroup holding such rows waits for its stores, adds 1 to *done_count, and the one that makes it done_target
     // raises *done_sig to done_val
-    unsigned* done_sig; unsigned* done_count;
+    // planes != 0 (the batched nets: no completion signal there): the two pointers are instead the fp16 hi / lo planes the rows
+    // are ALSO written to, K-blocked [ypad / 32][M][32] -- plane_gemm's operand format for the next layer (oph_planegemm.hip)
+    union { unsigned* done_sig; void* Yh; };
+    union { unsigned* done_count; void* Yl; };
     long long* done_stamp;          // diagnostics: the raising lane stores the constant clock here (or null)
     long long split_stride;         // raw = sum of nsplit partial buffers (split-K GEMM)
     long long out_bs;
@@ -76,6 +101,7 @@ struct EpiArgs {
     int out_T; int keep_lo, keep_hi; int out_t0;
     int lcc_T;                      // utterance of row m: lcc_T > 0 ? m / lcc_T : m % Bpad
     unsigned done_val, done_target; int coh0, coh1;
+    int planes;
 };
 static_assert(sizeof(EpiArgs) <= 256, "ln_rows' kernel arguments: four 64-byte lines");
 

@@ -156,10 +156,20 @@ static __device__ __forceinline__ void conv_gemm_f32_body(const GemmArgs& a, con
             const int col = n0 + wc * (BN / 2) + jn * 32 + r32;
             const float bv = split == 0 ? a.bias[col] : 0.f;
             float* Hs = ph.H + (size_t)split * a.split_stride;
+            // (a full tile stores without per-row branches: behind a branch the compiler waits for vmcnt(0) -- the bias load, as far
+            //  as it can tell -- before EVERY store, i.e. for the previous store's acknowledgement: 64 serialised round trips per wave)
+            if (m0 + BM <= a.M) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-                if (row < a.M) Hs[(size_t)row * a.ldh + col] = acc[i][jn][e] + bv;
+                for (int e = 0; e < 16; ++e) {
+                    const int row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                    Hs[(size_t)row * a.ldh + col] = acc[i][jn][e] + bv;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                    if (row < a.M) Hs[(size_t)row * a.ldh + col] = acc[i][jn][e] + bv;
+                }
             }
         }
 }
@@ -444,10 +454,20 @@ static __device__ __forceinline__ void conv_gemm_bf16x3_body(const GemmArgs& a, 
             const int col = n0 + wc * (BN / 2) + jn * 32 + r32;
             const float bv = split == 0 ? a.bias[col] : 0.f;
             float* Hs = ph.H + (size_t)split * a.split_stride;
+            // (a full tile stores without per-row branches: behind a branch the compiler waits for vmcnt(0) -- the bias load, as far
+            //  as it can tell -- before EVERY store, i.e. for the previous store's acknowledgement: 64 serialised round trips per wave)
+            if (m0 + BM <= a.M) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-                if (row < a.M) Hs[(size_t)row * a.ldh + col] = acc[i][jn][e] + bv;
+                for (int e = 0; e < 16; ++e) {
+                    const int row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                    Hs[(size_t)row * a.ldh + col] = acc[i][jn][e] + bv;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = m0 + wr * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                    if (row < a.M) Hs[(size_t)row * a.ldh + col] = acc[i][jn][e] + bv;
+                }
             }
         }
 }
@@ -621,8 +641,31 @@ __device__ __forceinline__ void ln_rows_body(const EpiArgs& a) {
     }
     float* y = a.Y + orow * a.ldy;
     const bool vec_ok = (a.ldy & 3) == 0;
-    const int pos = a.done_sig ? m / a.Bpad : -1;
-    const bool coh = a.done_sig && (pos == a.coh0 || pos == a.coh1);      // rows a running dec_loop reads
+    if (a.planes) {
+        // the next layer's contraction reads its operand as fp16 hi / lo planes (plane_gemm, oph_planegemm.hip): the row is split
+        // here, once, instead of in that kernel's K loop once per tap; K-blocked [ypad / 32][M][32], pad channels zero
+        typedef _Float16 h16x4_ __attribute__((ext_vector_type(4)));
+        _Float16* ph = (_Float16*)a.Yh; _Float16* pl = (_Float16*)a.Yl;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (c < a.ypad) {
+                h16x4_ hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xv = c + e < C ? x[v][e] : 0.f;
+                    hi[e] = (_Float16)xv;
+                    lo[e] = (_Float16)(xv - (float)hi[e]);
+                }
+                const size_t o = ((size_t)(c >> 5) * a.M + m) * 32 + (c & 31);
+                *(h16x4_*)(ph + o) = hi;
+                *(h16x4_*)(pl + o) = lo;
+            }
+        }
+    }
+    const bool sig = !a.planes && a.done_sig;                              // (planes: the two pointers are the planes, EpiArgs)
+    const int pos = sig ? m / a.Bpad : -1;
+    const bool coh = sig && (pos == a.coh0 || pos == a.coh1);      // rows a running dec_loop reads
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const int c = (v * 64 + lane) * 4;
@@ -649,8 +692,9 @@ __device__ __forceinline__ void ln_rows_body(const EpiArgs& a) {
 template <int NV>
 __global__ __launch_bounds__(256) void ln_rows(EpiArgs a) {
     ln_rows_body<NV>(a);
-    const int pos_b = a.done_sig ? (int)(blockIdx.x * 4) / a.Bpad : -1;       // Bpad % 4 == 0: a workgroup's 4 rows share a position
-    if (a.done_sig && (pos_b == a.coh0 || pos_b == a.coh1)) {
+    const bool sig = !a.planes && a.done_sig;
+    const int pos_b = sig ? (int)(blockIdx.x * 4) / a.Bpad : -1;       // Bpad % 4 == 0: a workgroup's 4 rows share a position
+    if (sig && (pos_b == a.coh0 || pos_b == a.coh1)) {
         // this launch writes a level of a cone: once the tap rows have left (write-through stores, no fence), one lane
         // raises the word the decoder loop kernel polls for that level (instead of a signalling kernel behind the cone)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

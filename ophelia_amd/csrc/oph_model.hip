@@ -387,6 +387,18 @@ int oph_finalize_weights(oph_handle* h) {
         if (l.Wt && (!split(l.Wt, n1, false, l.Wh, l.Wl) || !split(l.Wt, n1, true, l.Wh16, l.Wl16))) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
         if (l.Wt2 && (!split(l.Wt2, n2, false, l.Wh2, l.Wl2) || !split(l.Wt2, n2, true, l.Wh2_16, l.Wl2_16))) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
     }
+    // plane_gemm reads the fp16 planes K-blocked (batched nets only: SSRN here, TextEnc below)
+    auto kblock = [&](const void* src, int rows, int ld, void*& dst) {
+        dst = h->dalloc<unsigned short>((size_t)rows * ld);
+        if (!dst) return false;
+        launch_kblock_planes(src, dst, rows, ld, h->stream);
+        return true;
+    };
+    for (Layer& l : h->ssrn) {
+        const int taps = l.kind == K_CONVT ? 2 : l.ntaps;
+        if (l.Wh16 && (!kblock(l.Wh16, l.Nalloc, taps * l.kc, l.Wkh) || !kblock(l.Wl16, l.Nalloc, taps * l.kc, l.Wkl))) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
+        if (l.Wh2_16 && (!kblock(l.Wh2_16, l.Nalloc, l.kc, l.Wkh2) || !kblock(l.Wl2_16, l.Nalloc, l.kc, l.Wkl2))) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
+    }
     // The two many-row levels of the AudioDec history cone (1312 and 704 rows x 768 x 512 per step) on the split contraction.
     // Text2Mel feeds an argmax back into itself, so only fp32-class arithmetic qualifies as its default: split-fp16 x3
     // (22 significant bits per operand; measured against the fp32 MFMA flavour in tests/test_gpu_decode_modes.py) -- the
@@ -401,7 +413,8 @@ int oph_finalize_weights(oph_handle* h) {
     // argmax, so again only the fp32-class flavour is offered (oph_set_precision(h, 2, 0) selects the fp32 MFMA)
     h->textenc_prec = h->guard_text ? 0 : (h->opt.textenc_prec >= 0 ? h->opt.textenc_prec : TEXTENC_PREC_DEFAULT);
     for (Layer& l : h->textenc)
-        if (!split(l.Wt, (size_t)l.Nalloc * l.ntaps * l.kc, true, l.Wh16, l.Wl16)) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
+        if (!split(l.Wt, (size_t)l.Nalloc * l.ntaps * l.kc, true, l.Wh16, l.Wl16) || !kblock(l.Wh16, l.Nalloc, l.ntaps * l.kc, l.Wkh) ||
+            !kblock(l.Wl16, l.Nalloc, l.ntaps * l.kc, l.Wkl)) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->cone_head_ok = !h->opt.no_cone_head && !(h->dm.flags & OPH_FLAG_NO_MONOTONIC) && h->audiodec[0].Wkn != nullptr && h->dm.d <= 256 && (h->dm.d % 4) == 0;
     if (h->cone_head_ok) {

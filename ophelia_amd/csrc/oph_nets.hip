@@ -35,10 +35,22 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
     float* const wsA = wsi ? h->actA2 : h->actA; float* const wsB = wsi ? h->actB2 : h->actB; float* const wsraw = wsi ? h->raw2 : h->raw;
     float* bufs[2] = {wsA, wsB};
     int flip = (in == wsA) ? 1 : 0;
+    // split-fp16 contractions read their activations as hi / lo planes where the previous layer's LayerNorm launch wrote them
+    // (plane_gemm, oph_planegemm.hip); a layer whose input has no planes (the first one, a speaker-embedding concat, tap offsets
+    // beyond the halo) runs conv_gemm_bf16x3 on the fp32 rows
+    const bool planes_on = prec == 2 && !h->opt.no_plane_gemm && h->actP[wsi ? 1 : 0][0][0];
+    auto wants_planes = [&](const Layer& l) {
+        if (!planes_on || l.ccat > 0 || !l.Wkh || !l.Wkl) return false;
+        if (l.kind == K_CONVT) return l.Wkh2 && l.Wkl2 && plane_gemm_ok(2, nullptr, l.kc, true);
+        return plane_gemm_ok(l.ntaps, l.off, l.kc, false);
+    };
+    const _Float16 *xh = nullptr, *xl = nullptr;      // planes of x (the current layer's input), if any
     for (size_t li = 0; li < layers.size(); ++li) {
         const Layer& l = layers[li];
         const bool last = li + 1 == layers.size();
         const int M = B * Tcur;
+        const bool use_planes = xh && wants_planes(l);
+        const bool write_planes = !last && wants_planes(layers[li + 1]);
         float* y = (last && final_out) ? final_out : bufs[flip];
         const int cout_pad = round_up(l.cout, 32);
         const int ldy = (last && final_out) ? final_ld : cout_pad;
@@ -65,7 +77,15 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
             g.Wt = l.Wt; g.Wh = f16 ? l.Wh16 : l.Wh; g.Wl = f16 ? l.Wl16 : l.Wl; g.f16 = f16; g.ldw = 2 * l.kc; g.ntaps = 2; g.off[0] = 0; g.off[1] = -1;
             GemmArgs g2 = g;
             g2.Wt = l.Wt2; g2.Wh = f16 ? l.Wh2_16 : l.Wh2; g2.Wl = f16 ? l.Wl2_16 : l.Wl2; g2.ldw = l.kc; g2.ntaps = 1; g2.off[0] = 0; g2.H = wsraw + l.Nalloc;
-            {   // both phases in one launch
+            if (use_planes) {    // both phases as one problem on the planes
+                PlaneGemmArgs pg{};
+                pg.Ah = xh; pg.Al = xl; pg.Wh = (const _Float16*)l.Wkh; pg.Wl = (const _Float16*)l.Wkl; pg.Wh2 = (const _Float16*)l.Wkh2; pg.Wl2 = (const _Float16*)l.Wkl2;
+                pg.bias = l.bias; pg.H = wsraw; pg.M = M; pg.N = l.N; pg.kc = l.kc; pg.T = Tcur; pg.nalloc = l.Nalloc; pg.ldh = 2 * l.Nalloc;
+                pg.ntaps = 2; pg.off[0] = 0; pg.off[1] = -1; pg.convt = 1;
+                h->pbegin(PC_GEMM_BF16);
+                launch_plane_gemm(pg, g_cur);
+                h->pend(PC_GEMM_BF16, ((double)g.M * l.cin + 2.0 * g.M * g.N + 3.0 * g.N * l.cin) * 4.0, 2.0 * g.M * g.N * 3.0 * l.cin);
+            } else {   // both phases in one launch
                 const int p2 = (prec && g.Wh && g2.Wh) ? std::min(prec, 2) : 0;
                 const int cls = p2 ? PC_GEMM_BF16 : (conv_gemm_tile_m(g.M, g.N) == 128 ? PC_GEMM : PC_GEMM64);
                 h->pbegin(cls);
@@ -74,16 +94,29 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
             }
             Tcur *= 2;
             e.ldh = l.Nalloc; e.M = B * Tcur; e.C = l.cout; e.mode = PRE_CONV; e.act = ACT_NONE;
+            if (write_planes) { e.planes = 1; e.Yh = h->actP[wsi ? 1 : 0][flip][0]; e.Yl = h->actP[wsi ? 1 : 0][flip][1]; }
             run_epi(h, e);
         } else {
             const bool f16 = prec >= 2;
             g.nprod = prec == 3 ? 2 : (prec == 4 ? 1 : 3);
             g.N = l.N; g.ldh = l.Nalloc; g.M = M; g.Wt = l.Wt; g.Wh = f16 ? l.Wh16 : l.Wh; g.Wl = f16 ? l.Wl16 : l.Wl; g.f16 = f16; g.ldw = l.ntaps * l.kc; g.ntaps = l.ntaps;
             for (int t = 0; t < 3; ++t) g.off[t] = l.off[t];
-            run_gemm(h, g, l.cin, g.Wh ? std::min(prec, 2) : 0);
+            if (use_planes) {
+                PlaneGemmArgs pg{};
+                pg.Ah = xh; pg.Al = xl; pg.Wh = (const _Float16*)l.Wkh; pg.Wl = (const _Float16*)l.Wkl;
+                pg.bias = l.bias; pg.H = wsraw; pg.M = M; pg.N = l.N; pg.kc = l.kc; pg.T = Tcur; pg.nalloc = l.Nalloc; pg.ldh = l.Nalloc;
+                pg.ntaps = l.ntaps;
+                for (int t = 0; t < 3; ++t) pg.off[t] = l.off[t];
+                h->pbegin(PC_GEMM_BF16);
+                launch_plane_gemm(pg, g_cur);
+                const double K = (double)l.ntaps * l.cin;
+                h->pend(PC_GEMM_BF16, ((double)M * l.cin + (double)M * l.N + (double)l.N * K) * 4.0, 2.0 * M * l.N * K);
+            } else
+                run_gemm(h, g, l.cin, g.Wh ? std::min(prec, 2) : 0);
             e.ldh = l.Nalloc; e.M = M; e.C = l.cout;
             if (l.kind == K_HC) { e.mode = PRE_HC; e.Xres = x; e.ldres = ldx; }
             else e.mode = PRE_CONV;
+            if (write_planes) { e.planes = 1; e.Yh = h->actP[wsi ? 1 : 0][flip][0]; e.Yl = h->actP[wsi ? 1 : 0][flip][1]; }
             run_epi(h, e);
             if (last && io.final_logits && l.kind == K_CONV) {      // the fetch surface's g.Z_logits / g.Y_logits: the same rows before the squash
                 EpiArgs el = e;
@@ -92,6 +125,7 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
             }
         }
         x = y; ldx = e.ldy;
+        xh = write_planes ? (const _Float16*)e.Yh : nullptr; xl = write_planes ? (const _Float16*)e.Yl : nullptr;
         flip ^= 1;
     }
     if (out_ld) *out_ld = ldx;
@@ -114,6 +148,10 @@ int ensure_batched_capacity(oph_handle* h, int B) {
     h->actA2 = h->dalloc<float>(h->act_elems);
     h->actB2 = h->dalloc<float>(h->act_elems);
     h->raw2 = h->dalloc<float>(h->raw_elems);
+    for (int w_ = 0; w_ < 2; ++w_) for (int b_ = 0; b_ < 2; ++b_) for (int p_ = 0; p_ < 2; ++p_) {
+        h->actP[w_][b_][p_] = h->dalloc<unsigned short>(h->act_elems);
+        if (!h->actP[w_][b_][p_]) { h->fail("out of device memory for batch %d", B); return OPH_ERR_DEVICE; }
+    }
     if (!h->actA || !h->actB || !h->raw || !h->actA2 || !h->actB2 || !h->raw2) { h->fail("out of device memory for batch %d", B); return OPH_ERR_DEVICE; }
     h->capB = B;
     return 0;

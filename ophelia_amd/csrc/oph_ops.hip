@@ -167,7 +167,22 @@ int oph_op_conv1d_transpose_prec(int device, const float* x, int B, int T, int C
         else { launch_split_bf16(dwe, dweh, dwel, we.size(), c.s); launch_split_bf16(dwo, dwoh, dwol, wo.size(), c.s); }
         g.Wh = dweh; g.Wl = dwel; g.f16 = precision == 2; g.nprod = 3;
         g2.Wh = dwoh; g2.Wl = dwol; g2.f16 = g.f16; g2.nprod = 3;
-        launch_conv_gemm_pair(g, g2, precision, c.s);
+        if (precision == 2) {       // split-fp16: the input as hi / lo planes (what the previous layer's LayerNorm launch writes in SSRN), both phases as one problem
+            unsigned short* dxh = c.alloc<unsigned short>((size_t)M * kc); unsigned short* dxl = c.alloc<unsigned short>((size_t)M * kc);
+            if (!c.ok) return OPH_ERR_DEVICE;
+            launch_rows_to_planes(dxp, kc, M, kc, dxh, dxl, c.s);
+            unsigned short* kweh = c.alloc<unsigned short>(we.size()); unsigned short* kwel = c.alloc<unsigned short>(we.size());
+            unsigned short* kwoh = c.alloc<unsigned short>(wo.size()); unsigned short* kwol = c.alloc<unsigned short>(wo.size());
+            if (!c.ok) return OPH_ERR_DEVICE;
+            launch_kblock_planes(dweh, kweh, Nalloc, 2 * kc, c.s); launch_kblock_planes(dwel, kwel, Nalloc, 2 * kc, c.s);
+            launch_kblock_planes(dwoh, kwoh, Nalloc, kc, c.s); launch_kblock_planes(dwol, kwol, Nalloc, kc, c.s);
+            PlaneGemmArgs pg{};
+            pg.Ah = (const _Float16*)dxh; pg.Al = (const _Float16*)dxl; pg.Wh = (const _Float16*)kweh; pg.Wl = (const _Float16*)kwel;
+            pg.Wh2 = (const _Float16*)kwoh; pg.Wl2 = (const _Float16*)kwol; pg.bias = dbias; pg.H = dh; pg.M = M; pg.N = Cout; pg.kc = kc; pg.T = T;
+            pg.nalloc = Nalloc; pg.ldh = 2 * Nalloc; pg.ntaps = 2; pg.off[0] = 0; pg.off[1] = -1; pg.convt = 1;
+            launch_plane_gemm(pg, c.s);
+        } else
+            launch_conv_gemm_pair(g, g2, precision, c.s);
     }
     EpiArgs e{};
     e.H = dh; e.ldh = Nalloc; e.M = 2 * M; e.C = Cout; e.mode = PRE_CONV; e.act = ACT_NONE; e.g1 = dg; e.b1 = db; e.Y = dy; e.ldy = Cout; e.ypad = Cout;
@@ -207,10 +222,42 @@ int oph_bench_conv1d_transpose(int device, int B, int T, int Cin, int Cout, int 
     if (!c.ok) return OPH_ERR_DEVICE;
     if (precision >= 2) { launch_split_f16(dwe, dweh, dwel, we.size(), c.s); launch_split_f16(dwo, dwoh, dwol, wo.size(), c.s); }
     else { launch_split_bf16(dwe, dweh, dwel, we.size(), c.s); launch_split_bf16(dwo, dwoh, dwol, wo.size(), c.s); }
+    // precision 2 (the SSRN path's default): the input arrives as fp16 hi / lo planes (written by the previous layer's LayerNorm launch),
+    // and this layer's LayerNorm launch writes planes for the next layer beside its fp32 rows; precision 5: the round-3 launches
+    // (fp32 rows split inside the paired contraction)
+    int pg_dbg = 0;
+    if (precision >= 6 && precision <= 9) { pg_dbg = 1 << (precision - 6); precision = 2; }      // measurement only: plane_gemm without its MFMAs / without its operand stream
+    const bool planes = precision == 2;
+    unsigned short *dxh = nullptr, *dxl = nullptr, *dyh = nullptr, *dyl = nullptr, *kweh = nullptr, *kwel = nullptr, *kwoh = nullptr, *kwol = nullptr;
+    if (planes) {
+        dxh = c.alloc<unsigned short>((size_t)M * kc); dxl = c.alloc<unsigned short>((size_t)M * kc);
+        dyh = c.alloc<unsigned short>((size_t)2 * M * round_up(Cout, 32)); dyl = c.alloc<unsigned short>((size_t)2 * M * round_up(Cout, 32));
+        if (!c.ok) return OPH_ERR_DEVICE;
+        launch_rows_to_planes(dx, kc, M, kc, dxh, dxl, c.s);
+        kweh = c.alloc<unsigned short>(we.size()); kwel = c.alloc<unsigned short>(we.size());
+        kwoh = c.alloc<unsigned short>(wo.size()); kwol = c.alloc<unsigned short>(wo.size());
+        if (!c.ok) return OPH_ERR_DEVICE;
+        launch_kblock_planes(dweh, kweh, Nalloc, 2 * kc, c.s); launch_kblock_planes(dwel, kwel, Nalloc, 2 * kc, c.s);
+        launch_kblock_planes(dwoh, kwoh, Nalloc, kc, c.s); launch_kblock_planes(dwol, kwol, Nalloc, kc, c.s);
+    }
+    if (precision == 5) precision = 2;
     hipStreamSynchronize(c.s);
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { g_op_error = "event creation failed"; return OPH_ERR_DEVICE; }
     auto once = [&]() {
+        if (planes) {
+            PlaneGemmArgs pg{};
+            pg.Ah = (const _Float16*)dxh; pg.Al = (const _Float16*)dxl; pg.Wh = (const _Float16*)kweh; pg.Wl = (const _Float16*)kwel;
+            pg.Wh2 = (const _Float16*)kwoh; pg.Wl2 = (const _Float16*)kwol; pg.bias = dbias; pg.H = dh; pg.M = M; pg.N = Cout; pg.kc = kc; pg.T = T;
+            pg.nalloc = Nalloc; pg.ldh = 2 * Nalloc; pg.ntaps = 2; pg.off[0] = 0; pg.off[1] = -1; pg.convt = 1; pg.dbg = pg_dbg;
+            launch_plane_gemm(pg, c.s);
+            EpiArgs e{};
+            e.H = dh; e.ldh = Nalloc; e.M = 2 * M; e.C = Cout; e.mode = PRE_CONV; e.act = ACT_NONE; e.g1 = dg; e.b1 = db; e.Y = dy; e.ldy = Cout; e.ypad = round_up(Cout, 32);
+            e.planes = 1; e.Yh = dyh; e.Yl = dyl;
+            if (e.ldy < e.ypad) e.ypad = e.ldy;
+            launch_epilogue(e, c.s);
+            return;
+        }
         GemmArgs g{};
         g.X = dx; g.ldx = kc; g.bias = dbias; g.ldh = 2 * Nalloc; g.M = M; g.N = Cout; g.kc = kc; g.mode = 0; g.T = T;
         g.Wt = dwe; g.Wh = dweh; g.Wl = dwel; g.f16 = precision >= 2; g.nprod = precision == 3 ? 2 : (precision == 4 ? 1 : 3); g.ldw = 2 * kc; g.ntaps = 2; g.off[0] = 0; g.off[1] = -1; g.H = dh;

@@ -1,0 +1,380 @@
+// plane_gemm: the batched nets' conv-as-GEMM on operands that ARRIVE as fp16 hi / lo planes (modules.conv1d 91-146, hc 148-207,
+// conv1d_transpose 209-258 behind networks.SSRN 437-537 / TextEnc 121-212).
+//
+// conv_gemm_bf16x3 (oph_kernels.hip) reads fp32 activation rows and splits them into 16-bit terms by VALU work + ds_write inside
+// its K loop, once per tap; its 64x64 instance (what D_4 / D_7 run on) reads four LDS fragments for three MFMAs.  Here the
+// producing LayerNorm launch (ln_rows) has already written its rows as planes, K-blocked [channel / 32][row][32] (one K-step of
+// one row = 64 contiguous bytes, one K-step of a tile = one contiguous run), so
+//   * both operands reach LDS by global_load_lds_dwordx4 (no VGPR staging, no split, no ds_write);
+//   * the activation tile is loaded ONCE per 32-channel block with a halo of 16 rows each side and every tap of a k = 3 layer
+//     (or x[t], x[t-1] of the transposed convolution) reads it at a row offset -- rows whose tap falls outside the utterance are
+//     zeroed in registers (a wave-uniform branch: only tiles that straddle an utterance boundary pay for it);
+//   * a workgroup is 128 rows x 128 columns, a wave 64 x 64 (four accumulator tiles): 8 fragment reads per 12 MFMAs;
+//   * conv1d_transpose is ONE problem: a workgroup owns 128 input rows x 64 channels of BOTH phases (columns = 64 even-phase +
+//     64 odd-phase channels).  x[t] multiplies [Kt0 | Kt1] as a 128-column step, x[t-1] multiplies Kt2 into the even half only:
+//     every workgroup does the same 3 units of work (the paired launch ran 2-unit and 1-unit workgroups side by side).
+// Arithmetic: a.b = ah.bh + al.bh + ah.bl on v_mfma_f32_32x32x16_f16, fp32 accumulate -- the three products of
+// conv_gemm_bf16x3<.., F16 = true>; the K order is (channel block, tap) instead of (tap, channel block), so the two kernels differ
+// in the last bits of the fp32 sums.  The order does not depend on where a row sits in its tile or on the number of rows, so a
+// streamed SSRN chunk reproduces the one-piece evaluation bit for bit as before.
+#include "oph_internal.h"
+#include "oph_device.h"
+
+#include <type_traits>
+
+namespace oph {
+
+typedef _Float16 h16;
+typedef h16 h16x8 __attribute__((ext_vector_type(8)));
+typedef h16 h16x4 __attribute__((ext_vector_type(4)));
+
+#define OPH_GLDS16(g, l) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g), (__attribute__((address_space(3))) void*)(l), 16, 0, 0)
+
+template <int NT, bool CONVT> struct PlaneGemmCfg {
+    static constexpr int HALO = NT == 1 ? 0 : PLANE_GEMM_HALO;
+    static constexpr int AROWS = 128 + 2 * HALO;           // activation rows per stage
+    static constexpr int A_WCH = AROWS / 16;               // 1 KB wave pieces (16 rows x 64 B) per plane
+    static constexpr int A_OPS = 2 * A_WCH / 4;            // pieces per wave and stage (hi and lo planes together): 5 (halo) / 4
+    static constexpr int A_BUF = 2 * AROWS * 32;           // halves: [hi plane | lo plane]
+    static constexpr int b_pl(int tap) { return (CONVT && tap == 1) ? 64 * 32 : 128 * 32; }      // halves of one weight plane of a tap
+    static constexpr int b_at(int tap) { return tap == 0 ? A_BUF : b_at(tap - 1) + 2 * b_pl(tap - 1); }   // where a tap's planes start in a stage
+    static constexpr int STAGE = b_at(NT);                 // halves per stage: activations + every tap's weights of one 32-channel block
+    static constexpr int STAGES = CONVT ? 3 : (NT == 1 ? 4 : 2);      // what fits 160 KB: 132 / 128 / 136 KB
+    static constexpr int NOPS = A_OPS + (CONVT ? 6 : 4 * NT);         // global_load_lds per wave and stage
+    static constexpr size_t LDS_BYTES = (size_t)STAGES * STAGE * 2;
+};
+
+template <int NT, bool CONVT, int DBG = 0>        // DBG (measurement only): 1 = no MFMAs (the operand stream alone), 2 = no operand stream in the loop
+__global__ __launch_bounds__(256, 1) void plane_gemm(PlaneGemmArgs a) {
+    static_assert(!CONVT || NT == 2, "transposed convolution: taps x[t], x[t-1]");
+    typedef PlaneGemmCfg<NT, CONVT> Cfg;
+    constexpr int HALO = Cfg::HALO, AROWS = Cfg::AROWS, A_WCH = Cfg::A_WCH, A_OPS = Cfg::A_OPS, STAGE = Cfg::STAGE, STAGES = Cfg::STAGES;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    h16* Ss = (h16*)smem;                            // [STAGES][STAGE]
+
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int BNC = CONVT ? 64 : 128;            // output channels per workgroup
+    const int MT = (a.M + 127) / 128, NTL = (a.N + BNC - 1) / BNC;
+    const int ntiles = MT * NTL;
+    int id;
+    {   // XCD-aware bijective remap (workgroups b, b + 8, .. share an XCD / L2): a contiguous chunk of tiles per XCD
+        const int bid = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    constexpr int GM = 8;                            // 8 row tiles x all column tiles per group: both panels stay in the L2
+    const int width = GM * NTL, g = id / width, first_m = g * GM;
+    const int gsz = min(MT - first_m, GM);
+    const int tm = first_m + (id % width) % gsz, tn = (id % width) / gsz;
+    const int m0 = tm * 128, n0 = tn * BNC;
+
+    // ---- what each lane copies.  A piece = 64 lanes x 16 B = 16 LDS rows of 64 B; lane -> (row lane >> 2, 16-byte position
+    // lane & 3); the position a lane FETCHES is swizzled with the LDS row's (row >> 2) & 3 (= (lane >> 4) & 3: pieces start at
+    // multiples of 16 rows), so a fragment read of 16 consecutive rows touches 16 distinct 4-bank groups
+    const int lrow = lane >> 2, sp = ((lane & 3) ^ ((lane >> 4) & 3)) << 3;
+    const h16* ap[A_OPS];
+#pragma unroll
+    for (int j = 0; j < A_OPS; ++j) {
+        const int wq = j * 4 + w, plane = wq / A_WCH, i = (wq % A_WCH) * 16 + lrow;
+        const int gr = min(max(m0 - HALO + i, 0), a.M - 1);         // (halo / tail rows outside the problem: clamped, never used unmasked)
+        ap[j] = (plane ? a.Al : a.Ah) + (size_t)gr * 32 + sp;
+    }
+    const h16* bp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int wq = j * 4 + w, plane = wq >> 3, rr = (wq & 7) * 16 + lrow;
+        if (CONVT && rr >= 64) bp[j] = (plane ? a.Wl2 : a.Wh2) + (size_t)(n0 + rr - 64) * 32 + sp;      // odd phase: Kt1
+        else bp[j] = (plane ? a.Wl : a.Wh) + (size_t)(n0 + rr) * 32 + sp;
+    }
+    const size_t w_kstride = (size_t)a.nalloc * 32;  // halves between two K blocks of a weight plane
+    const h16* bp1[2] = {nullptr, nullptr};          // transposed convolution, x[t-1]: 64 rows of Kt2 (the even phase's second tap)
+    if constexpr (CONVT) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int wq = j * 4 + w, plane = wq >> 2, rr = (wq & 3) * 16 + lrow;
+            bp1[j] = (plane ? a.Wl : a.Wh) + (size_t)(a.kc >> 5) * w_kstride + (size_t)(n0 + rr) * 32 + sp;
+        }
+    }
+    const size_t a_kstride = (size_t)a.M * 32;       // halves between two K blocks of the activation planes
+    // one stage = the activation rows and every tap's weights of one 32-channel block: NOPS 1 KB pieces per wave
+    auto issue_op = [&](auto op_c, int kb, int stage) {      // piece `op` of block kb -> ring stage `stage`
+        constexpr int op = decltype(op_c)::value;
+        h16* st = Ss + stage * STAGE;
+        if constexpr (op < A_OPS) OPH_GLDS16(ap[op] + (size_t)kb * a_kstride, st + (op * 4 + w) * 512);
+        else if constexpr (CONVT) {
+            constexpr int j = op - A_OPS;
+            if constexpr (j < 4) OPH_GLDS16(bp[j] + kb * w_kstride, st + Cfg::b_at(0) + (j * 4 + w) * 512);
+            else OPH_GLDS16(bp1[j - 4] + kb * w_kstride, st + Cfg::b_at(1) + ((j - 4) * 4 + w) * 512);      // [hi 64 rows | lo 64 rows]
+        } else {
+            constexpr int tap = (op - A_OPS) / 4, j = (op - A_OPS) % 4;
+            OPH_GLDS16(bp[j] + (size_t)(tap * (a.kc >> 5) + kb) * w_kstride, st + Cfg::b_at(tap) + (j * 4 + w) * 512);
+        }
+    };
+    auto issue = [&](int kb, int stage) {
+        auto go = [&](auto self, auto op_c) {
+            constexpr int op = decltype(op_c)::value;
+            if constexpr (op < Cfg::NOPS) { issue_op(op_c, kb, stage); self(self, std::integral_constant<int, op + 1>{}); }
+        };
+        go(go, std::integral_constant<int, 0>{});
+    };
+
+    // ---- fragments.  32x32x16 operand: lane l holds row (l & 31), k = 8 (l >> 5) .. + 7 of the 16-wide slice
+    const int wr = w >> 1, wc = w & 1, r32 = lane & 31, kh = lane >> 5;
+    int aoff[NT][2];                                 // halves into a stage's hi plane, K slice 0 (slice 1: ^ 16)
+    unsigned keep[NT][2];                            // all ones, or 0 where this lane's row has no source for the tap (utterance boundary):
+                                                     // the fragment is AND-ed with it -- no branch in the K loop
+#pragma unroll
+    for (int tap = 0; tap < NT; ++tap) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int lr = HALO + wr * 64 + i * 32 + r32 + a.off[tap];
+            aoff[tap][i] = lr * 32 + ((kh ^ ((lr >> 2) & 3)) << 3);
+            const int m = m0 + wr * 64 + i * 32 + r32, tt = m % a.T + a.off[tap];
+            keep[tap][i] = (tt < 0 || tt >= a.T) ? 0u : 0xffffffffu;
+        }
+    }
+    int boff[2];
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+        const int br = (CONVT ? jn * 64 + wc * 32 : wc * 64 + jn * 32) + r32;
+        boff[jn] = br * 32 + ((kh ^ ((br >> 2) & 3)) << 3);
+    }
+
+    float bias_v[2];                                 // (requested before the K loop: no round trip between the loop and the stores)
+    bias_v[0] = a.bias[CONVT ? n0 + wc * 32 + r32 : n0 + wc * 64 + r32];
+    bias_v[1] = CONVT ? bias_v[0] : a.bias[n0 + wc * 64 + 32 + r32];
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
+
+    // A K block is 2 NT slices (tap, 16-wide K slice); a slice = its fragment reads (8, or 6 for the x[t-1] step of the transposed
+    // convolution), the boundary masks and 12 (6) MFMAs.  Software-pipelined by hand: slice q + 1's fragments are read into the
+    // other register set behind slice q's first MFMAs, one read per MFMA, and the order is pinned with sched_barrier -- left alone
+    // the compiler reads two fragments, waits, issues two MFMAs, waits, ... (13 exposed LDS round trips per block with one wave
+    // per SIMD).  Fragment f of a slice: 0..3 = A rows (al0, al1, ah0, ah1), 4.. = B columns (bh0, [bh1], bl0, [bl1]).
+    h16x8 fr[2][8];
+    constexpr int NQ = 2 * NT, D = STAGES - 1;
+    // EARLY (two or more blocks in flight): the barrier that releases block kb + 1 stands BEFORE block kb's last slice, and that slice
+    // reads block kb + 1's first fragments behind its MFMAs -- no exposed LDS round trip at the top of a block.  (With one block
+    // in flight -- the 3-tap layers, whose stage is 68 KB -- the block has to be awaited at the very end.)
+    constexpr bool EARLY = D >= 2;
+    struct Sl {       // per slice: MFMAs, LDS reads issued behind them (the next slice's fragments), operand pieces requested before it
+        static constexpr int tn(int q) { return (CONVT && ((q % (2 * NT)) >> 1) == 1) ? 1 : 2; }
+        static constexpr int nm(int q) { return 6 * tn(q); }
+        static constexpr int nr(int q) { return (q + 1 < 2 * NT || EARLY) ? 4 + 2 * tn(q + 1) : 0; }
+        static constexpr int base(int q) { return q == 0 ? 0 : base(q - 1) + 12 - nr(q - 1); }
+    };
+    static_assert(Sl::base(NQ) >= Cfg::NOPS, "every operand piece of a stage has a slot");
+    auto read_frag = [&](auto q_c, auto f_c, const h16* st) {
+        constexpr int q = decltype(q_c)::value % NQ, f = decltype(f_c)::value, tap = q >> 1, ks = q & 1;
+        constexpr int TNt = (CONVT && tap == 1) ? 1 : 2;
+        if constexpr (f < 4) {
+            constexpr int i = f & 1, lo = f < 2;
+            fr[q & 1][f] = *(const h16x8*)(st + (lo ? AROWS * 32 : 0) + (aoff[tap][i] ^ (ks * 16)));
+        } else {
+            constexpr int g = f - 4, lo = g >= TNt, jn = g % TNt;
+            fr[q & 1][f] = *(const h16x8*)(st + Cfg::b_at(tap) + (lo ? Cfg::b_pl(tap) : 0) + (boff[jn] ^ (ks * 16)));
+        }
+    };
+    auto mfma_k = [&](auto q_c, auto k_c) {
+        constexpr int q = decltype(q_c)::value, k = decltype(k_c)::value, tap = q >> 1;
+        constexpr int TNt = (CONVT && tap == 1) ? 1 : 2;
+        // product by product over the tiles (al.bh, ah.bl, ah.bh): consecutive MFMAs never share an accumulator
+        constexpr int p = k / (2 * TNt), i = (k / TNt) & 1, jn = k % TNt;
+        constexpr int fa = p == 0 ? i : 2 + i, fb = 4 + (p == 1 ? TNt : 0) + jn;
+        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[q & 1][fa], fr[q & 1][fb], acc[i][jn], 0, 0, 0);
+    };
+    // A K block is 2 NT slices (tap, 16-wide K slice); a slice = its fragment reads (8, or 6 for the x[t-1] step of the transposed
+    // convolution), the boundary masks and 12 (6) MFMAs.  Software-pipelined by hand: slice q + 1's fragments are read into the
+    // other register set behind slice q's first MFMAs, one read per MFMA, the operand pieces of block kb + D are requested behind
+    // the others, and the order is pinned with sched_barrier -- left alone the compiler reads two fragments, waits, issues two
+    // MFMAs, waits, ... (13 exposed LDS round trips per block with one wave per SIMD).
+    // Fragment f of a slice: 0..3 = A rows (al0, al1, ah0, ah1), 4.. = B columns (bh0, [bh1], bl0, [bl1]).
+    // st: this block's stage; stn: where slice q + 1 lives (the same stage, or the next block's for the last slice)
+    auto slice = [&](auto q_c, const h16* stn, int kbn, int stage_n) {
+        constexpr int q = decltype(q_c)::value, tap = q >> 1;
+        constexpr int nm = Sl::nm(q), nr = Sl::nr(q);
+        constexpr bool masked = CONVT ? tap == 1 : (NT == 3 && tap != 1);                              // taps at an offset can leave the utterance
+        if constexpr (masked) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int f = 0; f < 4; ++f) fr[q & 1][f] = __builtin_bit_cast(h16x8, __builtin_bit_cast(u32x4, fr[q & 1][f]) & keep[tap][f & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        auto pair = [&](auto k_c) {
+            constexpr int k = decltype(k_c)::value;
+            if constexpr (k < nm) mfma_k(q_c, k_c);
+            // read order: what the next slice's first MFMAs need first (al0, bh.., al1, ah0, bl.., ah1)
+            if constexpr (k < nr) {
+                constexpr int TNn = (nr - 4) / 2;
+                constexpr int order2[8] = {0, 4, 5, 1, 2, 6, 7, 3}, order1[6] = {0, 4, 1, 2, 5, 3};
+                constexpr int f = TNn == 2 ? order2[k] : order1[k];
+                read_frag(std::integral_constant<int, q + 1>{}, std::integral_constant<int, f>{}, stn);
+            }
+            if constexpr (k >= nr && !(DBG & 2)) {
+                constexpr int op = Sl::base(q) + k - nr;
+                if constexpr (op < Cfg::NOPS) issue_op(std::integral_constant<int, op>{}, kbn, stage_n);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        pair(std::integral_constant<int, 0>{}); pair(std::integral_constant<int, 1>{}); pair(std::integral_constant<int, 2>{});
+        pair(std::integral_constant<int, 3>{}); pair(std::integral_constant<int, 4>{}); pair(std::integral_constant<int, 5>{});
+        pair(std::integral_constant<int, 6>{}); pair(std::integral_constant<int, 7>{}); pair(std::integral_constant<int, 8>{});
+        pair(std::integral_constant<int, 9>{}); pair(std::integral_constant<int, 10>{}); pair(std::integral_constant<int, 11>{});
+    };
+    auto read_slice0 = [&](const h16* st) {
+        read_frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, st); read_frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}, st);
+        read_frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{}, st); read_frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, st);
+        read_frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, st); read_frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 6>{}, st);
+        read_frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 7>{}, st); read_frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, st);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- K loop over 32-channel blocks, STAGES - 1 blocks requested ahead (an LDS-DMA piece lands ~1 us after its issue under
+    // load, a block's MFMAs take 0.5 - 1 us): one workgroup per CU, the ring takes most of its LDS
+    const int nkb = (DBG & 8) ? 3 : a.kc / 32;       // (DBG 8: three blocks only -- what is left is the fixed cost of a workgroup)
+#pragma unroll
+    for (int s = 0; s < D; ++s) if (s < nkb) issue(s, s);
+    // (s_barrier directly: __syncthreads() carries a workgroup-scope fence, which the compiler turns into vmcnt(0) -- the pieces of
+    //  the younger stages would have to land before every barrier)
+    if (nkb >= D) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * Cfg::NOPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if constexpr (EARLY && !(DBG & 1)) read_slice0(Ss);
+    int stage = 0;                                   // kb % STAGES
+    for (int kb = 0; kb < nkb; ++kb) {
+        // block kb + D is requested during this block's MFMAs, into the stage block kb - 1 was read from (every wave is past the
+        // barrier behind those reads).  No branch in the loop body: past the end the last block is requested again, into that same
+        // free stage
+        const bool more = kb + D < nkb;
+        const int kbn = more ? kb + D : nkb - 1;
+        const int stage_n = stage == 0 ? STAGES - 1 : stage - 1;      // (kb + D) % STAGES
+        const int stage_1 = stage + 1 == STAGES ? 0 : stage + 1;      // (kb + 1) % STAGES
+        const h16* st = Ss + stage * STAGE;
+        if constexpr (DBG & 1) {
+            if (more) issue(kbn, stage_n);
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * Cfg::NOPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else if constexpr (EARLY) {
+            slice(std::integral_constant<int, 0>{}, st, kbn, stage_n);
+            if constexpr (NQ > 2) { slice(std::integral_constant<int, 1>{}, st, kbn, stage_n); slice(std::integral_constant<int, 2>{}, st, kbn, stage_n); }
+            // block kb + 1 is complete when nothing older than this iteration's own requests (and the D - 2 blocks between) is
+            // outstanding: pieces complete in issue order, and every iteration issues exactly NOPS of them
+            constexpr int before = Sl::base(NQ - 1) < Cfg::NOPS ? Sl::base(NQ - 1) : Cfg::NOPS;
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * Cfg::NOPS + before) : "memory");
+            __builtin_amdgcn_s_barrier();
+            slice(std::integral_constant<int, NQ - 1>{}, Ss + stage_1 * STAGE, kbn, stage_n);
+        } else {
+            read_slice0(st);
+            slice(std::integral_constant<int, 0>{}, st, kbn, stage_n); slice(std::integral_constant<int, 1>{}, st, kbn, stage_n);
+            slice(std::integral_constant<int, 2>{}, st, kbn, stage_n); slice(std::integral_constant<int, 3>{}, st, kbn, stage_n);
+            slice(std::integral_constant<int, 4>{}, st, kbn, stage_n); slice(std::integral_constant<int, 5>{}, st, kbn, stage_n);
+            // D == 1: the block requested during this one has to be complete now
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        stage = stage_1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (no piece may land in LDS that the next workgroup already owns)
+
+    // ---- raw rows (bias added).  C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            const int col = CONVT ? n0 + wc * 32 + r32 : n0 + wc * 64 + jn * 32 + r32;
+            const float bv = bias_v[CONVT ? 0 : jn];
+            float* Hc = a.H + (CONVT ? (size_t)jn * (a.ldh >> 1) : (size_t)0) + col;      // transposed: row 2t (+ 1) = H + (2 m + phase) * Nalloc
+            // (a full tile stores without per-row branches: behind a branch the compiler waits for vmcnt(0) before every store, i.e.
+            //  for the previous store's acknowledgement)
+            if ((DBG & 4) && a.M > 0) continue;          // (DBG 4: no stores)
+            if (m0 + 128 <= a.M) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                    Hc[(size_t)row * a.ldh] = acc[i][jn][e] + bv;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                    if (row < a.M) Hc[(size_t)row * a.ldh] = acc[i][jn][e] + bv;
+                }
+            }
+        }
+}
+
+template <int NT, bool CONVT, int DBG = 0>
+static void launch_plane_gemm_t(const PlaneGemmArgs& a, hipStream_t s) {
+    constexpr size_t lds = PlaneGemmCfg<NT, CONVT>::LDS_BYTES;
+    static bool attr_set[64] = {false};          // function attributes are per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 63]) {
+        (void)hipFuncSetAttribute((const void*)plane_gemm<NT, CONVT, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set[dev & 63] = true;
+    }
+    const int MT = (a.M + 127) / 128, NTL = CONVT ? (a.N + 63) / 64 : (a.N + 127) / 128;
+    hipLaunchKernelGGL((plane_gemm<NT, CONVT, DBG>), dim3(MT * NTL), dim3(256), lds, s, a);
+}
+// a.convt: conv1d_transpose (taps x[t], x[t-1] on the even phase's planes Wh / Wl, x[t] on the odd phase's Wh2 / Wl2; raw rows
+// interleaved, a.ldh = 2 Nalloc); otherwise a.ntaps = 1 or 3 taps at offsets a.off[] (|offset| <= PLANE_GEMM_HALO)
+void launch_plane_gemm(const PlaneGemmArgs& a, hipStream_t s) {
+    if (a.convt) {
+        if (a.dbg == 1) launch_plane_gemm_t<2, true, 1>(a, s);
+        else if (a.dbg == 2) launch_plane_gemm_t<2, true, 2>(a, s);
+        else if (a.dbg == 4) launch_plane_gemm_t<2, true, 4>(a, s);
+        else if (a.dbg == 8) launch_plane_gemm_t<2, true, 8>(a, s);
+        else launch_plane_gemm_t<2, true>(a, s);
+    } else if (a.ntaps == 1) launch_plane_gemm_t<1, false>(a, s);
+    else launch_plane_gemm_t<3, false>(a, s);
+}
+bool plane_gemm_ok(int ntaps, const int* off, int kc, bool convt) {
+    if (kc % 32) return false;
+    if (convt) return true;
+    if (ntaps != 1 && ntaps != 3) return false;
+    for (int t = 0; t < ntaps; ++t) if (off[t] > PLANE_GEMM_HALO || off[t] < -PLANE_GEMM_HALO) return false;
+    if (off[ntaps >> 1] != 0) return false;         // the centre tap is never masked ('same' padding; the kernel relies on it)
+    return true;
+}
+
+// a 2-byte plane [rows][ld] (k contiguous) -> K-blocked [ld / 32][rows][32]; 16 bytes per thread
+__global__ __launch_bounds__(256) void kblock_planes_k(const uint4* src, uint4* dst, int rows, int ld) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int per_row = ld >> 3;
+    const size_t r = i / per_row;
+    if (r >= (size_t)rows) return;
+    const int c8 = (int)(i - r * per_row);          // 8-element piece of the row
+    dst[((size_t)(c8 >> 2) * rows + r) * 4 + (c8 & 3)] = src[i];
+}
+void launch_kblock_planes(const void* src, void* dst, int rows, int ld, hipStream_t s) {
+    const size_t n = (size_t)rows * (ld >> 3);
+    hipLaunchKernelGGL(kblock_planes_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, rows, ld);
+}
+
+// fp32 rows [M][ld] -> fp16 hi / lo planes, K-blocked [kc / 32][M][32] (what ln_rows writes for the layers behind it; this kernel
+// serves inputs that no LayerNorm launch produced: the per-operator entry points and the timing of a single layer)
+__global__ __launch_bounds__(256) void rows_to_planes_k(const float* x, int ld, int M, int kc, h16* ph, h16* pl) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;          // one thread = 4 channels of one row
+    const int per_row = kc >> 2;
+    const size_t m = i / per_row;
+    if (m >= (size_t)M) return;
+    const int c = (int)(i - m * per_row) * 4;
+    const f32x4 v = *(const f32x4*)(x + m * ld + c);
+    h16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { hi[e] = (h16)v[e]; lo[e] = (h16)(v[e] - (float)hi[e]); }
+    const size_t o = ((size_t)(c >> 5) * M + m) * 32 + (c & 31);
+    *(h16x4*)(ph + o) = hi;
+    *(h16x4*)(pl + o) = lo;
+}
+void launch_rows_to_planes(const float* x, int ld, int M, int kc, void* ph, void* pl, hipStream_t s) {
+    const size_t n = (size_t)M * (kc >> 2);
+    hipLaunchKernelGGL(rows_to_planes_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, ld, M, kc, (h16*)ph, (h16*)pl);
+}
+
+}  // namespace oph
