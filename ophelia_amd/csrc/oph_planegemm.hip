@@ -165,7 +165,11 @@ __global__ __launch_bounds__(256, 1) void plane_gemm(PlaneGemmArgs a) {
         static constexpr int tn(int q) { return (CONVT && ((q % (2 * NT)) >> 1) == 1) ? 1 : 2; }
         static constexpr int nm(int q) { return 6 * tn(q); }
         static constexpr int nr(int q) { return (q + 1 < 2 * NT || EARLY) ? 4 + 2 * tn(q + 1) : 0; }
-        static constexpr int base(int q) { return q == 0 ? 0 : base(q - 1) + 12 - nr(q - 1); }
+        // operand pieces requested before slice q.  EARLY: one per MFMA that has no LDS read behind it.  One block in flight: the
+        // block requested now is awaited at the end of this one, so every pair of the first slices carries a request (the last
+        // piece leaves a third into the block instead of five sixths)
+        static constexpr int base(int q) { return q == 0 ? 0 : base(q - 1) + (EARLY ? 12 - nr(q - 1) : 12); }
+        static constexpr int first(int q) { return EARLY ? nr(q) : 0; }      // first pair of slice q that carries a request
     };
     static_assert(Sl::base(NQ) >= Cfg::NOPS, "every operand piece of a stage has a slot");
     auto read_frag = [&](auto q_c, auto f_c, const h16* st) {
@@ -214,8 +218,8 @@ __global__ __launch_bounds__(256, 1) void plane_gemm(PlaneGemmArgs a) {
                 constexpr int f = TNn == 2 ? order2[k] : order1[k];
                 read_frag(std::integral_constant<int, q + 1>{}, std::integral_constant<int, f>{}, stn);
             }
-            if constexpr (k >= nr && !(DBG & 2)) {
-                constexpr int op = Sl::base(q) + k - nr;
+            if constexpr (k >= Sl::first(q) && !(DBG & 2)) {
+                constexpr int op = Sl::base(q) + k - Sl::first(q);
                 if constexpr (op < Cfg::NOPS) issue_op(std::integral_constant<int, op>{}, kbn, stage_n);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -281,31 +285,37 @@ __global__ __launch_bounds__(256, 1) void plane_gemm(PlaneGemmArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (no piece may land in LDS that the next workgroup already owns)
 
-    // ---- raw rows (bias added).  C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    // ---- raw rows (bias added), through LDS: the accumulators' layout (C/D of the 32x32 MFMA: column = lane & 31, row = (reg & 3)
+    // + 8 (reg >> 2) + 4 (lane >> 5)) would leave as 64 four-byte stores per lane in 128-byte runs (measured 4 us of D_4's 22);
+    // as a [128][128] tile in the ring's LDS it leaves as 16 sixteen-byte stores per lane in 512-byte (transposed conv: 256-byte) runs
+    __builtin_amdgcn_s_barrier();                    // every wave is done with the ring
+    constexpr int LDO = 132;                         // floats per staged row
+    float* Os = smem;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int jn = 0; jn < 2; ++jn) {
-            const int col = CONVT ? n0 + wc * 32 + r32 : n0 + wc * 64 + jn * 32 + r32;
+            const int cl = CONVT ? jn * 64 + wc * 32 + r32 : wc * 64 + jn * 32 + r32;      // (transposed: [64 even-phase | 64 odd-phase] channels)
             const float bv = bias_v[CONVT ? 0 : jn];
-            float* Hc = a.H + (CONVT ? (size_t)jn * (a.ldh >> 1) : (size_t)0) + col;      // transposed: row 2t (+ 1) = H + (2 m + phase) * Nalloc
-            // (a full tile stores without per-row branches: behind a branch the compiler waits for vmcnt(0) before every store, i.e.
-            //  for the previous store's acknowledgement)
-            if ((DBG & 4) && a.M > 0) continue;          // (DBG 4: no stores)
-            if (m0 + 128 <= a.M) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-                    Hc[(size_t)row * a.ldh] = acc[i][jn][e] + bv;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-                    if (row < a.M) Hc[(size_t)row * a.ldh] = acc[i][jn][e] + bv;
-                }
-            }
+            for (int e = 0; e < 16; ++e) Os[(wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh) * LDO + cl] = acc[i][jn][e] + bv;
         }
+    __syncthreads();
+    if constexpr (!(DBG & 4)) {
+        auto out = [&](auto guarded) {
+            f32x4 v[16];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) v[it] = *(const f32x4*)(Os + ((it * 256 + tid) >> 5) * LDO + (tid & 31) * 4);
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int row = (it * 256 + tid) >> 5, c4 = tid & 31;
+                float* dst = a.H + (size_t)(m0 + row) * a.ldh + (CONVT ? (size_t)(c4 >> 4) * (a.ldh >> 1) + n0 + (c4 & 15) * 4 : (size_t)n0 + c4 * 4);
+                if (!decltype(guarded)::value || m0 + row < a.M) *(f32x4*)dst = v[it];
+            }
+        };
+        // (a full tile stores without per-row branches, see conv_gemm_f32_body)
+        if (m0 + 128 <= a.M) out(std::false_type{}); else out(std::true_type{});
+    }
 }
 
 template <int NT, bool CONVT, int DBG = 0>
