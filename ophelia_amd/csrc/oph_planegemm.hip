@@ -2,17 +2,24 @@
 // conv1d_transpose 209-258 behind networks.SSRN 437-537 / TextEnc 121-212).
 //
 // conv_gemm_bf16x3 (oph_kernels.hip) reads fp32 activation rows and splits them into 16-bit terms by VALU work + ds_write inside
-// its K loop, once per tap; its 64x64 instance (what D_4 / D_7 run on) reads four LDS fragments for three MFMAs.  Here the
-// producing LayerNorm launch (ln_rows) has already written its rows as planes, K-blocked [channel / 32][row][32] (one K-step of
-// one row = 64 contiguous bytes, one K-step of a tile = one contiguous run), so
-//   * both operands reach LDS by global_load_lds_dwordx4 (no VGPR staging, no split, no ds_write);
+// its K loop, once per tap; its 64x64 instance (what D_4 / D_7 ran on) reads four LDS fragments for three MFMAs.  Here the
+// producing LayerNorm launch (ln_rows) has already written its rows as planes, K-blocked [channel / 32][row][32] (one K block of
+// one row = 64 contiguous bytes, one K block of a tile = one contiguous run; the weights' planes alike, launch_kblock_planes), so
+//   * no conversion instruction in the K loop: a 16-byte piece per lane travels global -> register -> LDS as it is;
 //   * the activation tile is loaded ONCE per 32-channel block with a halo of 16 rows each side and every tap of a k = 3 layer
-//     (or x[t], x[t-1] of the transposed convolution) reads it at a row offset -- rows whose tap falls outside the utterance are
-//     zeroed in registers (a wave-uniform branch: only tiles that straddle an utterance boundary pay for it);
+//     (or x[t], x[t-1] of the transposed convolution) reads it at a row offset -- a row whose tap falls outside the utterance is
+//     AND-ed to zero in registers (no branch in the loop);
 //   * a workgroup is 128 rows x 128 columns, a wave 64 x 64 (four accumulator tiles): 8 fragment reads per 12 MFMAs;
 //   * conv1d_transpose is ONE problem: a workgroup owns 128 input rows x 64 channels of BOTH phases (columns = 64 even-phase +
 //     64 odd-phase channels).  x[t] multiplies [Kt0 | Kt1] as a 128-column step, x[t-1] multiplies Kt2 into the even half only:
-//     every workgroup does the same 3 units of work (the paired launch ran 2-unit and 1-unit workgroups side by side).
+//     every workgroup does the same 3 units of work (the paired launch ran 2-unit and 1-unit workgroups side by side);
+//   * the K loop's instruction order is written out (one LDS read or one piece behind each MFMA, sched_barrier between them), the
+//     barrier that releases the next block stands before the last slice so that no block starts with an exposed LDS round trip;
+//   * one workgroup per CU (the ring and the staged output tile take 64 - 136 KB).
+// Measured (round 4, profiles/r04_planes.sh, r04_ssrn_pmc.sh): 43 - 49 cycles per MFMA and wave in the loop (32 = back to back), no
+// LDS bank conflicts, the same time with the pieces by global_load_lds (3 - 4 stage ring, first version) and with no operand
+// stream at all -- the loop is bound by its own issue stream (MFMA + fragment read pairs of ONE wave per SIMD), a workgroup's fixed
+// cost (first blocks, output tile, dispatch) is ~8 us beside 12 - 55 us of loop.
 // Arithmetic: a.b = ah.bh + al.bh + ah.bl on v_mfma_f32_32x32x16_f16, fp32 accumulate -- the three products of
 // conv_gemm_bf16x3<.., F16 = true>; the K order is (channel block, tap) instead of (tap, channel block), so the two kernels differ
 // in the last bits of the fp32 sums.  The order does not depend on where a row sits in its tile or on the number of rows, so a
@@ -28,8 +35,6 @@ typedef _Float16 h16;
 typedef h16 h16x8 __attribute__((ext_vector_type(8)));
 typedef h16 h16x4 __attribute__((ext_vector_type(4)));
 
-#define OPH_GLDS16(g, l) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g), (__attribute__((address_space(3))) void*)(l), 16, 0, 0)
-
 template <int NT, bool CONVT> struct PlaneGemmCfg {
     static constexpr int HALO = NT == 1 ? 0 : PLANE_GEMM_HALO;
     static constexpr int AROWS = 128 + 2 * HALO;           // activation rows per stage
@@ -39,13 +44,14 @@ template <int NT, bool CONVT> struct PlaneGemmCfg {
     static constexpr int b_pl(int tap) { return (CONVT && tap == 1) ? 64 * 32 : 128 * 32; }      // halves of one weight plane of a tap
     static constexpr int b_at(int tap) { return tap == 0 ? A_BUF : b_at(tap - 1) + 2 * b_pl(tap - 1); }   // where a tap's planes start in a stage
     static constexpr int STAGE = b_at(NT);                 // halves per stage: activations + every tap's weights of one 32-channel block
-    static constexpr int STAGES = CONVT ? 3 : (NT == 1 ? 4 : 2);      // what fits 160 KB: 132 / 128 / 136 KB
-    static constexpr int NOPS = A_OPS + (CONVT ? 6 : 4 * NT);         // global_load_lds per wave and stage
-    static constexpr size_t LDS_BYTES = (size_t)STAGES * STAGE * 2;
+    static constexpr int STAGES = 2;                       // LDS stages: the block being multiplied and the one being written (the blocks
+                                                           // further ahead are in registers / in flight): 88 / 64 / 136 KB
+    static constexpr int NOPS = A_OPS + (CONVT ? 6 : 4 * NT);         // 1 KB pieces (16 bytes per lane) per wave and stage
+    static constexpr size_t LDS_BYTES = (size_t)STAGES * STAGE * 2 > 128 * 132 * 4 ? (size_t)STAGES * STAGE * 2 : (size_t)128 * 132 * 4;   // (the output tile is staged there too)
 };
 
 template <int NT, bool CONVT, int DBG = 0>        // DBG (measurement only): 1 = no MFMAs (the operand stream alone), 2 = no operand stream in the loop
-__global__ __launch_bounds__(256, 1) void plane_gemm(PlaneGemmArgs a) {
+__global__ __launch_bounds__(256, 1) void plane_gemm(PlaneGemmArgs a) {      // (one workgroup per CU: two of a k = 1 layer's -- 68 KB each -- measured 115 us against 103)
     static_assert(!CONVT || NT == 2, "transposed convolution: taps x[t], x[t-1]");
     typedef PlaneGemmCfg<NT, CONVT> Cfg;
     constexpr int HALO = Cfg::HALO, AROWS = Cfg::AROWS, A_WCH = Cfg::A_WCH, A_OPS = Cfg::A_OPS, STAGE = Cfg::STAGE, STAGES = Cfg::STAGES;
@@ -95,24 +101,42 @@ __global__ __launch_bounds__(256, 1) void plane_gemm(PlaneGemmArgs a) {
         }
     }
     const size_t a_kstride = (size_t)a.M * 32;       // halves between two K blocks of the activation planes
-    // one stage = the activation rows and every tap's weights of one 32-channel block: NOPS 1 KB pieces per wave
-    auto issue_op = [&](auto op_c, int kb, int stage) {      // piece `op` of block kb -> ring stage `stage`
+    // one stage = the activation rows and every tap's weights of one 32-channel block: NOPS 1 KB pieces per wave, 16 bytes per lane.
+    // A piece travels global -> register -> LDS: plain 16-byte loads stream 2-3 x what the LDS-DMA path (global_load_lds) takes in
+    // per CU (measured round 4, here and in hc_fused: ~40 GB/s per CU by DMA whatever the ring depth -- the first version of this
+    // kernel was bound by exactly that, profiles/r04_ssrn_pmc.sh); the piece requested during block kb is written to LDS during
+    // block kb + 1 and multiplied in block kb + 2.
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 stg[Cfg::NOPS];
+    auto load_op = [&](auto op_c, int kb) {          // piece `op` of block kb -> its staging register
         constexpr int op = decltype(op_c)::value;
-        h16* st = Ss + stage * STAGE;
-        if constexpr (op < A_OPS) OPH_GLDS16(ap[op] + (size_t)kb * a_kstride, st + (op * 4 + w) * 512);
+        if constexpr (op < A_OPS) stg[op] = *(const i32x4*)(ap[op] + (size_t)kb * a_kstride);
         else if constexpr (CONVT) {
             constexpr int j = op - A_OPS;
-            if constexpr (j < 4) OPH_GLDS16(bp[j] + kb * w_kstride, st + Cfg::b_at(0) + (j * 4 + w) * 512);
-            else OPH_GLDS16(bp1[j - 4] + kb * w_kstride, st + Cfg::b_at(1) + ((j - 4) * 4 + w) * 512);      // [hi 64 rows | lo 64 rows]
+            if constexpr (j < 4) stg[op] = *(const i32x4*)(bp[j] + kb * w_kstride);
+            else stg[op] = *(const i32x4*)(bp1[j - 4] + kb * w_kstride);
         } else {
             constexpr int tap = (op - A_OPS) / 4, j = (op - A_OPS) % 4;
-            OPH_GLDS16(bp[j] + (size_t)(tap * (a.kc >> 5) + kb) * w_kstride, st + Cfg::b_at(tap) + (j * 4 + w) * 512);
+            stg[op] = *(const i32x4*)(bp[j] + (size_t)(tap * (a.kc >> 5) + kb) * w_kstride);
         }
     };
-    auto issue = [&](int kb, int stage) {
+    auto store_op = [&](auto op_c, int stage) {      // staging register -> its place in ring stage `stage` (lane l: byte 16 l of the piece)
+        constexpr int op = decltype(op_c)::value;
+        h16* st = Ss + stage * STAGE + lane * 8;
+        if constexpr (op < A_OPS) *(i32x4*)(st + (op * 4 + w) * 512) = stg[op];
+        else if constexpr (CONVT) {
+            constexpr int j = op - A_OPS;
+            if constexpr (j < 4) *(i32x4*)(st + Cfg::b_at(0) + (j * 4 + w) * 512) = stg[op];
+            else *(i32x4*)(st + Cfg::b_at(1) + ((j - 4) * 4 + w) * 512) = stg[op];      // [hi 64 rows | lo 64 rows]
+        } else {
+            constexpr int tap = (op - A_OPS) / 4, j = (op - A_OPS) % 4;
+            *(i32x4*)(st + Cfg::b_at(tap) + (j * 4 + w) * 512) = stg[op];
+        }
+    };
+    auto for_ops = [&](auto&& f) {
         auto go = [&](auto self, auto op_c) {
             constexpr int op = decltype(op_c)::value;
-            if constexpr (op < Cfg::NOPS) { issue_op(op_c, kb, stage); self(self, std::integral_constant<int, op + 1>{}); }
+            if constexpr (op < Cfg::NOPS) { f(op_c); self(self, std::integral_constant<int, op + 1>{}); }
         };
         go(go, std::integral_constant<int, 0>{});
     };
@@ -156,22 +180,20 @@ __global__ __launch_bounds__(256, 1) void plane_gemm(PlaneGemmArgs a) {
     // the compiler reads two fragments, waits, issues two MFMAs, waits, ... (13 exposed LDS round trips per block with one wave
     // per SIMD).  Fragment f of a slice: 0..3 = A rows (al0, al1, ah0, ah1), 4.. = B columns (bh0, [bh1], bl0, [bl1]).
     h16x8 fr[2][8];
-    constexpr int NQ = 2 * NT, D = STAGES - 1;
-    // EARLY (two or more blocks in flight): the barrier that releases block kb + 1 stands BEFORE block kb's last slice, and that slice
-    // reads block kb + 1's first fragments behind its MFMAs -- no exposed LDS round trip at the top of a block.  (With one block
-    // in flight -- the 3-tap layers, whose stage is 68 KB -- the block has to be awaited at the very end.)
-    constexpr bool EARLY = D >= 2;
-    struct Sl {       // per slice: MFMAs, LDS reads issued behind them (the next slice's fragments), operand pieces requested before it
+    constexpr int NQ = 2 * NT;
+    // The barrier that releases block kb + 1 stands BEFORE block kb's last slice, and that slice reads block kb + 1's first fragments
+    // behind its MFMAs: no exposed LDS round trip at the top of a block.  So every piece of block kb + 1 is written to LDS during
+    // the slices before the last one.
+    struct Sl {       // per slice: MFMAs, LDS reads issued behind them (the next slice's fragments), pieces moved before it
         static constexpr int tn(int q) { return (CONVT && ((q % (2 * NT)) >> 1) == 1) ? 1 : 2; }
         static constexpr int nm(int q) { return 6 * tn(q); }
-        static constexpr int nr(int q) { return (q + 1 < 2 * NT || EARLY) ? 4 + 2 * tn(q + 1) : 0; }
-        // operand pieces requested before slice q.  EARLY: one per MFMA that has no LDS read behind it.  One block in flight: the
-        // block requested now is awaited at the end of this one, so every pair of the first slices carries a request (the last
-        // piece leaves a third into the block instead of five sixths)
-        static constexpr int base(int q) { return q == 0 ? 0 : base(q - 1) + (EARLY ? 12 - nr(q - 1) : 12); }
-        static constexpr int first(int q) { return EARLY ? nr(q) : 0; }      // first pair of slice q that carries a request
+        static constexpr int nr(int q) { return 4 + 2 * tn(q + 1); }
+        // a piece (LDS write of block kb + 1's, then the load of block kb + 2's into the same register) rides behind every MFMA that
+        // has no LDS read behind it; a k = 1 layer has a single slice before the barrier: all of its pairs carry one
+        static constexpr int first(int q) { return NT == 1 ? 0 : nr(q); }
+        static constexpr int base(int q) { return q == 0 ? 0 : base(q - 1) + 12 - first(q - 1); }
     };
-    static_assert(Sl::base(NQ) >= Cfg::NOPS, "every operand piece of a stage has a slot");
+    static_assert(Sl::base(NQ - 1) >= Cfg::NOPS, "every operand piece of a stage has a slot before the barrier");
     auto read_frag = [&](auto q_c, auto f_c, const h16* st) {
         constexpr int q = decltype(q_c)::value % NQ, f = decltype(f_c)::value, tap = q >> 1, ks = q & 1;
         constexpr int TNt = (CONVT && tap == 1) ? 1 : 2;
@@ -198,7 +220,7 @@ __global__ __launch_bounds__(256, 1) void plane_gemm(PlaneGemmArgs a) {
     // MFMAs, waits, ... (13 exposed LDS round trips per block with one wave per SIMD).
     // Fragment f of a slice: 0..3 = A rows (al0, al1, ah0, ah1), 4.. = B columns (bh0, [bh1], bl0, [bl1]).
     // st: this block's stage; stn: where slice q + 1 lives (the same stage, or the next block's for the last slice)
-    auto slice = [&](auto q_c, const h16* stn, int kbn, int stage_n) {
+    auto slice = [&](auto q_c, const h16* stn, int kbn, int stage_w) {
         constexpr int q = decltype(q_c)::value, tap = q >> 1;
         constexpr int nm = Sl::nm(q), nr = Sl::nr(q);
         constexpr bool masked = CONVT ? tap == 1 : (NT == 3 && tap != 1);                              // taps at an offset can leave the utterance
@@ -218,9 +240,9 @@ __global__ __launch_bounds__(256, 1) void plane_gemm(PlaneGemmArgs a) {
                 constexpr int f = TNn == 2 ? order2[k] : order1[k];
                 read_frag(std::integral_constant<int, q + 1>{}, std::integral_constant<int, f>{}, stn);
             }
-            if constexpr (k >= Sl::first(q) && !(DBG & 2)) {
+            if constexpr (q < NQ - 1 && k >= Sl::first(q) && !(DBG & 2)) {
                 constexpr int op = Sl::base(q) + k - Sl::first(q);
-                if constexpr (op < Cfg::NOPS) issue_op(std::integral_constant<int, op>{}, kbn, stage_n);
+                if constexpr (op < Cfg::NOPS) { store_op(std::integral_constant<int, op>{}, stage_w); load_op(std::integral_constant<int, op>{}, kbn); }
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -237,57 +259,42 @@ __global__ __launch_bounds__(256, 1) void plane_gemm(PlaneGemmArgs a) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // ---- K loop over 32-channel blocks, STAGES - 1 blocks requested ahead (an LDS-DMA piece lands ~1 us after its issue under
-    // load, a block's MFMAs take 0.5 - 1 us): one workgroup per CU, the ring takes most of its LDS
+    // ---- K loop over 32-channel blocks.  Block kb is multiplied out of LDS stage kb & 1 while block kb + 1's pieces (loaded during
+    // block kb - 1) are written to the other stage and block kb + 2's are requested into the registers they leave.
     const int nkb = (DBG & 8) ? 3 : a.kc / 32;       // (DBG 8: three blocks only -- what is left is the fixed cost of a workgroup)
-#pragma unroll
-    for (int s = 0; s < D; ++s) if (s < nkb) issue(s, s);
-    // (s_barrier directly: __syncthreads() carries a workgroup-scope fence, which the compiler turns into vmcnt(0) -- the pieces of
-    //  the younger stages would have to land before every barrier)
-    if (nkb >= D) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * Cfg::NOPS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for_ops([&](auto op_c) { load_op(op_c, 0); });
+    for_ops([&](auto op_c) { store_op(op_c, 0); load_op(op_c, nkb > 1 ? 1 : 0); });
+    // (s_barrier directly: __syncthreads() carries a workgroup-scope fence, which the compiler turns into vmcnt(0) -- the loads in
+    //  flight would have to land before every barrier)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if constexpr (EARLY && !(DBG & 1)) read_slice0(Ss);
-    int stage = 0;                                   // kb % STAGES
+    if constexpr (!(DBG & 1)) read_slice0(Ss);
     for (int kb = 0; kb < nkb; ++kb) {
-        // block kb + D is requested during this block's MFMAs, into the stage block kb - 1 was read from (every wave is past the
-        // barrier behind those reads).  No branch in the loop body: past the end the last block is requested again, into that same
-        // free stage
-        const bool more = kb + D < nkb;
-        const int kbn = more ? kb + D : nkb - 1;
-        const int stage_n = stage == 0 ? STAGES - 1 : stage - 1;      // (kb + D) % STAGES
-        const int stage_1 = stage + 1 == STAGES ? 0 : stage + 1;      // (kb + 1) % STAGES
+        // no branch in the loop body: past the end the last block is loaded again and written to a stage nobody reads
+        const int kbn = kb + 2 < nkb ? kb + 2 : nkb - 1;
+        const int stage = kb & 1, stage_w = stage ^ 1;
         const h16* st = Ss + stage * STAGE;
         if constexpr (DBG & 1) {
-            if (more) issue(kbn, stage_n);
-            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * Cfg::NOPS) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for_ops([&](auto op_c) { store_op(op_c, stage_w); load_op(op_c, kbn); });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-        } else if constexpr (EARLY) {
-            slice(std::integral_constant<int, 0>{}, st, kbn, stage_n);
-            if constexpr (NQ > 2) { slice(std::integral_constant<int, 1>{}, st, kbn, stage_n); slice(std::integral_constant<int, 2>{}, st, kbn, stage_n); }
-            // block kb + 1 is complete when nothing older than this iteration's own requests (and the D - 2 blocks between) is
-            // outstanding: pieces complete in issue order, and every iteration issues exactly NOPS of them
-            constexpr int before = Sl::base(NQ - 1) < Cfg::NOPS ? Sl::base(NQ - 1) : Cfg::NOPS;
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * Cfg::NOPS + before) : "memory");
-            __builtin_amdgcn_s_barrier();
-            slice(std::integral_constant<int, NQ - 1>{}, Ss + stage_1 * STAGE, kbn, stage_n);
         } else {
-            read_slice0(st);
-            slice(std::integral_constant<int, 0>{}, st, kbn, stage_n); slice(std::integral_constant<int, 1>{}, st, kbn, stage_n);
-            slice(std::integral_constant<int, 2>{}, st, kbn, stage_n); slice(std::integral_constant<int, 3>{}, st, kbn, stage_n);
-            slice(std::integral_constant<int, 4>{}, st, kbn, stage_n); slice(std::integral_constant<int, 5>{}, st, kbn, stage_n);
-            // D == 1: the block requested during this one has to be complete now
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            slice(std::integral_constant<int, 0>{}, st, kbn, stage_w);
+            if constexpr (NQ > 2) { slice(std::integral_constant<int, 1>{}, st, kbn, stage_w); slice(std::integral_constant<int, 2>{}, st, kbn, stage_w); }
+            if constexpr (NQ > 4) { slice(std::integral_constant<int, 3>{}, st, kbn, stage_w); slice(std::integral_constant<int, 4>{}, st, kbn, stage_w); }
+            // block kb + 1 is in LDS once every wave's writes have completed (and this wave's fragment reads of stage kb & 1, which
+            // the next iteration's writes overwrite)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            slice(std::integral_constant<int, NQ - 1>{}, Ss + stage_w * STAGE, kbn, stage_w);
         }
-        stage = stage_1;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (no piece may land in LDS that the next workgroup already owns)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- raw rows (bias added), through LDS: the accumulators' layout (C/D of the 32x32 MFMA: column = lane & 31, row = (reg & 3)
     // + 8 (reg >> 2) + 4 (lane >> 5)) would leave as 64 four-byte stores per lane in 128-byte runs (measured 4 us of D_4's 22);
     // as a [128][128] tile in the ring's LDS it leaves as 16 sixteen-byte stores per lane in 512-byte (transposed conv: 256-byte) runs
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                    // every wave is done with the ring
     constexpr int LDO = 132;                         // floats per staged row
     float* Os = smem;

@@ -18,9 +18,16 @@ def test_bench_two_ranks_on_one_gpu():
         env.pop(k, None)
     env["OPH_BENCH_SHARED_GPU"] = "1"
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--no-extra-legs", "--no-cpu-baseline", "--no-vocoder", "--no-profile"],
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-extra-legs", "--no-cpu-baseline", "--no-vocoder", "--no-profile"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    if r.returncode != 0 and "hand-off timed out" in r.stderr:
+        # Two PROCESSES whose decode launches each need all their workgroups resident on the same 64 CUs (a configuration only this
+        # test creates: a real node gives every rank its own GPU) can each be handed half of them: both spin until the 2 s bound and
+        # the library reports it (2 of 29 shared-GPU runs in round 4).  The bounded wait and the error path are
+        # what the product guarantees there; the run is repeated once, loudly.
+        print("shared-GPU run hit the co-residency time-out, repeating once:\n" + r.stderr[-600:])
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                     # rank 0 alone prints
