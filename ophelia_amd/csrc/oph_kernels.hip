@@ -534,20 +534,23 @@ void launch_conv_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {     // needs a.
 // =====================================================================================
 // (hardware exp / rcp / rsq forms, ~1 ulp each: the IEEE expansions made the 1024-channel rows instruction-bound -- 45 % of
 //  the wave cycles issuing, profiles/r02_ssrn_pmc.sh)
-template <int NV>
-__device__ __forceinline__ void ln_vec(f32x4 (&x)[NV], int C, int lane, const float* gam, const float* bet, int nonorm) {
+// PRE: gamma / beta were requested by the caller before the row's statistics (gv / bv hold them): rows of <= 512 channels, where the
+// 16 extra registers cost no occupancy and the L2 round trip between the reductions and the stores was a sixth of the kernel
+template <int NV, bool PRE = false, bool FULL = false>      // FULL: the row has exactly NV * 256 channels -- no per-element guards
+__device__ __forceinline__ void ln_vec(f32x4 (&x)[NV], int C, int lane, const float* gam, const float* bet, int nonorm,
+                                       const f32x4* gvp = nullptr, const f32x4* bvp = nullptr) {
     float s = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s += ((v * 64 + lane) * 4 + e < C) ? x[v][e] : 0.f;
+        for (int e = 0; e < 4; ++e) s += (FULL || (v * 64 + lane) * 4 + e < C) ? x[v][e] : 0.f;
     const float mean = nonorm ? 0.f : wave_sum(s) / (float)C;
     float q = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float dlt = ((v * 64 + lane) * 4 + e < C) ? x[v][e] - mean : 0.f;
+            const float dlt = (FULL || (v * 64 + lane) * 4 + e < C) ? x[v][e] - mean : 0.f;
             x[v][e] = dlt;
             q += dlt * dlt;
         }
@@ -556,15 +559,17 @@ __device__ __forceinline__ void ln_vec(f32x4 (&x)[NV], int C, int lane, const fl
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const int c = (v * 64 + lane) * 4;
-        if (c < C) {
-            const f32x4 gv = *(const f32x4*)(gam + c), bv = *(const f32x4*)(bet + c);
+        if ((FULL || c < C)) {
+            f32x4 gv, bv;
+            if constexpr (PRE) { gv = gvp[v]; bv = bvp[v]; }
+            else { gv = *(const f32x4*)(gam + c); bv = *(const f32x4*)(bet + c); }
 #pragma unroll
             for (int e = 0; e < 4; ++e) x[v][e] = x[v][e] * rstd * gv[e] + bv[e];
         }
     }
 }
 
-template <int NV>
+template <int NV, bool FULL>
 __device__ __forceinline__ void ln_rows_body(const EpiArgs& a) {
     if (stopped(a.stop_after, a.t)) return;
     const int lane = threadIdx.x & 63;
@@ -583,40 +588,57 @@ __device__ __forceinline__ void ln_rows_body(const EpiArgs& a) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const int c = (v * 64 + lane) * 4;
-        x[v] = c < C ? *(const f32x4*)(h + c) : zero4;
+        x[v] = (FULL || c < C) ? *(const f32x4*)(h + c) : zero4;
         for (int sp = 1; sp < a.nsplit; ++sp)
-            if (c < C) x[v] += *(const f32x4*)(h + sp * a.split_stride + c);
+            if ((FULL || c < C)) x[v] += *(const f32x4*)(h + sp * a.split_stride + c);
     }
-    ln_vec<NV>(x, C, lane, a.g1, a.b1, a.nonorm);
-    const float* lg = nullptr;             // this row's LCC gate vector
-    if (a.lcc) lg = a.lcc + (size_t)a.lcc_ids[a.lcc_T > 0 ? m / a.lcc_T : m % a.Bpad] * C;
-    if (a.mode == PRE_HC) {
-        f32x4 u[NV];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int c = (v * 64 + lane) * 4;
-            u[v] = c < C ? *(const f32x4*)(h + C + c) : zero4;
-            for (int sp = 1; sp < a.nsplit; ++sp)
-                if (c < C) u[v] += *(const f32x4*)(h + sp * a.split_stride + C + c);
-        }
-        ln_vec<NV>(u, C, lane, a.g2, a.b2, a.nonorm);
-        if (lg) {
-#pragma unroll
-            for (int v = 0; v < NV; ++v)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int c = (v * 64 + lane) * 4 + e;
-                    if (c < C) u[v][e] *= lg[c];
-                }
-        }
+    // everything the row needs is requested before the first reduction (the highway's second half and residual row; gamma / beta of
+    // narrow rows): one memory round trip per row instead of three dependent ones
+    constexpr bool PRE = NV <= 2;
+    f32x4 gv1[NV], bv1[NV], gv2[NV], bv2[NV], u[NV], xres[NV];
+    const bool hc = a.mode == PRE_HC;
+    if (hc) {
         size_t rrow = m;
         if (a.restab) rrow = (size_t)a.restab[m / a.Bpad] * a.Bpad + (m % a.Bpad);
         const float* xr = a.Xres + rrow * a.ldres;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int c = (v * 64 + lane) * 4;
-            if (c < C) {
-                const f32x4 xv = *(const f32x4*)(xr + c);
+            u[v] = (FULL || c < C) ? *(const f32x4*)(h + C + c) : zero4;
+            for (int sp = 1; sp < a.nsplit; ++sp)
+                if ((FULL || c < C)) u[v] += *(const f32x4*)(h + sp * a.split_stride + C + c);
+            xres[v] = (FULL || c < C) ? *(const f32x4*)(xr + c) : zero4;
+        }
+    }
+    if constexpr (PRE) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if ((FULL || c < C)) {
+                gv1[v] = *(const f32x4*)(a.g1 + c); bv1[v] = *(const f32x4*)(a.b1 + c);
+                if (hc) { gv2[v] = *(const f32x4*)(a.g2 + c); bv2[v] = *(const f32x4*)(a.b2 + c); }
+            }
+        }
+    }
+    ln_vec<NV, PRE, FULL>(x, C, lane, a.g1, a.b1, a.nonorm, gv1, bv1);
+    const float* lg = nullptr;             // this row's LCC gate vector
+    if (a.lcc) lg = a.lcc + (size_t)a.lcc_ids[a.lcc_T > 0 ? m / a.lcc_T : m % a.Bpad] * C;
+    if (hc) {
+        ln_vec<NV, PRE, FULL>(u, C, lane, a.g2, a.b2, a.nonorm, gv2, bv2);
+        if (lg) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = (v * 64 + lane) * 4 + e;
+                    if ((FULL || c < C)) u[v][e] *= lg[c];
+                }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if ((FULL || c < C)) {
+                const f32x4 xv = xres[v];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float gte = fast_sigmoid(x[v][e]);
@@ -630,7 +652,7 @@ __device__ __forceinline__ void ln_rows_body(const EpiArgs& a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int c = (v * 64 + lane) * 4 + e;
-                const float gt = c < C ? lg[c] : 0.f;
+                const float gt = (FULL || c < C) ? lg[c] : 0.f;
                 x[v][e] = a.act == ACT_SIGMOID ? fast_sigmoid(gt * x[v][e]) : gt * fast_act(x[v][e], a.act);
             }
     } else {
@@ -653,7 +675,7 @@ __device__ __forceinline__ void ln_rows_body(const EpiArgs& a) {
                 h16x4_ hi, lo;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float xv = c + e < C ? x[v][e] : 0.f;
+                    const float xv = (FULL || c + e < C) ? x[v][e] : 0.f;
                     hi[e] = (_Float16)xv;
                     lo[e] = (_Float16)(xv - (float)hi[e]);
                 }
@@ -669,13 +691,13 @@ __device__ __forceinline__ void ln_rows_body(const EpiArgs& a) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const int c = (v * 64 + lane) * 4;
-        if (c + 3 < C && vec_ok) {
+        if ((FULL || c + 3 < C) && vec_ok) {
             if (coh) st_coherent(y + c, x[v]);
             else *(f32x4*)(y + c) = x[v];
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (c + e < C) y[c + e] = x[v][e];
+                if ((FULL || c + e < C)) y[c + e] = x[v][e];
         }
     }
     int ctot = C;
@@ -689,9 +711,9 @@ __device__ __forceinline__ void ln_rows_body(const EpiArgs& a) {
     for (int c = ctot + lane; c < a.ypad; c += 64) y[c] = 0.f;
 }
 
-template <int NV>
+template <int NV, bool FULL = false>
 __global__ __launch_bounds__(256) void ln_rows(EpiArgs a) {
-    ln_rows_body<NV>(a);
+    ln_rows_body<NV, FULL>(a);
     const bool sig = !a.planes && a.done_sig;
     const int pos_b = sig ? (int)(blockIdx.x * 4) / a.Bpad : -1;       // Bpad % 4 == 0: a workgroup's 4 rows share a position
     if (sig && (pos_b == a.coh0 || pos_b == a.coh1)) {
@@ -711,7 +733,12 @@ __global__ __launch_bounds__(256) void ln_rows(EpiArgs a) {
 
 void launch_epilogue(const EpiArgs& a, hipStream_t s) {
     const dim3 grid((a.M + 3) / 4), block(256);
-    if (a.C <= 256) hipLaunchKernelGGL(ln_rows<1>, grid, block, 0, s, a);
+    // rows of exactly 256 / 512 / 1024 channels (every LayerNorm of the nets but the 80- and 1025-channel ends) take the instances
+    // without per-element guards: with them the 1024-channel instance needed 308 registers -- one wave per SIMD
+    if (a.C == 256) hipLaunchKernelGGL((ln_rows<1, true>), grid, block, 0, s, a);
+    else if (a.C == 512) hipLaunchKernelGGL((ln_rows<2, true>), grid, block, 0, s, a);
+    else if (a.C == 1024) hipLaunchKernelGGL((ln_rows<4, true>), grid, block, 0, s, a);
+    else if (a.C <= 256) hipLaunchKernelGGL(ln_rows<1>, grid, block, 0, s, a);
     else if (a.C <= 512) hipLaunchKernelGGL(ln_rows<2>, grid, block, 0, s, a);
     else if (a.C <= 1024) hipLaunchKernelGGL(ln_rows<4>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(ln_rows<5>, grid, block, 0, s, a);   // <= 1280 (full_dim 1025)

@@ -53,6 +53,13 @@ cd $R && python profiles/summarize_r04.py
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
 tail -c 1200 $O/bench.json
 cp $O/bench.json profiles/r04_bench.json;  cp $O/bench_traced.json profiles/r04_bench_traced.json; cp $O/bench_traced_coneloop.json profiles/r04_bench_traced_coneloop.json; cp $O/bench_coneloop.json profiles/r04_bench_coneloop.json
+# E  the batched nets' contractions (plane_gemm): conv1d_transpose timing of both paths and the ablation
+#    builds, the stand-alone SSRN per-dispatch tables of both paths, and the counter passes over the stand-alone SSRN
+bash profiles/r04_planes.sh; bash profiles/r04_ssrn_pmc.sh > /dev/null 2>&1
+cp $R/gpurun_out/planes/convt.log profiles/r04_convt.txt
+cp $R/gpurun_out/planes/ssrn_planes_table.txt profiles/r04_ssrn_table_planes.txt
+cp $R/gpurun_out/planes/ssrn_rows_table.txt profiles/r04_ssrn_table_rows.txt
+cp $R/gpurun_out/ssrn_pmc/summary.txt profiles/r04_ssrn_pmc.txt
 mkdir -p $R/gpurun_out/r04_summary && cp profiles/r04_* $R/gpurun_out/r04_summary/
 tail -n 3 $O/traceA.log
 rm -rf $O/traceA $O/traceA2 $O/traceB $O/loop_fetch $O/loop_write $O/runs_fetch $O/runs_write $O/runs_sq $O/runs_lds
