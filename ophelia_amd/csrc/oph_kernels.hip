@@ -1306,37 +1306,56 @@ __global__ __launch_bounds__(256) void attn_rows(AttnRowsArgs a) {
 // 16 waves first compute that position's Q . Wq + bias row (K split over the waves, every weight request issued before
 // the first use), cache it in QW, and wave 0 finishes the row.  The other workgroups take 16 rows each of the remaining
 // positions, reading the cached QW.  First launch of a cone in dec_loop mode: waits for the loop kernel's signal.
-static __device__ __forceinline__ void cone_head_row(const ConeHeadArgs& a, int i, int b, int tq, const f32x4& qw, int lane) {
+// WF: window positions handled (4: every request of the row -- Q, the window's K rows, its V . Wc rows, gamma, beta -- is issued
+// before the first use, rows past the window clamped and masked out of the arithmetic; as loads under `if (w < nwin)` they were
+// 2 win + 3 dependent round trips per row, most of this launch's 8-11 us.  8: the general form, windows of 5..8 keys)
+template <int WF>
+static __device__ __forceinline__ void cone_head_row(const ConeHeadArgs& a, int i, int b, int tq, const f32x4& qw, int lane, int p) {
     const int d = a.d, c = lane * 4;
     const bool cok = c < d;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const size_t qrow = ((size_t)tq * a.Bpad + b) * d;
+    // attention window [p, p+win) under the CURRENT mask (networks.py:300-315); p = a.p[b], requested by the caller beside the row's time index
     const f32x4 q = cok ? *(const f32x4*)(a.Q + qrow + c) : zero4;
-    // attention window [p, p+win) under the CURRENT mask (networks.py:300-315)
-    const int p = a.p[b];
     const int nwin = min(a.win, a.N_keys - p);
     const float* Kb = a.KV + (size_t)b * a.N_keys * 2 * d;
     const float* VWb = a.VW + (size_t)b * a.N_keys * a.ldvw;
     const float scale = 1.0f / sqrtf((float)d);
-    float sc[ATT_WMAX], mx = -INFINITY;
+    f32x4 kvs[WF], vws[WF], gpre = zero4, bpre = zero4;
+    if constexpr (WF <= 4) {
 #pragma unroll
-    for (int w = 0; w < ATT_WMAX; ++w) {
+        for (int w = 0; w < WF; ++w) {
+            const int row = min(p + w, a.N_keys - 1);
+            kvs[w] = cok ? *(const f32x4*)(Kb + (size_t)row * 2 * d + c) : zero4;
+            vws[w] = cok ? *(const f32x4*)(VWb + (size_t)row * a.ldvw + c) : zero4;
+        }
+        if (cok) { gpre = *(const f32x4*)(a.gamma + c); bpre = *(const f32x4*)(a.beta + c); }
+    }
+    float sc[WF], mx = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < WF; ++w) {
         sc[w] = -INFINITY;
-        if (w < nwin) {
+        if constexpr (WF <= 4) {
+            const f32x4 kv = kvs[w];
+            const float v = wave_sum(q[0] * kv[0] + q[1] * kv[1] + q[2] * kv[2] + q[3] * kv[3]) * scale;
+            if (w < nwin) { sc[w] = v; mx = fmaxf(mx, v); }
+        } else if (w < nwin) {
             const f32x4 kv = cok ? *(const f32x4*)(Kb + (size_t)(p + w) * 2 * d + c) : zero4;
             sc[w] = wave_sum(q[0] * kv[0] + q[1] * kv[1] + q[2] * kv[2] + q[3] * kv[3]) * scale;
             mx = fmaxf(mx, sc[w]);
         }
     }
-    float den = 0.f, pr[ATT_WMAX];
+    float den = 0.f, pr[WF];
 #pragma unroll
-    for (int w = 0; w < ATT_WMAX; ++w) { pr[w] = w < nwin ? expf(sc[w] - mx) : 0.f; den += pr[w]; }
+    for (int w = 0; w < WF; ++w) { pr[w] = w < nwin ? expf(sc[w] - mx) : 0.f; den += pr[w]; }
     f32x4 h = qw;
 #pragma unroll
-    for (int w = 0; w < ATT_WMAX; ++w) {
+    for (int w = 0; w < WF; ++w) {
         if (w < nwin) {
             const float pw = pr[w] / den;
-            const f32x4 vw = cok ? *(const f32x4*)(VWb + (size_t)(p + w) * a.ldvw + c) : zero4;
+            f32x4 vw;
+            if constexpr (WF <= 4) vw = vws[w];
+            else vw = cok ? *(const f32x4*)(VWb + (size_t)(p + w) * a.ldvw + c) : zero4;
 #pragma unroll
             for (int n = 0; n < 4; ++n) h[n] = fmaf(pw, vw[n], h[n]);
         }
@@ -1350,7 +1369,9 @@ static __device__ __forceinline__ void cone_head_row(const ConeHeadArgs& a, int 
     const float rstd = a.nonorm ? 1.0f : 1.0f / sqrtf(wave_sum(qq) * invd + LN_EPS);
     float* y = a.Y + ((size_t)i * a.Bpad + b) * a.ldy;
     if (cok) {
-        const f32x4 g = *(const f32x4*)(a.gamma + c), bt = *(const f32x4*)(a.beta + c);
+        f32x4 g, bt;
+        if constexpr (WF <= 4) { g = gpre; bt = bpre; }
+        else { g = *(const f32x4*)(a.gamma + c); bt = *(const f32x4*)(a.beta + c); }
         f32x4 o;
 #pragma unroll
         for (int n = 0; n < 4; ++n) o[n] = h[n] * rstd * g[n] + bt[n];
@@ -1433,7 +1454,8 @@ __global__ __launch_bounds__(1024) void cone_head(ConeHeadArgs a) {
                     for (int ww = 0; ww < 16; ++ww) qw += *(const f32x4*)&ps[ww][c];
                     *(f32x4*)(a.QW + qrow + c) = qw;          // cached: every later step reads this position's term
                 }
-                cone_head_row(a, a.i_new, b, tq, qw, lane);
+                const int pb = a.p[b];
+                if (a.win <= 4) cone_head_row<4>(a, a.i_new, b, tq, qw, lane, pb); else cone_head_row<ATT_WMAX>(a, a.i_new, b, tq, qw, lane, pb);
             }
         }
     } else if (live) {
@@ -1441,11 +1463,12 @@ __global__ __launch_bounds__(1024) void cone_head(ConeHeadArgs a) {
         int i = rl / a.Bpad; const int b = rl - i * a.Bpad;
         if (a.i_new >= 0 && i >= a.i_new) ++i;
         if (i < a.npos && b < a.B) {
+            const int pb = a.p[b];
             const int tq = a.j - a.off[i];
             if (tq >= 0) {
                 const int c = lane * 4;
                 const f32x4 qw = c < d ? *(const f32x4*)(a.QW + ((size_t)tq * a.Bpad + b) * d + c) : zero4;
-                cone_head_row(a, i, b, tq, qw, lane);
+                if (a.win <= 4) cone_head_row<4>(a, i, b, tq, qw, lane, pb); else cone_head_row<ATT_WMAX>(a, i, b, tq, qw, lane, pb);
             }
         }
     }
