@@ -120,6 +120,7 @@ struct Options {
     int ssrn_chunk = 40;             // OPH_SSRN_CHUNK: mel frames per streamed SSRN chunk (0 = SSRN only after the decode)
     int cl_wgs_per_cu = 2, cl_dbg = 0;   // OPH_CL_WGS_PER_CU (cone_loop workgroups per CU: 1 or 2), OPH_CL_DBG
     bool no_fused_cone = false;      // OPH_NO_FUSED_CONE: the cone's levels as contraction + ln_rows launches instead of hc_fused
+    int pg_waves = 0;                // OPH_PG_WAVES=4|8: plane_gemm's waves per workgroup forced (measurement; 0 = the launcher's choice)
     bool no_plane_gemm = false;      // OPH_NO_PLANE_GEMM: the batched nets' split-fp16 contractions on fp32 rows (conv_gemm_bf16x3) instead of planes (plane_gemm)
     bool no_chain = false;           // OPH_NO_CHAIN: the whole-decode launch as dec_loop (generic) even where dec_chain (specialised) fits
     void read() {
@@ -151,7 +152,7 @@ struct Options {
         run_stamps = flag("OPH_RUN_STAMPS");
         ssrn_chunk = std::max(0, num("OPH_SSRN_CHUNK", 40));
         cl_wgs_per_cu = num("OPH_CL_WGS_PER_CU", 2) == 1 ? 1 : 2; cl_dbg = num("OPH_CL_DBG", 0);
-        no_chain = flag("OPH_NO_CHAIN"); no_fused_cone = flag("OPH_NO_FUSED_CONE"); no_plane_gemm = flag("OPH_NO_PLANE_GEMM");
+        no_chain = flag("OPH_NO_CHAIN"); no_fused_cone = flag("OPH_NO_FUSED_CONE"); no_plane_gemm = flag("OPH_NO_PLANE_GEMM"); pg_waves = num("OPH_PG_WAVES", 0); if (pg_waves != 4 && pg_waves != 8) pg_waves = 0;
     }
     int cone_ksplit(int M) const { return M >= 512 ? ksplit_big : ksplit_small; }
 };

@@ -51,6 +51,7 @@ struct PlaneGemmArgs {
     int nalloc, ldh;                            // rows of the weight planes; raw row stride
     int ntaps, off[3];
     int convt;
+    int waves;                                  // 0: chosen by the launcher; 4 / 8: forced (measurement)
     int dbg;                                    // measurement only: 1 = no MFMAs (operand stream alone), 2 = no operand stream (MFMAs on whatever the LDS holds)
 };
 void launch_plane_gemm(const PlaneGemmArgs& a, hipStream_t s);

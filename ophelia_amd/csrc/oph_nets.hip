@@ -81,7 +81,7 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
                 PlaneGemmArgs pg{};
                 pg.Ah = xh; pg.Al = xl; pg.Wh = (const _Float16*)l.Wkh; pg.Wl = (const _Float16*)l.Wkl; pg.Wh2 = (const _Float16*)l.Wkh2; pg.Wl2 = (const _Float16*)l.Wkl2;
                 pg.bias = l.bias; pg.H = wsraw; pg.M = M; pg.N = l.N; pg.kc = l.kc; pg.T = Tcur; pg.nalloc = l.Nalloc; pg.ldh = 2 * l.Nalloc;
-                pg.ntaps = 2; pg.off[0] = 0; pg.off[1] = -1; pg.convt = 1;
+                pg.ntaps = 2; pg.off[0] = 0; pg.off[1] = -1; pg.convt = 1; pg.waves = h->opt.pg_waves;
                 h->pbegin(PC_GEMM_BF16);
                 launch_plane_gemm(pg, g_cur);
                 h->pend(PC_GEMM_BF16, ((double)g.M * l.cin + 2.0 * g.M * g.N + 3.0 * g.N * l.cin) * 4.0, 2.0 * g.M * g.N * 3.0 * l.cin);
@@ -107,6 +107,7 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
                 pg.bias = l.bias; pg.H = wsraw; pg.M = M; pg.N = l.N; pg.kc = l.kc; pg.T = Tcur; pg.nalloc = l.Nalloc; pg.ldh = l.Nalloc;
                 pg.ntaps = l.ntaps;
                 for (int t = 0; t < 3; ++t) pg.off[t] = l.off[t];
+                pg.waves = h->opt.pg_waves;
                 h->pbegin(PC_GEMM_BF16);
                 launch_plane_gemm(pg, g_cur);
                 const double K = (double)l.ntaps * l.cin;

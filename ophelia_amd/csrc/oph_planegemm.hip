@@ -35,31 +35,44 @@ typedef _Float16 h16;
 typedef h16 h16x8 __attribute__((ext_vector_type(8)));
 typedef h16 h16x4 __attribute__((ext_vector_type(4)));
 
-template <int NT, bool CONVT> struct PlaneGemmCfg {
+// WV = waves per workgroup.  4: 2 x 2 waves of 64 x 64 (transposed conv: 64 rows x [32 even- | 32 odd-phase] channels, 64 channels
+// per workgroup).  8: 2 x 4 waves -- two per SIMD, which fill each other's issue gaps (one wave per SIMD runs the loop at 43-49
+// cycles per MFMA) -- of 64 x 32 on the same 128 x 128 tile (transposed conv: the same wave tile, 128
+// channels of both phases per workgroup: half the workgroups, one round for D_7).
+template <int NT, bool CONVT, int WV> struct PlaneGemmCfg {
+    static constexpr int WC = WV / 2;                      // wave columns
+    static constexpr int BNC = CONVT ? 32 * WC : 128;      // output channels per workgroup
+    static constexpr int NCOLS = CONVT ? 2 * BNC : 128;    // columns of the workgroup's output tile (transposed conv: both phases)
+    static constexpr int TNW = CONVT ? 2 : 128 / WC / 32;  // 32-column accumulator tiles per wave (transposed conv: even, odd)
     static constexpr int HALO = NT == 1 ? 0 : PLANE_GEMM_HALO;
     static constexpr int AROWS = 128 + 2 * HALO;           // activation rows per stage
     static constexpr int A_WCH = AROWS / 16;               // 1 KB wave pieces (16 rows x 64 B) per plane
-    static constexpr int A_OPS = 2 * A_WCH / 4;            // pieces per wave and stage (hi and lo planes together): 5 (halo) / 4
+    static constexpr int A_PIECES = 2 * A_WCH;             // hi and lo planes together: 20 (halo) / 16
+    static constexpr int A_OPS = (A_PIECES + WV - 1) / WV; // per wave (a surplus slot repeats the last piece: the same bytes to the same place)
     static constexpr int A_BUF = 2 * AROWS * 32;           // halves: [hi plane | lo plane]
-    static constexpr int b_pl(int tap) { return (CONVT && tap == 1) ? 64 * 32 : 128 * 32; }      // halves of one weight plane of a tap
+    static constexpr int b_rows(int tap) { return CONVT ? (tap == 0 ? 2 * BNC : BNC) : 128; }       // weight rows of a tap's step
+    static constexpr int b_pl(int tap) { return b_rows(tap) * 32; }                                  // halves of one weight plane of a tap
+    static constexpr int b_ops(int tap) { return 2 * b_rows(tap) / 16 / WV; }                        // pieces per wave
     static constexpr int b_at(int tap) { return tap == 0 ? A_BUF : b_at(tap - 1) + 2 * b_pl(tap - 1); }   // where a tap's planes start in a stage
+    static constexpr int op_at(int tap) { return tap == 0 ? A_OPS : op_at(tap - 1) + b_ops(tap - 1); }     // first piece index of a tap
     static constexpr int STAGE = b_at(NT);                 // halves per stage: activations + every tap's weights of one 32-channel block
     static constexpr int STAGES = 2;                       // LDS stages: the block being multiplied and the one being written (the blocks
-                                                           // further ahead are in registers / in flight): 88 / 64 / 136 KB
-    static constexpr int NOPS = A_OPS + (CONVT ? 6 : 4 * NT);         // 1 KB pieces (16 bytes per lane) per wave and stage
-    static constexpr size_t LDS_BYTES = (size_t)STAGES * STAGE * 2 > 128 * 132 * 4 ? (size_t)STAGES * STAGE * 2 : (size_t)128 * 132 * 4;   // (the output tile is staged there too)
+                                                           // further ahead are in registers / in flight): 64 - 136 KB
+    static constexpr int NOPS = op_at(NT);                 // 1 KB pieces (16 bytes per lane) per wave and stage
+    static constexpr int LDO = NCOLS + 4;                  // floats per row of the staged output tile
+    static constexpr size_t LDS_BYTES = (size_t)STAGES * STAGE * 2 > (size_t)128 * LDO * 4 ? (size_t)STAGES * STAGE * 2 : (size_t)128 * LDO * 4;
 };
 
-template <int NT, bool CONVT, int DBG = 0>        // DBG (measurement only): 1 = no MFMAs (the operand stream alone), 2 = no operand stream in the loop
-__global__ __launch_bounds__(256, 1) void plane_gemm(PlaneGemmArgs a) {      // (one workgroup per CU: two of a k = 1 layer's -- 68 KB each -- measured 115 us against 103)
+template <int NT, bool CONVT, int WV = 4, int DBG = 0>        // DBG (measurement only): 1 = no MFMAs, 2 = no operand stream in the loop, 4 = no stores, 8 = three K blocks
+__global__ __launch_bounds__(64 * WV, 1) void plane_gemm(PlaneGemmArgs a) {      // (one workgroup per CU: two of a k = 1 layer's -- 68 KB each -- measured 115 us against 103)
     static_assert(!CONVT || NT == 2, "transposed convolution: taps x[t], x[t-1]");
-    typedef PlaneGemmCfg<NT, CONVT> Cfg;
+    typedef PlaneGemmCfg<NT, CONVT, WV> Cfg;
     constexpr int HALO = Cfg::HALO, AROWS = Cfg::AROWS, A_WCH = Cfg::A_WCH, A_OPS = Cfg::A_OPS, STAGE = Cfg::STAGE, STAGES = Cfg::STAGES;
+    constexpr int WC = Cfg::WC, BNC = Cfg::BNC, TNW = Cfg::TNW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     h16* Ss = (h16*)smem;                            // [STAGES][STAGE]
 
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int BNC = CONVT ? 64 : 128;            // output channels per workgroup
     const int MT = (a.M + 127) / 128, NTL = (a.N + BNC - 1) / BNC;
     const int ntiles = MT * NTL;
     int id;
@@ -77,27 +90,27 @@ __global__ __launch_bounds__(256, 1) void plane_gemm(PlaneGemmArgs a) {      // 
     // lane & 3); the position a lane FETCHES is swizzled with the LDS row's (row >> 2) & 3 (= (lane >> 4) & 3: pieces start at
     // multiples of 16 rows), so a fragment read of 16 consecutive rows touches 16 distinct 4-bank groups
     const int lrow = lane >> 2, sp = ((lane & 3) ^ ((lane >> 4) & 3)) << 3;
-    const h16* ap[A_OPS];
+    const size_t w_kstride = (size_t)a.nalloc * 32;  // halves between two K blocks of a weight plane
+    const h16* pp[Cfg::NOPS];                        // this lane's 16 bytes of every piece of block 0
+    int pdst[Cfg::NOPS];                             // where the piece starts in a stage (halves)
 #pragma unroll
     for (int j = 0; j < A_OPS; ++j) {
-        const int wq = j * 4 + w, plane = wq / A_WCH, i = (wq % A_WCH) * 16 + lrow;
+        const int wq = min(j * WV + w, Cfg::A_PIECES - 1), plane = wq / A_WCH, i = (wq % A_WCH) * 16 + lrow;
         const int gr = min(max(m0 - HALO + i, 0), a.M - 1);         // (halo / tail rows outside the problem: clamped, never used unmasked)
-        ap[j] = (plane ? a.Al : a.Ah) + (size_t)gr * 32 + sp;
+        pp[j] = (plane ? a.Al : a.Ah) + (size_t)gr * 32 + sp;
+        pdst[j] = wq * 512;
     }
-    const h16* bp[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int wq = j * 4 + w, plane = wq >> 3, rr = (wq & 7) * 16 + lrow;
-        if (CONVT && rr >= 64) bp[j] = (plane ? a.Wl2 : a.Wh2) + (size_t)(n0 + rr - 64) * 32 + sp;      // odd phase: Kt1
-        else bp[j] = (plane ? a.Wl : a.Wh) + (size_t)(n0 + rr) * 32 + sp;
-    }
-    const size_t w_kstride = (size_t)a.nalloc * 32;  // halves between two K blocks of a weight plane
-    const h16* bp1[2] = {nullptr, nullptr};          // transposed convolution, x[t-1]: 64 rows of Kt2 (the even phase's second tap)
-    if constexpr (CONVT) {
+    for (int tap = 0; tap < NT; ++tap) {
+        const int rows = Cfg::b_rows(tap), ppl = rows / 16;          // pieces per plane
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int wq = j * 4 + w, plane = wq >> 2, rr = (wq & 3) * 16 + lrow;
-            bp1[j] = (plane ? a.Wl : a.Wh) + (size_t)(a.kc >> 5) * w_kstride + (size_t)(n0 + rr) * 32 + sp;
+        for (int j = 0; j < Cfg::b_ops(tap); ++j) {
+            const int wq = j * WV + w, plane = wq / ppl, rr = (wq % ppl) * 16 + lrow;
+            const h16* src;
+            if (CONVT && tap == 0 && rr >= BNC) src = (plane ? a.Wl2 : a.Wh2) + (size_t)(n0 + rr - BNC) * 32;        // odd phase: Kt1
+            else src = (plane ? a.Wl : a.Wh) + (size_t)(tap * (a.kc >> 5)) * w_kstride + (size_t)(n0 + rr) * 32;    // (transposed conv, tap 1: Kt2 behind Kt0)
+            pp[Cfg::op_at(tap) + j] = src + sp;
+            pdst[Cfg::op_at(tap) + j] = Cfg::b_at(tap) + wq * 512;
         }
     }
     const size_t a_kstride = (size_t)a.M * 32;       // halves between two K blocks of the activation planes
@@ -110,28 +123,11 @@ __global__ __launch_bounds__(256, 1) void plane_gemm(PlaneGemmArgs a) {      // 
     i32x4 stg[Cfg::NOPS];
     auto load_op = [&](auto op_c, int kb) {          // piece `op` of block kb -> its staging register
         constexpr int op = decltype(op_c)::value;
-        if constexpr (op < A_OPS) stg[op] = *(const i32x4*)(ap[op] + (size_t)kb * a_kstride);
-        else if constexpr (CONVT) {
-            constexpr int j = op - A_OPS;
-            if constexpr (j < 4) stg[op] = *(const i32x4*)(bp[j] + kb * w_kstride);
-            else stg[op] = *(const i32x4*)(bp1[j - 4] + kb * w_kstride);
-        } else {
-            constexpr int tap = (op - A_OPS) / 4, j = (op - A_OPS) % 4;
-            stg[op] = *(const i32x4*)(bp[j] + (size_t)(tap * (a.kc >> 5) + kb) * w_kstride);
-        }
+        stg[op] = *(const i32x4*)(pp[op] + (size_t)kb * (op < A_OPS ? a_kstride : w_kstride));
     };
     auto store_op = [&](auto op_c, int stage) {      // staging register -> its place in ring stage `stage` (lane l: byte 16 l of the piece)
         constexpr int op = decltype(op_c)::value;
-        h16* st = Ss + stage * STAGE + lane * 8;
-        if constexpr (op < A_OPS) *(i32x4*)(st + (op * 4 + w) * 512) = stg[op];
-        else if constexpr (CONVT) {
-            constexpr int j = op - A_OPS;
-            if constexpr (j < 4) *(i32x4*)(st + Cfg::b_at(0) + (j * 4 + w) * 512) = stg[op];
-            else *(i32x4*)(st + Cfg::b_at(1) + ((j - 4) * 4 + w) * 512) = stg[op];      // [hi 64 rows | lo 64 rows]
-        } else {
-            constexpr int tap = (op - A_OPS) / 4, j = (op - A_OPS) % 4;
-            *(i32x4*)(st + Cfg::b_at(tap) + (j * 4 + w) * 512) = stg[op];
-        }
+        *(i32x4*)(Ss + stage * STAGE + pdst[op] + lane * 8) = stg[op];
     };
     auto for_ops = [&](auto&& f) {
         auto go = [&](auto self, auto op_c) {
@@ -142,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void plane_gemm(PlaneGemmArgs a) {      // 
     };
 
     // ---- fragments.  32x32x16 operand: lane l holds row (l & 31), k = 8 (l >> 5) .. + 7 of the 16-wide slice
-    const int wr = w >> 1, wc = w & 1, r32 = lane & 31, kh = lane >> 5;
+    const int wr = w / WC, wc = w % WC, r32 = lane & 31, kh = lane >> 5;
     int aoff[NT][2];                                 // halves into a stage's hi plane, K slice 0 (slice 1: ^ 16)
     unsigned keep[NT][2];                            // all ones, or 0 where this lane's row has no source for the tap (utterance boundary):
                                                      // the fragment is AND-ed with it -- no branch in the K loop
@@ -156,47 +152,42 @@ __global__ __launch_bounds__(256, 1) void plane_gemm(PlaneGemmArgs a) {      // 
             keep[tap][i] = (tt < 0 || tt >= a.T) ? 0u : 0xffffffffu;
         }
     }
-    int boff[2];
+    int boff[TNW];
 #pragma unroll
-    for (int jn = 0; jn < 2; ++jn) {
-        const int br = (CONVT ? jn * 64 + wc * 32 : wc * 64 + jn * 32) + r32;
+    for (int jn = 0; jn < TNW; ++jn) {
+        const int br = (CONVT ? jn * BNC + wc * 32 : wc * (128 / WC) + jn * 32) + r32;
         boff[jn] = br * 32 + ((kh ^ ((br >> 2) & 3)) << 3);
     }
 
-    float bias_v[2];                                 // (requested before the K loop: no round trip between the loop and the stores)
-    bias_v[0] = a.bias[CONVT ? n0 + wc * 32 + r32 : n0 + wc * 64 + r32];
-    bias_v[1] = CONVT ? bias_v[0] : a.bias[n0 + wc * 64 + 32 + r32];
-    f32x16 acc[2][2];
+    float bias_v[TNW];                               // (requested before the K loop: no round trip between the loop and the stores)
+#pragma unroll
+    for (int jn = 0; jn < TNW; ++jn) bias_v[jn] = a.bias[CONVT ? n0 + wc * 32 + r32 : n0 + wc * (128 / WC) + jn * 32 + r32];
+    f32x16 acc[2][TNW];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
+        for (int jn = 0; jn < TNW; ++jn)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
 
-    // A K block is 2 NT slices (tap, 16-wide K slice); a slice = its fragment reads (8, or 6 for the x[t-1] step of the transposed
-    // convolution), the boundary masks and 12 (6) MFMAs.  Software-pipelined by hand: slice q + 1's fragments are read into the
-    // other register set behind slice q's first MFMAs, one read per MFMA, and the order is pinned with sched_barrier -- left alone
-    // the compiler reads two fragments, waits, issues two MFMAs, waits, ... (13 exposed LDS round trips per block with one wave
-    // per SIMD).  Fragment f of a slice: 0..3 = A rows (al0, al1, ah0, ah1), 4.. = B columns (bh0, [bh1], bl0, [bl1]).
     h16x8 fr[2][8];
     constexpr int NQ = 2 * NT;
     // The barrier that releases block kb + 1 stands BEFORE block kb's last slice, and that slice reads block kb + 1's first fragments
     // behind its MFMAs: no exposed LDS round trip at the top of a block.  So every piece of block kb + 1 is written to LDS during
     // the slices before the last one.
     struct Sl {       // per slice: MFMAs, LDS reads issued behind them (the next slice's fragments), pieces moved before it
-        static constexpr int tn(int q) { return (CONVT && ((q % (2 * NT)) >> 1) == 1) ? 1 : 2; }
+        static constexpr int tn(int q) { return CONVT ? (((q % (2 * NT)) >> 1) == 1 ? 1 : 2) : TNW; }
         static constexpr int nm(int q) { return 6 * tn(q); }
         static constexpr int nr(int q) { return 4 + 2 * tn(q + 1); }
         // a piece (LDS write of block kb + 1's, then the load of block kb + 2's into the same register) rides behind every MFMA that
         // has no LDS read behind it; a k = 1 layer has a single slice before the barrier: all of its pairs carry one
-        static constexpr int first(int q) { return NT == 1 ? 0 : nr(q); }
+        static constexpr int first(int q) { return NT == 1 ? 0 : (nr(q) < nm(q) ? nr(q) : nm(q)); }
         static constexpr int base(int q) { return q == 0 ? 0 : base(q - 1) + 12 - first(q - 1); }
     };
     static_assert(Sl::base(NQ - 1) >= Cfg::NOPS, "every operand piece of a stage has a slot before the barrier");
     auto read_frag = [&](auto q_c, auto f_c, const h16* st) {
         constexpr int q = decltype(q_c)::value % NQ, f = decltype(f_c)::value, tap = q >> 1, ks = q & 1;
-        constexpr int TNt = (CONVT && tap == 1) ? 1 : 2;
+        constexpr int TNt = Sl::tn(q);
         if constexpr (f < 4) {
             constexpr int i = f & 1, lo = f < 2;
             fr[q & 1][f] = *(const h16x8*)(st + (lo ? AROWS * 32 : 0) + (aoff[tap][i] ^ (ks * 16)));
@@ -206,8 +197,8 @@ __global__ __launch_bounds__(256, 1) void plane_gemm(PlaneGemmArgs a) {      // 
         }
     };
     auto mfma_k = [&](auto q_c, auto k_c) {
-        constexpr int q = decltype(q_c)::value, k = decltype(k_c)::value, tap = q >> 1;
-        constexpr int TNt = (CONVT && tap == 1) ? 1 : 2;
+        constexpr int q = decltype(q_c)::value, k = decltype(k_c)::value;
+        constexpr int TNt = Sl::tn(q);
         // product by product over the tiles (al.bh, ah.bl, ah.bh): consecutive MFMAs never share an accumulator
         constexpr int p = k / (2 * TNt), i = (k / TNt) & 1, jn = k % TNt;
         constexpr int fa = p == 0 ? i : 2 + i, fb = 4 + (p == 1 ? TNt : 0) + jn;
@@ -252,10 +243,12 @@ __global__ __launch_bounds__(256, 1) void plane_gemm(PlaneGemmArgs a) {      // 
         pair(std::integral_constant<int, 9>{}); pair(std::integral_constant<int, 10>{}); pair(std::integral_constant<int, 11>{});
     };
     auto read_slice0 = [&](const h16* st) {
-        read_frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, st); read_frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}, st);
-        read_frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{}, st); read_frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, st);
-        read_frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, st); read_frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 6>{}, st);
-        read_frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 7>{}, st); read_frag(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, st);
+        constexpr int nf = 4 + 2 * Sl::tn(0);
+        auto go = [&](auto self, auto f_c) {
+            constexpr int f = decltype(f_c)::value;
+            if constexpr (f < nf) { read_frag(std::integral_constant<int, 0>{}, f_c, st); self(self, std::integral_constant<int, f + 1>{}); }
+        };
+        go(go, std::integral_constant<int, 0>{});
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -296,27 +289,28 @@ __global__ __launch_bounds__(256, 1) void plane_gemm(PlaneGemmArgs a) {      // 
     // as a [128][128] tile in the ring's LDS it leaves as 16 sixteen-byte stores per lane in 512-byte (transposed conv: 256-byte) runs
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                    // every wave is done with the ring
-    constexpr int LDO = 132;                         // floats per staged row
+    constexpr int LDO = Cfg::LDO, NCOLS = Cfg::NCOLS;
     float* Os = smem;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn) {
-            const int cl = CONVT ? jn * 64 + wc * 32 + r32 : wc * 64 + jn * 32 + r32;      // (transposed: [64 even-phase | 64 odd-phase] channels)
-            const float bv = bias_v[CONVT ? 0 : jn];
+        for (int jn = 0; jn < TNW; ++jn) {
+            const int cl = CONVT ? jn * BNC + wc * 32 + r32 : wc * (128 / WC) + jn * 32 + r32;      // (transposed: [even-phase | odd-phase] channels)
+            const float bv = bias_v[jn];
 #pragma unroll
             for (int e = 0; e < 16; ++e) Os[(wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh) * LDO + cl] = acc[i][jn][e] + bv;
         }
     __syncthreads();
     if constexpr (!(DBG & 4)) {
+        constexpr int C4 = NCOLS / 4, ITS = 128 * C4 / (64 * WV);      // 16-byte pieces per row; per thread
         auto out = [&](auto guarded) {
-            f32x4 v[16];
+            f32x4 v[ITS];
 #pragma unroll
-            for (int it = 0; it < 16; ++it) v[it] = *(const f32x4*)(Os + ((it * 256 + tid) >> 5) * LDO + (tid & 31) * 4);
+            for (int it = 0; it < ITS; ++it) { const int idx = it * 64 * WV + tid; v[it] = *(const f32x4*)(Os + (idx / C4) * LDO + (idx % C4) * 4); }
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int row = (it * 256 + tid) >> 5, c4 = tid & 31;
-                float* dst = a.H + (size_t)(m0 + row) * a.ldh + (CONVT ? (size_t)(c4 >> 4) * (a.ldh >> 1) + n0 + (c4 & 15) * 4 : (size_t)n0 + c4 * 4);
+            for (int it = 0; it < ITS; ++it) {
+                const int idx = it * 64 * WV + tid, row = idx / C4, c4 = idx % C4;
+                float* dst = a.H + (size_t)(m0 + row) * a.ldh + (CONVT ? (size_t)(c4 / (BNC / 4)) * (a.ldh >> 1) + n0 + (c4 % (BNC / 4)) * 4 : (size_t)n0 + c4 * 4);
                 if (!decltype(guarded)::value || m0 + row < a.M) *(f32x4*)dst = v[it];
             }
         };
@@ -325,30 +319,38 @@ __global__ __launch_bounds__(256, 1) void plane_gemm(PlaneGemmArgs a) {      // 
     }
 }
 
-template <int NT, bool CONVT, int DBG = 0>
+template <int NT, bool CONVT, int WV = 4, int DBG = 0>
 static void launch_plane_gemm_t(const PlaneGemmArgs& a, hipStream_t s) {
-    constexpr size_t lds = PlaneGemmCfg<NT, CONVT>::LDS_BYTES;
+    typedef PlaneGemmCfg<NT, CONVT, WV> Cfg;
+    constexpr size_t lds = Cfg::LDS_BYTES;
     static bool attr_set[64] = {false};          // function attributes are per device
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr_set[dev & 63]) {
-        (void)hipFuncSetAttribute((const void*)plane_gemm<NT, CONVT, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)plane_gemm<NT, CONVT, WV, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set[dev & 63] = true;
     }
-    const int MT = (a.M + 127) / 128, NTL = CONVT ? (a.N + 63) / 64 : (a.N + 127) / 128;
-    hipLaunchKernelGGL((plane_gemm<NT, CONVT, DBG>), dim3(MT * NTL), dim3(256), lds, s, a);
+    const int MT = (a.M + 127) / 128, NTL = (a.N + Cfg::BNC - 1) / Cfg::BNC;
+    hipLaunchKernelGGL((plane_gemm<NT, CONVT, WV, DBG>), dim3(MT * NTL), dim3(64 * WV), lds, s, a);
 }
 // a.convt: conv1d_transpose (taps x[t], x[t-1] on the even phase's planes Wh / Wl, x[t] on the odd phase's Wh2 / Wl2; raw rows
-// interleaved, a.ldh = 2 Nalloc); otherwise a.ntaps = 1 or 3 taps at offsets a.off[] (|offset| <= PLANE_GEMM_HALO)
+// interleaved, a.ldh = 2 Nalloc); otherwise a.ntaps = 1 or 3 taps at offsets a.off[] (|offset| <= PLANE_GEMM_HALO).
+// a.waves: 0 = chosen here, 4 / 8 forced (measurement)
 void launch_plane_gemm(const PlaneGemmArgs& a, hipStream_t s) {
+    const int MT = (a.M + 127) / 128;
     if (a.convt) {
-        if (a.dbg == 1) launch_plane_gemm_t<2, true, 1>(a, s);
-        else if (a.dbg == 2) launch_plane_gemm_t<2, true, 2>(a, s);
-        else if (a.dbg == 4) launch_plane_gemm_t<2, true, 4>(a, s);
-        else if (a.dbg == 8) launch_plane_gemm_t<2, true, 8>(a, s);
-        else launch_plane_gemm_t<2, true>(a, s);
-    } else if (a.ntaps == 1) launch_plane_gemm_t<1, false>(a, s);
-    else launch_plane_gemm_t<3, false>(a, s);
+        if (a.dbg == 1) return launch_plane_gemm_t<2, true, 4, 1>(a, s);
+        if (a.dbg == 2) return launch_plane_gemm_t<2, true, 4, 2>(a, s);
+        if (a.dbg == 4) return launch_plane_gemm_t<2, true, 4, 4>(a, s);
+        if (a.dbg == 8) return launch_plane_gemm_t<2, true, 4, 8>(a, s);
+        // more 64-channel workgroups than CUs would take two rounds at one per CU: 128 channels per workgroup, 8 waves
+        const bool wide = a.waves ? a.waves == 8 : (MT * ((a.N + 63) / 64) > 256 && a.N % 128 == 0);
+        if (wide) launch_plane_gemm_t<2, true, 8>(a, s); else launch_plane_gemm_t<2, true, 4>(a, s);
+    } else if (a.ntaps == 1) {
+        if (a.waves == 8) launch_plane_gemm_t<1, false, 8>(a, s); else launch_plane_gemm_t<1, false, 4>(a, s);
+    } else {
+        if (a.waves == 8) launch_plane_gemm_t<3, false, 8>(a, s); else launch_plane_gemm_t<3, false, 4>(a, s);
+    }
 }
 bool plane_gemm_ok(int ntaps, const int* off, int kc, bool convt) {
     if (kc % 32) return false;
