@@ -146,6 +146,37 @@ def test_c3_ssrn_full_size(c2):
         assert np.abs(Zr - O.synth_mel2mag(hp, W, Yr)).max() < 1e-3 / 4
 
 
+def test_plane_gemm_wave_forms_and_the_row_kernel_agree(c2):
+    """SSRN's split-fp16 contractions run on pre-split fp16 planes (plane_gemm, oph_planegemm.hip).  Its 4-wave and 8-wave forms sum
+    every output element in the same order -- bitwise equal -- and the round-3 kernel on fp32 rows (OPH_NO_PLANE_GEMM: another
+    K order) agrees within the fp32 class; the default picks the 8-wave transposed convolution only where the 64-channel form
+    would need two rounds (D_7 at this size), so the default equals both forced forms bit for bit too."""
+    import os
+    hp, W, L, _ = c2
+    Y0 = np.random.default_rng(5).random((16, hp.max_T, hp.n_mels), dtype=np.float32)
+    Z0 = O.synth_mel2mag(hp, W, Y0)
+    out = {}
+    for name, env in (("default", {}), ("waves4", {"OPH_PG_WAVES": "4"}), ("waves8", {"OPH_PG_WAVES": "8"}), ("rows", {"OPH_NO_PLANE_GEMM": "1"})):
+        saved = {k: os.environ.get(k) for k in ("OPH_PG_WAVES", "OPH_NO_PLANE_GEMM")}
+        for k in saved:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        try:
+            e = _engine(hp, W)                      # the switches are read once per handle
+            out[name] = e.ssrn(Y0)
+            e.close()
+        finally:
+            for k, v in saved.items():
+                os.environ.pop(k, None)
+                if v is not None:
+                    os.environ[k] = v
+    for name, Z in out.items():
+        print("%s: max-abs vs oracle %.3e" % (name, np.abs(Z - Z0).max()))
+        assert np.abs(Z - Z0).max() < TOL
+    assert np.array_equal(out["waves4"], out["waves8"]) and np.array_equal(out["default"], out["waves4"])
+    assert np.abs(out["rows"] - out["default"]).max() < 2e-5
+
+
 def test_pipelined_batches_equal_sequential(c2):
     """SSRN of batch i overlapping decode of batch i+1 (own CU partition, Y/Z ping-pong) changes nothing."""
     hp, W, L, eng = c2

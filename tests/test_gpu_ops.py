@@ -83,10 +83,12 @@ def test_conv1d_transpose(B, T, C):
 
 
 @pytest.mark.parametrize("B,T,C,prec,tol", [(2, 37, 512, 2, 2e-5), (16, 200, 512, 2, 2e-5), (1, 1, 512, 2, 2e-5), (3, 50, 512, 1, 3e-4),
-                                            (2, 33, 256, 2, 2e-5)])
+                                            (2, 33, 256, 2, 2e-5), (16, 400, 512, 2, 2e-5), (11, 397, 512, 2, 2e-5)])
 def test_conv1d_transpose_split_precisions(B, T, C, prec, tol):
-    """The launches the SSRN path makes for D_4 / D_7 at the split precisions (both phases in one launch of conv_gemm_bf16x3_pair,
-    then ln_rows; ragged last tile, T = 1) against the oracle (modules.py:209-258)."""
+    """The launches the SSRN path makes for D_4 / D_7 at the split precisions (2: the input as fp16 planes, both phases as one
+    plane_gemm problem -- its 4-wave form, and from 33 row tiles on, (16, 400) and the ragged (11, 397), the 8-wave form with 128
+    channels per workgroup; 1: both phases in one launch of conv_gemm_bf16x3_pair; then ln_rows; ragged last tile, T = 1) against
+    the oracle (modules.py:209-258)."""
     from ophelia_amd import modules as M
     x = _r(B, T, C)
     W = {"d/conv2d_transpose/kernel": _r(1, 3, C, C, sc=(2.6 / (3 * C)) ** 0.5), "d/conv2d_transpose/bias": _r(C, sc=0.02)}
