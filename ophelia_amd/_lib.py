@@ -125,8 +125,11 @@ class OpheliaHipError(RuntimeError):
 
 
 def _hipcc_shared(out, srcs, deps, extra, verbose):
-    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+    # OPH_HIPCC_FLAGS: extra compiler flags (measurement builds, e.g. -DOPH_ABLATE); such a build is never taken for up to date
+    more = os.environ.get("OPH_HIPCC_FLAGS", "").split()
+    if not more and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
+    extra = list(extra) + more
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # several ranks may find the library stale at the same time: each builds into its own temporary file and renames
     # it into place (atomic on one filesystem), so a reader never maps a half-written library

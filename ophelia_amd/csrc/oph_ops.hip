@@ -226,7 +226,13 @@ int oph_bench_conv1d_transpose(int device, int B, int T, int Cin, int Cout, int 
     // and this layer's LayerNorm launch writes planes for the next layer beside its fp32 rows; precision 5: the round-3 launches
     // (fp32 rows split inside the paired contraction)
     int pg_dbg = 0;
-    if (precision >= 6 && precision <= 9) { pg_dbg = 1 << (precision - 6); precision = 2; }      // measurement only: plane_gemm without its MFMAs / without its operand stream
+    if (precision >= 6 && precision <= 9) {
+#ifdef OPH_ABLATE
+        pg_dbg = 1 << (precision - 6); precision = 2;
+#else
+        g_op_error = "precisions 6..9 (ablation builds of plane_gemm) exist only in libraries built with -DOPH_ABLATE"; return OPH_ERR_UNSUPPORTED;
+#endif
+    }      // measurement only: plane_gemm without its MFMAs / without its operand stream
     const bool planes = precision == 2;
     unsigned short *dxh = nullptr, *dxl = nullptr, *dyh = nullptr, *dyl = nullptr, *kweh = nullptr, *kwel = nullptr, *kwoh = nullptr, *kwol = nullptr;
     if (planes) {

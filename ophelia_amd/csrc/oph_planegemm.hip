@@ -339,10 +339,12 @@ static void launch_plane_gemm_t(const PlaneGemmArgs& a, hipStream_t s) {
 void launch_plane_gemm(const PlaneGemmArgs& a, hipStream_t s) {
     const int MT = (a.M + 127) / 128;
     if (a.convt) {
+#ifdef OPH_ABLATE      // the ablation builds of the kernel behind DESIGN.md section 10.7 (oph_bench_conv1d_transpose precisions 6..9)
         if (a.dbg == 1) return launch_plane_gemm_t<2, true, 4, 1>(a, s);
         if (a.dbg == 2) return launch_plane_gemm_t<2, true, 4, 2>(a, s);
         if (a.dbg == 4) return launch_plane_gemm_t<2, true, 4, 4>(a, s);
         if (a.dbg == 8) return launch_plane_gemm_t<2, true, 4, 8>(a, s);
+#endif
         // more 64-channel workgroups than CUs would take two rounds at one per CU: 128 channels per workgroup, 8 waves
         const bool wide = a.waves ? a.waves == 8 : (MT * ((a.N + 63) / 64) > 256 && a.N % 128 == 0);
         if (wide) launch_plane_gemm_t<2, true, 8>(a, s); else launch_plane_gemm_t<2, true, 4>(a, s);
