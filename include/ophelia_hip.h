@@ -276,7 +276,8 @@ int oph_op_attention(int device, const float* Q, const float* K, const float* V,
  * data already in HBM -- the measurement behind bench.py's kernel_rooflines.  precision: 0 exact fp32 MFMA, 1 split-bf16 x3,
  * 2 split-fp16 x3 as SSRN runs it (operands arrive as fp16 planes, plane_gemm + LayerNorm rows that write fp32 rows and planes),
  * 5 split-fp16 x3 as round 3 ran it (fp32 rows split inside the paired contraction); 3 / 4: precision 5 with two / one of the
- * three products; 6..9: ablation builds of plane_gemm (no MFMAs / no operand stream / no stores / three K blocks) -- measurement only.
+ * three products; 6..9: ablation builds of plane_gemm (no MFMAs / no operand stream / no stores / three K blocks) -- measurement only, present
+ * only in a library built with -DOPH_ABLATE (OPH_ERR_UNSUPPORTED otherwise).
  * Returns the average time of one layer evaluation and its ALGORITHMIC bytes / flops. */
 int oph_bench_conv1d_transpose(int device, int B, int T, int Cin, int Cout, int precision, int warmup, int iters,
                                double* avg_us, double* alg_bytes, double* alg_flops);
