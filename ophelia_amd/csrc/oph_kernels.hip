@@ -536,21 +536,23 @@ void launch_conv_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {     // needs a.
 //  the wave cycles issuing, profiles/r02_ssrn_pmc.sh)
 // PRE: gamma / beta were requested by the caller before the row's statistics (gv / bv hold them): rows of <= 512 channels, where the
 // 16 extra registers cost no occupancy and the L2 round trip between the reductions and the stores was a sixth of the kernel
-template <int NV, bool PRE = false, bool FULL = false>      // FULL: the row has exactly NV * 256 channels -- no per-element guards
+// FULL: the row has exactly NV * 256 channels -- no per-element guards.  Otherwise (NV - 1) * 256 < C < NV * 256 (launch_epilogue
+// picks NV that way): only the last 256-channel vector is guarded
+template <int NV, bool PRE = false, bool FULL = false>
 __device__ __forceinline__ void ln_vec(f32x4 (&x)[NV], int C, int lane, const float* gam, const float* bet, int nonorm,
                                        const f32x4* gvp = nullptr, const f32x4* bvp = nullptr) {
     float s = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s += (FULL || (v * 64 + lane) * 4 + e < C) ? x[v][e] : 0.f;
+        for (int e = 0; e < 4; ++e) s += (FULL || v < NV - 1 || (v * 64 + lane) * 4 + e < C) ? x[v][e] : 0.f;
     const float mean = nonorm ? 0.f : wave_sum(s) / (float)C;
     float q = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float dlt = (FULL || (v * 64 + lane) * 4 + e < C) ? x[v][e] - mean : 0.f;
+            const float dlt = (FULL || v < NV - 1 || (v * 64 + lane) * 4 + e < C) ? x[v][e] - mean : 0.f;
             x[v][e] = dlt;
             q += dlt * dlt;
         }
@@ -559,7 +561,7 @@ __device__ __forceinline__ void ln_vec(f32x4 (&x)[NV], int C, int lane, const fl
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const int c = (v * 64 + lane) * 4;
-        if ((FULL || c < C)) {
+        if ((FULL || v < NV - 1 || c < C)) {
             f32x4 gv, bv;
             if constexpr (PRE) { gv = gvp[v]; bv = bvp[v]; }
             else { gv = *(const f32x4*)(gam + c); bv = *(const f32x4*)(bet + c); }
@@ -588,9 +590,9 @@ __device__ __forceinline__ void ln_rows_body(const EpiArgs& a) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const int c = (v * 64 + lane) * 4;
-        x[v] = (FULL || c < C) ? *(const f32x4*)(h + c) : zero4;
+        x[v] = (FULL || v < NV - 1 || c < C) ? *(const f32x4*)(h + c) : zero4;
         for (int sp = 1; sp < a.nsplit; ++sp)
-            if ((FULL || c < C)) x[v] += *(const f32x4*)(h + sp * a.split_stride + c);
+            if ((FULL || v < NV - 1 || c < C)) x[v] += *(const f32x4*)(h + sp * a.split_stride + c);
     }
     // everything the row needs is requested before the first reduction (the highway's second half and residual row; gamma / beta of
     // narrow rows): one memory round trip per row instead of three dependent ones
@@ -604,17 +606,17 @@ __device__ __forceinline__ void ln_rows_body(const EpiArgs& a) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int c = (v * 64 + lane) * 4;
-            u[v] = (FULL || c < C) ? *(const f32x4*)(h + C + c) : zero4;
+            u[v] = (FULL || v < NV - 1 || c < C) ? *(const f32x4*)(h + C + c) : zero4;
             for (int sp = 1; sp < a.nsplit; ++sp)
-                if ((FULL || c < C)) u[v] += *(const f32x4*)(h + sp * a.split_stride + C + c);
-            xres[v] = (FULL || c < C) ? *(const f32x4*)(xr + c) : zero4;
+                if ((FULL || v < NV - 1 || c < C)) u[v] += *(const f32x4*)(h + sp * a.split_stride + C + c);
+            xres[v] = (FULL || v < NV - 1 || c < C) ? *(const f32x4*)(xr + c) : zero4;
         }
     }
     if constexpr (PRE) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int c = (v * 64 + lane) * 4;
-            if ((FULL || c < C)) {
+            if ((FULL || v < NV - 1 || c < C)) {
                 gv1[v] = *(const f32x4*)(a.g1 + c); bv1[v] = *(const f32x4*)(a.b1 + c);
                 if (hc) { gv2[v] = *(const f32x4*)(a.g2 + c); bv2[v] = *(const f32x4*)(a.b2 + c); }
             }
@@ -631,13 +633,13 @@ __device__ __forceinline__ void ln_rows_body(const EpiArgs& a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int c = (v * 64 + lane) * 4 + e;
-                    if ((FULL || c < C)) u[v][e] *= lg[c];
+                    if ((FULL || v < NV - 1 || c < C)) u[v][e] *= lg[c];
                 }
         }
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int c = (v * 64 + lane) * 4;
-            if ((FULL || c < C)) {
+            if ((FULL || v < NV - 1 || c < C)) {
                 const f32x4 xv = xres[v];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -652,7 +654,7 @@ __device__ __forceinline__ void ln_rows_body(const EpiArgs& a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int c = (v * 64 + lane) * 4 + e;
-                const float gt = (FULL || c < C) ? lg[c] : 0.f;
+                const float gt = (FULL || v < NV - 1 || c < C) ? lg[c] : 0.f;
                 x[v][e] = a.act == ACT_SIGMOID ? fast_sigmoid(gt * x[v][e]) : gt * fast_act(x[v][e], a.act);
             }
     } else {
@@ -675,7 +677,7 @@ __device__ __forceinline__ void ln_rows_body(const EpiArgs& a) {
                 h16x4_ hi, lo;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float xv = (FULL || c + e < C) ? x[v][e] : 0.f;
+                    const float xv = (FULL || v < NV - 1 || c + e < C) ? x[v][e] : 0.f;
                     hi[e] = (_Float16)xv;
                     lo[e] = (_Float16)(xv - (float)hi[e]);
                 }
@@ -691,13 +693,13 @@ __device__ __forceinline__ void ln_rows_body(const EpiArgs& a) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const int c = (v * 64 + lane) * 4;
-        if ((FULL || c + 3 < C) && vec_ok) {
+        if ((FULL || v < NV - 1 || c + 3 < C) && vec_ok) {
             if (coh) st_coherent(y + c, x[v]);
             else *(f32x4*)(y + c) = x[v];
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if ((FULL || c + e < C)) y[c + e] = x[v][e];
+                if ((FULL || v < NV - 1 || c + e < C)) y[c + e] = x[v][e];
         }
     }
     int ctot = C;
@@ -740,6 +742,7 @@ void launch_epilogue(const EpiArgs& a, hipStream_t s) {
     else if (a.C == 1024) hipLaunchKernelGGL((ln_rows<4, true>), grid, block, 0, s, a);
     else if (a.C <= 256) hipLaunchKernelGGL(ln_rows<1>, grid, block, 0, s, a);
     else if (a.C <= 512) hipLaunchKernelGGL(ln_rows<2>, grid, block, 0, s, a);
+    else if (a.C <= 768) hipLaunchKernelGGL(ln_rows<3>, grid, block, 0, s, a);
     else if (a.C <= 1024) hipLaunchKernelGGL(ln_rows<4>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(ln_rows<5>, grid, block, 0, s, a);   // <= 1280 (full_dim 1025)
 }
