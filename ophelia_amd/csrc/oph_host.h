@@ -120,7 +120,8 @@ struct Options {
     int ssrn_chunk = 40;             // OPH_SSRN_CHUNK: mel frames per streamed SSRN chunk (0 = SSRN only after the decode)
     int cl_wgs_per_cu = 2, cl_dbg = 0;   // OPH_CL_WGS_PER_CU (cone_loop workgroups per CU: 1 or 2), OPH_CL_DBG
     bool no_fused_cone = false;      // OPH_NO_FUSED_CONE: the cone's levels as contraction + ln_rows launches instead of hc_fused
-    int pg_waves = 0;                // OPH_PG_WAVES=4|8: plane_gemm's waves per workgroup forced (measurement; 0 = the launcher's choice)
+    int pg_waves = 0;                // OPH_PG_WAVES=4|8: the transposed convolution's plane_gemm form forced (64 channels per workgroup on 4 waves | 128 on 8;
+                                     // 0 = the launcher's choice); in -DOPH_ABLATE builds 8 also selects the 8-wave forms of the other layers
     bool no_plane_gemm = false;      // OPH_NO_PLANE_GEMM: the batched nets' split-fp16 contractions on fp32 rows (conv_gemm_bf16x3) instead of planes (plane_gemm)
     bool no_chain = false;           // OPH_NO_CHAIN: the whole-decode launch as dec_loop (generic) even where dec_chain (specialised) fits
     void read() {

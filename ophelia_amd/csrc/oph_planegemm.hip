@@ -349,9 +349,15 @@ void launch_plane_gemm(const PlaneGemmArgs& a, hipStream_t s) {
         const bool wide = a.waves ? a.waves == 8 : (MT * ((a.N + 63) / 64) > 256 && a.N % 128 == 0);
         if (wide) launch_plane_gemm_t<2, true, 8>(a, s); else launch_plane_gemm_t<2, true, 4>(a, s);
     } else if (a.ntaps == 1) {
-        if (a.waves == 8) launch_plane_gemm_t<1, false, 8>(a, s); else launch_plane_gemm_t<1, false, 4>(a, s);
+#ifdef OPH_ABLATE      // (the 8-wave forms of the k = 1 / 3-tap layers measured slower, DESIGN.md section 10.7: measurement builds only)
+        if (a.waves == 8) return launch_plane_gemm_t<1, false, 8>(a, s);
+#endif
+        launch_plane_gemm_t<1, false, 4>(a, s);
     } else {
-        if (a.waves == 8) launch_plane_gemm_t<3, false, 8>(a, s); else launch_plane_gemm_t<3, false, 4>(a, s);
+#ifdef OPH_ABLATE
+        if (a.waves == 8) return launch_plane_gemm_t<3, false, 8>(a, s);
+#endif
+        launch_plane_gemm_t<3, false, 4>(a, s);
     }
 }
 bool plane_gemm_ok(int ntaps, const int* off, int kc, bool convt) {

@@ -1,5 +1,6 @@
 #!/bin/bash
-# plane_gemm with 4 waves per workgroup (one per SIMD) against 8 (two per SIMD, OPH_PG_WAVES): stand-alone SSRN per-dispatch tables
+# plane_gemm with 4 waves per workgroup (one per SIMD) against 8 (two per SIMD, OPH_PG_WAVES): stand-alone SSRN per-dispatch tables.
+# The 8-wave forms of the k = 1 / 3-tap layers exist only in a -DOPH_ABLATE build (OPH_HIPCC_FLAGS=-DOPH_ABLATE, as profiles/r04_convt_ablate.sh builds one)
 cd /root/repo; mkdir -p gpurun_out/planes; export TMPDIR=/tmp
 for v in 4 8 0; do
   if [ $v = 0 ]; then unset OPH_PG_WAVES; else export OPH_PG_WAVES=$v; fi

@@ -147,10 +147,10 @@ def test_c3_ssrn_full_size(c2):
 
 
 def test_plane_gemm_wave_forms_and_the_row_kernel_agree(c2):
-    """SSRN's split-fp16 contractions run on pre-split fp16 planes (plane_gemm, oph_planegemm.hip).  Its 4-wave and 8-wave forms sum
-    every output element in the same order -- bitwise equal -- and the round-3 kernel on fp32 rows (OPH_NO_PLANE_GEMM: another
-    K order) agrees within the fp32 class; the default picks the 8-wave transposed convolution only where the 64-channel form
-    would need two rounds (D_7 at this size), so the default equals both forced forms bit for bit too."""
+    """SSRN's split-fp16 contractions run on pre-split fp16 planes (plane_gemm, oph_planegemm.hip).  The transposed convolution has
+    a 4-wave form (64 channels of both phases per workgroup) and an 8-wave form (128); they sum every output element in the same
+    order -- bitwise equal, whichever the launcher picks (D_4: 4 waves, D_7: 8 at this size) -- and the round-3 kernel on fp32 rows
+    (OPH_NO_PLANE_GEMM: another K order) agrees within the fp32 class."""
     import os
     hp, W, L, _ = c2
     Y0 = np.random.default_rng(5).random((16, hp.max_T, hp.n_mels), dtype=np.float32)
