@@ -144,7 +144,11 @@ int oph_set_mag_destination(oph_handle* h, float* Z);
  * the previous decode, [2] SSRN chunks launched while a decode was running, [3] whole-decode launches, [4] fall-backs from the
  * whole-decode launch to two launches per step, [5] tiles resumed to their batch's stop step, [6] persistent cone launches,
  * [7] fp16 range guard: bit 0 SSRN, bit 1 cone, bit 2 TextEnc -- a weight of that net exceeds fp16's range (|w| > 6e4), so its
- *     split-fp16 contractions are pinned to the fp32-operand MFMA. */
+ *     split-fp16 contractions are pinned to the fp32-operand MFMA,
+ * [8] 1 if this handle holds the device's CU-masked streams (one handle per device and process at a time: the three partitions
+ *     chain | cone | SSRN are created once per process and lent out), 0 if it runs on ordinary streams (no whole-decode launch),
+ * [9] decodes in which an in-kernel wait timed out (workgroups of a launch not co-resident) and the affected steps were redone on
+ *     the per-step launch path. */
 int oph_get_counters(oph_handle* h, int64_t* out, int n);
 /* oph_text2mel_graph  replaces ONE sess.run([g.Y, g.max_attentions, g.alignments], feed) of the reference's loop
  *     (synthesize.py:172,181-183) and serves as the fetch surface for the graph tensors of architectures.py:188-239:

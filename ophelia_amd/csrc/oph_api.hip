@@ -6,6 +6,8 @@
 // HIP kernels in oph_kernels.hip.
 #include "oph_host.h"
 
+#include <mutex>
+
 thread_local std::string g_create_error;
 thread_local hipStream_t g_cur = nullptr;    // stream the launch wrappers of THIS host thread target
 thread_local int g_group_cls = -1;
@@ -19,6 +21,42 @@ extern "C" {
 int oph_abi_version(void) { return OPH_ABI_VERSION; }
 
 const char* oph_last_error(const oph_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+// The CU-masked streams of a device, process-wide: created on first use, never destroyed (see oph_create).
+namespace {
+struct MaskedSet { std::vector<uint32_t> key; hipStream_t s[3] = {nullptr, nullptr, nullptr}; bool in_use = false; };
+std::mutex g_masked_mutex;
+std::map<int, std::vector<MaskedSet>> g_masked;       // device -> sets (one per distinct partition; normally one)
+bool masked_streams_acquire(int device, int words, const uint32_t* m_dec, const uint32_t* m_conep, const uint32_t* m_ssrn,
+                            hipStream_t* sdec, hipStream_t* scone, hipStream_t* sssrn) {
+    std::lock_guard<std::mutex> lock(g_masked_mutex);
+    std::vector<uint32_t> key;
+    for (const uint32_t* m : {m_dec, m_conep, m_ssrn}) key.insert(key.end(), m, m + words);
+    std::vector<MaskedSet>& sets = g_masked[device];
+    for (MaskedSet& q : sets) {
+        if (q.in_use) return false;                  // another live handle holds masked queues on this device: none for this one
+    }
+    for (MaskedSet& q : sets)
+        if (q.key == key) { q.in_use = true; *sdec = q.s[0]; *scone = q.s[1]; *sssrn = q.s[2]; return true; }
+    MaskedSet q;
+    q.key = key;
+    const uint32_t* masks[3] = {m_dec, m_conep, m_ssrn};
+    for (int i = 0; i < 3; ++i)
+        if (hipExtStreamCreateWithCUMask(&q.s[i], words, masks[i]) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;                            // (streams created so far stay allocated but unused: never destroyed by design)
+        }
+    q.in_use = true;
+    sets.push_back(q);
+    *sdec = q.s[0]; *scone = q.s[1]; *sssrn = q.s[2];
+    return true;
+}
+void masked_streams_release(int device, hipStream_t sdec) {
+    std::lock_guard<std::mutex> lock(g_masked_mutex);
+    for (MaskedSet& q : g_masked[device])
+        if (q.s[0] == sdec) q.in_use = false;
+}
+}  // namespace
 
 int oph_create(const oph_dims* dims, int device, oph_handle** out) {
     if (!dims || !out) { g_create_error = "null argument"; return OPH_ERR_INVALID; }
@@ -70,12 +108,14 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
                 }
             }
             // CU-masked queues are a scarce resource: with four alive the queues get time-sliced and even sequential batches
-            // run 2x slower (measured), and re-creating masked streams after destroying one hung hipStreamSynchronize: exactly
-            // three are created here, once: critical chain | cone | SSRN partitions.  All three or none.
+            // run 2x slower (measured), and re-creating masked streams after destroying some has hung hipStreamSynchronize.
+            // So the three masked streams of a device (critical chain | cone | SSRN partitions) are created ONCE per process,
+            // never destroyed, and lent to one handle at a time (masked_streams_acquire); a second handle that is alive at the
+            // same time runs on ordinary streams (mask_words = 0: no whole-decode launch, the per-step paths) and says so in
+            // its counters.  All three or none.
             h->mask_words = words;
-            if (hipExtStreamCreateWithCUMask(&h->sdec, words, m_dec) != hipSuccess) { h->sdec = nullptr; h->mask_words = 0; }
-            if (h->mask_words && hipExtStreamCreateWithCUMask(&h->scone, words, m_conep) != hipSuccess) { h->scone = nullptr; h->mask_words = 0; }
-            if (h->mask_words && hipExtStreamCreateWithCUMask(&h->sssrn, words, m_ssrn) != hipSuccess) { h->sssrn = nullptr; h->mask_words = 0; }
+            if (!masked_streams_acquire(device, words, m_dec, m_conep, m_ssrn, &h->sdec, &h->scone, &h->sssrn)) { h->sdec = h->scone = h->sssrn = nullptr; h->mask_words = 0; }
+            else h->masked_borrowed = true;
             h->ndec_cus = h->mask_words ? ndec : ncu;
         } else h->ndec_cus = ncu;
         (void)hipGetLastError();
@@ -138,6 +178,10 @@ int oph_destroy(oph_handle* h) {
     h->free_pool(0); h->free_pool(1);
     if (h->host_prog) hipHostFree((void*)h->host_prog);
     TRACE("destroy: streams");
+    if (h->masked_borrowed) {                     // the masked streams go back to the process-wide set (never destroyed)
+        masked_streams_release(h->device, h->sdec);
+        h->sdec = h->scone = h->sssrn = nullptr;
+    }
     for (hipStream_t st : {h->scone, h->sssrn, h->sdec, h->scopy, h->stream}) if (st) { TRACE("  destroy stream %p", (void*)st); hipStreamDestroy(st); }
     TRACE("destroy: done");
     delete h;
@@ -343,9 +387,10 @@ int oph_set_precision(oph_handle* h, int which, int mode) {
 // [3] whole-decode launches  [4] fallbacks from the whole-decode launch to two launches per step  [5] tiles resumed to the batch's stop step
 int oph_get_counters(oph_handle* h, int64_t* out, int n) {
     if (!h || !out) return OPH_ERR_INVALID;
-    const long long v[8] = {h->n_textenc, h->n_preenc_used, h->n_chunks_streamed, h->n_loop_decodes, h->n_loop_fallbacks, h->n_tile_resumes, h->n_cone_loops,
-                            (long long)((h->guard_ssrn ? 1 : 0) | (h->guard_cone ? 2 : 0) | (h->guard_text ? 4 : 0))};
-    for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
+    const long long v[10] = {h->n_textenc, h->n_preenc_used, h->n_chunks_streamed, h->n_loop_decodes, h->n_loop_fallbacks, h->n_tile_resumes, h->n_cone_loops,
+                             (long long)((h->guard_ssrn ? 1 : 0) | (h->guard_cone ? 2 : 0) | (h->guard_text ? 4 : 0)),
+                             h->mask_words > 0 ? 1 : 0, h->n_recoveries};
+    for (int i = 0; i < n && i < 10; ++i) out[i] = v[i];
     return OPH_OK;
 }
 // Where the speculative SSRN of the NEXT oph_text2mel copies its rows while the decoder is still running: a host buffer of

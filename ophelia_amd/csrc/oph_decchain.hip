@@ -1,8 +1,8 @@
 // dec_chain: the whole decode loop of a 16-utterance tile in ONE launch (all steps x all AudioEnc / Attention / AudioDec layers,
 // synthesize.py:181-209 over networks.py:214-435) -- the lean successor of dec_loop (oph_decrun.hip) for the standard geometry.
 //
-// Same protocol as dec_loop (oph_internal.h: LoopArgs, packed layer descriptors, 8-byte {epoch, value} granule hand-offs, cone
-// level words, stop word, progress words), same arithmetic in the same order (bitwise the same results), different code:
+// Same protocol as dec_loop (oph_internal.h: LoopArgs, packed layer descriptors, cone level words, stop word, progress words;
+// the layer hand-offs travel tag-free since round 5, see CH_SENT below), same arithmetic in the same order (bitwise the same results), different code:
 // round 4's stamps showed that a layer of dec_loop is bound by its own instruction stream, not by the hand-off -- every first
 // sweep pass found its granules already there, and a wave executed ~1500 instructions per layer (one wave per SIMD, in order),
 // a third of them scalar-register spills (v_readlane / v_writelane), exec-masked branches around single loads and descriptor
@@ -29,6 +29,16 @@ constexpr int CH_R = 8, CH_RQ = 2, CH_PF = 6, CH_PT = 2;      // rows per workgr
 constexpr int CH_D = 256;                                   // channels per row
 constexpr int CH_LDXS = 3 * CH_D + 16;                      // operand row stride in LDS (+16: the 4 rows' b128 reads hit disjoint banks)
 constexpr int CH_AW = 4;                                    // attention window rows held in registers
+// Hand-off transport (round 5): the raw outputs of a layer travel as plain 4-byte values -- no {epoch, value} granules.  A slot
+// [step parity][layer][row][512] holds either the values of that (step, layer) or CH_SENT in every word: the producer of (t, l)
+// resets its columns of the OTHER parity's slot (the values of step t-1, consumed a whole step ago by every reader: each of them
+// has since published something this workgroup gathered) at the top of the layer, waits for its own sweep (s_waitcnt vmcnt(0):
+// the reset is acknowledged) and only then publishes (t, l); the slot is rewritten a full step later.  A reader polls until none
+// of its words is the sentinel.  A word is never torn, so 16-byte sc1 loads and stores carry four values each: a wave's row is
+// 2 requests instead of 8, a workgroup's publish 32 stores instead of 128, half the bytes -- profiles/handoff2_probe.hip: 1.55 us
+// per all-to-all against 2.06 us for the granules.  CH_SENT is a NaN pattern no arithmetic produces (a result with exactly
+// these bits is published as the canonical NaN).
+constexpr unsigned CH_SENT = 0xFFFFFFFFu;
 enum { P_CONV = 0, P_HC = 1, P_ATTN = 2, P_MEL = 3 };       // prologue kinds
 enum { C_K1 = 0, C_HC3 = 1 };                               // contraction kinds
 template <int V> using ic = std::integral_constant<int, V>;
@@ -55,6 +65,35 @@ __global__ __launch_bounds__(64 * CH_R) void dec_chain(LoopArgs a) {
     int p = a.t_begin > 0 ? a.p[(a.t_begin & 1) * Bpad + grow] : 0;       // prev_max of this wave's utterance
     int* const stop_word = a.ctl + 1;
     int* const err = a.ctl + 2;
+    // the hand-off buffer [2 step parities][LOOP_MAX_LAYERS][Bpad][RUN_GCOLS] floats through ONE buffer resource: scalar offset =
+    // slot and row, lane offset = column (16-byte sc1 requests)
+    const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc((void*)a.vbuf, 0, 0x7fffffff, 0x00020000);
+    auto slot_off = [&](int step, int layer, int row) -> int {      // byte offset of a row of slot (step & 1, layer)
+        return ((((step & 1) * LOOP_MAX_LAYERS + layer) * Bpad + row) * RUN_GCOLS) * 4;
+    };
+    auto vld = [&](int soff, int voff) -> f32x4 { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vres, voff, soff, 16 /* sc1 */)); };
+    auto vst = [&](int soff, int voff, const f32x4& v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_, v), vres, voff, soff, 16 /* sc1 */); };
+    // one wave re-reads its row until no word is the sentinel; bounded like every spin of the launch (error word, results undefined then)
+    auto sweep_vals = [&](int soff, int v1, bool cok, int v2, bool two, f32x4& av, f32x4& uv) -> int {
+        long long t0 = 0;
+        for (int it = 0;; ++it) {
+            const f32x4 ga = vld(soff, v1);
+            f32x4 gu = ga;
+            if (two) gu = vld(soff, v2);
+            bool ok = true;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ok = ok && (__float_as_uint(ga[e]) != CH_SENT || !cok) && (__float_as_uint(gu[e]) != CH_SENT || !two);
+            bool give_up = false;
+            if (!__all(ok) && it >= 64 && (it & 63) == 0) {
+                const long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                give_up = now - t0 > RUN_TIMEOUT_TICKS || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                if (give_up && lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (__all(ok) || give_up) { av = ga; uv = gu; return it + 1; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
     if (a.clk && tid == 0) atomicMin((unsigned long long*)a.clk, (unsigned long long)wall_clock64());      // device-side witness: first workgroup in
 
     f32x4 xprev = zero4;
@@ -168,17 +207,16 @@ __global__ __launch_bounds__(64 * CH_R) void dec_chain(LoopArgs a) {
                 // ---- 2. this wave's raw row of the producing layer (layer 0: the last layer of the previous step): first pass of the
                 //         sweep requested now, looked at after the older taps' share of the contraction
                 CH_STAMP(0);
-                const int slot = PRO == P_MEL ? NL - 1 : l - 1;
-                const unsigned ep = a.epoch0 + (unsigned)((PRO == P_MEL ? t - 1 : t) * LOOP_MAX_LAYERS + slot + 1);
-                const u64* const grow_p = a.gbuf + ((size_t)slot * Bpad + grow) * RUN_GCOLS;
-                u64 ga[4], gu[4];
+                // (before it: this workgroup's columns of the other parity's slot of this layer go back to the sentinel -- see CH_SENT)
+                if (cols && tid < 16 * R && (tid & 3) == 1) {
+                    const f32x4 sv = {__uint_as_float(CH_SENT), __uint_as_float(CH_SENT), __uint_as_float(CH_SENT), __uint_as_float(CH_SENT)};
+                    vst(slot_off(t + 1, l, row0 + (tid >> 4)), (n0 + (tid & 12)) * 4, sv);
+                }
+                const int in_off = slot_off(PRO == P_MEL ? t - 1 : t, PRO == P_MEL ? NL - 1 : l - 1, grow);
+                f32x4 ga = zero4, gu = zero4;
                 if (!no_input) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) ga[e] = granule_load(grow_p + ci + e);
-                    if (two) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) gu[e] = granule_load(grow_p + CH_D + c + e);
-                    }
+                    ga = vld(in_off, ci * 4);
+                    if (two) gu = vld(in_off, (CH_D + c) * 4);
                 }
                 f32x4 acc[RQ][2], accq[RQ];
 #pragma unroll
@@ -209,19 +247,19 @@ __global__ __launch_bounds__(64 * CH_R) void dec_chain(LoopArgs a) {
                 if (!no_input) {
                     bool ok = true;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) ok = ok && ((unsigned)(ga[e] >> 32) == ep || !cok);
+                    for (int e = 0; e < 4; ++e) ok = ok && (__float_as_uint(ga[e]) != CH_SENT || !cok);
                     if (two) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) ok = ok && (unsigned)(gu[e] >> 32) == ep;
+                        for (int e = 0; e < 4; ++e) ok = ok && __float_as_uint(gu[e]) != CH_SENT;
                     }
                     passes = 1;
-                    if (__all(ok)) {
+                    if (!__all(ok)) passes += sweep_vals(in_off, ci * 4, cok, (CH_D + c) * 4, two, ga, gu);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { av[e] = cok ? __uint_as_float((unsigned)ga[e]) : 0.f; if (two) uv[e] = __uint_as_float((unsigned)gu[e]); }
-                    } else {
-                        passes += sweep_row(grow_p, c, cok, CH_D + c, two, ep, lane, err, av, uv, false);
-                    }
+                    for (int e = 0; e < 4; ++e) { av[e] = cok ? ga[e] : 0.f; if (two) uv[e] = gu[e]; }
                 }
+                // every request of this wave has returned -- the sentinel store above included: it is acknowledged before this layer's
+                // publish is issued (the protocol's one ordering requirement)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 CH_STAMP(1);
                 if (STAMPS && stp && lane == 0) stp[l * 8 + 6] = passes;
                 desc_pin(nxt);
@@ -435,8 +473,12 @@ __global__ __launch_bounds__(64 * CH_R) void dec_chain(LoopArgs a) {
                     float v = bias_v;
 #pragma unroll
                     for (int ww = 0; ww < R; ww += 2) v += pv[ww] + pv[ww + 1];
-                    granule_store(a.gbuf + ((size_t)l * Bpad + row0 + row) * RUN_GCOLS + n0 + col,
-                                  a.epoch0 + (unsigned)(t * LOOP_MAX_LAYERS + l + 1), v);
+                    {   // four adjacent columns of a row sit in one quad: lane (col & 3) == 0 stores the 16 bytes
+                        if (__float_as_uint(v) == CH_SENT) v = __uint_as_float(0x7FC00000u);
+                        f32x4 q;
+                        q[0] = dpp_mov<0x00>(v); q[1] = dpp_mov<0x55>(v); q[2] = dpp_mov<0xAA>(v); q[3] = dpp_mov<0xFF>(v);
+                        if ((col & 3) == 0) vst(slot_off(t, l, row0 + row), (n0 + col) * 4, q);
+                    }
                     if (PRO == P_ATTN) {
                         // QW[t] = Q[t] . Wq + bias for the cone head's cache (written through: the cone kernels read it after their acquire)
                         const float* pq = partq + (col * RQ + (row >> 2)) * 4 + (row & 3);
@@ -488,8 +530,9 @@ __global__ __launch_bounds__(64 * CH_R) void dec_chain(LoopArgs a) {
             const bool cok = c < cin;
             f32x4 g1v = zero4, b1v = zero4, av = zero4, uv = zero4;
             if (cok) { g1v = *(const f32x4*)(cur.lnp() + c); b1v = *(const f32x4*)(cur.lnp() + cur.ls() + c); }
-            sweep_row(a.gbuf + ((size_t)(NL - 1) * Bpad + grow) * RUN_GCOLS, c, cok, cin + c, false,
-                      a.epoch0 + (unsigned)(t_last * LOOP_MAX_LAYERS + NL), lane, err, av, uv);
+            sweep_vals(slot_off(t_last, NL - 1, grow), (cok ? c : 0) * 4, cok, 0, false, av, uv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[e] = cok ? av[e] : 0.f;
             const float invc = __builtin_amdgcn_rcpf((float)cin);
             const float m1 = wave_sum(av[0] + av[1] + av[2] + av[3]) * invc;
             float q1 = 0.f;

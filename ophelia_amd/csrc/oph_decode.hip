@@ -59,6 +59,7 @@ int ensure_decode_state(oph_handle* h, int B) {
     h->d_amax = h->dalloc<long long>((size_t)nBpad * m.max_T);
     // ---- scratch shared by the tiles
     h->d_gbuf = h->dalloc<unsigned long long>((size_t)LOOP_MAX_LAYERS * Bpad * RUN_GCOLS);
+    h->d_vbuf = h->dalloc<float>((size_t)2 * LOOP_MAX_LAYERS * Bpad * RUN_GCOLS);
     h->run_epoch = 0;
     h->d_clk = h->dalloc<long long>((size_t)2 * 512); h->clk_used = 0;
     if (h->opt.run_stamps) {
@@ -572,7 +573,12 @@ int decode_loop(oph_handle* h, int t_begin, int t_end, int stop_mode) {
         hipMemcpyAsync(a.clk, clk_init, sizeof clk_init, hipMemcpyHostToDevice, h->sdec);
     }
     // the generic kernel when stamps or ablation bits other than "no side stream" are asked for (they live there)
-    if (h->chain_ok && !h->fixed_att && a.QW != nullptr && (dbg & ~32) == 0) launch_dec_chain(a, h->loop_slices, h->sdec);
+    if (h->chain_ok && !h->fixed_att && a.QW != nullptr && (dbg & ~32) == 0 && h->d_vbuf) {
+        // every hand-off slot starts as the sentinel (what the previous launch left in them is stale)
+        a.vbuf = h->d_vbuf;
+        hipMemsetAsync(h->d_vbuf, 0xFF, (size_t)2 * LOOP_MAX_LAYERS * h->Bpad * RUN_GCOLS * sizeof(float), h->sdec);
+        launch_dec_chain(a, h->loop_slices, h->sdec);
+    }
     else launch_dec_loop(a, h->loop_slices, h->loop_rows, h->loop_kmax, h->sdec);
     h->pend(PC_DECLOOP, bytes * (t_end - t_begin), flops * (t_end - t_begin));
     if (h->want_preenc && h->next_staged && !h->preenc_valid) {
@@ -1017,7 +1023,10 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
         HIPCHK(h, hipMemcpyAsync(ctl, h->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (ctl[2] != 0) {
-            h->fail(ctl[2] == 3 ? "decoder loop: the side stream never saw the attention signal (time-out)" : ctl[2] == 2 ? "decoder loop: the side stream's cone never signalled (time-out)" : "decoder run: a workgroup hand-off timed out (workgroups of one run were not co-resident)");
+            h->last_wait_err = ctl[2];
+            h->fail(ctl[2] == 3 ? "decoder loop: the side stream never saw the attention signal (time-out)" : ctl[2] == 2 ? "decoder loop: the side stream's cone never signalled (time-out)" :
+                    ctl[2] == 4 ? "cone level: the column tiles of a row block never saw each other's statistics (time-out: workgroups of one launch were not co-resident)" :
+                                  "decoder run: a workgroup hand-off timed out (workgroups of one run were not co-resident)");
             recover_loop_state(h);
             return OPH_ERR_DEVICE;
         }
@@ -1043,20 +1052,39 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
 int decode_batch(oph_handle* h, int t_end, int stop_mode, int32_t* steps_run) {
     const int ntiles = (h->nB + TILE - 1) / TILE;
     int batch_steps = 0;
-    bool retried = false;
+    // A launch whose workgroups wait for each other (the whole-decode launch, the fused cone levels) needs them co-resident; nothing
+    // guarantees that when another client holds CUs of the partition.  Every such wait is bounded (2 s) and ends in an error word; the
+    // answer here is to redo the tile on a path that needs less: first the cone's levels as contraction + ln_rows launches (no
+    // exchange between workgroups), then two launches per step instead of the whole-decode launch, then one launch per layer.
+    // The fast paths are tried again after `rearm` decodes (16, then 4 x as many each time they fail again).
+    if (h->degraded_left > 0 && --h->degraded_left == 0) {
+        TRACE("re-arming the whole-decode launch / fused cone after a degraded period");
+        h->use_loop = h->use_loop_wanted; h->use_run = h->use_run_wanted; if (h->hcf_capacity == 0 && h->hcf_capacity_was_ok) h->hcf_capacity = -1;
+    }
+    // steps [t0, t1) of the current tile; after a failure the tile is redone from step 0 (a continued range without the stop rule:
+    // the same frames as stop + resume)
+    auto range_with_recovery = [&](int t0, int t1, int stop, int32_t* st) -> int {
+        int rc = decode_range(h, t0, t1, stop, st);
+        for (int attempt = 0; rc == OPH_ERR_DEVICE && attempt < 3; ++attempt) {
+            const char* what = nullptr;
+            if (h->last_wait_err == 4 && h->hcf_capacity != 0) { h->hcf_capacity_was_ok = true; h->hcf_capacity = 0; what = "the cone's levels as separate contraction + LayerNorm launches"; }
+            else if (h->use_loop) { h->use_loop = false; h->n_loop_fallbacks++; what = "two launches per step"; }
+            else if (h->use_run) { h->use_run = false; what = "one launch per layer"; }
+            else break;
+            TRACE("decode failed (%s): redoing the tile with %s", h->err.c_str(), what);
+            h->last_wait_err = 0;
+            h->n_recoveries++;
+            h->degraded_left = h->degraded_next; h->degraded_next = std::min(h->degraded_next * 4, 1 << 20);
+            reset_decode(h);
+            rc = decode_range(h, 0, t1, t0 == 0 ? stop : OPH_STOP_NEVER, st);
+        }
+        return rc;
+    };
     for (int j = 0; j < ntiles; ++j) {
         select_tile(h, j);
         reset_decode(h);
         int32_t st = 0;
-        int rc = decode_range(h, 0, t_end, stop_mode, &st);
-        if (rc == OPH_ERR_DEVICE && h->use_loop && !retried) {
-            // the whole-decode launch could not run here (e.g. another process holds CUs of its partition): fall back to the
-            // two-launches-per-step path for the rest of this handle's life and redo the tile
-            TRACE("whole-decode launch failed (%s): falling back to two launches per step", h->err.c_str());
-            h->use_loop = false; retried = true; h->n_loop_fallbacks++;
-            reset_decode(h);
-            rc = decode_range(h, 0, t_end, stop_mode, &st);
-        }
+        int rc = range_with_recovery(0, t_end, stop_mode, &st);
         if (rc) return rc;
         batch_steps = std::max(batch_steps, (int)st);
         // a tile that ran to the end has all its frames: what SSRN has not covered yet goes to the SSRN partition now, under the
@@ -1078,7 +1106,8 @@ int decode_batch(oph_handle* h, int t_end, int stop_mode, int32_t* steps_run) {
                 h->tiles[j].ssrn_done = std::min(h->tiles[j].ssrn_done, std::max(0, h->tiles[j].steps - ahead));
                 h->tiles[j].z_copied = std::min(h->tiles[j].z_copied, h->tiles[j].ssrn_done);
             }
-            const int rc = decode_range(h, h->tiles[j].steps, batch_steps, OPH_STOP_NEVER, nullptr);
+            int32_t st_ = 0;
+            const int rc = range_with_recovery(h->tiles[j].steps, batch_steps, OPH_STOP_NEVER, &st_);
             if (rc) return rc;
             h->n_tile_resumes++;
             h->tiles[j].steps = batch_steps;

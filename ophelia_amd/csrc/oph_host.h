@@ -192,6 +192,7 @@ struct oph_handle {
     bool ssrn_inflight[2] = {false, false};
     int buf = 0; bool pipelined = false;
     uint32_t m_cone[16] = {0}, m_conep[16] = {0}, m_ssrn[16] = {0}; int mask_words = 0;   // CU partitions (0 words = no masking)
+    bool masked_borrowed = false;      // sdec / scone / sssrn are the device's process-wide CU-masked streams (oph_api.hip): returned, not destroyed
     int ssrn_prec = 2;                 // SSRN contractions: 2 = split-fp16 x3 (fp32 accumulate, fp32-class accuracy), 1 = split-bf16 x3, 0 = fp32 MFMA
     hipEvent_t ev_attn = nullptr, ev_cone = nullptr;
     // The two per-step cross-stream dependencies (cone(t+1) after row_chain B(t); AudioDec(t) after cone(t)) as stream
@@ -206,6 +207,7 @@ struct oph_handle {
     // persistent runs of decoder layers (oph_decrun.hip): two launches per step instead of nineteen
     bool use_run = false;               // this configuration takes the dec_run path
     unsigned long long* d_gbuf = nullptr;   // hand-off granules [LOOP_MAX_LAYERS][16][RUN_GCOLS]
+    float* d_vbuf = nullptr;                // dec_chain's tag-free hand-off slots [2][LOOP_MAX_LAYERS][16][RUN_GCOLS]
     uint32_t run_epoch = 0;             // advanced per launch: a tag value is never reused
     long long* d_sigdbg = nullptr;      // OPH_RUN_STAMPS diagnostics: [max_T][8] stamps of the cross-stream signals
     long long* d_lvldbg = nullptr;      // ... and [max_T][8]: when the side stream completed cone level k of step t
@@ -250,6 +252,10 @@ struct oph_handle {
     bool txt_ran = false;               // the current text has been through a run (a staged next text may take its place)
     bool kv_pre = false;                // bKV[kv_cur] already holds the current text's K,V (pre-encoded while the previous batch decoded)
     long long n_textenc = 0, n_preenc_used = 0, n_chunks_streamed = 0, n_loop_decodes = 0, n_loop_fallbacks = 0, n_tile_resumes = 0;   // oph_get_counters
+    int last_wait_err = 0;             // ctl[2] of the last failed decode (1 hand-off, 2 cone level, 3 attention signal, 4 hc_fused statistics)
+    bool use_loop_wanted = false, use_run_wanted = false, hcf_capacity_was_ok = false;
+    int degraded_left = 0, degraded_next = 16;     // decodes until the fast paths are tried again after a recovery (decode_batch)
+    long long n_recoveries = 0;        // decodes in which a co-residency time-out was recovered on the per-step path (oph_get_counters[9])
     int* bTends = nullptr;
     float* bKV[2] = {nullptr, nullptr}; int kv_cur = 0;      // K | V rows [nB][max_N][2d]; the other buffer receives the next batch's pre-encode
     float *bYout[2] = {nullptr, nullptr}, *bZ[2] = {nullptr, nullptr}, *bAlign = nullptr;      // Y / Z ping-pong over pipelined batches

@@ -346,6 +346,8 @@ struct LoopArgs {
     const int* spk_ids;
     unsigned long long* gbuf;           // granules [LOOP_MAX_LAYERS][Bpad][RUN_GCOLS]
     unsigned epoch0;                    // tag of (step t, layer l) = epoch0 + t * LOOP_MAX_LAYERS + l + 1
+    float* vbuf;                        // dec_chain's tag-free hand-off slots [2 step parities][LOOP_MAX_LAYERS][Bpad][RUN_GCOLS], every word
+                                        // 0xFFFFFFFF when the launch starts (oph_decchain.hip: CH_SENT)
     long long* stamps; int stamp_t;
     const float* KV; int N_keys; int win; int max_T;
     int* p;                             // prev_max double buffer [2][Bpad] (read by the cone kernels)

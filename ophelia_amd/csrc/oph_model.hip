@@ -493,6 +493,7 @@ int oph_finalize_weights(oph_handle* h) {
     // The whole-decode launch needs its own CU partition (all its workgroups resident while the cone runs beside it) and
     // the mapped progress words.
     h->use_loop = h->use_run && h->opt.decode == 0 && h->d_sig && h->host_prog && h->mask_words > 0;
+    h->use_loop_wanted = h->use_loop; h->use_run_wanted = h->use_run;
     h->finalized = true;
     return OPH_OK;
 }

@@ -46,13 +46,17 @@ def load_weights_broadcast(eng, W, src=0, device=None):
     loaded engine.  ONE flat fp32 tensor is broadcast (RCCL over xGMI when `device` is a GPU) and the receive buffer is handed to
     the library as it is (oph_set_weights_device): the variables are repacked by device kernels, nothing goes back through the host
     (round 3 copied the 210 MB to the host, unflattened them and re-uploaded them variable by variable on every rank).
-    Without a process group this is eng.load_weights(W)."""
+    Without a process group this is eng.load_weights(W).
+    Returns what the collective did, as the process group itself reports it (a run's evidence that RCCL carried the broadcast:
+    bench.py prints it as config.collective): backend, world size, bytes, the broadcast's wall time on this rank (barrier on both
+    sides, so the slowest peer's) and a 4-byte sum check of the received tensor against the root's."""
+    import time
     import torch
     from . import weights as WT
     dist = _dist()
     if dist is None:
         eng.load_weights(W)
-        return
+        return {"backend": None, "world_size": 1, "bytes": 0, "weight_broadcast_ms": 0.0, "GB_per_s": None}
     inventory = eng.inventory()
     n = int(sum(int(np.prod(s)) for _, s in inventory))
     on_gpu = torch.cuda.is_available()
@@ -61,7 +65,20 @@ def load_weights_broadcast(eng, W, src=0, device=None):
         flat = torch.from_numpy(WT.flatten(W, inventory)).to(dev)
     else:
         flat = torch.empty(n, dtype=torch.float32, device=dev)
+    def _sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+    dist.barrier(); _sync()
+    t0 = time.perf_counter()
     dist.broadcast(flat, src=src)
+    _sync(); dist.barrier()
+    ms = (time.perf_counter() - t0) * 1e3
+    # every rank holds the root's bytes: compare a checksum (float64 sum of the fp32 tensor) across ranks, loudly
+    chk = flat.double().sum().reshape(1)
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if float(lo.item()) != float(hi.item()):
+        raise RuntimeError("weight broadcast: ranks hold different tensors (checksum min %r max %r)" % (float(lo.item()), float(hi.item())))
     if on_gpu:
         if flat.device.type != "cuda":                 # gloo process group (tests: ranks sharing one GPU): one upload of the flat tensor
             flat = flat.to(torch.device("cuda", eng.device))
@@ -69,6 +86,9 @@ def load_weights_broadcast(eng, W, src=0, device=None):
         eng.load_weights_device(flat.data_ptr(), n)    # `flat` stays alive until the repack is done
     else:
         eng.load_weights(WT.unflatten(flat.numpy(), inventory))
+    nbytes = 4 * n
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "tensor_device": str(dev), "bytes": nbytes,
+            "weight_broadcast_ms": ms, "GB_per_s": nbytes / (ms * 1e-3) / 1e9 if ms > 0 else None, "checksum_equal_on_all_ranks": True}
 
 
 def global_max_int(value, device=None):

@@ -21,13 +21,10 @@ def test_bench_two_ranks_on_one_gpu():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--no-extra-legs", "--no-cpu-baseline", "--no-vocoder", "--no-profile"]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
-    if r.returncode != 0 and "hand-off timed out" in r.stderr:
-        # Two PROCESSES whose decode launches each need all their workgroups resident on the same 64 CUs (a configuration only this
-        # test creates: a real node gives every rank its own GPU) can each be handed half of them: both spin until the 2 s bound and
-        # the library reports it (2 of 29 shared-GPU runs in round 4).  The bounded wait and the error path are
-        # what the product guarantees there; the run is repeated once, loudly.
-        print("shared-GPU run hit the co-residency time-out, repeating once:\n" + r.stderr[-600:])
-        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    # Two PROCESSES whose decode launches each need all their workgroups resident on the same 64 CUs (a configuration only this
+    # test creates: a real node gives every rank its own GPU) can each be handed half of them.  The library's answer is not an
+    # error any more: the bounded wait ends, the tile is redone on a launch path that needs no co-residency and the run goes on
+    # (oph_get_counters[9], reported as config.recoveries).  No retry here: a product failure fails the test.
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                     # rank 0 alone prints
@@ -40,6 +37,7 @@ def test_bench_two_ranks_on_one_gpu():
     assert abs(out["value"] - cfg["frames_per_step"] / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
     assert cfg["cross_stream_sync"] == "stream value operations"           # multi-rank runs select OPH_STREAM_VALUE
     assert "all ranks on one GPU" in cfg["parallelism"]
+    assert len(cfg["recoveries"]) == 2 and all(n >= 0 for n in cfg["recoveries"])      # per rank; > 0 only when the ranks collided
     # a rank must not need a whole host core to drive its GPU: 8 of them share a node's cores
     assert len(cfg["rank_host_cores"]) == 2 and all(0.0 < c < 0.8 for c in cfg["rank_host_cores"]), cfg["rank_host_cores"]
 
