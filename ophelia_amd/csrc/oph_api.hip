@@ -7,6 +7,7 @@
 #include "oph_host.h"
 
 #include <mutex>
+#include <dlfcn.h>
 
 thread_local std::string g_create_error;
 thread_local hipStream_t g_cur = nullptr;    // stream the launch wrappers of THIS host thread target
@@ -22,22 +23,27 @@ int oph_abi_version(void) { return OPH_ABI_VERSION; }
 
 const char* oph_last_error(const oph_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
+constexpr int OPH_AQL_DEFAULT = 0;      // (see oph_host.h: aql_mode; DESIGN.md section 12 has the measurements behind the default)
 // The CU-masked streams of a device, process-wide: created on first use, never destroyed (see oph_create).
 namespace {
-struct MaskedSet { std::vector<uint32_t> key; hipStream_t s[3] = {nullptr, nullptr, nullptr}; bool in_use = false; };
+struct MaskedSet { std::vector<uint32_t> key; hipStream_t s[3] = {nullptr, nullptr, nullptr}; int users = 0; AqlQueue* aql = nullptr; bool aql_tried = false; };
 std::mutex g_masked_mutex;
 std::map<int, std::vector<MaskedSet>> g_masked;       // device -> sets (one per distinct partition; normally one)
+std::map<int, std::recursive_mutex> g_device_mutex;   // device -> the lock under which the handles of a device share its masked streams
+// Handles of one device SHARE the masked streams (a second set would put six masked queues on the device: time-slicing): whatever a
+// call enqueues on them goes in under the device's lock (DevGuard at the API entry points), so the launches of two handles never
+// interleave inside a decode -- each call's work is one contiguous run in stream order.  A handle that asks for a different CU
+// partition than the one alive (OPH_CU_SPLIT sweeps) gets ordinary streams.
 bool masked_streams_acquire(int device, int words, const uint32_t* m_dec, const uint32_t* m_conep, const uint32_t* m_ssrn,
                             hipStream_t* sdec, hipStream_t* scone, hipStream_t* sssrn) {
     std::lock_guard<std::mutex> lock(g_masked_mutex);
     std::vector<uint32_t> key;
     for (const uint32_t* m : {m_dec, m_conep, m_ssrn}) key.insert(key.end(), m, m + words);
     std::vector<MaskedSet>& sets = g_masked[device];
-    for (MaskedSet& q : sets) {
-        if (q.in_use) return false;                  // another live handle holds masked queues on this device: none for this one
-    }
     for (MaskedSet& q : sets)
-        if (q.key == key) { q.in_use = true; *sdec = q.s[0]; *scone = q.s[1]; *sssrn = q.s[2]; return true; }
+        if (q.key == key) { q.users++; *sdec = q.s[0]; *scone = q.s[1]; *sssrn = q.s[2]; return true; }
+    for (MaskedSet& q : sets)
+        if (q.users > 0) return false;               // a different partition is in use on this device
     MaskedSet q;
     q.key = key;
     const uint32_t* masks[3] = {m_dec, m_conep, m_ssrn};
@@ -46,16 +52,95 @@ bool masked_streams_acquire(int device, int words, const uint32_t* m_dec, const 
             (void)hipGetLastError();
             return false;                            // (streams created so far stay allocated but unused: never destroyed by design)
         }
-    q.in_use = true;
+    q.users = 1;
     sets.push_back(q);
     *sdec = q.s[0]; *scone = q.s[1]; *sssrn = q.s[2];
     return true;
 }
+// The cone partition's AQL queue of the set that owns `sdec` (created on first use, once per process like the streams; nullptr when
+// the HSA side is not available -- the cone then runs on the masked HIP stream as before).  OPH_NO_AQL=1 switches it off.
+AqlQueue* masked_set_aql(int device, hipStream_t sdec, int words, const uint32_t* m_conep, std::string* why) {
+    std::lock_guard<std::mutex> lock(g_masked_mutex);
+    for (MaskedSet& q : g_masked[device]) {
+        if (q.s[0] != sdec) continue;
+        if (!q.aql_tried) {
+            q.aql_tried = true;
+            Dl_info info;
+            std::string path;
+            if (dladdr((const void*)&oph_create, &info) && info.dli_fname) {
+                path = info.dli_fname;
+                const size_t slash = path.rfind('/');
+                path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/oph_cone_kernels.co";
+            }
+            std::string err;
+            const int want = getenv("OPH_AQL_LANES") ? std::max(1, std::min(3, atoi(getenv("OPH_AQL_LANES")))) : 2;
+            q.aql = path.empty() ? nullptr : aql_create(device, m_conep, words, path.c_str(), 4096, 4, &err);
+            if (!q.aql && why) *why = err.empty() ? "library path unknown" : err;
+            if (q.aql) {
+                // Which of the four hardware queues run freely beside the two HIP streams that are busy for a whole decode (the chain's and
+                // SSRN's)?  A 150 us spin on the stream, a stamp launch on the lane: on a shared pipe the stamp comes ~8 us late (oph_aql.h).
+                AqlKernel kst;
+                long long* d_st = nullptr;
+                double late[4] = {0, 0, 0, 0};
+                if (aql_kernel(q.aql, "oph_probe_stamp", &kst, &err) && hipMalloc((void**)&d_st, 4096) == hipSuccess) {
+                    // 16 stamp launches back to back on the lane while the stream's spin runs: ~1 us per launch on a pipe of its own, the pipe's
+                    // rotation period (~8 us) per launch on a shared one
+                    constexpr int NST = 16;
+                    long long* h_args[NST * 2];
+                    for (int i = 0; i < NST; ++i) { h_args[2 * i] = d_st + 8 + i; h_args[2 * i + 1] = nullptr; }
+                    long long** d_arg = (long long**)(d_st + 64);
+                    for (int lane = 0; lane < aql_lanes(q.aql); ++lane) {
+                        const int one[1] = {lane};
+                        aql_use_lanes(q.aql, 1, one);
+                        for (int si : {0, 2}) {
+                            double best = 1e30;
+                            for (int rep = 0; rep < 2; ++rep) {
+                                hipMemset(d_st, 0, 512);
+                                hipMemcpy(d_arg, h_args, sizeof h_args, hipMemcpyHostToDevice);
+                                hipDeviceSynchronize();
+                                launch_probe_spin(40000, d_st, q.s[si]);                          // 400 us
+                                struct timespec ts = {0, 50000}; nanosleep(&ts, nullptr);        // (the spin has started)
+                                for (int i = 0; i < NST; ++i) aql_dispatch(q.aql, 0, kst, 1, 64, 0, d_arg + 2 * i, false);
+                                aql_ring(q.aql);
+                                (void)aql_wait_idle(q.aql, 2.0);
+                                hipStreamSynchronize(q.s[si]);
+                                long long hst[8 + NST];
+                                hipMemcpy(hst, d_st, sizeof hst, hipMemcpyDeviceToHost);
+                                best = std::min(best, (double)(hst[8 + NST - 1] - hst[8]) * 0.01 / (NST - 1));
+                            }
+                            late[lane] = std::max(late[lane], best);
+                        }
+                    }
+                    hipFree(d_st);
+                    (void)hipGetLastError();
+                    int pick[4], np = 0;
+                    for (int lane = 0; lane < aql_lanes(q.aql) && np < want; ++lane) if (late[lane] < 3.0) pick[np++] = lane;
+                    TRACE("AQL lanes: us per launch beside the busy streams %.2f %.2f %.2f %.2f -> using %d lane(s)", late[0], late[1], late[2], late[3], np);
+                    if (np == 0) { pick[0] = 0; np = 1; }
+                    aql_use_lanes(q.aql, np == 3 ? 3 : (np >= 2 ? 2 : 1), pick);
+                } else {
+                    const int ident[2] = {0, 1};
+                    aql_use_lanes(q.aql, want >= 2 ? 2 : 1, ident);
+                }
+            }
+        }
+        return q.aql;
+    }
+    return nullptr;
+}
 void masked_streams_release(int device, hipStream_t sdec) {
     std::lock_guard<std::mutex> lock(g_masked_mutex);
     for (MaskedSet& q : g_masked[device])
-        if (q.s[0] == sdec) q.in_use = false;
+        if (q.s[0] == sdec && q.users > 0) q.users--;
 }
+std::recursive_mutex& device_mutex(int device) {
+    std::lock_guard<std::mutex> lock(g_masked_mutex);
+    return g_device_mutex[device];
+}
+struct DevGuard {
+    std::unique_lock<std::recursive_mutex> lk;
+    explicit DevGuard(const oph_handle* h) { if (h) lk = std::unique_lock<std::recursive_mutex>(device_mutex(h->device)); }
+};
 }  // namespace
 
 int oph_create(const oph_dims* dims, int device, oph_handle** out) {
@@ -110,12 +195,23 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
             // CU-masked queues are a scarce resource: with four alive the queues get time-sliced and even sequential batches
             // run 2x slower (measured), and re-creating masked streams after destroying some has hung hipStreamSynchronize.
             // So the three masked streams of a device (critical chain | cone | SSRN partitions) are created ONCE per process,
-            // never destroyed, and lent to one handle at a time (masked_streams_acquire); a second handle that is alive at the
-            // same time runs on ordinary streams (mask_words = 0: no whole-decode launch, the per-step paths) and says so in
-            // its counters.  All three or none.
+            // never destroyed, and SHARED by the handles of that device under the device's lock (masked_streams_acquire).
+            // All three or none.
             h->mask_words = words;
             if (!masked_streams_acquire(device, words, m_dec, m_conep, m_ssrn, &h->sdec, &h->scone, &h->sssrn)) { h->sdec = h->scone = h->sssrn = nullptr; h->mask_words = 0; }
-            else h->masked_borrowed = true;
+            else {
+                h->masked_borrowed = true;
+                h->aql_mode = getenv("OPH_AQL") ? std::max(0, std::min(2, atoi(getenv("OPH_AQL")))) : OPH_AQL_DEFAULT;
+                if (getenv("OPH_NO_AQL")) h->aql_mode = 0;
+                if (h->aql_mode) {
+                    std::string why;
+                    h->aql = masked_set_aql(device, h->sdec, words, m_conep, &why);
+                    std::string e1, e2;
+                    if (h->aql && !(aql_kernel(h->aql, "oph_cone_head_coh", &h->aql_k[0], &e1) && aql_kernel(h->aql, "oph_hc_fused_coh", &h->aql_k[1], &e2) &&
+                                    aql_kernel(h->aql, "oph_cone_head_plain", &h->aql_k[2], &e1) && aql_kernel(h->aql, "oph_hc_fused_plain", &h->aql_k[3], &e2))) { why = e1 + " " + e2; h->aql = nullptr; }
+                    if (!h->aql) TRACE("pipelined cone off (no AQL queue: %s): the cone's launches go through the HIP stream", why.c_str());
+                }
+            }
             h->ndec_cus = h->mask_words ? ndec : ncu;
         } else h->ndec_cus = ncu;
         (void)hipGetLastError();
@@ -166,10 +262,13 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
 }
 
 int oph_destroy(oph_handle* h) {
+    DevGuard dev_guard(h);
     if (!h) return OPH_OK;
     hipSetDevice(h->device);
     TRACE("destroy: sync streams");
     for (hipStream_t st : {h->stream, h->sdec, h->scone, h->sssrn, h->scopy}) if (st) hipStreamSynchronize(st);
+    if (h->aql && h->aql_used) { (void)aql_wait_idle(h->aql, 10.0); h->aql_used = false; }
+    if (h->aql_store.stage) hipHostFree(h->aql_store.stage);
     for (auto& pc : h->prof)
         for (auto& e : pc.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (hipEvent_t e : {h->ev0, h->ev1, h->ev_attn, h->ev_cone, h->ev_in, h->ev_out, h->ev_dec_done, h->ev_ssrn_done[0], h->ev_ssrn_done[1], h->ev_preenc, h->ev_copy, h->ev_chunk, h->ev_cs, h->ev_ce})
@@ -239,6 +338,7 @@ static int upload_text(oph_handle* h, int slot, const int32_t* L, const int32_t*
 }
 
 int oph_stage_text(oph_handle* h, const int32_t* L, const int32_t* ends, const int32_t* spk, int B) {
+    DevGuard dev_guard(h);
     int rc = check_ready(h, B);
     if (rc) return rc;
     if ((rc = check_text(h, L, ends, spk, B))) return rc;
@@ -270,6 +370,7 @@ static int advance_text(oph_handle* h) {
 // previously staged next text current first and then stages the new one behind it, so a caller simply alternates
 //     oph_stage_text(t0); oph_stage_text_next(t1);  loop { run(); oph_stage_text_next(t_{i+2}); }
 int oph_stage_text_next(oph_handle* h, const int32_t* L, const int32_t* ends, const int32_t* spk, int B) {
+    DevGuard dev_guard(h);
     int rc = check_ready(h, B);
     if (rc) return rc;
     if (!h->bKV[0]) { h->fail("stage a first batch with oph_stage_text"); return OPH_ERR_STATE; }
@@ -283,6 +384,7 @@ int oph_stage_text_next(oph_handle* h, const int32_t* L, const int32_t* ends, co
 }
 
 int oph_decode_steps(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* steps_run) {
+    DevGuard dev_guard(h);
     if (!h || !h->bKV[0]) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
     if (stop_mode != OPH_STOP_REFERENCE && stop_mode != OPH_STOP_NEVER) { h->fail("unknown stop mode %d", stop_mode); return OPH_ERR_INVALID; }
     if (t_begin < 0 || t_end < t_begin || t_end > h->dm.max_T) { h->fail("steps [%d, %d) are outside [0, max_T = %d]", t_begin, t_end, h->dm.max_T); return OPH_ERR_INVALID; }
@@ -324,6 +426,7 @@ static int set_pipelined(oph_handle* h, bool pipe) {
 }
 
 int oph_run_ssrn_resident(oph_handle* h) {
+    DevGuard dev_guard(h);
     if (!h || !h->bKV[0]) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
     g_cur = h->stream;
@@ -331,6 +434,7 @@ int oph_run_ssrn_resident(oph_handle* h) {
 }
 
 int oph_run_resident(oph_handle* h, int stop_mode, int run_ssrn, int32_t* steps_run) {
+    DevGuard dev_guard(h);
     if (!h || !h->bKV[0]) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
     if (stop_mode != OPH_STOP_REFERENCE && stop_mode != OPH_STOP_NEVER) { h->fail("unknown stop mode %d", stop_mode); return OPH_ERR_INVALID; }
     if (run_ssrn < 0 || run_ssrn > 2) { h->fail("run_ssrn must be 0, 1 or 2"); return OPH_ERR_INVALID; }
@@ -409,6 +513,7 @@ int oph_set_streaming(oph_handle* h, int on) {
 }
 
 int oph_synchronize(oph_handle* h) {
+    DevGuard dev_guard(h);
     if (!h) return OPH_ERR_INVALID;
     if (h->sssrn) HIPCHK(h, hipStreamSynchronize(h->sssrn));
     if (h->scopy) HIPCHK(h, hipStreamSynchronize(h->scopy));
@@ -418,6 +523,7 @@ int oph_synchronize(oph_handle* h) {
 }
 
 int oph_fetch_kv(oph_handle* h, float* K, float* V) {
+    DevGuard dev_guard(h);
     if (!h || !h->bKV[0]) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
     const oph_dims& m = h->dm;
     const size_t rows = (size_t)h->nB * m.max_N, w = (size_t)m.d * 4;
@@ -429,6 +535,7 @@ int oph_fetch_kv(oph_handle* h, float* K, float* V) {
 }
 
 int oph_fetch_mel(oph_handle* h, float* Y, int32_t* t_ends, float* alignments) {
+    DevGuard dev_guard(h);
     if (!h || !h->bKV[0]) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
     const oph_dims& m = h->dm;
     if (Y) HIPCHK(h, hipMemcpy2DAsync(Y, (size_t)m.n_mels * 4, h->bYout[h->buf], (size_t)h->ldy * 4, (size_t)m.n_mels * 4,
@@ -440,6 +547,7 @@ int oph_fetch_mel(oph_handle* h, float* Y, int32_t* t_ends, float* alignments) {
 }
 
 int oph_fetch_mag(oph_handle* h, float* Z) {
+    DevGuard dev_guard(h);
     if (!h || !h->bKV[0] || !Z) { if (h) h->fail("no staged batch / null"); return OPH_ERR_STATE; }
     if (h->sssrn) HIPCHK(h, hipStreamSynchronize(h->sssrn));
     const oph_dims& m = h->dm;
@@ -465,6 +573,7 @@ int oph_device_mag(oph_handle* h, const float** d_mag, int64_t* utt_stride, int3
 // the work that is still running.  Pinned buffers (oph_host_alloc) make those copies asynchronous DMA.  What the
 // reference's two clocks bracket (synthesize.py:553-576).
 int oph_run_host(oph_handle* h, int stop_mode, float* K, float* V, float* Y, int32_t* t_ends, float* alignments, float* Z, int32_t* steps_run) {
+    DevGuard dev_guard(h);
     if (!h || !h->bKV[0]) { if (h) h->fail("no staged batch"); return OPH_ERR_STATE; }
     if (stop_mode != OPH_STOP_REFERENCE && stop_mode != OPH_STOP_NEVER) { h->fail("unknown stop mode %d", stop_mode); return OPH_ERR_INVALID; }
     HIPCHK(h, hipSetDevice(h->device));
@@ -522,6 +631,7 @@ int oph_run_host(oph_handle* h, int stop_mode, float* K, float* V, float* Y, int
 
 // ---- host-buffer session calls ---------------------------------------------------------------
 int oph_encode_text(oph_handle* h, const int32_t* L, const int32_t* spk, int B, float* K, float* V) {
+    DevGuard dev_guard(h);
     int rc = check_ready(h, B);
     if (rc) return rc;
     if (!L || !K || !V) { h->fail("null argument"); return OPH_ERR_INVALID; }
@@ -565,6 +675,7 @@ static int stage_decode_inputs(oph_handle* h, const float* K, const float* V, bo
 
 int oph_text2mel(oph_handle* h, const float* K, const float* V, const int32_t* ends, const int32_t* spk, int B,
                  int stop_mode, float* Y, int32_t* t_ends, float* alignments, int32_t* steps_run) {
+    DevGuard dev_guard(h);
     int rc = check_ready(h, B);
     if (rc) return rc;
     if (!ends) { h->fail("null argument"); return OPH_ERR_INVALID; }
@@ -583,6 +694,7 @@ int oph_text2mel(oph_handle* h, const float* K, const float* V, const int32_t* e
 
 int oph_text2mel_durations(oph_handle* h, const float* K, const float* V, const float* durations, const int32_t* spk,
                            int B, int n_steps, float* Y, int32_t* t_ends, float* alignments, int32_t* steps_run) {
+    DevGuard dev_guard(h);
     int rc = check_ready(h, B);
     if (rc) return rc;
     if (!durations) { h->fail("null argument"); return OPH_ERR_INVALID; }
@@ -634,6 +746,7 @@ int oph_text2mel_durations(oph_handle* h, const float* K, const float* V, const 
 int oph_text2mel_graph(oph_handle* h, const float* K, const float* V, const float* mels, const int32_t* prev_max,
                        const int32_t* ends, const int32_t* spk, int B,
                        float* Q, float* R, float* Y_logits, float* Y, float* alignments, int32_t* max_attentions) {
+    DevGuard dev_guard(h);
     int rc = check_ready(h, B);
     if (rc) return rc;
     if (!K || !V || !mels || !prev_max) { h->fail("null argument"); return OPH_ERR_INVALID; }
@@ -695,6 +808,7 @@ int oph_text2mel_graph(oph_handle* h, const float* K, const float* V, const floa
 // oph_ssrn / oph_ssrn_logits.  Y == NULL: the mel frames the last decode call left in HBM (B and T must be that batch's);
 // whatever its streamed SSRN has not covered yet is computed now.
 static int ssrn_common(oph_handle* h, const float* Y, int B, int T, float* Z, float* Z_logits) {
+    DevGuard dev_guard(h);
     int rc = check_ready(h, B);
     if (rc) return rc;
     if (!Z || T < 1) { h->fail("bad argument"); return OPH_ERR_INVALID; }

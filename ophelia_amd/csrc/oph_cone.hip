@@ -9,6 +9,24 @@
 // offsets Hset[k] (84, 82, 44, 14, 4, 2 positions for rates 1,3,9,27,1,1).  It depends only on
 // p_t and Q[<t], both known right after attn_step(t-1): it runs on the SIDE stream, concurrently
 // with the AudioEnc chain of step t, into the ping-pong buffer cone[t&1].
+// Do the workgroups of every hc_fused launch of a cone fit the cone partition at once (the column tiles of a row block wait for each
+// other's statistics)?  Evaluated once per handle (hcf_capacity: -1 unknown, 0 no -- also set after a time-out --, 1 yes).
+bool hcf_fits(oph_handle* h) {
+    if (h->hcf_capacity < 0) {
+        const int nh = h->n_hc_dec;
+        int ncu = 0;
+        for (int i = 0; i < h->mask_words; ++i) ncu += __builtin_popcount(h->m_conep[i]);
+        if (h->mask_words == 0) { hipDeviceProp_t prop; ncu = hipGetDeviceProperties(&prop, h->device) == hipSuccess ? prop.multiProcessorCount : 0; }
+        bool fits = true;
+        for (int k = 0; k + 1 < nh; ++k) {
+            const int Mk = (int)h->Hset[k + 1].size() * h->Bpad;
+            fits = fits && hc_fused_grid(Mk) <= hc_fused_blocks_per_cu(Mk) * ncu;
+        }
+        h->hcf_capacity = fits ? 1 : 0;
+    }
+    return h->hcf_capacity != 0;
+}
+
 void launch_cone(oph_handle* h, int t) {
     const oph_dims& m = h->dm;
     const int d = m.d, Bpad = h->Bpad, B = h->B;
@@ -46,10 +64,10 @@ void launch_cone(oph_handle* h, int t) {
         const bool spk_next = pre > 1 && h->audiodec[1].ccat > 0;
         if (spk_next) { ch.Y = h->coneTmp; ch.ldy = h->audiodec[1].kc; ch.spk_table = h->emb_spk; ch.spk_ids = h->d_spk; ch.spk_dim = h->audiodec[1].ccat; }
         else { ch.Y = cone[0]; ch.ldy = h->audiodec[pre].kc; }
-        ch.stop_after = stop_after; ch.t = t;
+        ch.ctl = h->d_ctl; ch.t = t; ch.lvl_out = -1;
         const bool fused = h->cone_fused_ok && !spk_next && h->cone_prec == 2 && h->hcf_capacity != 0;
         if (fused) { ch.Yh = h->coneH[t & 1][0]; ch.Yl = h->coneL[t & 1][0]; }
-        ch.wait_sig = ar.wait_sig; ch.wait_val = ar.wait_val; ch.wait_err = ar.wait_err;
+        ch.wait_sig = ar.wait_sig; ch.wait_val = ar.wait_val;
         ch.npos = n0; ch.i_new = 0;
         for (int i = 1; i < n0; ++i) if (h->Hset[0][i] < h->Hset[0][ch.i_new]) ch.i_new = i;
         if (h->qw_from_loop) ch.i_new = -1;          // dec_loop's attention layer wrote QW[t-1] before it released this cone
@@ -62,31 +80,31 @@ void launch_cone(oph_handle* h, int t) {
             ch.done_sig = h->d_sig + LOOP_SIG_LEVEL0; ch.done_val = h->cone_done_val; ch.done_count = h->d_cone_count; ch.done_target = h->cone_done_total[0];
             ch.done_stamp = stamp_of(0);
         }
-        h->pbegin(PC_CONEHEAD);
-        launch_cone_head(ch, g_cur);
-        h->pend(PC_CONEHEAD, ((double)n0 * B * (3.0 * d + 2.0 * m.attention_win_size * d) + (double)d * d) * 4.0, (double)n0 * B * 4.0 * m.attention_win_size * d + 2.0 * B * d * d);
+        int head_wgs = 0;          // (pipelined cone: the head's launch has this many workgroups, each counts into shard blockIdx & 7)
+        if (h->aql_rec && fused && ch.i_new < 0) {
+            // the pipelined cone (oph_aql.h): the launch is recorded as an AQL packet instead of being launched on the HIP stream
+            ch.rb = 4;
+            if (h->aql_rec->pipelined) { ch.lvl_count = h->d_lvl_count; ch.lvl_out = 0; ch.lvl_nth = (short)h->aql_rec->nth; }
+            // (4 rows per workgroup, 4 waves: small enough to be placed beside a resident hc_fused workgroup -- a 16-wave workgroup needs a
+            //  CU to itself and is starved by the next level's waiting workgroups: measured, 2 s time-outs)
+            head_wgs = (ch.npos * ch.Bpad + 3) / 4;
+            h->aql_rec->add(h->aql_rec->pipelined ? 0 : 2, (uint32_t)head_wgs, 256, 0, &ch, sizeof ch);
+        } else {
+            h->pbegin(PC_CONEHEAD);
+            launch_cone_head(ch, g_cur);
+            h->pend(PC_CONEHEAD, ((double)n0 * B * (3.0 * d + 2.0 * m.attention_win_size * d) + (double)d * d) * 4.0, (double)n0 * B * 4.0 * m.attention_win_size * d + 2.0 * B * d * d);
+        }
         pre_first = 1;
         if (fused) {
             // levels 1 .. nh-1: one hc_fused launch each (contraction on the planes + LayerNorm x 2 + gate + mix)
             // the 8 workgroups of a row block exchange statistics: every workgroup of a launch must be resident (the cone's launches run
             // one after the other on their own CU partition)
-            bool fits = h->hcf_capacity != 0;
-            if (h->hcf_capacity < 0) {
-                int ncu = 0;
-                for (int i = 0; i < h->mask_words; ++i) ncu += __builtin_popcount(h->m_conep[i]);
-                if (h->mask_words == 0) { hipDeviceProp_t prop; ncu = hipGetDeviceProperties(&prop, h->device) == hipSuccess ? prop.multiProcessorCount : 0; }
-                fits = true;
-                for (int k = 0; k + 1 < nh; ++k) {
-                    const int Mk = (int)h->Hset[k + 1].size() * Bpad;
-                    fits = fits && hc_fused_grid(Mk) <= hc_fused_blocks_per_cu(Mk) * ncu;
-                }
-                h->hcf_capacity = fits ? 1 : 0;
-            }
+            const bool fits = hcf_fits(h);
             if (!fits) h->hcf_capacity = 0;        // (this launch already wrote the planes; harmless) -> the unfused path from here on
             else {
                 if (h->hcf_epoch > 0xF0000000u) {
                     hipStreamSynchronize(h->scone);
-                    hipMemsetAsync(h->d_hcf_stats, 0, (size_t)nh * h->hcf_stats_stride * sizeof(unsigned long long), g_cur);
+                    hipMemsetAsync(h->d_hcf_stats, 0, (size_t)2 * nh * h->hcf_stats_stride * sizeof(unsigned long long), g_cur);
                     h->hcf_epoch = 0;
                 }
                 for (int k = 0; k + 1 < nh; ++k) {
@@ -97,8 +115,9 @@ void launch_cone(oph_handle* h, int t) {
                     f.tab = h->d_tab[k]; f.need = h->d_need[k]; f.n_out = n_out; f.j = t; f.Bpad = Bpad; f.M = n_out * Bpad;
                     f.Wh = l.Wph; f.Wl = l.Wpl; f.bias = l.bias_p; f.g1 = l.g1; f.b1 = l.b1; f.g2 = l.g2; f.b2 = l.b2;
                     f.Y = cone[k + 1]; f.Yh = h->coneH[t & 1][k + 1]; f.Yl = h->coneL[t & 1][k + 1];
-                    f.stats = h->d_hcf_stats + (size_t)k * h->hcf_stats_stride; f.epoch = ++h->hcf_epoch; f.err = h->d_ctl + 2; f.zeros = h->d_zeros;
-                    f.stop_after = stop_after; f.t = t;
+                    // (the statistics regions alternate with the step parity: consecutive steps' launches of a level may overlap in the pipelined cone)
+                    f.stats = h->d_hcf_stats + ((size_t)k * 2 + (t & 1)) * h->hcf_stats_stride; f.epoch = ++h->hcf_epoch; f.ctl = h->d_ctl; f.zeros = h->d_zeros;
+                    f.t = t; f.lvl_io = 0xffu | 0xffu << 8;
                     if (h->cone_inline_sig && k + 1 < LOOP_MAX_LEVELS) {
                         const Layer& tl = h->audiodec[pre + k + 1];
                         f.coh0 = idx_of(h->Hset[k + 1], -tl.off[0]); f.coh1 = idx_of(h->Hset[k + 1], -tl.off[1]);
@@ -107,6 +126,17 @@ void launch_cone(oph_handle* h, int t) {
                         f.done_stamp = stamp_of(k + 1);
                     }
                     if (h->d_cldbg && t == m.max_T / 2) f.dbg = h->d_cldbg + 8 * k;
+                    if (h->aql_rec && head_wgs > 0) {
+                        // wait for every workgroup of the producing launch (level k: the head, or the previous hc_fused: 8 column tiles per row block)
+                        const int in_units = k == 0 ? head_wgs : (f.in_rows + 63) / 64, in_mult = k == 0 ? 1 : 8;
+                        if (h->aql_rec->pipelined) {
+                            f.lvl_count = h->d_lvl_count;
+                            f.lvl_io = (unsigned)k | (unsigned)(k + 1) << 8 | (unsigned)in_mult << 16;
+                            f.lvl_n = (unsigned)in_units | (unsigned)h->aql_rec->nth << 16;
+                        }
+                        h->aql_rec->add(h->aql_rec->pipelined ? 1 : 3, (uint32_t)hc_fused_grid(f.M), 512, (uint32_t)hc_fused_lds_bytes(), &f, sizeof f);
+                        continue;
+                    }
                     h->pbegin(PC_HCFUSED);
                     launch_hc_fused(f, g_cur);
                     h->pend(PC_HCFUSED, ((double)f.M * 3.0 * l.cin + (double)f.M * l.cout + (double)l.N * 3.0 * l.cin) * 4.0, 2.0 * f.M * l.N * 3.0 * l.cin);

@@ -155,7 +155,7 @@ int ensure_decode_state(oph_handle* h, int B) {
     h->d_cone_count = h->dalloc<unsigned>(LOOP_MAX_LEVELS); for (uint32_t& v : h->cone_done_total) v = 0;
     if (h->cone_fused_ok) {
         h->hcf_stats_stride = (size_t)((maxrows * Bpad + 63) / 64) * 2 * 2 * 32 * 8 * 2;      // granules per level: [row block][2][2][32 rows][8 tiles][2 values]
-        h->d_hcf_stats = h->dalloc<unsigned long long>((size_t)nh * h->hcf_stats_stride);
+        h->d_hcf_stats = h->dalloc<unsigned long long>((size_t)2 * nh * h->hcf_stats_stride);      // two per level: alternating with the step parity
         h->hcf_epoch = 0;
         if (!h->d_hcf_stats) { h->fail("out of device memory for decode state"); return OPH_ERR_DEVICE; }
     }
@@ -652,7 +652,90 @@ int decode_loop(oph_handle* h, int t_begin, int t_end, int stop_mode) {
             nanosleep(&ts, nullptr);
         }
     }
-    for (int t = std::max(1, t_begin); t < t_end && !(dbg & 32) && !cone_in_loop; ++t) {
+    // ---- the pipelined cone (oph_aql.h): every launch of every step as an AQL packet without the barrier bit.  The launches order
+    // themselves on the device (attention signal -> head; level counters -> each hc_fused), so the host is not on the path at all: a
+    // fixed-length decode is written out in one go, a decode that may stop early in chunks of `lookahead` steps behind the chain's
+    // progress word (what is queued beyond the stop step early-outs on the device).
+    bool cone_aql = false;
+    if (h->aql && !cone_in_loop && h->qw_from_loop && h->cone_fused_ok && h->cone_head_ok && h->cone_prec == 2 && !h->opt.skip_cone && !(dbg & 32) &&
+        !(h->audiodec.size() > 1 && h->dec_pre > 1 && h->audiodec[1].ccat > 0) && t_end > std::max(1, t_begin) && hcf_fits(h) && *aql_error(h->aql) == 0) {
+        AqlRecorder& rec = h->aql_store;
+        const size_t need = (size_t)(m.max_T + 1) * (size_t)(h->n_hc_dec + 1) * 256;
+        if (rec.stage_cap < need) {
+            if (rec.stage) hipHostFree(rec.stage);
+            rec.stage = nullptr; rec.stage_cap = 0;
+            void* p_ = nullptr;
+            if (hipHostMalloc(&p_, need, hipHostMallocDefault) == hipSuccess) { rec.stage = (char*)p_; rec.stage_cap = need; } else (void)hipGetLastError();
+        }
+        if (h->kernarg_cap < need) {
+            if (h->d_kernarg) hipFree(h->d_kernarg);
+            h->d_kernarg = nullptr; h->kernarg_cap = 0;
+            void* p_ = nullptr;
+            if (hipMalloc(&p_, need) == hipSuccess) { h->d_kernarg = (char*)p_; h->kernarg_cap = need; } else (void)hipGetLastError();
+        }
+        if (!h->d_lvl_count) {
+            void* p_ = nullptr;
+            if (hipMalloc(&p_, (size_t)LOOP_MAX_LEVELS * 9 * 16 * sizeof(unsigned)) == hipSuccess) h->d_lvl_count = (unsigned*)p_; else (void)hipGetLastError();
+        }
+        cone_aql = rec.stage && h->d_kernarg && h->d_lvl_count;
+    }
+    if (cone_aql) {
+        AqlRecorder& rec = h->aql_store;
+        if (h->aql_used) { if (!aql_wait_idle(h->aql, 10.0)) { h->fail("the cone's AQL queue did not drain: %s", aql_error(h->aql)); return OPH_ERR_DEVICE; } h->aql_used = false; }
+        rec.pk.clear(); rec.used = 0; rec.nth = 0; rec.overflow = false; rec.pipelined = h->aql_mode == 2;
+        hipMemsetAsync(h->d_lvl_count, 0, (size_t)LOOP_MAX_LEVELS * 9 * 16 * sizeof(unsigned), h->scopy);
+        const int t_first = std::max(1, t_begin);
+        const int chunk = stop_mode == OPH_STOP_NEVER ? (t_end - t_first) : std::max(4, 2 * lookahead);
+        int t_next = t_first;
+        size_t pk_done = 0;
+        auto submit = [&](int t1) -> int {
+            const size_t arg0 = rec.used;
+            for (int t = t_next; t < t1; ++t) {
+                rec.nth++;
+                h->cone_inline_sig = true; h->cone_wait_val = (t == t_begin) ? 0u : h->sig_base + (uint32_t)t; h->cone_done_val = h->sig_base + (uint32_t)t;
+                h->aql_rec = &rec;
+                launch_cone(h, t);
+                h->aql_rec = nullptr;
+                h->cone_inline_sig = false;
+            }
+            t_next = t1;
+            if (rec.overflow || rec.pk.size() == pk_done) { h->fail("internal: the pipelined cone's launches could not be recorded"); return OPH_ERR_STATE; }
+            // the arguments go to device memory in one copy (the launches read them there at full speed), then the packets are written
+            if (hipMemcpyAsync(h->d_kernarg + arg0, rec.stage + arg0, rec.used - arg0, hipMemcpyHostToDevice, h->scopy) != hipSuccess ||
+                hipStreamSynchronize(h->scopy) != hipSuccess) { h->fail("kernel-argument upload failed"); return OPH_ERR_DEVICE; }
+            for (; pk_done < rec.pk.size(); ++pk_done) {
+                const AqlPacketRec& r = rec.pk[pk_done];
+                if (!aql_dispatch(h->aql, rec.pipelined ? (int)pk_done : 0, h->aql_k[r.kernel], r.grid, r.block, r.lds, h->d_kernarg + r.arg_off, !rec.pipelined)) { h->fail("AQL dispatch failed: %s", aql_error(h->aql)); return OPH_ERR_DEVICE; }
+            }
+            aql_ring(h->aql);
+            h->aql_used = true;
+            return OPH_OK;
+        };
+        { const int rc = submit(std::min(t_end, t_first + chunk)); if (rc) return rc; }
+        h->n_aql_decodes++;
+        auto t_prog = std::chrono::steady_clock::now();
+        int last_prog = -2;
+        for (;;) {
+            const int prog = h->host_prog[0], stopped_at = h->host_prog[1];
+            if (stopped_at != INT_MAX || prog >= t_end - 1) break;
+            if (t_next < t_end && prog >= t_next - 1 - lookahead) { const int rc = submit(std::min(t_end, t_next + chunk)); if (rc) return rc; }
+            bool more_chunks = false;
+            if (stream_ssrn) {
+                Tile& tl = h->tiles[h->tile];
+                more_chunks = tl.ssrn_done + h->opt.ssrn_chunk < m.max_T;
+                if (more_chunks) { const int rc = ssrn_stream_chunks(h, prog, false); if (rc) return rc; }
+            }
+            if (t_next >= t_end && !more_chunks) break;          // nothing left for the host to do while the decode runs
+            if (prog != last_prog) { last_prog = prog; t_prog = std::chrono::steady_clock::now(); }
+            else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_prog).count() > 10.0) {
+                h->fail("decode loop kernel made no progress for 10 s (step %d)", prog);
+                return OPH_ERR_DEVICE;
+            }
+            struct timespec ts = {0, 50000};
+            nanosleep(&ts, nullptr);
+        }
+    }
+    for (int t = std::max(1, t_begin); t < t_end && !(dbg & 32) && !cone_in_loop && !cone_aql; ++t) {
         // bounded run-ahead, so that an early stop leaves at most `lookahead` queued cones (they early-out on the device)
         auto t_wait0 = std::chrono::steady_clock::now();
         while (h->host_prog[0] < t - 1 - lookahead && h->host_prog[1] == INT_MAX) {
@@ -821,6 +904,7 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode) {
 // CUs) the cross-stream words and counters are out of step: bring them back to a quiet state so that the handle stays usable.
 void recover_loop_state(oph_handle* h) {
     for (hipStream_t st : {h->sdec, h->scone, h->sssrn, h->stream}) if (st) hipStreamSynchronize(st);
+    if (h->aql && h->aql_used) { (void)aql_wait_idle(h->aql, 10.0); h->aql_used = false; }
     (void)hipGetLastError();
     hipMemsetAsync(h->d_sig, 0, LOOP_SIG_WORDS * sizeof(uint32_t), h->stream);
     hipMemsetAsync(h->d_cone_count, 0, LOOP_MAX_LEVELS * sizeof(unsigned), h->stream);
@@ -1013,6 +1097,13 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
         }
     }
     // join: the API stream continues (SSRN, fetches) only after both decode streams drained
+    if (h->aql && h->aql_used) {
+        // (the chain's last step waited for the last cone it needs; what is left in the queue are launches beyond a stop step, which
+        //  early-out -- they must be gone before the tile's state is reset for the next decode)
+        hipStreamSynchronize(h->sdec);
+        if (!aql_wait_idle(h->aql, 10.0)) { h->fail("the cone's AQL queue did not drain: %s", aql_error(h->aql)); recover_loop_state(h); return OPH_ERR_DEVICE; }
+        h->aql_used = false;
+    }
     hipEventRecord(h->ev_out, h->sdec);
     hipStreamWaitEvent(h->stream, h->ev_out, 0);
     hipEventRecord(h->ev_out, h->scone);
@@ -1072,6 +1163,13 @@ int decode_batch(oph_handle* h, int t_end, int stop_mode, int32_t* steps_run) {
             else if (h->use_run) { h->use_run = false; what = "one launch per layer"; }
             else break;
             TRACE("decode failed (%s): redoing the tile with %s", h->err.c_str(), what);
+            if (g_trace && h->d_lvl_count) {       // the pipelined cone's completion counters at the time of the failure
+                std::vector<unsigned> lc((size_t)LOOP_MAX_LEVELS * 9 * 16);
+                hipMemcpy(lc.data(), h->d_lvl_count, lc.size() * 4, hipMemcpyDeviceToHost);
+                for (int k = 0; k < h->n_hc_dec; ++k)
+                    TRACE("  level %d: shard counters %u %u %u %u %u %u %u %u; steps complete %u, shards complete %u", k, lc[(k * 8 + 0) * 16], lc[(k * 8 + 1) * 16], lc[(k * 8 + 2) * 16],
+                          lc[(k * 8 + 3) * 16], lc[(k * 8 + 4) * 16], lc[(k * 8 + 5) * 16], lc[(k * 8 + 6) * 16], lc[(k * 8 + 7) * 16], lc[(LOOP_MAX_LEVELS * 8 + k) * 16], lc[(LOOP_MAX_LEVELS * 8 + k) * 16 + 1]);
+            }
             h->last_wait_err = 0;
             h->n_recoveries++;
             h->degraded_left = h->degraded_next; h->degraded_next = std::min(h->degraded_next * 4, 1 << 20);

@@ -36,7 +36,12 @@ constexpr long long HF_TIMEOUT_TICKS = 200000000LL;      // 2 s of the 100 MHz c
 // (Round 4 also ran the small levels 3..5 on a second, unmasked stream -- level 2 handed over through a device word, write-through
 // rows, sc1 loads -- so that they would overlap the next step's large levels: with a fourth queue busy beside the three CU-masked
 // ones the queues time-slice, 50 ms per decode instead of 20.4; removed.)
-__global__ __launch_bounds__(512) void hc_fused(HcFusedArgs a) {
+// COH (round 5, oph_aql.h): the pipelined form.  The launch is dispatched while its predecessor level is still running: it requests
+// what does not depend on that level (tables, bias, the first K-steps of the weights' planes), then waits until every workgroup of
+// the producing launch has counted in (8 sharded counters, one lane each), reads the level's planes and residual rows past its L1
+// (sc1: the producer stored write-through), stores everything write-through itself and counts in when its stores have drained.
+template <bool COH>
+static __device__ __forceinline__ void hc_fused_body(const HcFusedArgs& a) {
     // Every output row must get the SAME arithmetic whatever register or lane holds it (an utterance's result may not depend on its
     // row of the tile: tests/test_gpu_properties.py).  With contraction left to the compiler the unrolled epilogue got v_fma for some
     // register pairs and mul + add for others -- rows with (b & 1) ^ (b >> 3) set rounded differently (profiles/r04_alone.py).
@@ -64,7 +69,12 @@ __global__ __launch_bounds__(512) void hc_fused(HcFusedArgs a) {
     const int bid = blockIdx.x, xcd = bid & 7, jt = (bid >> 3) & 7, tm = (bid >> 6) * 8 + xcd;
     const int MT = (a.M + HF_BM - 1) / HF_BM;
     const bool active = tm < MT;
-    const bool live = !stopped(a.stop_after, a.t);
+    // the stop word is written by the running decode kernel at any time: ONE thread reads it (past the L1), the workgroup shares
+    // the answer -- every barrier below sits under a workgroup-uniform condition
+    __shared__ int live_s;
+    if (tid == 0) live_s = !(a.t > __hip_atomic_load(a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    __syncthreads();
+    const bool live = live_s != 0;
     const int m0 = tm * HF_BM, n0 = jt * HF_BN;
     long long* const dbg = (a.dbg && bid == 0 && tid == 0) ? a.dbg : nullptr;      // diagnostics (OPH_RUN_STAMPS): phase stamps of workgroup 0
     if (dbg) dbg[0] = wall_clock64();
@@ -94,36 +104,49 @@ __global__ __launch_bounds__(512) void hc_fused(HcFusedArgs a) {
         // the residual rows x[res(m)] of this lane's 16 output rows (H1 waves): requested first, used after the exchange.  The wave's
         // 32 rows are two positions (16 utterances each): rows (e & 3) + 4 kh + 8 ((e >> 2) & 1) of position 2 wr + (e >> 3)
         float xres[16];
-        if (wc == 0 && kpart == 0) {
-            const int ipa = min((m0 >> 4) + 2 * wr, a.n_out - 1), ipb = min((m0 >> 4) + 2 * wr + 1, a.n_out - 1);
-            const int ra = a.restab[ipa] * 16, rb = a.restab[ipb] * 16;
+        auto load_xres = [&]() {
+            if (wc == 0 && kpart == 0) {
+                const int ipa = min((m0 >> 4) + 2 * wr, a.n_out - 1), ipb = min((m0 >> 4) + 2 * wr + 1, a.n_out - 1);
+                const int ra = a.restab[ipa] * 16, rb = a.restab[ipb] * 16;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int b = (e & 3) + 4 * kh + 8 * ((e >> 2) & 1);
-                xres[e] = a.Xres[(size_t)((e >> 3) ? rb + b : ra + b) * HF_C + colh];
+                for (int e = 0; e < 16; ++e) {
+                    const int b = (e & 3) + 4 * kh + 8 * ((e >> 2) & 1);
+                    const float* px = a.Xres + (size_t)((e >> 3) ? rb + b : ra + b) * HF_C + colh;
+                    xres[e] = COH ? __hip_atomic_load(px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *px;
+                }
             }
-        }
+        };
+        if (!COH) load_xres();
         // Operand planes: global -> registers -> LDS (16 bytes per lane and request; a wave's request covers 8 whole cache lines).
         // (Measured first, round 4: the same chunks through global_load_lds -- 39 GB/s per CU whatever the ring depth or the K-step
         // width, the LDS-DMA path's own limit; plain loads stream 2-3x that from L2 / MALL.)  Software pipeline, prefetch distance 2:
         // while step s is multiplied out of LDS buffer s & 1, step s + 1 sits in one register set and step s + 2 is in flight.
         typedef int i32x4 __attribute__((ext_vector_type(4)));
         struct Regs { i32x4 ah[1], al[1], bh[1], bl[1]; };
-        auto load_step = [&](int s, Regs& q) {
+        const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc((void*)a.Xh, 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc((void*)a.Xl, 0, 0x7fffffff, 0x00020000);
+        auto load_a = [&](int s, Regs& q) {
             const int tap = s >> 2;
             const size_t kb = (size_t)(s & 3) * a.in_rows * HF_BK;        // planes are K-blocked: [channel / 64][row][64]
-#pragma unroll
-            for (int i = 0; i < 1; ++i) {
-                const int so = asrc[tap];
+            const int so = asrc[tap];
+            if (COH) {
+                const i32x4 z = {0, 0, 0, 0};
+                const int bo = (int)(((size_t)(so >= 0 ? so : 0) + kb) * 2);
+                q.ah[0] = so >= 0 ? __builtin_amdgcn_raw_buffer_load_b128(rxh, bo, 0, 16 /* sc1 */) : z;
+                q.al[0] = so >= 0 ? __builtin_amdgcn_raw_buffer_load_b128(rxl, bo, 0, 16 /* sc1 */) : z;
+            } else {
                 const h16* gh = so >= 0 ? Xh + so + kb : zrow;
                 const h16* gl = so >= 0 ? Xl + so + kb : zrow;
-                q.ah[i] = *(const i32x4*)gh;
-                q.al[i] = *(const i32x4*)gl;
-                const size_t bo = (((size_t)jt * (HF_K / HF_BK) + s) * HF_BN + rq0 + 8 * i) * HF_BK + gp;      // [column tile][K-step][64 columns][64]
-                q.bh[i] = *(const i32x4*)(Wh + bo);
-                q.bl[i] = *(const i32x4*)(Wl + bo);
+                q.ah[0] = *(const i32x4*)gh;
+                q.al[0] = *(const i32x4*)gl;
             }
         };
+        auto load_b = [&](int s, Regs& q) {
+            const size_t bo = (((size_t)jt * (HF_K / HF_BK) + s) * HF_BN + rq0) * HF_BK + gp;      // [column tile][K-step][64 columns][64]
+            q.bh[0] = *(const i32x4*)(Wh + bo);
+            q.bl[0] = *(const i32x4*)(Wl + bo);
+        };
+        auto load_step = [&](int s, Regs& q) { load_a(s, q); load_b(s, q); };
         auto store_step = [&](int buf, const Regs& q) {
 #pragma unroll
             for (int i = 0; i < 1; ++i) {
@@ -156,8 +179,47 @@ __global__ __launch_bounds__(512) void hc_fused(HcFusedArgs a) {
         // prefetch distance HF_AHEAD: step s + 1 waits in registers, steps s + 2 .. s + HF_AHEAD are in flight (the loop is fully
         // unrolled: every register-set index is a constant)
         Regs q[HF_AHEAD];
+        if (COH) {
+            // the weights' first K-steps are on their way while this workgroup waits for the producing level
 #pragma unroll
-        for (int s = 0; s < HF_AHEAD; ++s) load_step(s, q[s]);
+            for (int s = 0; s < HF_AHEAD; ++s) load_b(s, q[s]);
+            const int lvl_in = (int)(a.lvl_io & 0xff) == 0xff ? -1 : (int)(a.lvl_io & 0xff);
+            if (lvl_in >= 0) {
+                if (w8 == 0) {
+                    // ONE word per level and step to poll (the producers count in two stages: shard counters, the last of a shard counts
+                    // the shard in, the last shard raises the word): a launch's waiting workgroups are up to 168 pollers -- on eight
+                    // counters, every lane polling, they took the memory channels of those lines away from the producers
+                    const unsigned nth = a.lvl_n >> 16;
+                    const unsigned* word = a.lvl_count + (LOOP_MAX_LEVELS * 8 + lvl_in) * 16;
+                    long long t0 = 0;
+                    for (int it = 0;; ++it) {
+                        const unsigned v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((int)(v - nth) >= 0) break;
+                        __builtin_amdgcn_s_sleep(16);
+                        if ((it & 127) == 127) {
+                            const long long now = wall_clock64();
+                            if (t0 == 0) t0 = now;
+                            if (now - t0 > HF_TIMEOUT_TICKS || __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                                if (lane == 0) __hip_atomic_store(a.ctl + 2, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                break;
+                            }
+                        }
+                    }
+                    // (this launch was dispatched long before its step: the decode may have stopped meanwhile)
+                    if (lane == 0) live_s = !(a.t > __hip_atomic_load(a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                }
+                __syncthreads();
+            }
+        }
+        if (!COH || live_s != 0) {
+        if (COH) {
+            load_xres();
+#pragma unroll
+            for (int s = 0; s < HF_AHEAD; ++s) load_a(s, q[s]);
+        } else {
+#pragma unroll
+            for (int s = 0; s < HF_AHEAD; ++s) load_step(s, q[s]);
+        }
         store_step(0, q[0]);
         __syncthreads();
 #pragma unroll
@@ -238,8 +300,8 @@ __global__ __launch_bounds__(512) void hc_fused(HcFusedArgs a) {
                 if (!__all(ok) && it >= 64 && (it & 63) == 0) {
                     const long long now = wall_clock64();
                     if (t0 == 0) t0 = now;
-                    give_up = now - t0 > HF_TIMEOUT_TICKS || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-                    if (give_up && lane == 0) __hip_atomic_store(a.err, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    give_up = now - t0 > HF_TIMEOUT_TICKS || __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                    if (give_up && lane == 0) __hip_atomic_store(a.ctl + 2, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (__all(ok) || give_up) {
 #pragma unroll
@@ -290,7 +352,7 @@ __global__ __launch_bounds__(512) void hc_fused(HcFusedArgs a) {
                 const f32x4 y0 = *(const f32x4*)(ys + rt * 36 + c8), y1 = *(const f32x4*)(ys + rt * 36 + c8 + 4);
                 const size_t o = (size_t)m * HF_C + jt * 32 + c8;
                 const int pos_m = m >> 4;
-                if (a.done_sig && (pos_m == a.coh0 || pos_m == a.coh1)) { st_coherent(a.Y + o, y0); st_coherent(a.Y + o + 4, y1); }     // a row the running decode kernel reads
+                if (COH || (a.done_sig && (pos_m == a.coh0 || pos_m == a.coh1))) { st_coherent(a.Y + o, y0); st_coherent(a.Y + o + 4, y1); }     // a row a RUNNING kernel reads
                 else { *(f32x4*)(a.Y + o) = y0; *(f32x4*)(a.Y + o + 4) = y1; }
                 h16x8 hi, lo;
 #pragma unroll
@@ -300,10 +362,16 @@ __global__ __launch_bounds__(512) void hc_fused(HcFusedArgs a) {
                 }
                 const int ch = jt * 32 + c8;
                 const size_t po = ((size_t)(ch >> 6) * a.M + m) * HF_BK + (ch & 63);
-                *(h16x8*)((h16*)a.Yh + po) = hi;
-                *(h16x8*)((h16*)a.Yl + po) = lo;
+                if (COH) {
+                    st_sc1_b128((float*)a.Yh, (unsigned)(po * 2), __builtin_bit_cast(f32x4, hi));
+                    st_sc1_b128((float*)a.Yl, (unsigned)(po * 2), __builtin_bit_cast(f32x4, lo));
+                } else {
+                    *(h16x8*)((h16*)a.Yh + po) = hi;
+                    *(h16x8*)((h16*)a.Yl + po) = lo;
+                }
             }
         }
+        }       // live after the wait
     }
     if (dbg) dbg[4] = wall_clock64();
     // ---- completion of a cone level: the tap rows have left (write-through), one lane raises the level's word (as ln_rows does)
@@ -322,9 +390,27 @@ __global__ __launch_bounds__(512) void hc_fused(HcFusedArgs a) {
             }
         }
     }
-}
 
-static size_t hc_fused_lds_bytes() { return (size_t)2 * (2 * HF_BM + 2 * HF_BN) * HF_BK * 2; }      // (the epilogue's 18.2 KB alias the operand buffers)
+    // pipelined cone: every workgroup that belongs to the level counts in when its rows have left, whether or not it stored any
+    if (COH && a.lvl_count && active) {
+        const int lvl_out = (int)((a.lvl_io >> 8) & 0xff);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            // this launch has out_units row blocks of 8 column tiles; row block u counts into shard u & 7 (= xcd)
+            const unsigned nth = a.lvl_n >> 16;
+            const unsigned shard_total = nth * (unsigned)(((MT + 7 - xcd) >> 3) * HF_NT);
+            level_count_in(a.lvl_count, lvl_out, xcd, shard_total, nth, (unsigned)min(MT, 8));
+        }
+    }
+}
+__global__ __launch_bounds__(512) void hc_fused(HcFusedArgs a) { hc_fused_body<false>(a); }
+// the pipelined form, dispatched through the AQL queue (oph_aql.h) by its unmangled name
+extern "C" __global__ __launch_bounds__(512) void oph_hc_fused_coh(HcFusedArgs a) { hc_fused_body<true>(a); }
+extern "C" __global__ __launch_bounds__(512) void oph_hc_fused_plain(HcFusedArgs a) { hc_fused_body<false>(a); }
+
+#ifndef OPH_DEVICE_CODE_OBJECT
+size_t hc_fused_lds_bytes() { return (size_t)2 * (2 * HF_BM + 2 * HF_BN) * HF_BK * 2; }      // (the epilogue's 18.2 KB alias the operand buffers)
 
 // number of workgroups the launch will have / of those that do work (one per (row block, column tile))
 int hc_fused_grid(int M) { const int MT = (M + HF_BM - 1) / HF_BM; return ((MT + 7) / 8) * 64; }
@@ -356,5 +442,7 @@ int hc_fused_blocks_per_cu(int M) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)hc_fused, 512, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return n;
 }
+
+#endif
 
 }  // namespace oph

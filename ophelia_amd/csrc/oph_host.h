@@ -9,6 +9,7 @@
 //   oph_ops.hip     per-operator entry points (unit parity) and the conv1d_transpose timing probe
 #pragma once
 #include "oph_internal.h"
+#include "oph_aql.h"
 #pragma GCC visibility push(default)      // the library is built with -fvisibility=hidden: only the C ABI is exported
 #include "../../include/ophelia_hip.h"
 #pragma GCC visibility pop
@@ -174,6 +175,24 @@ struct Tile {
                                             // <= ssrn_done: chunks computed while no destination was set (a resumed decode) are not copied
 };
 
+// The pipelined cone's launches of a run of decode steps, recorded by launch_cone instead of being launched on the HIP stream:
+// kernel arguments in a pinned staging area (one 256-byte slot per launch), one record per AQL packet (oph_aql.h)
+struct AqlPacketRec { int kernel; uint32_t grid, block, lds; size_t arg_off; };
+struct AqlRecorder {
+    std::vector<AqlPacketRec> pk;
+    char* stage = nullptr; size_t stage_cap = 0, used = 0;
+    int nth = 0;                        // cone steps recorded since the level counters were zeroed (1-based while a step is being recorded)
+    bool overflow = false;
+    bool pipelined = false;             // the launches order themselves on the device (hc_fused<true> / cone_head<true> on alternating lanes); else
+                                        // the plain kernels on one lane with the barrier bit: what the HIP stream did, without its host cost
+    void add(int kernel, uint32_t grid, uint32_t block, uint32_t lds, const void* args, size_t bytes) {
+        if (used + 256 > stage_cap || bytes > 256) { overflow = true; return; }
+        memcpy(stage + used, args, bytes);
+        pk.push_back({kernel, grid, block, lds, used});
+        used += 256;
+    }
+};
+
 struct oph_handle {
     oph_dims dm{};
     Options opt;
@@ -192,6 +211,14 @@ struct oph_handle {
     bool ssrn_inflight[2] = {false, false};
     int buf = 0; bool pipelined = false;
     uint32_t m_cone[16] = {0}, m_conep[16] = {0}, m_ssrn[16] = {0}; int mask_words = 0;   // CU partitions (0 words = no masking)
+    // pipelined cone (oph_aql.h): an AQL queue of our own on the cone partition's CUs, lent with the masked streams
+    AqlQueue* aql = nullptr; AqlKernel aql_k[4];        // [0] oph_cone_head_coh, [1] oph_hc_fused_coh, [2] oph_cone_head_plain, [3] oph_hc_fused_plain
+    int aql_mode = 0;                                   // OPH_AQL: 0 off (HIP stream), 1 one lane + barrier bits + plain kernels, 2 pipelined on two lanes
+    AqlRecorder aql_store; AqlRecorder* aql_rec = nullptr;      // aql_rec != null while launch_cone records instead of launching
+    char* d_kernarg = nullptr; size_t kernarg_cap = 0;  // device copy of the recorded kernel arguments
+    unsigned* d_lvl_count = nullptr;                    // completion counters [LOOP_MAX_LEVELS][8 shards][16 words]
+    bool aql_used = false;                              // packets were submitted since the queue was last seen idle
+    long long n_aql_decodes = 0;
     bool masked_borrowed = false;      // sdec / scone / sssrn are the device's process-wide CU-masked streams (oph_api.hip): returned, not destroyed
     int ssrn_prec = 2;                 // SSRN contractions: 2 = split-fp16 x3 (fp32 accumulate, fp32-class accuracy), 1 = split-bf16 x3, 0 = fp32 MFMA
     hipEvent_t ev_attn = nullptr, ev_cone = nullptr;
@@ -422,6 +449,7 @@ int finish_ssrn(oph_handle* h);
 
 // ---- oph_cone.hip
 void launch_cone(oph_handle* h, int t);
+bool hcf_fits(oph_handle* h);
 
 // ---- oph_decode.hip
 constexpr int TILE = 16;       // utterances per decode tile = rows of every decode kernel's row block

@@ -162,10 +162,14 @@ struct ConeHeadArgs {
     float* Y;                           // output rows (layer input of the next cone stage)
     void* Yh; void* Yl;                 // optional: the same rows as fp16 hi / lo planes, K-blocked [d / 64][nrows][64] (hc_fused's operand format)
     const float* spk_table; const int* spk_ids;       // optional embedding appended after the d channels
-    const int* stop_after;
-    const unsigned* wait_sig; int* wait_err;
+    int* ctl;                           // the tile's control words: [1] stop_after, [2] error (set when a bounded wait gives up)
+    const unsigned* wait_sig;
     unsigned* done_sig; unsigned* done_count;          // as EpiArgs: cone level 0 written
     long long* done_stamp;
+    unsigned* lvl_count;                // pipelined cone (oph_aql.h): completion counters [level][8 shards][16 words]; every workgroup of a
+                                        // launch counts into (level lvl_out, shard blockIdx & 7) when its rows have left (write-through)
+    short lvl_out;                      // -1: not pipelined (a HIP stream orders the launches)
+    short lvl_nth;                      // this is the nth cone step since the counters were zeroed (1-based)
     int d, N_keys, win, ldvw, ldn, nonorm;
     int B, Bpad, nrows, j;
     int npos; int i_new;                // positions (nrows = npos * Bpad); index of the newest one (smallest offset)
@@ -175,6 +179,7 @@ struct ConeHeadArgs {
 };
 static_assert(sizeof(ConeHeadArgs) <= 256, "cone_head's kernel arguments: four 64-byte lines");
 void launch_cone_head(const ConeHeadArgs& a, hipStream_t s);
+void launch_probe_spin(long long ticks, long long* out, hipStream_t s);
 
 // ---- hc_fused: a level of the AudioDec history cone as ONE launch (oph_hcfused.hip): split-fp16 x3 contraction with both operands
 // as fp16 hi / lo planes through global_load_lds, then LayerNorm x 2 + gate + highway mix in the same kernel -- the 8 column tiles of
@@ -190,11 +195,15 @@ struct HcFusedArgs {
     const float *g1, *b1, *g2, *b2;                     // LayerNorm parameters of H1 / H2 (channel order)
     float* Y; void* Yh; void* Yl;                       // level k rows: fp32 [M][256] and K-blocked planes [4][M][64]
     unsigned long long* stats;                          // exchange granules [row block][2][2][32][8][2]
-    int* err; const float* zeros;
-    const int* stop_after;
+    int* ctl; const float* zeros;                       // ctl: the tile's control words ([1] stop_after, [2] error)
     unsigned* done_sig; unsigned* done_count;           // as EpiArgs
     long long* done_stamp;
     long long* dbg;                                     // diagnostics: phase stamps of workgroup 0 [8], or null
+    unsigned* lvl_count;                                // pipelined cone (hc_fused<true>, oph_aql.h): completion counters [level][8 shards][16 words]
+    unsigned lvl_io;                                    // ... lvl_in | lvl_out << 8 | in_mult << 16: wait until every workgroup of level lvl_in's launch
+                                                        // of this step has counted in, count into lvl_out when this workgroup's rows have left
+    unsigned lvl_n;                                     // ... in_units | nth << 16: the producer's launch has in_mult workgroups per unit, unit u in shard
+                                                        // u & 7; this is the nth cone step since the counters were zeroed
     int in_rows, n_out, j;
     int Bpad, M;                                        // M = n_out * Bpad output rows
     unsigned epoch;                                     // tag of this launch's granules (never reused)
@@ -203,6 +212,7 @@ struct HcFusedArgs {
 };
 static_assert(sizeof(HcFusedArgs) <= 256, "hc_fused's kernel arguments: four 64-byte lines");
 void launch_hc_fused(const HcFusedArgs& a, hipStream_t s);
+size_t hc_fused_lds_bytes();
 int hc_fused_grid(int M);
 int hc_fused_active(int M);
 int hc_fused_holders(int M, int Bpad, int pos, int pos2);
