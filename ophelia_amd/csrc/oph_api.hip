@@ -117,6 +117,10 @@ AqlQueue* masked_set_aql(int device, hipStream_t sdec, int words, const uint32_t
                     for (int lane = 0; lane < aql_lanes(q.aql) && np < want; ++lane) if (late[lane] < 3.0) pick[np++] = lane;
                     TRACE("AQL lanes: us per launch beside the busy streams %.2f %.2f %.2f %.2f -> using %d lane(s)", late[0], late[1], late[2], late[3], np);
                     if (np == 0) { pick[0] = 0; np = 1; }
+                    if (const char* e = getenv("OPH_AQL_PICK")) {      // experiments: which hardware queues serve as lanes 0 and 1
+                        int a_ = 0, b_ = 1;
+                        if (sscanf(e, "%d%*[,:-]%d", &a_, &b_) == 2 && a_ >= 0 && b_ >= 0 && a_ < aql_lanes(q.aql) && b_ < aql_lanes(q.aql) && a_ != b_) { pick[0] = a_; pick[1] = b_; np = 2; }
+                    }
                     aql_use_lanes(q.aql, np == 3 ? 3 : (np >= 2 ? 2 : 1), pick);
                 } else {
                     const int ident[2] = {0, 1};
@@ -201,14 +205,15 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
             if (!masked_streams_acquire(device, words, m_dec, m_conep, m_ssrn, &h->sdec, &h->scone, &h->sssrn)) { h->sdec = h->scone = h->sssrn = nullptr; h->mask_words = 0; }
             else {
                 h->masked_borrowed = true;
-                h->aql_mode = getenv("OPH_AQL") ? std::max(0, std::min(2, atoi(getenv("OPH_AQL")))) : OPH_AQL_DEFAULT;
+                h->aql_mode = getenv("OPH_AQL") ? std::max(0, std::min(3, atoi(getenv("OPH_AQL")))) : OPH_AQL_DEFAULT;
                 if (getenv("OPH_NO_AQL")) h->aql_mode = 0;
                 if (h->aql_mode) {
                     std::string why;
                     h->aql = masked_set_aql(device, h->sdec, words, m_conep, &why);
                     std::string e1, e2;
                     if (h->aql && !(aql_kernel(h->aql, "oph_cone_head_coh", &h->aql_k[0], &e1) && aql_kernel(h->aql, "oph_hc_fused_coh", &h->aql_k[1], &e2) &&
-                                    aql_kernel(h->aql, "oph_cone_head_plain", &h->aql_k[2], &e1) && aql_kernel(h->aql, "oph_hc_fused_plain", &h->aql_k[3], &e2))) { why = e1 + " " + e2; h->aql = nullptr; }
+                                    aql_kernel(h->aql, "oph_cone_head_plain", &h->aql_k[2], &e1) && aql_kernel(h->aql, "oph_hc_fused_plain", &h->aql_k[3], &e2) &&
+                                    aql_kernel(h->aql, "oph_gate", &h->aql_k[4], &e1))) { why = e1 + " " + e2; h->aql = nullptr; }
                     if (!h->aql) TRACE("pipelined cone off (no AQL queue: %s): the cone's launches go through the HIP stream", why.c_str());
                 }
             }
@@ -269,6 +274,7 @@ int oph_destroy(oph_handle* h) {
     for (hipStream_t st : {h->stream, h->sdec, h->scone, h->sssrn, h->scopy}) if (st) hipStreamSynchronize(st);
     if (h->aql && h->aql_used) { (void)aql_wait_idle(h->aql, 10.0); h->aql_used = false; }
     if (h->aql_store.stage) hipHostFree(h->aql_store.stage);
+    for (void* p_ : {(void*)h->d_kernarg, (void*)h->d_lvl_count}) if (p_) hipFree(p_);
     for (auto& pc : h->prof)
         for (auto& e : pc.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (hipEvent_t e : {h->ev0, h->ev1, h->ev_attn, h->ev_cone, h->ev_in, h->ev_out, h->ev_dec_done, h->ev_ssrn_done[0], h->ev_ssrn_done[1], h->ev_preenc, h->ev_copy, h->ev_chunk, h->ev_cs, h->ev_ce})

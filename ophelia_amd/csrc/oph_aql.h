@@ -35,7 +35,19 @@ bool aql_kernel(AqlQueue* q, const char* mangled_name, AqlKernel* out, std::stri
 // `kernarg` (must hold k.kernarg_size bytes, 16-byte aligned, and stay untouched until the launch has run).  barrier: wait for
 // every earlier packet of this queue to complete first (what a HIP stream does).  The packet is only written; aql_ring() makes
 // everything written so far visible to the packet processor.
-bool aql_dispatch(AqlQueue* q, int lane, const AqlKernel& k, uint32_t grid_wgs, uint32_t block_x, uint32_t dyn_lds, const void* kernarg, bool barrier);
+// done_signal >= 0: the launch's completion sets dependency signal `done_signal` (aql_signals) to 0.
+bool aql_dispatch(AqlQueue* q, int lane, const AqlKernel& k, uint32_t grid_wgs, uint32_t block_x, uint32_t dyn_lds, const void* kernarg, bool barrier, int done_signal = -1);
+// Dependencies between lanes, kept by the packet processor (no kernel waits, no CU is held while waiting): a pool of device-only
+// signals; aql_signal_arm(i) marks signal i pending (host side, before the packets that use it are rung); a launch dispatched with
+// done_signal = i clears it when it completes; aql_wait_signal writes a barrier-AND packet on `lane`: the lane's later packets
+// start only when signal i is clear (and, the packet carrying the barrier bit, when the lane's earlier packets have completed).
+bool aql_signals(AqlQueue* q, int n);
+void aql_signal_arm(AqlQueue* q, int i);
+bool aql_wait_signal(AqlQueue* q, int lane, int signal);
+// A RUNNING kernel may clear a signal itself: an 8-byte store of 0 (system scope) to the signal's value word
+// (aql_signal_value_ptr; nullptr if the runtime does not give it out).  aql_signal_clear: the same from the host.
+long long* aql_signal_value_ptr(AqlQueue* q, int i);
+void aql_signal_clear(AqlQueue* q, int i);
 void aql_ring(AqlQueue* q);
 // packets written and not yet consumed by the packet processor (0 = the ring is empty; launches may still be running)
 uint64_t aql_pending(AqlQueue* q);
@@ -47,6 +59,7 @@ bool aql_wait_idle(AqlQueue* q, double timeout_s);
 // much later: the caller measures which hardware queues run freely beside its busy HIP streams and uses those.)
 int aql_lanes(AqlQueue* q);
 void aql_use_lanes(AqlQueue* q, int n, const int* hw);
+std::string aql_state(AqlQueue* q);      // diagnostics: every lane's write / read index, the first dependency signals
 const char* aql_error(AqlQueue* q);      // sticky error of the queue (asynchronous queue errors land here), or ""
 
 }  // namespace oph

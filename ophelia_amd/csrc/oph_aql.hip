@@ -29,6 +29,7 @@ struct AqlQueue {
     uint64_t written[MAXQ] = {0, 0, 0, 0};       // next packet index to write (== the lane's write index as we keep it)
     uint64_t rung[MAXQ] = {0, 0, 0, 0};          // doorbell value last stored + 1
     int map[MAXQ] = {0, 1, 2, 3}; int nmap = 0;  // logical lane -> hardware queue (aql_use_lanes); nmap = 0: identity over nq
+    std::vector<hsa_signal_t> dep;               // dependency signals between lanes (aql_signals): 1 = pending, 0 = the producing launch has completed
     std::string error;
     std::mutex mu;
 };
@@ -126,6 +127,7 @@ void aql_destroy(AqlQueue* q) {
     if (q->have_exe) (void)hsa_executable_destroy(q->exe);
     if (q->have_reader) (void)hsa_code_object_reader_destroy(q->reader);
     for (int i = 0; i < AqlQueue::MAXQ; ++i) if (q->have_sig[i]) (void)hsa_signal_destroy(q->idle_sig[i]);
+    for (hsa_signal_t s : q->dep) (void)hsa_signal_destroy(s);
     delete q;
     std::lock_guard<std::mutex> lock(g_hsa_mu);
     if (g_hsa_refs > 0) { --g_hsa_refs; (void)hsa_shut_down(); }
@@ -148,13 +150,12 @@ bool aql_kernel(AqlQueue* q, const char* mangled_name, AqlKernel* out, std::stri
     return true;
 }
 
-bool aql_dispatch(AqlQueue* q, int lane, const AqlKernel& k, uint32_t grid_wgs, uint32_t block_x, uint32_t dyn_lds, const void* kernarg, bool barrier) {
-    lane = q->nmap > 0 ? q->map[lane % q->nmap] : lane % q->nq;
-    hsa_queue_t* hq = q->q[lane];
-    uint64_t& written = q->written[lane];
-    // room in the ring: the packet processor advances the read index as it consumes packets
+namespace {
+// room for one more packet in the lane's ring: the packet processor advances the read index as it consumes packets
+bool ring_room(AqlQueue* q, int hw_lane) {
+    hsa_queue_t* hq = q->q[hw_lane];
     const auto t0 = std::chrono::steady_clock::now();
-    while (written - hsa_queue_load_read_index_scacquire(hq) >= hq->size) {
+    while (q->written[hw_lane] - hsa_queue_load_read_index_scacquire(hq) >= hq->size) {
         aql_ring(q);
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) {
             std::lock_guard<std::mutex> lock(q->mu);
@@ -163,6 +164,58 @@ bool aql_dispatch(AqlQueue* q, int lane, const AqlKernel& k, uint32_t grid_wgs, 
         }
         std::this_thread::yield();
     }
+    return true;
+}
+}  // namespace
+
+bool aql_signals(AqlQueue* q, int n) {
+    while ((int)q->dep.size() < n) {
+        hsa_signal_t s{};
+        // device-only signals: written by the packet processor at a launch's completion, read by the packet processor of another
+        // lane (barrier-AND packet) -- no interrupt, no host wake-up per completion
+        hsa_status_t st = hsa_amd_signal_create(1, 0, nullptr, HSA_AMD_SIGNAL_AMD_GPU_ONLY, &s);
+        if (st != HSA_STATUS_SUCCESS) st = hsa_signal_create(1, 0, nullptr, &s);
+        if (st != HSA_STATUS_SUCCESS) {
+            std::lock_guard<std::mutex> lock(q->mu);
+            if (q->error.empty()) q->error = std::string("hsa_signal_create: ") + st_name(st);
+            return false;
+        }
+        q->dep.push_back(s);
+    }
+    return true;
+}
+void aql_signal_arm(AqlQueue* q, int i) { if (i >= 0 && i < (int)q->dep.size()) hsa_signal_store_relaxed(q->dep[i], 1); }
+void aql_signal_clear(AqlQueue* q, int i) { if (i >= 0 && i < (int)q->dep.size()) hsa_signal_store_screlease(q->dep[i], 0); }
+long long* aql_signal_value_ptr(AqlQueue* q, int i) {
+    if (i < 0 || i >= (int)q->dep.size()) return nullptr;
+    volatile hsa_signal_value_t* p = nullptr;
+    if (hsa_amd_signal_value_pointer(q->dep[i], &p) != HSA_STATUS_SUCCESS) return nullptr;
+    return (long long*)p;
+}
+
+bool aql_wait_signal(AqlQueue* q, int lane, int signal) {
+    if (signal < 0 || signal >= (int)q->dep.size()) return false;
+    lane = q->nmap > 0 ? q->map[lane % q->nmap] : lane % q->nq;
+    if (!ring_room(q, lane)) return false;
+    hsa_queue_t* hq = q->q[lane];
+    hsa_barrier_and_packet_t* p = (hsa_barrier_and_packet_t*)hq->base_address + (q->written[lane] & (hq->size - 1));
+    memset((char*)p + 2, 0, sizeof(*p) - 2);
+    p->dep_signal[0] = q->dep[signal];
+    // in order behind the lane's earlier packets; what the producing launch released (agent scope) is acquired by the launch behind
+    const uint16_t header = (uint16_t)(HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (uint16_t)(1u << HSA_PACKET_HEADER_BARRIER) |
+                            (uint16_t)(HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
+                            (uint16_t)(HSA_FENCE_SCOPE_NONE << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+    __atomic_store_n((uint16_t*)p, header, __ATOMIC_RELEASE);
+    ++q->written[lane];
+    hsa_queue_store_write_index_relaxed(hq, q->written[lane]);
+    return true;
+}
+
+bool aql_dispatch(AqlQueue* q, int lane, const AqlKernel& k, uint32_t grid_wgs, uint32_t block_x, uint32_t dyn_lds, const void* kernarg, bool barrier, int done_signal) {
+    lane = q->nmap > 0 ? q->map[lane % q->nmap] : lane % q->nq;
+    hsa_queue_t* hq = q->q[lane];
+    uint64_t& written = q->written[lane];
+    if (!ring_room(q, lane)) return false;
     hsa_kernel_dispatch_packet_t* p = (hsa_kernel_dispatch_packet_t*)hq->base_address + (written & (hq->size - 1));
     p->setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
     p->workgroup_size_x = (uint16_t)block_x; p->workgroup_size_y = 1; p->workgroup_size_z = 1;
@@ -173,7 +226,7 @@ bool aql_dispatch(AqlQueue* q, int lane, const AqlKernel& k, uint32_t grid_wgs, 
     p->kernel_object = k.object;
     p->kernarg_address = const_cast<void*>(kernarg);
     p->reserved2 = 0;
-    p->completion_signal.handle = 0;
+    p->completion_signal.handle = (done_signal >= 0 && done_signal < (int)q->dep.size()) ? q->dep[done_signal].handle : 0;
     // agent-scope acquire at the start (L1 / scalar caches of the CUs), agent-scope release at the end; what a running consumer
     // reads of a running producer travels write-through and is read past the L1 (the kernels' business)
     uint16_t header = (uint16_t)(HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) |
@@ -239,6 +292,18 @@ int aql_lanes(AqlQueue* q) { return q->nq; }
 void aql_use_lanes(AqlQueue* q, int n, const int* hw) {
     q->nmap = 0;
     for (int i = 0; i < n && i < AqlQueue::MAXQ; ++i) if (hw[i] >= 0 && hw[i] < q->nq) q->map[q->nmap++] = hw[i];
+}
+
+std::string aql_state(AqlQueue* q) {
+    char buf[512];
+    std::string out;
+    for (int i = 0; i < q->nq; ++i) {
+        snprintf(buf, sizeof buf, "lane %d: written %llu read %llu; ", i, (unsigned long long)q->written[i], (unsigned long long)hsa_queue_load_read_index_scacquire(q->q[i]));
+        out += buf;
+    }
+    out += "signals:";
+    for (size_t i = 0; i < q->dep.size() && i < 6; ++i) { snprintf(buf, sizeof buf, " %lld", (long long)hsa_signal_load_relaxed(q->dep[i])); out += buf; }
+    return out;
 }
 
 const char* aql_error(AqlQueue* q) {

@@ -88,7 +88,16 @@ void launch_cone(oph_handle* h, int t) {
             // (4 rows per workgroup, 4 waves: small enough to be placed beside a resident hc_fused workgroup -- a 16-wave workgroup needs a
             //  CU to itself and is starved by the next level's waiting workgroups: measured, 2 s time-outs)
             head_wgs = (ch.npos * ch.Bpad + 3) / 4;
-            h->aql_rec->add(h->aql_rec->pipelined ? 0 : 2, (uint32_t)head_wgs, 256, 0, &ch, sizeof ch);
+            // split mode: the head of step t starts behind a packet-processor dependency on the chain's per-step signal (2 t + 1), not as
+            // a resident launch that spins (the in-kernel wait stays: it finds its word set)
+            // split mode: the head of step t starts behind a one-wave gate that waits for the chain's attention word (the head's own
+            // wait then finds the word set): a resident head spinning for the chain would hold the wave slots the previous step's
+            // small levels (second lane) need -- and the chain waits for those
+            if (h->aql_rec->split > 0 && ch.wait_sig && ch.wait_val != 0u) {
+                GateArgs ga{}; ga.w32 = ch.wait_sig; ga.want = ch.wait_val; ga.ctl = h->d_ctl; ga.t = t;
+                h->aql_rec->add(4, 1, 64, 0, &ga, sizeof ga, 0);
+            }
+            h->aql_rec->add(h->aql_rec->pipelined ? 0 : 2, (uint32_t)head_wgs, 256, 0, &ch, sizeof ch, 0);
         } else {
             h->pbegin(PC_CONEHEAD);
             launch_cone_head(ch, g_cur);
@@ -134,7 +143,19 @@ void launch_cone(oph_handle* h, int t) {
                             f.lvl_io = (unsigned)k | (unsigned)(k + 1) << 8 | (unsigned)in_mult << 16;
                             f.lvl_n = (unsigned)in_units | (unsigned)h->aql_rec->nth << 16;
                         }
-                        h->aql_rec->add(h->aql_rec->pipelined ? 1 : 3, (uint32_t)hc_fused_grid(f.M), 512, (uint32_t)hc_fused_lds_bytes(), &f, sizeof f);
+                        {
+                            // split mode: level k + 1 is produced on lane 1 from `split` on; the first such launch of a step waits for the
+                            // launch before it (lane 0) through the step's signal
+                            const int sp = h->aql_rec->split, lvl = k + 1, sig = t;
+                            const bool tail = sp > 0 && lvl >= sp;
+                            if (sp > 0 && lvl == sp) {
+                                // the second lane's step begins with a gate on the completion signal of level sp - 1's launch (first lane)
+                                GateArgs ga{}; ga.w64 = aql_signal_value_ptr(h->aql, sig); ga.ctl = h->d_ctl; ga.t = t;
+                                h->aql_rec->add(4, 1, 64, 0, &ga, sizeof ga, 1);
+                            }
+                            h->aql_rec->add(h->aql_rec->pipelined ? 1 : 3, (uint32_t)hc_fused_grid(f.M), 512, (uint32_t)hc_fused_lds_bytes(), &f, sizeof f,
+                                            tail ? 1 : 0, -1, (sp > 0 && lvl + 1 == sp) ? sig : -1);
+                        }
                         continue;
                     }
                     h->pbegin(PC_HCFUSED);

@@ -211,6 +211,30 @@ __global__ __launch_bounds__(1024) void cone_head(ConeHeadArgs a) { cone_head_bo
 extern "C" __global__ __launch_bounds__(1024) void oph_cone_head_coh(ConeHeadArgs a) { cone_head_body<true>(a); }
 extern "C" __global__ __launch_bounds__(1024) void oph_cone_head_plain(ConeHeadArgs a) { cone_head_body<false>(a); }
 
+// Split cone (OPH_AQL=3, oph_aql.h): ONE wave that holds its lane until a word another launch writes has the wanted value -- the
+// chain's attention word in front of a head (w32), or the completion signal of the launch that produced the lane's input (w64: the
+// packet processor clears it when that launch has completed and released its stores).  A waiting head or hc_fused launch holds
+// hundreds of wave slots and starves the launches of the other lane that its own producer waits for (measured: 2 s time-outs); a
+// packet-processor dependency (barrier-AND packet) costs ~30 us per hop (measured: 143 us per step).  Bounded like every wait.
+extern "C" __global__ void oph_gate(GateArgs a) {
+    if (threadIdx.x != 0) return;
+    long long t0 = 0;
+    for (int it = 0;; ++it) {
+        const bool ok = a.w32 ? (int)(__hip_atomic_load(a.w32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.want) >= 0
+                              : __hip_atomic_load(a.w64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) <= 0;
+        if (ok) break;
+        if (a.w32) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(16);
+        if ((it & 127) == 127) {
+            const long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            if (now - t0 > 200000000LL || __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                __hip_atomic_store(a.ctl + 2, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+}
+
 // lane calibration (oph_api.hip): the constant clock when this launch started
 extern "C" __global__ void oph_probe_stamp(long long* out) { if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = wall_clock64(); }
 // ... and a launch that keeps a HIP stream's queue busy for `ticks` of that clock

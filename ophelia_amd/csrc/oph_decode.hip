@@ -573,7 +573,20 @@ int decode_loop(oph_handle* h, int t_begin, int t_end, int stop_mode) {
         hipMemcpyAsync(a.clk, clk_init, sizeof clk_init, hipMemcpyHostToDevice, h->sdec);
     }
     // the generic kernel when stamps or ablation bits other than "no side stream" are asked for (they live there)
-    if (h->chain_ok && !h->fixed_att && a.QW != nullptr && (dbg & ~32) == 0 && h->d_vbuf) {
+    const bool use_chain = h->chain_ok && !h->fixed_att && a.QW != nullptr && (dbg & ~32) == 0 && h->d_vbuf;
+    // Split cone (OPH_AQL=3, oph_aql.h): the cone's small levels of step t on a second lane, beside the head and the large levels of
+    // step t + 1; the lanes meet through a completion signal per step (armed here, before anything can clear it)
+    int aql_split = 0;
+    if (use_chain && h->aql && h->aql_mode == 3 && h->n_hc_dec >= 3 && h->qw_from_loop && h->cone_fused_ok && h->cone_head_ok && h->cone_prec == 2 && !h->opt.skip_cone &&
+        !(dbg & 32) && !(h->cone_loop_ok && !h->opt.no_cone_loop) && !(h->audiodec.size() > 1 && h->dec_pre > 1 && h->audiodec[1].ccat > 0) && t_end > std::max(1, t_begin) &&
+        hcf_fits(h) && *aql_error(h->aql) == 0 && aql_signals(h->aql, m.max_T + 2) && aql_signal_value_ptr(h->aql, 0)) {
+        const int sp = h->opt.aql_split > 0 ? h->opt.aql_split : (h->n_hc_dec + 1) / 2;      // 6 levels: 0..2 | 3..5
+        if (sp >= 2 && sp < h->n_hc_dec) {
+            aql_split = sp;
+            for (int t = std::max(1, t_begin); t < t_end; ++t) aql_signal_arm(h->aql, t);
+        }
+    }
+    if (use_chain) {
         // every hand-off slot starts as the sentinel (what the previous launch left in them is stale)
         a.vbuf = h->d_vbuf;
         hipMemsetAsync(h->d_vbuf, 0xFF, (size_t)2 * LOOP_MAX_LAYERS * h->Bpad * RUN_GCOLS * sizeof(float), h->sdec);
@@ -660,7 +673,7 @@ int decode_loop(oph_handle* h, int t_begin, int t_end, int stop_mode) {
     if (h->aql && !cone_in_loop && h->qw_from_loop && h->cone_fused_ok && h->cone_head_ok && h->cone_prec == 2 && !h->opt.skip_cone && !(dbg & 32) &&
         !(h->audiodec.size() > 1 && h->dec_pre > 1 && h->audiodec[1].ccat > 0) && t_end > std::max(1, t_begin) && hcf_fits(h) && *aql_error(h->aql) == 0) {
         AqlRecorder& rec = h->aql_store;
-        const size_t need = (size_t)(m.max_T + 1) * (size_t)(h->n_hc_dec + 1) * 256;
+        const size_t need = (size_t)(m.max_T + 1) * (size_t)(h->n_hc_dec + 3) * 256;      // (head + levels + the split mode's two gates)
         if (rec.stage_cap < need) {
             if (rec.stage) hipHostFree(rec.stage);
             rec.stage = nullptr; rec.stage_cap = 0;
@@ -683,6 +696,7 @@ int decode_loop(oph_handle* h, int t_begin, int t_end, int stop_mode) {
         AqlRecorder& rec = h->aql_store;
         if (h->aql_used) { if (!aql_wait_idle(h->aql, 10.0)) { h->fail("the cone's AQL queue did not drain: %s", aql_error(h->aql)); return OPH_ERR_DEVICE; } h->aql_used = false; }
         rec.pk.clear(); rec.used = 0; rec.nth = 0; rec.overflow = false; rec.pipelined = h->aql_mode == 2;
+        rec.split = aql_split;
         hipMemsetAsync(h->d_lvl_count, 0, (size_t)LOOP_MAX_LEVELS * 9 * 16 * sizeof(unsigned), h->scopy);
         const int t_first = std::max(1, t_begin);
         const int chunk = stop_mode == OPH_STOP_NEVER ? (t_end - t_first) : std::max(4, 2 * lookahead);
@@ -705,7 +719,8 @@ int decode_loop(oph_handle* h, int t_begin, int t_end, int stop_mode) {
                 hipStreamSynchronize(h->scopy) != hipSuccess) { h->fail("kernel-argument upload failed"); return OPH_ERR_DEVICE; }
             for (; pk_done < rec.pk.size(); ++pk_done) {
                 const AqlPacketRec& r = rec.pk[pk_done];
-                if (!aql_dispatch(h->aql, rec.pipelined ? (int)pk_done : 0, h->aql_k[r.kernel], r.grid, r.block, r.lds, h->d_kernarg + r.arg_off, !rec.pipelined)) { h->fail("AQL dispatch failed: %s", aql_error(h->aql)); return OPH_ERR_DEVICE; }
+                if (r.wait_sig >= 0 && !aql_wait_signal(h->aql, r.lane, r.wait_sig)) { h->fail("AQL dependency packet failed: %s", aql_error(h->aql)); return OPH_ERR_DEVICE; }
+                if (!aql_dispatch(h->aql, rec.pipelined ? (int)pk_done : r.lane, h->aql_k[r.kernel], r.grid, r.block, r.lds, h->d_kernarg + r.arg_off, !rec.pipelined, r.done_sig)) { h->fail("AQL dispatch failed: %s", aql_error(h->aql)); return OPH_ERR_DEVICE; }
             }
             aql_ring(h->aql);
             h->aql_used = true;
@@ -724,6 +739,22 @@ int decode_loop(oph_handle* h, int t_begin, int t_end, int stop_mode) {
                 Tile& tl = h->tiles[h->tile];
                 more_chunks = tl.ssrn_done + h->opt.ssrn_chunk < m.max_T;
                 if (more_chunks) { const int rc = ssrn_stream_chunks(h, prog, false); if (rc) return rc; }
+            }
+            static const bool aql_state_dbg = getenv("OPH_AQL_STATE") != nullptr;
+            if (aql_state_dbg) {       // diagnostics: where the lanes stand when the chain stops making progress
+                static int dumped = 0;
+                if (prog != last_prog) { last_prog = prog; t_prog = std::chrono::steady_clock::now(); }
+                else if (dumped < 3 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_prog).count() > 0.3) {
+                    ++dumped;
+                    unsigned sg[LOOP_SIG_LEVEL0 + 16 * 8];
+                    hipMemcpyAsync(sg, h->d_sig, sizeof sg, hipMemcpyDeviceToHost, h->scopy); hipStreamSynchronize(h->scopy);
+                    TRACE("no progress at step %d (sig_base %u): attention word %u, level words %u %u %u %u %u %u; %s", prog, h->sig_base, sg[0], sg[LOOP_SIG_LEVEL0], sg[LOOP_SIG_LEVEL0 + 16],
+                          sg[LOOP_SIG_LEVEL0 + 32], sg[LOOP_SIG_LEVEL0 + 48], sg[LOOP_SIG_LEVEL0 + 64], sg[LOOP_SIG_LEVEL0 + 80], aql_state(h->aql).c_str());
+                    t_prog = std::chrono::steady_clock::now();
+                }
+                struct timespec ts = {0, 50000};
+                nanosleep(&ts, nullptr);
+                continue;
             }
             if (t_next >= t_end && !more_chunks) break;          // nothing left for the host to do while the decode runs
             if (prog != last_prog) { last_prog = prog; t_prog = std::chrono::steady_clock::now(); }
@@ -1101,6 +1132,7 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
         // (the chain's last step waited for the last cone it needs; what is left in the queue are launches beyond a stop step, which
         //  early-out -- they must be gone before the tile's state is reset for the next decode)
         hipStreamSynchronize(h->sdec);
+        if (g_trace && getenv("OPH_AQL_STATE")) TRACE("AQL queues when the chain ended: %s", aql_state(h->aql).c_str());
         if (!aql_wait_idle(h->aql, 10.0)) { h->fail("the cone's AQL queue did not drain: %s", aql_error(h->aql)); recover_loop_state(h); return OPH_ERR_DEVICE; }
         h->aql_used = false;
     }

@@ -124,6 +124,7 @@ struct Options {
     int pg_waves = 0;                // OPH_PG_WAVES=4|8: the transposed convolution's plane_gemm form forced (64 channels per workgroup on 4 waves | 128 on 8;
                                      // 0 = the launcher's choice); in -DOPH_ABLATE builds 8 also selects the 8-wave forms of the other layers
     bool no_plane_gemm = false;      // OPH_NO_PLANE_GEMM: the batched nets' split-fp16 contractions on fp32 rows (conv_gemm_bf16x3) instead of planes (plane_gemm)
+    int aql_split = 0;               // OPH_AQL_SPLIT: first cone level of the second lane in OPH_AQL=3 (0 = the middle: 3 of 6)
     bool no_chain = false;           // OPH_NO_CHAIN: the whole-decode launch as dec_loop (generic) even where dec_chain (specialised) fits
     void read() {
         auto flag = [](const char* n) { return getenv(n) != nullptr; };
@@ -154,6 +155,7 @@ struct Options {
         run_stamps = flag("OPH_RUN_STAMPS");
         ssrn_chunk = std::max(0, num("OPH_SSRN_CHUNK", 40));
         cl_wgs_per_cu = num("OPH_CL_WGS_PER_CU", 2) == 1 ? 1 : 2; cl_dbg = num("OPH_CL_DBG", 0);
+        aql_split = num("OPH_AQL_SPLIT", 0);
         no_chain = flag("OPH_NO_CHAIN"); no_fused_cone = flag("OPH_NO_FUSED_CONE"); no_plane_gemm = flag("OPH_NO_PLANE_GEMM"); pg_waves = num("OPH_PG_WAVES", 0); if (pg_waves != 4 && pg_waves != 8) pg_waves = 0;
     }
     int cone_ksplit(int M) const { return M >= 512 ? ksplit_big : ksplit_small; }
@@ -177,7 +179,7 @@ struct Tile {
 
 // The pipelined cone's launches of a run of decode steps, recorded by launch_cone instead of being launched on the HIP stream:
 // kernel arguments in a pinned staging area (one 256-byte slot per launch), one record per AQL packet (oph_aql.h)
-struct AqlPacketRec { int kernel; uint32_t grid, block, lds; size_t arg_off; };
+struct AqlPacketRec { int kernel; uint32_t grid, block, lds; size_t arg_off; int lane, wait_sig, done_sig; };
 struct AqlRecorder {
     std::vector<AqlPacketRec> pk;
     char* stage = nullptr; size_t stage_cap = 0, used = 0;
@@ -185,10 +187,14 @@ struct AqlRecorder {
     bool overflow = false;
     bool pipelined = false;             // the launches order themselves on the device (hc_fused<true> / cone_head<true> on alternating lanes); else
                                         // the plain kernels on one lane with the barrier bit: what the HIP stream did, without its host cost
-    void add(int kernel, uint32_t grid, uint32_t block, uint32_t lds, const void* args, size_t bytes) {
+    int split = 0;                      // > 0 (OPH_AQL=3): the cone's levels >= split run on a second lane, behind a packet-processor dependency on
+                                        // the launch of level split - 1 (a device-only signal per step): the small levels of step t overlap the head
+                                        // and the large levels of step t + 1.  Plain kernels, barrier bits within a lane.
+    // lane / wait_sig / done_sig: split mode only (wait_sig >= 0: a barrier-AND packet on that signal goes in front of the launch)
+    void add(int kernel, uint32_t grid, uint32_t block, uint32_t lds, const void* args, size_t bytes, int lane = 0, int wait_sig = -1, int done_sig = -1) {
         if (used + 256 > stage_cap || bytes > 256) { overflow = true; return; }
         memcpy(stage + used, args, bytes);
-        pk.push_back({kernel, grid, block, lds, used});
+        pk.push_back({kernel, grid, block, lds, used, lane, wait_sig, done_sig});
         used += 256;
     }
 };
@@ -212,8 +218,9 @@ struct oph_handle {
     int buf = 0; bool pipelined = false;
     uint32_t m_cone[16] = {0}, m_conep[16] = {0}, m_ssrn[16] = {0}; int mask_words = 0;   // CU partitions (0 words = no masking)
     // pipelined cone (oph_aql.h): an AQL queue of our own on the cone partition's CUs, lent with the masked streams
-    AqlQueue* aql = nullptr; AqlKernel aql_k[4];        // [0] oph_cone_head_coh, [1] oph_hc_fused_coh, [2] oph_cone_head_plain, [3] oph_hc_fused_plain
-    int aql_mode = 0;                                   // OPH_AQL: 0 off (HIP stream), 1 one lane + barrier bits + plain kernels, 2 pipelined on two lanes
+    AqlQueue* aql = nullptr; AqlKernel aql_k[5];        // [0] oph_cone_head_coh, [1] oph_hc_fused_coh, [2] oph_cone_head_plain, [3] oph_hc_fused_plain, [4] oph_gate
+    int aql_mode = 0;                                   // OPH_AQL: 0 off (HIP stream), 1 one lane + barrier bits + plain kernels, 2 pipelined on two lanes,
+                                                        // 3 split: head + large levels on lane 0, the small levels on lane 1 behind a signal dependency
     AqlRecorder aql_store; AqlRecorder* aql_rec = nullptr;      // aql_rec != null while launch_cone records instead of launching
     char* d_kernarg = nullptr; size_t kernarg_cap = 0;  // device copy of the recorded kernel arguments
     unsigned* d_lvl_count = nullptr;                    // completion counters [LOOP_MAX_LEVELS][8 shards][16 words]

@@ -345,6 +345,8 @@ constexpr int LOOP_DESC_WORDS = 20, LOOP_DESC_STRIDE = 32;
 // modes); sig[LOOP_SIG_LEVEL0 + 16 k] level k of the cone of step t written (dec_loop: the layer whose taps read level k
 // waits for that word only -- the cone's later levels are still being computed while the chain's first tap layers run).
 constexpr int LOOP_SIG_LEVEL0 = 32, LOOP_SIG_WORDS = 256, LOOP_MAX_LEVELS = 8;
+// oph_gate (oph_conehead.hip): one wave spins until *w32 >= want (w32 non-null) or *w64 <= 0
+struct GateArgs { const unsigned* w32; const long long* w64; int* ctl; unsigned want; int t; };
 struct LoopArgs {
     int nlayers; int B; int Bpad; int t_begin, t_end; int stop_mode;      // steps [t_begin, t_end)
     int attn_layer;                     // index of the RUN_ATTN layer
