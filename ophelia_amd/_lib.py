@@ -127,10 +127,21 @@ class OpheliaHipError(RuntimeError):
     pass
 
 
-def _hipcc_shared(out, srcs, deps, extra, verbose):
-    # OPH_HIPCC_FLAGS: extra compiler flags (measurement builds, e.g. -DOPH_ABLATE); such a build is never taken for up to date
+def libpath():
+    """The library this process builds and loads.  OPH_HIPCC_FLAGS (measurement builds, e.g. -DOPH_ABLATE) selects a file of its
+    own, named after the flags: a measurement build never replaces the production library, and is itself up to date when its
+    sources are older (every rank of a multi-rank run finds it built)."""
     more = os.environ.get("OPH_HIPCC_FLAGS", "").split()
-    if not more and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+    if not more:
+        return LIBPATH
+    import hashlib
+    return os.path.join(LIBDIR, "libophelia_hip.%s.so" % hashlib.md5(" ".join(more).encode()).hexdigest()[:8])
+
+
+def _hipcc_shared(out, srcs, deps, extra, verbose):
+    # OPH_HIPCC_FLAGS: extra compiler flags (measurement builds); they go into a file of their own (libpath())
+    more = os.environ.get("OPH_HIPCC_FLAGS", "").split() if os.path.basename(out).startswith("libophelia_hip") else []
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
     extra = list(extra) + more
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -152,13 +163,12 @@ def _hipcc_shared(out, srcs, deps, extra, verbose):
 
 def _hipcc_code_object(out, src, deps, verbose):
     """One translation unit compiled for the device only, as a bare gfx950 code object (an ELF the HSA loader takes)."""
-    more = os.environ.get("OPH_HIPCC_FLAGS", "").split()
-    if not more and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tmp = "%s.%d.tmp" % (out, os.getpid())
     cmd = [hipcc, "--offload-arch=gfx950", "--cuda-device-only", "--no-gpu-bundle-output", "-O3", "-std=c++17",
-           "-Wno-unused-value", "-Wno-unused-result", src] + more + ["-o", tmp]
+           "-Wno-unused-value", "-Wno-unused-result", src] + ["-o", tmp]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout)
@@ -177,12 +187,12 @@ def build(verbose=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     hdrs = [os.path.join(CSRC, "oph_internal.h"), os.path.join(CSRC, "oph_device.h"), os.path.join(CSRC, "oph_loopdev.h"), os.path.join(CSRC, "oph_host.h"),
             os.path.join(CSRC, "oph_aql.h"), os.path.join(inc, "ophelia_hip.h")]
-    _hipcc_shared(LIBPATH, srcs, srcs + hdrs, ["-fvisibility=hidden", "-L/opt/rocm/lib", "-lhsa-runtime64", "-ldl", "-Wl,-rpath,/opt/rocm/lib"], verbose)
+    _hipcc_shared(libpath(), srcs, srcs + hdrs, ["-fvisibility=hidden", "-L/opt/rocm/lib", "-lhsa-runtime64", "-ldl", "-Wl,-rpath,/opt/rocm/lib"], verbose)
     _hipcc_code_object(CONE_CO_PATH, os.path.join(CSRC, CONE_CO_SOURCES[0]), [os.path.join(CSRC, f) for f in CONE_CO_SOURCES] + hdrs, verbose)
     vsrcs = [os.path.join(CSRC, s) for s in VOCODER_SOURCES]
     _hipcc_shared(VOCODER_LIBPATH, vsrcs, vsrcs + [os.path.join(inc, "ophelia_vocoder.h")],
                   ["-L/opt/rocm/lib", "-lhipfft", "-Wl,-rpath,/opt/rocm/lib"], verbose)
-    return LIBPATH
+    return libpath()
 
 
 def load():
@@ -190,11 +200,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIBPATH):
+    path = libpath()
+    if not os.path.exists(path):
         raise OpheliaHipError(
             "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(there is no CPU fallback)" % LIBPATH)
-    lib = C.CDLL(LIBPATH)
+            "(there is no CPU fallback)" % path)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError if the header and the library disagree
         fn.restype = res

@@ -445,24 +445,12 @@ int build_loop_proto(oph_handle* h) {
         // fragment request of a wave is 1 KB contiguous (8 full lines) instead of 16 half lines 3 KB apart: the CU's
         // address unit was the bottleneck of the weight prefetch (profiles/r02 ablation: 0.9 us of a 5.3 us layer).
         {
+            // (packed on the device, like every other layout: oph_pack.hip)
             const int slices = round_up(q.N, 16) / 16, nch = (q.ntaps * q.kc) / 16;
-            std::vector<float> Wh((size_t)slices * 16 * q.ldw, 0.f);
-            const size_t rows_have = (size_t)std::min(slices * 16, round_up(q.N, 16));
-            if (hipMemcpy(Wh.data(), q.Wt, rows_have * q.ldw * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { h->fail("weight read-back failed"); return OPH_ERR_DEVICE; }
-            std::vector<float> Ws((size_t)slices * R * PF * 64 * 4, 0.f);
-            for (int g = 0; g < slices; ++g)
-                for (int w = 0; w < R; ++w)
-                    for (int pf = 0; pf < PF; ++pf) {
-                        const int ch = std::min(w + R * pf, nch - 1);
-                        for (int lane = 0; lane < 64; ++lane) {
-                            const int col = 16 * g + 4 * (lane >> 4) + (lane & 3), k = 16 * ch + 4 * ((lane >> 2) & 3);
-                            float* dst = &Ws[((((size_t)g * R + w) * PF + pf) * 64 + lane) * 4];
-                            for (int e = 0; e < 4; ++e) dst[e] = Wh[(size_t)col * q.ldw + k + e];
-                        }
-                    }
-            float* dsw = h->dalloc<float>(Ws.size());
+            const int rows_have = std::min(slices * 16, round_up(q.N, 16));
+            float* dsw = h->dalloc<float>((size_t)slices * R * PF * 64 * 4);
             if (!dsw) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
-            if (hipMemcpy(dsw, Ws.data(), Ws.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { h->fail("weight upload failed"); return OPH_ERR_DEVICE; }
+            launch_pack_loop(q.Wt, q.ldw, rows_have, nch, slices, R, PF, dsw, h->stream);
             q.Wt = dsw;
         }
         if (q.g1) {       // the prologue's LayerNorm parameters side by side: one pointer instead of four
@@ -476,6 +464,7 @@ int build_loop_proto(oph_handle* h) {
             h->loop_lnp[i] = lnp;
         }
     }
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { h->fail("weight repack failed"); return OPH_ERR_DEVICE; }     // (the packed copies are read from other streams)
     h->loop_proto = v;
     // dec_chain (oph_decchain.hip) is dec_loop specialised for the standard geometry: 256 channels per row, 8 rows per workgroup,
     // LayerNorm everywhere, a window of <= 4 keys, the attention layer emitting QW, k = 3 layers 3 x 256 wide, k = 1 layers <= 512 wide

@@ -119,6 +119,7 @@ struct Options {
     bool stream_value = false;       // OPH_STREAM_VALUE: per-step launch paths chain their two streams with stream value operations
     bool run_stamps = false;         // OPH_RUN_STAMPS: clock stamps of the decode kernels' phases (printed under OPH_TRACE)
     int ssrn_chunk = 40;             // OPH_SSRN_CHUNK: mel frames per streamed SSRN chunk (0 = SSRN only after the decode)
+    int ssrn_last = 0;               // OPH_SSRN_LAST: frames of the final piece (0 = whatever the chunks leave: max_T mod chunk, or a whole chunk)
     int cl_wgs_per_cu = 2, cl_dbg = 0;   // OPH_CL_WGS_PER_CU (cone_loop workgroups per CU: 1 or 2), OPH_CL_DBG
     bool no_fused_cone = false;      // OPH_NO_FUSED_CONE: the cone's levels as contraction + ln_rows launches instead of hc_fused
     int pg_waves = 0;                // OPH_PG_WAVES=4|8: the transposed convolution's plane_gemm form forced (64 channels per workgroup on 4 waves | 128 on 8;
@@ -153,7 +154,7 @@ struct Options {
         textenc_prec = num("OPH_TEXTENC_PREC", -1); if (textenc_prec != 0 && textenc_prec != 2) textenc_prec = -1;
         { const char* sv = getenv("OPH_STREAM_VALUE"); stream_value = sv && atoi(sv) != 0; }
         run_stamps = flag("OPH_RUN_STAMPS");
-        ssrn_chunk = std::max(0, num("OPH_SSRN_CHUNK", 40));
+        ssrn_chunk = std::max(0, num("OPH_SSRN_CHUNK", 40)); ssrn_last = std::max(0, num("OPH_SSRN_LAST", 0));
         cl_wgs_per_cu = num("OPH_CL_WGS_PER_CU", 2) == 1 ? 1 : 2; cl_dbg = num("OPH_CL_DBG", 0);
         aql_split = num("OPH_AQL_SPLIT", 0);
         no_chain = flag("OPH_NO_CHAIN"); no_fused_cone = flag("OPH_NO_FUSED_CONE"); no_plane_gemm = flag("OPH_NO_PLANE_GEMM"); pg_waves = num("OPH_PG_WAVES", 0); if (pg_waves != 4 && pg_waves != 8) pg_waves = 0;

@@ -421,6 +421,8 @@ void launch_pack_convT(const float* kt, float* We, float* Wo, int cin, int cout,
 void launch_pack_wkn(const float* k, float* Wkn, int cin, int N, int kc, int ldn, hipStream_t s);
 void launch_pack_wtc(const float* k, float* Wc, int d, int kc_c, int ldvw, hipStream_t s);
 void launch_pack_hcf(const float* kr, const float* bs, float* wp, float* bp, hipStream_t s);
+void launch_pack_coneloop(const float* kr, float* ws, int nch, hipStream_t s);
+void launch_pack_loop(const float* Wt, int ldw, int rows_have, int nch, int slices, int R, int PF, float* dst, hipStream_t s);
 void launch_pad_copy(const float* src, float* dst, size_t n, size_t npad, int mode, int row0, hipStream_t s);
 void launch_maxabs(const float* x, size_t n, unsigned* out, hipStream_t s);
 

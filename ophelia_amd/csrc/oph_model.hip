@@ -329,9 +329,17 @@ int oph_set_weights_device(oph_handle* h, const float* d_flat, int64_t n_floats)
     return OPH_OK;
 }
 
+static int finalize_weights_impl(oph_handle* h);
 int oph_finalize_weights(oph_handle* h) {
     if (!h) return OPH_ERR_INVALID;
     if (h->finalized) return OPH_OK;
+    const int rc = finalize_weights_impl(h);
+    // whatever happened, the caller's device buffer (oph_set_weights_device) is not referenced beyond this call: after a failure
+    // the weights have to be handed over again
+    h->d_flat = nullptr;
+    return rc;
+}
+static int finalize_weights_impl(oph_handle* h) {
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->d_flat)
         for (const auto& it : h->inventory)
@@ -433,26 +441,18 @@ int oph_finalize_weights(oph_handle* h) {
     //   k      = 192 (lane >> 4) + 4 i + e                               (k over [tap x[t-2r] | tap x[t-r] | x[t]] x 256 channels)
     {
         const int pre = h->dec_pre, nh = h->n_hc_dec, d = h->dm.d;
-        bool ok = !h->opt.no_cone_loop && !h->d_flat && h->cone_head_ok && pre == 1 && d == 256 && !(h->dm.flags & (OPH_FLAG_LCC | OPH_FLAG_NORM_NONE | OPH_FLAG_NO_MONOTONIC)) &&
-                  h->dm.attention_win_size <= 4 && nh >= 2 && nh <= CL_MAX_LEVELS;      // (the opt-in persistent cone swizzles its weights on the host)
+        bool ok = !h->opt.no_cone_loop && h->cone_head_ok && pre == 1 && d == 256 && !(h->dm.flags & (OPH_FLAG_LCC | OPH_FLAG_NORM_NONE | OPH_FLAG_NO_MONOTONIC)) &&
+                  h->dm.attention_win_size <= 4 && nh >= 2 && nh <= CL_MAX_LEVELS;      // (opt-in persistent cone; packed on the device like the rest)
         for (int k = 0; ok && k + 1 < nh; ++k) {
             const Layer& l = h->audiodec[pre + k];
             ok = l.kind == K_HC && l.ntaps == 3 && l.kc == 256 && l.cout == 256 && l.cin == 256 && l.ln && !l.lcc && l.ccat == 0 && l.causal;
         }
         for (int k = 0; ok && k + 1 < nh; ++k) {
             Layer& l = h->audiodec[pre + k];
-            const std::vector<float>& kr = *getw(h, l.scope + "/conv1d/kernel");      // (3, 256, 512)
-            std::vector<float> ws((size_t)8 * 4 * CL_NCH * 64 * 4);
-            for (int cg = 0; cg < 8; ++cg)
-                for (int w = 0; w < 4; ++w)
-                    for (int i = 0; i < CL_NCH; ++i)
-                        for (int lane = 0; lane < 64; ++lane)
-                            for (int e = 0; e < 4; ++e) {
-                                const int col = (w >> 1) * 256 + 32 * cg + 16 * (w & 1) + (lane & 15);
-                                const int kk = 192 * (lane >> 4) + 4 * i + e, tap = kk / 256, c = kk % 256;
-                                ws[((((size_t)cg * 4 + w) * CL_NCH + i) * 64 + lane) * 4 + e] = kr[((size_t)tap * 256 + c) * 512 + col];
-                            }
-            l.Wsw_cone = upload(h, ws);
+            const float* kr = dev_tensor(h, l.scope + "/conv1d/kernel");      // (3, 256, 512)
+            float* ws = h->dalloc<float>((size_t)8 * 4 * CL_NCH * 64 * 4);
+            if (kr && ws) launch_pack_coneloop(kr, ws, CL_NCH, h->stream);
+            l.Wsw_cone = (kr && ws) ? ws : nullptr;
             if (!l.Wsw_cone) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
         }
         h->cone_loop_ok = ok;

@@ -267,7 +267,10 @@ int ssrn_stream_chunks(oph_handle* h, int frames_ready, bool final, bool side_ta
         if (final) b = m.max_T;
         else {
             b = a + ch;
-            if (b + ahead > frames_ready || b >= m.max_T) break;     // (the last frames always belong to the final chunk)
+            // (the last frames always belong to the final piece; OPH_SSRN_LAST = x > 0 keeps it to x frames: the frames in front of them
+            //  leave as one shorter chunk on the partition as soon as they can)
+            if (b >= m.max_T && h->opt.ssrn_last > 0 && a < m.max_T - h->opt.ssrn_last) b = m.max_T - h->opt.ssrn_last;
+            if (b + ahead > frames_ready || b >= m.max_T) break;
             // one chunk in flight on the partition; its measured duration tells whether another one can still finish before
             // the decode does -- if not, those frames are cheaper in the final piece on the whole chip
             if (h->chunk_inflight) {
@@ -280,7 +283,7 @@ int ssrn_stream_chunks(oph_handle* h, int frames_ready, bool final, bool side_ta
                 // (dec_t0 is the launch of steps [dec_tbegin, dec_tend): a resumed decode counts its own frames only)
                 const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - h->dec_t0).count() * 1e3;
                 const double remaining = elapsed / std::max(1, frames_ready - h->dec_tbegin) * std::max(0, h->dec_tend - frames_ready);
-                if (h->chunk_ms > remaining) break;
+                if (h->chunk_ms > remaining && b - a >= ch) break;       // (the short chunk in front of a bounded final piece goes anyway)
             }
         }
         // while the decode runs: the SSRN partition; afterwards, not pipelined: the whole chip through the API stream (which

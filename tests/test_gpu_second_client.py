@@ -1,0 +1,94 @@
+"""The decode beside a second client of the GPU.
+
+The whole-decode launch (dec_chain), the cone's fused levels (hc_fused) and the cone head spin on words that other workgroups or
+other launches write; they are ordinary launches, so their forward progress rests on all of their workgroups being resident on
+their CU partition.  A second client -- here the Griffin-Lim vocoder running 50 iterations over a batch of spectrograms on its own
+(unmasked) stream from a second host thread, for the whole duration of the decode -- competes for exactly those CUs.  What the
+product guarantees: the call returns the SAME results as without the second client (bit for bit when the same launches ran; within
+test_gpu_decode_modes.py's cross-flavour bar, with the identical attention trace, when the recovery ladder reran a tile on a launch
+path that needs no co-residency), never an error and never a hang; oph_get_counters reports how often a tile had to be redone."""
+import os
+import sys
+import threading
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from conftest import hp_from_snapshot
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+pytestmark = pytest.mark.gpu
+
+VHP = SimpleNamespace(n_fft=2048, hop_length=275, win_length=1102, power=1.5, n_iter=50, preemphasis=0.97, max_db=100,
+                      ref_db=20, sr=22050)
+
+
+def _mags(n, T, seed):
+    rng = np.random.default_rng(seed)
+    return [np.abs(rng.standard_normal((T, 1025))).astype(np.float32) * 0.3 for _ in range(n)]
+
+
+@pytest.mark.timeout(600)
+def test_decode_results_do_not_depend_on_a_second_client():
+    from oracle import ophelia_oracle as O
+    from ophelia_amd.engine import Engine
+    from ophelia_amd.vocoder import Vocoder
+    hp = hp_from_snapshot("lj_tutorial.cfg", max_T=120)
+    W = O.random_weights(hp, 5)
+    eng = Engine(hp, device=0)
+    voc = Vocoder(VHP, 0)
+    try:
+        eng.load_weights(W)
+        L = O.random_text(hp, 16, 21, min_len=60, max_len=149)
+        ends = O.get_text_lengths(L).astype(np.int32)
+
+        def run():
+            r0 = eng.counters()["recoveries"]
+            eng.stage_text(L, ends)
+            steps = eng.run_resident(stop_mode=1, run_ssrn=True, pipelined=False)
+            Y, t_ends, al = eng.fetch_mel()
+            return steps, np.array(Y), np.array(t_ends), np.array(al), np.array(eng.fetch_mag()), eng.counters()["recoveries"] - r0
+
+        solo = run()
+        c0 = eng.counters()
+
+        # the second client: Griffin-Lim over 16 spectrograms of 480 frames, again and again, until the decodes are through
+        mags = _mags(16, 480, 3)
+        stop = threading.Event()
+        errors, rounds = [], [0]
+
+        def client():
+            try:
+                while not stop.is_set():
+                    voc.spectrogram2wav_batch(mags)
+                    rounds[0] += 1
+            except Exception as e:       # noqa: BLE001  (reported by the main thread)
+                errors.append(e)
+
+        th = threading.Thread(target=client, daemon=True)
+        th.start()
+        try:
+            shared = [run() for _ in range(6)]
+        finally:
+            stop.set()
+            th.join(120)
+        assert not th.is_alive(), "the second client did not come back"
+        assert not errors, errors
+        assert rounds[0] >= 1, "the second client never ran beside a decode"
+        c1 = eng.counters()
+        for k, got in enumerate(shared):
+            assert got[0] == solo[0], "decode %d ran %d steps, alone %d" % (k, got[0], solo[0])
+            for a, b, what in zip(got[1:5], solo[1:5], ("Y", "t_ends", "alignments", "Z")):
+                if got[5] == 0:      # the same launches as alone: the same bits
+                    assert np.array_equal(a, b), "decode %d beside the second client: %s differs from the decode alone" % (k, what)
+                else:                # a tile was redone on the per-step launch path: another summation order (test_decode_flavours_agree's bar)
+                    assert np.abs(a.astype(np.float64) - b).max() <= 1e-4, "decode %d (tile redone): %s off" % (k, what)
+            assert np.array_equal(got[3].argmax(1), solo[3].argmax(1)), "decode %d: attention trace differs" % k
+        # redone tiles are allowed (and counted); errors are not
+        print("decodes beside the second client: 6, vocoder rounds %d, tiles redone %d, whole-decode launches %d" %
+              (rounds[0], c1["recoveries"] - c0["recoveries"], c1["loop_decodes"] - c0["loop_decodes"]))
+        assert c1["recoveries"] - c0["recoveries"] <= 6
+    finally:
+        voc.close()
+        eng.close()
