@@ -173,7 +173,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
     h->dm = m;
     h->device = device;
     h->opt.read();
-    static const char* names[PC_COUNT] = {"conv_gemm_f32<128,128>", "conv_gemm_f32<64,64>", "conv_gemm_bf16x3", "ln_rows", "dec_layer16", "row_chain", "attn_rows", "misc", "dec_run", "dec_loop", "cone_head", "hc_fused"};
+    static const char* names[PC_COUNT] = {"conv_gemm_f32<128,128>", "conv_gemm_f32<64,64>", "conv_gemm_bf16x3", "ln_rows", "dec_layer16", "row_chain", "attn_rows", "misc", "dec_run", "dec_loop", "cone_head", "hc_fused", "plane_gemm"};
     for (int i = 0; i < PC_COUNT; ++i) h->prof[i].name = names[i];
     // CU partition for the decode loop (MI355X: 256 CUs, mask bit i -> XCD i%8): the dependent layers of a step get a
     // private slice of 8 CUs in every XCD so the concurrently running history-cone GEMMs (the next 16 CUs per XCD) and the

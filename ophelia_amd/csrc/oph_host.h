@@ -161,7 +161,7 @@ struct Options {
     }
     int cone_ksplit(int M) const { return M >= 512 ? ksplit_big : ksplit_small; }
 };
-enum { PC_GEMM = 0, PC_GEMM64, PC_GEMM_BF16, PC_LN, PC_DEC, PC_ROWCHAIN, PC_ATTN_ROWS, PC_MISC, PC_DECRUN, PC_DECLOOP, PC_CONEHEAD, PC_HCFUSED, PC_COUNT };   // PC_GEMM = the <128,128> instance
+enum { PC_GEMM = 0, PC_GEMM64, PC_GEMM_BF16, PC_LN, PC_DEC, PC_ROWCHAIN, PC_ATTN_ROWS, PC_MISC, PC_DECRUN, PC_DECLOOP, PC_CONEHEAD, PC_HCFUSED, PC_PLANEGEMM, PC_COUNT };   // PC_GEMM = the <128,128> instance
 
 
 // Decode state of one 16-utterance tile that has to survive between decode calls on the same utterances (a batch of

@@ -82,9 +82,9 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
                 pg.Ah = xh; pg.Al = xl; pg.Wh = (const _Float16*)l.Wkh; pg.Wl = (const _Float16*)l.Wkl; pg.Wh2 = (const _Float16*)l.Wkh2; pg.Wl2 = (const _Float16*)l.Wkl2;
                 pg.bias = l.bias; pg.H = wsraw; pg.M = M; pg.N = l.N; pg.kc = l.kc; pg.T = Tcur; pg.nalloc = l.Nalloc; pg.ldh = 2 * l.Nalloc;
                 pg.ntaps = 2; pg.off[0] = 0; pg.off[1] = -1; pg.convt = 1; pg.waves = h->opt.pg_waves;
-                h->pbegin(PC_GEMM_BF16);
+                h->pbegin(PC_PLANEGEMM);
                 launch_plane_gemm(pg, g_cur);
-                h->pend(PC_GEMM_BF16, ((double)g.M * l.cin + 2.0 * g.M * g.N + 3.0 * g.N * l.cin) * 4.0, 2.0 * g.M * g.N * 3.0 * l.cin);
+                h->pend(PC_PLANEGEMM, ((double)g.M * l.cin + 2.0 * g.M * g.N + 3.0 * g.N * l.cin) * 4.0, 2.0 * g.M * g.N * 3.0 * l.cin);
             } else {   // both phases in one launch
                 const int p2 = (prec && g.Wh && g2.Wh) ? std::min(prec, 2) : 0;
                 const int cls = p2 ? PC_GEMM_BF16 : (conv_gemm_tile_m(g.M, g.N) == 128 ? PC_GEMM : PC_GEMM64);
@@ -108,10 +108,10 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
                 pg.ntaps = l.ntaps;
                 for (int t = 0; t < 3; ++t) pg.off[t] = l.off[t];
                 pg.waves = h->opt.pg_waves;
-                h->pbegin(PC_GEMM_BF16);
+                h->pbegin(PC_PLANEGEMM);
                 launch_plane_gemm(pg, g_cur);
                 const double K = (double)l.ntaps * l.cin;
-                h->pend(PC_GEMM_BF16, ((double)M * l.cin + (double)M * l.N + (double)l.N * K) * 4.0, 2.0 * M * l.N * K);
+                h->pend(PC_PLANEGEMM, ((double)M * l.cin + (double)M * l.N + (double)l.N * K) * 4.0, 2.0 * M * l.N * K);
             } else
                 run_gemm(h, g, l.cin, g.Wh ? std::min(prec, 2) : 0);
             e.ldh = l.Nalloc; e.M = M; e.C = l.cout;
