@@ -116,6 +116,10 @@ void launch_cone(oph_handle* h, int t) {
                     hipMemsetAsync(h->d_hcf_stats, 0, (size_t)2 * nh * h->hcf_stats_stride * sizeof(unsigned long long), g_cur);
                     h->hcf_epoch = 0;
                 }
+                // (opt-in, OPH_HC_PAIR) the last two levels as ONE launch (hc_fused_pair) when each is a single row block and the launches go through the HIP stream
+                const bool pair = h->opt.hc_pair && !h->aql_rec && nh >= 3 && h->d_hcpair && h->d_hcpair_sync &&
+                                  (int)h->Hset[nh - 2].size() * Bpad <= 64 && (int)h->Hset[nh - 1].size() * Bpad <= 64;
+                HcFusedArgs pair_f[2];
                 for (int k = 0; k + 1 < nh; ++k) {
                     const Layer& l = h->audiodec[pre + k];
                     const int n_out = (int)h->Hset[k + 1].size();
@@ -156,6 +160,33 @@ void launch_cone(oph_handle* h, int t) {
                             h->aql_rec->add(h->aql_rec->pipelined ? 1 : 3, (uint32_t)hc_fused_grid(f.M), 512, (uint32_t)hc_fused_lds_bytes(), &f, sizeof f,
                                             tail ? 1 : 0, -1, (sp > 0 && lvl + 1 == sp) ? sig : -1);
                         }
+                        continue;
+                    }
+                    if (pair && k + 3 >= nh) {
+                        pair_f[k + 3 - nh] = f;
+                        if (k + 2 < nh) continue;               // (the pair is launched when its second level's arguments are there)
+                        const int q = t & 1;
+                        if (!h->hcpair_ready[q]) {
+                            // the step-independent part, once per step parity (ctl, t, epoch, the completion values and the stamps are patched in by the launch)
+                            // (in stream order on the cone's stream: a null-stream copy would wait for the running whole-decode launch, which waits for this cone)
+                            memcpy(h->hcpair_host + 2 * q, pair_f, sizeof pair_f);
+                            if (hipMemcpyAsync(h->d_hcpair + 2 * q, h->hcpair_host + 2 * q, sizeof pair_f, hipMemcpyHostToDevice, g_cur) != hipSuccess) { (void)hipGetLastError(); h->hcf_capacity = 0; g_cur = saved; return; }
+                            h->hcpair_ready[q] = true;
+                        }
+                        if (h->hcpair_syncs > 0xF0000000u) { hipStreamSynchronize(h->scone); hipMemsetAsync(h->d_hcpair_sync, 0, 64 * sizeof(unsigned), g_cur); h->hcpair_syncs = 0; }
+                        HcPairArgs pa{};
+                        pa.lv = h->d_hcpair + 2 * q; pa.sync = h->d_hcpair_sync; pa.ctl = h->d_ctl; pa.t = t;
+                        h->hcpair_syncs += 8u; pa.sync_target = h->hcpair_syncs;
+                        pa.epoch0 = pair_f[0].epoch; pa.epoch1 = pair_f[1].epoch; pa.done_val = pair_f[1].done_val;
+                        pa.done_target0 = pair_f[0].done_target; pa.done_target1 = pair_f[1].done_target;
+                        pa.done_sig0 = pair_f[0].done_sig; pa.done_sig1 = pair_f[1].done_sig; pa.done_count0 = pair_f[0].done_count; pa.done_count1 = pair_f[1].done_count;
+                        pa.coh00 = pair_f[0].coh0; pa.coh01 = pair_f[0].coh1; pa.coh10 = pair_f[1].coh0; pa.coh11 = pair_f[1].coh1;
+                        pa.done_stamp0 = pair_f[0].done_stamp; pa.done_stamp1 = pair_f[1].done_stamp; pa.dbg0 = pair_f[0].dbg; pa.dbg1 = pair_f[1].dbg;
+                        h->pbegin(PC_HCFUSED);
+                        launch_hc_fused_pair(pa, g_cur);
+                        { const hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { TRACE("hc_fused_pair launch failed: %s", hipGetErrorString(e_)); h->hcf_capacity = 0; } }
+                        const Layer& l0 = h->audiodec[pre + k - 1];
+                        h->pend(PC_HCFUSED, ((double)(pair_f[0].M + pair_f[1].M) * (3.0 * l.cin + l.cout) + (double)(l.N + l0.N) * 3.0 * l.cin) * 4.0, 2.0 * (pair_f[0].M + pair_f[1].M) * l.N * 3.0 * l.cin);
                         continue;
                     }
                     h->pbegin(PC_HCFUSED);

@@ -157,7 +157,9 @@ int ensure_decode_state(oph_handle* h, int B) {
         h->hcf_stats_stride = (size_t)((maxrows * Bpad + 63) / 64) * 2 * 2 * 32 * 8 * 2;      // granules per level: [row block][2][2][32 rows][8 tiles][2 values]
         h->d_hcf_stats = h->dalloc<unsigned long long>((size_t)2 * nh * h->hcf_stats_stride);      // two per level: alternating with the step parity
         h->hcf_epoch = 0;
-        if (!h->d_hcf_stats) { h->fail("out of device memory for decode state"); return OPH_ERR_DEVICE; }
+        h->d_hcpair = h->dalloc<HcFusedArgs>(4); h->d_hcpair_sync = h->dalloc<unsigned>(64);      // (zero-filled pool)
+        h->hcpair_ready[0] = h->hcpair_ready[1] = false; h->hcpair_syncs = 0;
+        if (!h->d_hcf_stats || !h->d_hcpair || !h->d_hcpair_sync) { h->fail("out of device memory for decode state"); return OPH_ERR_DEVICE; }
     }
     if (h->cone_loop_ok) {
         bool fits = nh <= CL_MAX_LEVELS;
@@ -512,6 +514,22 @@ int build_loop_layers(oph_handle* h) {
     if (hipMemcpy(dl, words.data(), words.size() * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) { h->fail("descriptor upload failed"); return OPH_ERR_DEVICE; }
     h->tiles[h->tile].d_loop_layers = h->d_loop_layers = dl;
     return OPH_OK;
+}
+
+// diagnostics (OPH_TRACE) at the moment a decode's wait timed out: the level words, the levels' arrival counters against their
+// targets, hc_fused_pair's word, the tile's control words
+static void trace_cone_state(oph_handle* h) {
+    if (!g_trace || !h->d_sig || !h->d_cone_count) return;
+    unsigned sg[LOOP_SIG_LEVEL0 + 16 * 8], cc[LOOP_MAX_LEVELS], ps[1] = {0};
+    int ctl[4] = {0, 0, 0, 0};
+    hipMemcpy(sg, h->d_sig, sizeof sg, hipMemcpyDeviceToHost); hipMemcpy(cc, h->d_cone_count, sizeof cc, hipMemcpyDeviceToHost);
+    hipMemcpy(ctl, h->d_ctl, sizeof ctl, hipMemcpyDeviceToHost);
+    if (h->d_hcpair_sync) hipMemcpy(ps, h->d_hcpair_sync, sizeof ps, hipMemcpyDeviceToHost);
+    (void)hipGetLastError();
+    TRACE("  sig_base %u: attention word %u; level words %u %u %u %u %u %u; arrivals %u/%u %u/%u %u/%u %u/%u %u/%u %u/%u; pair word %u of %u; ctl %d %d %d %d", h->sig_base, sg[0],
+          sg[LOOP_SIG_LEVEL0], sg[LOOP_SIG_LEVEL0 + 16], sg[LOOP_SIG_LEVEL0 + 32], sg[LOOP_SIG_LEVEL0 + 48], sg[LOOP_SIG_LEVEL0 + 64], sg[LOOP_SIG_LEVEL0 + 80],
+          cc[0], h->cone_done_total[0], cc[1], h->cone_done_total[1], cc[2], h->cone_done_total[2], cc[3], h->cone_done_total[3], cc[4], h->cone_done_total[4], cc[5], h->cone_done_total[5],
+          ps[0], h->hcpair_syncs, ctl[0], ctl[1], ctl[2], ctl[3]);
 }
 
 // The decode loop as ONE launch on the critical stream + the per-step cones on the side stream, chained by device words
@@ -1139,6 +1157,7 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
             h->fail(ctl[2] == 3 ? "decoder loop: the side stream never saw the attention signal (time-out)" : ctl[2] == 2 ? "decoder loop: the side stream's cone never signalled (time-out)" :
                     ctl[2] == 4 ? "cone level: the column tiles of a row block never saw each other's statistics (time-out: workgroups of one launch were not co-resident)" :
                                   "decoder run: a workgroup hand-off timed out (workgroups of one run were not co-resident)");
+            trace_cone_state(h);
             recover_loop_state(h);
             return OPH_ERR_DEVICE;
         }

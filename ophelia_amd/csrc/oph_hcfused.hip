@@ -40,7 +40,9 @@ constexpr long long HF_TIMEOUT_TICKS = 200000000LL;      // 2 s of the 100 MHz c
 // what does not depend on that level (tables, bias, the first K-steps of the weights' planes), then waits until every workgroup of
 // the producing launch has counted in (8 sharded counters, one lane each), reads the level's planes and residual rows past its L1
 // (sc1: the producer stored write-through), stores everything write-through itself and counts in when its stores have drained.
-template <bool COH>
+// CIN / COUT (round 5, hc_fused_pair): the coherent reads (level k-1 was written by workgroups that are still running) and the
+// write-through stores on their own, without the pipelined form's wait and count-in.
+template <bool COH, bool CIN = COH, bool COUT = COH>
 static __device__ __forceinline__ void hc_fused_body(const HcFusedArgs& a) {
     // Every output row must get the SAME arithmetic whatever register or lane holds it (an utterance's result may not depend on its
     // row of the tile: tests/test_gpu_properties.py).  With contraction left to the compiler the unrolled epilogue got v_fma for some
@@ -112,7 +114,7 @@ static __device__ __forceinline__ void hc_fused_body(const HcFusedArgs& a) {
                 for (int e = 0; e < 16; ++e) {
                     const int b = (e & 3) + 4 * kh + 8 * ((e >> 2) & 1);
                     const float* px = a.Xres + (size_t)((e >> 3) ? rb + b : ra + b) * HF_C + colh;
-                    xres[e] = COH ? __hip_atomic_load(px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *px;
+                    xres[e] = CIN ? __hip_atomic_load(px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *px;
                 }
             }
         };
@@ -129,7 +131,7 @@ static __device__ __forceinline__ void hc_fused_body(const HcFusedArgs& a) {
             const int tap = s >> 2;
             const size_t kb = (size_t)(s & 3) * a.in_rows * HF_BK;        // planes are K-blocked: [channel / 64][row][64]
             const int so = asrc[tap];
-            if (COH) {
+            if (CIN) {
                 const i32x4 z = {0, 0, 0, 0};
                 const int bo = (int)(((size_t)(so >= 0 ? so : 0) + kb) * 2);
                 q.ah[0] = so >= 0 ? __builtin_amdgcn_raw_buffer_load_b128(rxh, bo, 0, 16 /* sc1 */) : z;
@@ -352,7 +354,7 @@ static __device__ __forceinline__ void hc_fused_body(const HcFusedArgs& a) {
                 const f32x4 y0 = *(const f32x4*)(ys + rt * 36 + c8), y1 = *(const f32x4*)(ys + rt * 36 + c8 + 4);
                 const size_t o = (size_t)m * HF_C + jt * 32 + c8;
                 const int pos_m = m >> 4;
-                if (COH || (a.done_sig && (pos_m == a.coh0 || pos_m == a.coh1))) { st_coherent(a.Y + o, y0); st_coherent(a.Y + o + 4, y1); }     // a row a RUNNING kernel reads
+                if (COUT || (a.done_sig && (pos_m == a.coh0 || pos_m == a.coh1))) { st_coherent(a.Y + o, y0); st_coherent(a.Y + o + 4, y1); }     // a row a RUNNING kernel reads
                 else { *(f32x4*)(a.Y + o) = y0; *(f32x4*)(a.Y + o + 4) = y1; }
                 h16x8 hi, lo;
 #pragma unroll
@@ -362,7 +364,7 @@ static __device__ __forceinline__ void hc_fused_body(const HcFusedArgs& a) {
                 }
                 const int ch = jt * 32 + c8;
                 const size_t po = ((size_t)(ch >> 6) * a.M + m) * HF_BK + (ch & 63);
-                if (COH) {
+                if (COUT) {
                     st_sc1_b128((float*)a.Yh, (unsigned)(po * 2), __builtin_bit_cast(f32x4, hi));
                     st_sc1_b128((float*)a.Yl, (unsigned)(po * 2), __builtin_bit_cast(f32x4, lo));
                 } else {
@@ -405,6 +407,54 @@ static __device__ __forceinline__ void hc_fused_body(const HcFusedArgs& a) {
     }
 }
 __global__ __launch_bounds__(512) void hc_fused(HcFusedArgs a) { hc_fused_body<false>(a); }
+
+// hc_fused_pair (round 5): the cone's LAST TWO levels (64 and 32 rows at the shipped geometry: one row block each) in one launch.
+// A small level costs ~13 us as a launch of its own whatever its row count -- 1.5 us between two launches, ~3 us of prologue
+// (arguments, tables, first operand round trip), ~4 us of K loop, ~3 us of statistics exchange, ~1.3 us of stores -- and the eight
+// workgroups that do the work are the same eight (column tiles 0..7 of row block 0: one XCD) in both levels.  Here they run level A,
+// store its rows write-through (fp32 and planes), count in on one word once their stores have been acknowledged, and go on with
+// level B as soon as all eight have (reads of level A's rows past the L1: the producers sit on the same XCD, the lines are in its
+// L2).  The arguments of the two levels that do not change from step to step live in device memory (p.lv, per step parity); the
+// launch carries the per-step scalars.  Same arithmetic, same order as two hc_fused launches: bitwise the same rows.
+__global__ __launch_bounds__(512) void hc_fused_pair(HcPairArgs p) {
+    const int tid = threadIdx.x;
+    {
+        HcFusedArgs a = p.lv[0];
+        a.ctl = p.ctl; a.t = p.t; a.j = p.t; a.epoch = p.epoch0; a.done_val = p.done_val; a.done_target = p.done_target0; a.done_stamp = p.done_stamp0; a.dbg = p.dbg0;
+        a.done_sig = p.done_sig0; a.done_count = p.done_count0; a.coh0 = p.coh00; a.coh1 = p.coh01;
+        // (plain stores: the readers of these rows are the same eight workgroups' level B -- the same XCD, whose L2 is the point of coherence
+        //  for its CUs -- and the two tap positions the chain reads leave write-through as in every level)
+        hc_fused_body<false, false, false>(a);
+    }
+    // every store of this workgroup has been acknowledged by the XCD's L2 -> count in; the eight
+    // active workgroups (blockIdx & 7 == 0, row block 0) wait for each other, bounded like every wait of the cone
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (((int)blockIdx.x & 7) == 0 && ((int)blockIdx.x >> 6) == 0) {
+        if (tid == 0) {
+            __hip_atomic_fetch_add(p.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            long long t0 = 0;
+            for (int it = 0; (int)(__hip_atomic_load(p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.sync_target) < 0; ++it) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((it & 255) == 255) {
+                    const long long now = wall_clock64();
+                    if (t0 == 0) t0 = now;
+                    if (now - t0 > HF_TIMEOUT_TICKS || __hip_atomic_load(p.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                        __hip_atomic_store(p.ctl + 2, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    {
+        HcFusedArgs b = p.lv[1];
+        b.ctl = p.ctl; b.t = p.t; b.j = p.t; b.epoch = p.epoch1; b.done_val = p.done_val; b.done_target = p.done_target1; b.done_stamp = p.done_stamp1; b.dbg = p.dbg1;
+        b.done_sig = p.done_sig1; b.done_count = p.done_count1; b.coh0 = p.coh10; b.coh1 = p.coh11;
+        hc_fused_body<false, true, false>(b);
+    }
+}
 // the pipelined form, dispatched through the AQL queue (oph_aql.h) by its unmangled name
 extern "C" __global__ __launch_bounds__(512) void oph_hc_fused_coh(HcFusedArgs a) { hc_fused_body<true>(a); }
 extern "C" __global__ __launch_bounds__(512) void oph_hc_fused_plain(HcFusedArgs a) { hc_fused_body<false>(a); }
@@ -432,6 +482,14 @@ void launch_hc_fused(const HcFusedArgs& a, hipStream_t s) {
     (void)hipGetDevice(&dev);
     if (!done[dev]) { (void)hipFuncSetAttribute((const void*)hc_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done[dev] = true; }
     hipLaunchKernelGGL(hc_fused, dim3(hc_fused_grid(a.M)), dim3(512), lds, s, a);
+}
+void launch_hc_fused_pair(const HcPairArgs& p, hipStream_t s) {
+    static thread_local std::map<int, bool> done;
+    const size_t lds = hc_fused_lds_bytes();
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!done[dev]) { (void)hipFuncSetAttribute((const void*)hc_fused_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done[dev] = true; }
+    hipLaunchKernelGGL(hc_fused_pair, dim3(64), dim3(512), lds, s, p);       // (both levels: one row block -> hc_fused_grid = 64)
 }
 // workgroups of a launch that can be resident per CU
 int hc_fused_blocks_per_cu(int M) {

@@ -121,6 +121,8 @@ struct Options {
     int ssrn_chunk = 40;             // OPH_SSRN_CHUNK: mel frames per streamed SSRN chunk (0 = SSRN only after the decode)
     int ssrn_last = 0;               // OPH_SSRN_LAST: frames of the final piece (0 = whatever the chunks leave: max_T mod chunk, or a whole chunk)
     int cl_wgs_per_cu = 2, cl_dbg = 0;   // OPH_CL_WGS_PER_CU (cone_loop workgroups per CU: 1 or 2), OPH_CL_DBG
+    bool hc_pair = false;            // OPH_HC_PAIR: the cone's last two levels as one hc_fused_pair launch (opt-in: measured 0.6 - 1.8 % slower than two
+                                     // hc_fused launches, profiles/r05_pair.txt -- a launch boundary costs less than an in-launch hand-off)
     bool no_fused_cone = false;      // OPH_NO_FUSED_CONE: the cone's levels as contraction + ln_rows launches instead of hc_fused
     int pg_waves = 0;                // OPH_PG_WAVES=4|8: the transposed convolution's plane_gemm form forced (64 channels per workgroup on 4 waves | 128 on 8;
                                      // 0 = the launcher's choice); in -DOPH_ABLATE builds 8 also selects the 8-wave forms of the other layers
@@ -157,7 +159,7 @@ struct Options {
         ssrn_chunk = std::max(0, num("OPH_SSRN_CHUNK", 40)); ssrn_last = std::max(0, num("OPH_SSRN_LAST", 0));
         cl_wgs_per_cu = num("OPH_CL_WGS_PER_CU", 2) == 1 ? 1 : 2; cl_dbg = num("OPH_CL_DBG", 0);
         aql_split = num("OPH_AQL_SPLIT", 0);
-        no_chain = flag("OPH_NO_CHAIN"); no_fused_cone = flag("OPH_NO_FUSED_CONE"); no_plane_gemm = flag("OPH_NO_PLANE_GEMM"); pg_waves = num("OPH_PG_WAVES", 0); if (pg_waves != 4 && pg_waves != 8) pg_waves = 0;
+        no_chain = flag("OPH_NO_CHAIN"); no_fused_cone = flag("OPH_NO_FUSED_CONE"); hc_pair = flag("OPH_HC_PAIR"); no_plane_gemm = flag("OPH_NO_PLANE_GEMM"); pg_waves = num("OPH_PG_WAVES", 0); if (pg_waves != 4 && pg_waves != 8) pg_waves = 0;
     }
     int cone_ksplit(int M) const { return M >= 512 ? ksplit_big : ksplit_small; }
 };
@@ -347,6 +349,10 @@ struct oph_handle {
     std::vector<void*> coneH[2], coneL[2];
     unsigned long long* d_hcf_stats = nullptr; uint32_t hcf_epoch = 0; int hcf_capacity = -1;
     size_t hcf_stats_stride = 0;        // granules of one level's statistics region
+    // hc_fused_pair (the cone's last two levels in one launch): the two levels' step-independent arguments per step parity, the word
+    // their workgroups count into between the levels, how often they have (8 per launch)
+    HcFusedArgs hcpair_host[4];         // (the upload's source: alive for as long as the asynchronous copy may read it)
+    HcFusedArgs* d_hcpair = nullptr; unsigned* d_hcpair_sync = nullptr; bool hcpair_ready[2] = {false, false}; uint32_t hcpair_syncs = 0;
     int ldy = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -211,6 +211,18 @@ struct HcFusedArgs {
     unsigned done_val, done_target; int coh0, coh1;
 };
 static_assert(sizeof(HcFusedArgs) <= 256, "hc_fused's kernel arguments: four 64-byte lines");
+// hc_fused_pair: two consecutive one-row-block levels in one launch (oph_hcfused.hip)
+struct HcPairArgs {
+    const HcFusedArgs* lv;              // device memory: [2] the two levels' arguments as a launch of their own would get them; the fields below are patched in
+    unsigned* sync; int* ctl;           // the word the eight active workgroups count into between the levels; the tile's control words
+    long long* done_stamp0; long long* done_stamp1; long long* dbg0; long long* dbg1;
+    unsigned* done_sig0; unsigned* done_sig1; unsigned* done_count0; unsigned* done_count1;      // (null on launch paths that order the cone by stream operations)
+    unsigned sync_target; int t;
+    unsigned epoch0, epoch1, done_val, done_target0, done_target1;
+    int coh00, coh01, coh10, coh11;
+};
+static_assert(sizeof(HcPairArgs) <= 256, "hc_fused_pair's kernel arguments: four 64-byte lines");
+void launch_hc_fused_pair(const HcPairArgs& p, hipStream_t s);
 void launch_hc_fused(const HcFusedArgs& a, hipStream_t s);
 size_t hc_fused_lds_bytes();
 int hc_fused_grid(int M);

@@ -45,6 +45,7 @@ FLAVOURS = {
     "loop_nofc": {"OPH_CONE_FC_ROWS": "0"},
     "loop_fc256": {"OPH_CONE_FC_ROWS": "256", "OPH_CONE_FC_INSPLIT": "1"},
     "loop_nostream": {"OPH_NO_STREAM_SSRN": "1"},
+    "loop_pair": {"OPH_HC_PAIR": "1"},                     # the cone's last two levels as one hc_fused_pair launch (opt-in; default: two hc_fused launches)
     "loop_coneloop": {"OPH_CONE_LOOP": "1"},               # the cone as ONE persistent task-graph launch (opt-in) instead of nine launches per step
     "loop_conefp32": {"OPH_CONE_PREC": "0", "OPH_TEXTENC_PREC": "0"},      # fp32 MFMA for the cone's large levels and TextEnc (default: split-fp16 x3)
     "loop_conebf16": {"OPH_CONE_PREC": "1"},                                # the split-bf16 experiment
@@ -53,12 +54,14 @@ FLAVOURS = {
 
 # fp32-class flavours (fp32 MFMA, split-fp16 x3) differ at the level of summation order; the split-bf16 x3 cone experiment drops terms below 2^-16
 TOL = {"loop_conebf16": 3e-4}
+# flavours that only change how launches are cut, not what a row's arithmetic is
+BITWISE = {"loop_pair", "loop_nostream"}
 
 
 def _run(tmp_path, name, env_extra, max_T, B, stop_mode):
     out = str(tmp_path / (name + ".npz"))
     env = dict(os.environ)
-    for k in ("OPH_DECODE", "OPH_RUN_ROWS", "OPH_NO_CONE_HEAD", "OPH_CONE_FC_ROWS", "OPH_CONE_FC_INSPLIT", "OPH_NO_STREAM_SSRN", "OPH_CONE_LOOP", "OPH_CONE_BF16X3", "OPH_CONE_PREC", "OPH_TEXTENC_PREC"):
+    for k in ("OPH_DECODE", "OPH_RUN_ROWS", "OPH_NO_CONE_HEAD", "OPH_CONE_FC_ROWS", "OPH_CONE_FC_INSPLIT", "OPH_NO_STREAM_SSRN", "OPH_CONE_LOOP", "OPH_CONE_BF16X3", "OPH_CONE_PREC", "OPH_TEXTENC_PREC", "OPH_HC_PAIR"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, "-c", CHILD, ROOT, out, str(max_T), str(B), str(stop_mode)], env=env,
@@ -84,6 +87,8 @@ def test_decode_flavours_agree(tmp_path, stop_mode, max_T, B):
         print("%-16s vs loop: max-abs Y %.2e align %.2e" % (name, ey, ea))
         tol = TOL.get(name, 2e-5)
         assert ey < tol and ea < tol, name
+        if name in BITWISE:
+            assert np.array_equal(got["Y"], ref["Y"]) and np.array_equal(got["al"], ref["al"]), "%s: the same arithmetic in the same order must give the same bits" % name
         assert np.allclose(got["Zsum"], ref["Zsum"], rtol=1e-4), name
     # and the default flavour against the oracle (exact incremental algorithm) on the same K, V
     sys.path.insert(0, ROOT)
