@@ -136,7 +136,16 @@ static __device__ __forceinline__ void cone_head_body(const ConeHeadArgs& a) {
         __syncthreads();
     }
     // (the stop word is written by the running decode kernel: read past the L1; a pipelined launch was dispatched long before its step)
-    const bool live = !(a.ctl && a.t > __hip_atomic_load(a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    // (round 5: the row's two scalars -- prev_max of its utterance, its position's time offset -- are requested BESIDE the stop word,
+    //  not behind the branch on it: one round trip instead of two in front of the row's own requests)
+    const int rl_o = ((int)blockIdx.x - nb_new) * RB + w;       // row among the positions other than the newest
+    int i_o = rl_o / a.Bpad; const int b_o = rl_o - i_o * a.Bpad;
+    if (a.i_new >= 0 && i_o >= a.i_new) ++i_o;
+    const bool row_o = !newest && i_o < a.npos && b_o < a.B;
+    const int pb_o = row_o ? a.p[b_o] : 0, off_o = row_o ? a.off[i_o] : 0;
+    // (the stop word LAST: its value is wanted at once -- the comparison is wave-uniform -- and the wait for it covers the two above)
+    const int stop_v = a.ctl ? __hip_atomic_load(a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
+    const bool live = !(a.ctl && a.t > stop_v);
     const int d = a.d;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if (live && newest) {
@@ -172,12 +181,10 @@ static __device__ __forceinline__ void cone_head_body(const ConeHeadArgs& a) {
             }
         }
     } else if (live) {
-        const int rl = ((int)blockIdx.x - nb_new) * RB + w;       // row among the positions other than the newest
-        int i = rl / a.Bpad; const int b = rl - i * a.Bpad;
-        if (a.i_new >= 0 && i >= a.i_new) ++i;
-        if (i < a.npos && b < a.B) {
-            const int pb = a.p[b];
-            const int tq = a.j - a.off[i];
+        const int i = i_o, b = b_o;
+        if (row_o) {
+            const int pb = pb_o;
+            const int tq = a.j - off_o;
             if (tq >= 0) {
                 const int c = lane * 4;
                 const f32x4 qw = c < d ? *(const f32x4*)(a.QW + ((size_t)tq * a.Bpad + b) * d + c) : zero4;

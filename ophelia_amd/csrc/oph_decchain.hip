@@ -210,7 +210,8 @@ __global__ __launch_bounds__(64 * CH_R) void dec_chain(LoopArgs a) {
                 // (before it: this workgroup's columns of the other parity's slot of this layer go back to the sentinel -- see CH_SENT)
                 if (cols && tid < 16 * R && (tid & 3) == 1) {
                     const f32x4 sv = {__uint_as_float(CH_SENT), __uint_as_float(CH_SENT), __uint_as_float(CH_SENT), __uint_as_float(CH_SENT)};
-                    vst(slot_off(t + 1, l, row0 + (tid >> 4)), (n0 + (tid & 12)) * 4, sv);
+                    // (the row goes into the LANE offset: a scalar offset that differs between lanes makes the compiler loop over its values)
+                    vst(slot_off(t + 1, l, row0), ((tid >> 4) * RUN_GCOLS + n0 + (tid & 12)) * 4, sv);
                 }
                 const int in_off = slot_off(PRO == P_MEL ? t - 1 : t, PRO == P_MEL ? NL - 1 : l - 1, grow);
                 f32x4 ga = zero4, gu = zero4;
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(64 * CH_R) void dec_chain(LoopArgs a) {
                         if (__float_as_uint(v) == CH_SENT) v = __uint_as_float(0x7FC00000u);
                         f32x4 q;
                         q[0] = dpp_mov<0x00>(v); q[1] = dpp_mov<0x55>(v); q[2] = dpp_mov<0xAA>(v); q[3] = dpp_mov<0xFF>(v);
-                        if ((col & 3) == 0) vst(slot_off(t, l, row0 + row), (n0 + col) * 4, q);
+                        if ((col & 3) == 0) vst(slot_off(t, l, row0), (row * RUN_GCOLS + n0 + col) * 4, q);
                     }
                     if (PRO == P_ATTN) {
                         // QW[t] = Q[t] . Wq + bias for the cone head's cache (written through: the cone kernels read it after their acquire)

@@ -73,11 +73,22 @@ static __device__ __forceinline__ void hc_fused_body(const HcFusedArgs& a) {
     const bool active = tm < MT;
     // the stop word is written by the running decode kernel at any time: ONE thread reads it (past the L1), the workgroup shares
     // the answer -- every barrier below sits under a workgroup-uniform condition
+    const int m0 = tm * HF_BM, n0 = jt * HF_BN;
+    // The source-position tables of this wave's rows and the residual positions depend on the arguments alone: requested here, so that
+    // they are one round trip TOGETHER with the stop word (round 5: the prologue was four dependent round trips -- stop word, tap
+    // tables, residual table, first operands -- ~0.7 us each; now two)
+    int needv[3], tabv[3], rapos = 0, rbpos = 0;
+    {
+        const int ipc = min((m0 + 8 * w8) >> 4, a.n_out - 1);
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) { needv[tap] = a.need[tap * a.n_out + ipc]; tabv[tap] = a.tab[tap * a.n_out + ipc]; }
+        const int wr_ = (w8 & 3) >> 1;
+        rapos = a.restab[min((m0 >> 4) + 2 * wr_, a.n_out - 1)]; rbpos = a.restab[min((m0 >> 4) + 2 * wr_ + 1, a.n_out - 1)];
+    }
     __shared__ int live_s;
     if (tid == 0) live_s = !(a.t > __hip_atomic_load(a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     __syncthreads();
     const bool live = live_s != 0;
-    const int m0 = tm * HF_BM, n0 = jt * HF_BN;
     long long* const dbg = (a.dbg && bid == 0 && tid == 0) ? a.dbg : nullptr;      // diagnostics (OPH_RUN_STAMPS): phase stamps of workgroup 0
     if (dbg) dbg[0] = wall_clock64();
     if (active && live) {
@@ -93,10 +104,7 @@ static __device__ __forceinline__ void hc_fused_body(const HcFusedArgs& a) {
         const int gp = (pos ^ ((rq0 >> 1) & 7)) * 8;       // the chunk of the row this lane fetches (the swizzle, applied on the global side)
         int asrc[3];
         {
-            const int ipw = (m0 + 8 * w8) >> 4, ipc = min(ipw, a.n_out - 1), bq = rq0 & 15;
-            int needv[3], tabv[3];
-#pragma unroll
-            for (int tap = 0; tap < 3; ++tap) { needv[tap] = a.need[tap * a.n_out + ipc]; tabv[tap] = a.tab[tap * a.n_out + ipc]; }
+            const int ipw = (m0 + 8 * w8) >> 4, bq = rq0 & 15;
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap) asrc[tap] = (ipw < a.n_out && a.j >= needv[tap]) ? (tabv[tap] * 16 + bq) * HF_BK + gp : -1;
         }
@@ -108,8 +116,7 @@ static __device__ __forceinline__ void hc_fused_body(const HcFusedArgs& a) {
         float xres[16];
         auto load_xres = [&]() {
             if (wc == 0 && kpart == 0) {
-                const int ipa = min((m0 >> 4) + 2 * wr, a.n_out - 1), ipb = min((m0 >> 4) + 2 * wr + 1, a.n_out - 1);
-                const int ra = a.restab[ipa] * 16, rb = a.restab[ipb] * 16;
+                const int ra = rapos * 16, rb = rbpos * 16;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int b = (e & 3) + 4 * kh + 8 * ((e >> 2) & 1);
