@@ -45,7 +45,12 @@ FLAVOURS = {
     "loop_nofc": {"OPH_CONE_FC_ROWS": "0"},
     "loop_fc256": {"OPH_CONE_FC_ROWS": "256", "OPH_CONE_FC_INSPLIT": "1"},
     "loop_nostream": {"OPH_NO_STREAM_SSRN": "1"},
-    "loop_pair": {"OPH_HC_PAIR": "1"},                     # the cone's last two levels as one hc_fused_pair launch (opt-in; default: two hc_fused launches)
+    "loop_pair": {"OPH_HC_PAIR": "1"},
+    # the cone's launches through AQL queues of our own (opt-in, oph_aql.h): one lane with barrier bits (the plain kernels: the same bits),
+    # pipelined over two lanes (in-kernel waits, write-through rows), split over two lanes behind gate kernels (plain kernels again)
+    "loop_aql1": {"OPH_AQL": "1"},
+    "loop_aql2": {"OPH_AQL": "2"},
+    "loop_aql3": {"OPH_AQL": "3", "OPH_AQL_PICK": "0-2"},                     # the cone's last two levels as one hc_fused_pair launch (opt-in; default: two hc_fused launches)
     "loop_coneloop": {"OPH_CONE_LOOP": "1"},               # the cone as ONE persistent task-graph launch (opt-in) instead of nine launches per step
     "loop_conefp32": {"OPH_CONE_PREC": "0", "OPH_TEXTENC_PREC": "0"},      # fp32 MFMA for the cone's large levels and TextEnc (default: split-fp16 x3)
     "loop_conebf16": {"OPH_CONE_PREC": "1"},                                # the split-bf16 experiment
@@ -55,13 +60,13 @@ FLAVOURS = {
 # fp32-class flavours (fp32 MFMA, split-fp16 x3) differ at the level of summation order; the split-bf16 x3 cone experiment drops terms below 2^-16
 TOL = {"loop_conebf16": 3e-4}
 # flavours that only change how launches are cut, not what a row's arithmetic is
-BITWISE = {"loop_pair", "loop_nostream"}
+BITWISE = {"loop_pair", "loop_nostream", "loop_aql1", "loop_aql3"}      # (loop_aql2, the pipelined form, reproduces the fixed-length case bit for bit but not the early-stop one: 1.7e-6; a measured dead end)
 
 
 def _run(tmp_path, name, env_extra, max_T, B, stop_mode):
     out = str(tmp_path / (name + ".npz"))
     env = dict(os.environ)
-    for k in ("OPH_DECODE", "OPH_RUN_ROWS", "OPH_NO_CONE_HEAD", "OPH_CONE_FC_ROWS", "OPH_CONE_FC_INSPLIT", "OPH_NO_STREAM_SSRN", "OPH_CONE_LOOP", "OPH_CONE_BF16X3", "OPH_CONE_PREC", "OPH_TEXTENC_PREC", "OPH_HC_PAIR"):
+    for k in ("OPH_DECODE", "OPH_RUN_ROWS", "OPH_NO_CONE_HEAD", "OPH_CONE_FC_ROWS", "OPH_CONE_FC_INSPLIT", "OPH_NO_STREAM_SSRN", "OPH_CONE_LOOP", "OPH_CONE_BF16X3", "OPH_CONE_PREC", "OPH_TEXTENC_PREC", "OPH_HC_PAIR", "OPH_AQL", "OPH_AQL_PICK", "OPH_AQL_SPLIT"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, "-c", CHILD, ROOT, out, str(max_T), str(B), str(stop_mode)], env=env,
