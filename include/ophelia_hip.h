@@ -148,7 +148,9 @@ int oph_set_mag_destination(oph_handle* h, float* Z);
  * [8] 1 if this handle holds the device's CU-masked streams (one handle per device and process at a time: the three partitions
  *     chain | cone | SSRN are created once per process and lent out), 0 if it runs on ordinary streams (no whole-decode launch),
  * [9] decodes in which an in-kernel wait timed out (workgroups of a launch not co-resident) and the affected steps were redone on
- *     the per-step launch path. */
+ *     the per-step launch path,
+ * [10] decodes this handle will still run on the reduced launch paths after such a recovery (0 = the default launches are armed):
+ *     results on the reduced paths are within the cross-flavour bar (1e-4, identical attention traces), not bit-equal to the default's. */
 int oph_get_counters(oph_handle* h, int64_t* out, int n);
 /* oph_text2mel_graph  replaces ONE sess.run([g.Y, g.max_attentions, g.alignments], feed) of the reference's loop
  *     (synthesize.py:172,181-183) and serves as the fetch surface for the graph tensors of architectures.py:188-239:

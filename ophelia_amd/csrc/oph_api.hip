@@ -497,10 +497,10 @@ int oph_set_precision(oph_handle* h, int which, int mode) {
 // [3] whole-decode launches  [4] fallbacks from the whole-decode launch to two launches per step  [5] tiles resumed to the batch's stop step
 int oph_get_counters(oph_handle* h, int64_t* out, int n) {
     if (!h || !out) return OPH_ERR_INVALID;
-    const long long v[10] = {h->n_textenc, h->n_preenc_used, h->n_chunks_streamed, h->n_loop_decodes, h->n_loop_fallbacks, h->n_tile_resumes, h->n_cone_loops,
+    const long long v[11] = {h->n_textenc, h->n_preenc_used, h->n_chunks_streamed, h->n_loop_decodes, h->n_loop_fallbacks, h->n_tile_resumes, h->n_cone_loops,
                              (long long)((h->guard_ssrn ? 1 : 0) | (h->guard_cone ? 2 : 0) | (h->guard_text ? 4 : 0)),
-                             h->mask_words > 0 ? 1 : 0, h->n_recoveries};
-    for (int i = 0; i < n && i < 10; ++i) out[i] = v[i];
+                             h->mask_words > 0 ? 1 : 0, h->n_recoveries, h->degraded_left};
+    for (int i = 0; i < n && i < 11; ++i) out[i] = v[i];
     return OPH_OK;
 }
 // Where the speculative SSRN of the NEXT oph_text2mel copies its rows while the decoder is still running: a host buffer of

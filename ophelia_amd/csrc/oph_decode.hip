@@ -1187,7 +1187,8 @@ int decode_batch(oph_handle* h, int t_end, int stop_mode, int32_t* steps_run) {
     // guarantees that when another client holds CUs of the partition.  Every such wait is bounded (2 s) and ends in an error word; the
     // answer here is to redo the tile on a path that needs less: first the cone's levels as contraction + ln_rows launches (no
     // exchange between workgroups), then two launches per step instead of the whole-decode launch, then one launch per layer.
-    // The fast paths are tried again after `rearm` decodes (16, then 4 x as many each time they fail again).
+    // The fast paths are tried again after `rearm` decodes (16, then 4 x as many each time they fail again, at most 256);
+    // oph_get_counters[10] = decodes left on the reduced paths.
     if (h->degraded_left > 0 && --h->degraded_left == 0) {
         TRACE("re-arming the whole-decode launch / fused cone after a degraded period");
         h->use_loop = h->use_loop_wanted; h->use_run = h->use_run_wanted; if (h->hcf_capacity == 0 && h->hcf_capacity_was_ok) h->hcf_capacity = -1;
@@ -1195,8 +1196,11 @@ int decode_batch(oph_handle* h, int t_end, int stop_mode, int32_t* steps_run) {
     // steps [t0, t1) of the current tile; after a failure the tile is redone from step 0 (a continued range without the stop rule:
     // the same frames as stop + resume)
     auto range_with_recovery = [&](int t0, int t1, int stop, int32_t* st) -> int {
+        h->last_wait_err = 0;
         int rc = decode_range(h, t0, t1, stop, st);
-        for (int attempt = 0; rc == OPH_ERR_DEVICE && attempt < 3; ++attempt) {
+        // only a co-residency time-out of THIS decode (ctl[2], read back by decode_loop / decode_step's wait) enters the ladder: an upload
+        // failure, a device fault or the 10 s no-progress bound is not cured by another launch path and is returned as it is
+        for (int attempt = 0; rc == OPH_ERR_DEVICE && h->last_wait_err != 0 && attempt < 3; ++attempt) {
             const char* what = nullptr;
             if (h->last_wait_err == 4 && h->hcf_capacity != 0) { h->hcf_capacity_was_ok = true; h->hcf_capacity = 0; what = "the cone's levels as separate contraction + LayerNorm launches"; }
             else if (h->use_loop) { h->use_loop = false; h->n_loop_fallbacks++; what = "two launches per step"; }
@@ -1212,7 +1216,7 @@ int decode_batch(oph_handle* h, int t_end, int stop_mode, int32_t* steps_run) {
             }
             h->last_wait_err = 0;
             h->n_recoveries++;
-            h->degraded_left = h->degraded_next; h->degraded_next = std::min(h->degraded_next * 4, 1 << 20);
+            h->degraded_left = h->degraded_next; h->degraded_next = std::min(h->degraded_next * 4, 256);
             reset_decode(h);
             rc = decode_range(h, 0, t1, t0 == 0 ? stop : OPH_STOP_NEVER, st);
         }

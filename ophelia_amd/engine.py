@@ -346,10 +346,10 @@ class Engine(object):
 
     def counters(self):
         """What the pipeline did since the handle was created (oph_get_counters)."""
-        v = (C.c_int64 * 10)()
-        self._chk(self.lib.oph_get_counters(self._h, v, 10))
+        v = (C.c_int64 * 11)()
+        self._chk(self.lib.oph_get_counters(self._h, v, 11))
         return dict(zip(("textenc", "preenc_used", "chunks_streamed", "loop_decodes", "loop_fallbacks", "tile_resumes", "cone_loops", "fp16_guard",
-                         "masked_streams", "recoveries"), [int(x) for x in v]))
+                         "masked_streams", "recoveries", "degraded_left"), [int(x) for x in v]))
 
     def set_streaming(self, on=True):
         """SSRN over the frames a running decode has already produced (default on); off: SSRN only when asked for.

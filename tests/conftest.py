@@ -16,6 +16,27 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "hipfft_backend: runs the vocoder's generic hipFFT backend (may be skipped where rocFFT cannot compile its kernels)")
 
 
+# Under `-x` the driver's GPU run stops at the first failure: every oracle comparison is collected BEFORE the tests about
+# throughput plumbing, shared-GPU shapes and misuse, so that those can only fail after the parity record is complete.
+_GPU_ORDER = ("test_gpu_ops.py", "test_gpu_ops_sweep.py", "test_gpu_model.py", "test_gpu_configs_c4_c5.py", "test_gpu_synthesize.py",
+              "test_gpu_pipeline.py", "test_gpu_properties.py", "test_gpu_edge_cases.py", "test_gpu_decode_modes.py",
+              "test_gpu_call_sequences.py", "test_gpu_vocoder.py", "test_gpu_misuse.py", "test_gpu_second_client.py",
+              "test_gpu_bench_ranks.py")
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def rank(item):
+        name = os.path.basename(str(item.fspath))
+        if name in _GPU_ORDER:
+            return (1, _GPU_ORDER.index(name))
+        if name.startswith("test_gpu_"):
+            return (1, len(_GPU_ORDER) - 3)              # an unlisted GPU file: after the parity files, before misuse / bench
+        if item.get_closest_marker("gpu") is not None:     # GPU legs of the TF-1.x / librosa vector tests (skip without their fixture)
+            return (1, len(_GPU_ORDER) - 3)
+        return (0, 0)                                      # CPU tests keep their place in front
+    items.sort(key=rank)                                   # stable: the order inside a file is kept
+
+
 class HP(object):
     """Plain attribute bag standing in for the reference's Hyperparams in tests."""
     pass

@@ -33,14 +33,23 @@ def _oracle_check(hp, W, K, V, ends, idx, Y, al, Z, speakers=None):
     assert ey < TOL and ea < TOL and ez < TOL
 
 
+def _ssrn_fp32_leg(eng, hp, W, Y, idx):
+    """The fp32-operand MFMA flavour of SSRN (oph_set_ssrn_precision 0) on the same mels, against the oracle as well."""
+    eng.set_ssrn_precision(0)
+    Zp = eng.ssrn(np.ascontiguousarray(Y[idx[:4]]))
+    ez = np.abs(Zp - O.synth_mel2mag(hp, W, Y[idx[:4]])).max()
+    print("SSRN fp32-operand flavour vs oracle: %.3e" % ez)
+    assert ez < TOL
+    eng.set_ssrn_precision(2)
+
+
 def test_c4_lj_tutorial_batch_128():
     hp = hp_from_snapshot("lj_tutorial.cfg")
     W = O.random_weights(hp, 2)
     B = 128
     L = O.random_text(hp, B, 3, min_len=75, max_len=149)
     ends = O.get_text_lengths(L)
-    eng = _engine(hp, W)
-    eng.set_ssrn_precision(0)
+    eng = _engine(hp, W)                                     # the product's default arithmetic everywhere (split-fp16 x3 SSRN: what bench.py times)
     K, V = eng.encode_text(L)
     Y, t_ends, al, steps = eng.text2mel(K, V, ends, stop_mode=1)
     assert steps == hp.max_T and Y.shape == (B, hp.max_T, hp.n_mels)
@@ -59,6 +68,7 @@ def test_c4_lj_tutorial_batch_128():
     assert np.abs(Zs - Z[:16]).max() < 1e-6
     idx = np.arange(1, B, 4)                                 # 32 utterances, 4 from each of the 8 row tiles
     _oracle_check(hp, W, K, V, ends, idx, Y, al, Z)
+    _ssrn_fp32_leg(eng, hp, W, Y, idx)
     eng.close()
 
 
@@ -71,8 +81,7 @@ def test_c5_vctk_multispeaker_batch_32():
     ends = O.get_text_lengths(L)
     rng = np.random.Generator(np.random.PCG64(5))
     speakers = rng.integers(1, hp.nspeakers, size=(B, 1)).astype(np.int32)       # speaker ids ~U{1..}
-    eng = _engine(hp, W)
-    eng.set_ssrn_precision(0)
+    eng = _engine(hp, W)                                     # default arithmetic (split-fp16 x3 SSRN)
     K, V = eng.encode_text(L, speakers)
     K0, V0 = O.encode_text(hp, W, L[:8], speakers=speakers[:8])
     assert np.abs(K[:8] - K0).max() < TOL and np.abs(V[:8] - V0).max() < TOL
@@ -86,4 +95,5 @@ def test_c5_vctk_multispeaker_batch_32():
         assert np.array_equal(als.argmax(1), al[sl].argmax(1))
         assert np.abs(Ys - Y[sl]).max() < 1e-5 and np.abs(als - al[sl]).max() < 1e-5
     _oracle_check(hp, W, K, V, ends, np.arange(B), Y, al, Z, speakers=speakers)
+    _ssrn_fp32_leg(eng, hp, W, Y, np.arange(B))
     eng.close()

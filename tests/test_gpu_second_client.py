@@ -44,11 +44,12 @@ def test_decode_results_do_not_depend_on_a_second_client():
         ends = O.get_text_lengths(L).astype(np.int32)
 
         def run():
-            r0 = eng.counters()["recoveries"]
+            c = eng.counters()
+            r0, degraded = c["recoveries"], c["degraded_left"] > 1     # > 1: this decode still runs on the reduced launch paths
             eng.stage_text(L, ends)
             steps = eng.run_resident(stop_mode=1, run_ssrn=True, pipelined=False)
             Y, t_ends, al = eng.fetch_mel()
-            return steps, np.array(Y), np.array(t_ends), np.array(al), np.array(eng.fetch_mag()), eng.counters()["recoveries"] - r0
+            return steps, np.array(Y), np.array(t_ends), np.array(al), np.array(eng.fetch_mag()), (eng.counters()["recoveries"] - r0) + int(degraded)
 
         solo = run()
         c0 = eng.counters()
@@ -82,7 +83,7 @@ def test_decode_results_do_not_depend_on_a_second_client():
             for a, b, what in zip(got[1:5], solo[1:5], ("Y", "t_ends", "alignments", "Z")):
                 if got[5] == 0:      # the same launches as alone: the same bits
                     assert np.array_equal(a, b), "decode %d beside the second client: %s differs from the decode alone" % (k, what)
-                else:                # a tile was redone on the per-step launch path: another summation order (test_decode_flavours_agree's bar)
+                else:                # a tile was redone on the per-step launch path, or the handle is still on it (oph_get_counters[10]): another summation order (test_decode_flavours_agree's bar)
                     assert np.abs(a.astype(np.float64) - b).max() <= 1e-4, "decode %d (tile redone): %s off" % (k, what)
             assert np.array_equal(got[3].argmax(1), solo[3].argmax(1)), "decode %d: attention trace differs" % k
         # redone tiles are allowed (and counted); errors are not
