@@ -79,6 +79,17 @@ typedef struct oph_handle oph_handle;
  *           + tf.Session()                    (synthesize.py:511,525,536)        */
 int oph_abi_version(void);
 int oph_create(const oph_dims* dims, int device, oph_handle** out);
+/* oph_create with launch-path / arithmetic options: "NAME=value NAME ..." (NULL or "" = oph_create).  The library reads NO
+ * environment variable for these (only OPH_TRACE, diagnostics on stderr): what a handle computes and how fast cannot depend on an
+ * inherited environment.  Every option selects a launch path the library also takes by itself (geometries outside the default
+ * kernels', the recovery ladder of oph_get_counters[9]) or an arithmetic flavour of oph_set_precision; results stay within
+ * 1e-4 of the default's with identical attention traces (tests/test_gpu_decode_modes.py).  Names:
+ *   DECODE=loop|runs|layers  RUN_ROWS=4|8  NO_CHAIN  NO_CONE_HEAD  NO_FUSED_CONE  NO_LOOP_QW  CONE_FC_ROWS=n  CONE_FC_INSPLIT=n
+ *   CONE_KSPLIT=a,b  LOOP_LOOKAHEAD=n  STREAM_VALUE=1  NO_STREAM_SSRN  SSRN_CHUNK=n  NO_PREENCODE  NO_PLANE_GEMM  PG_WAVES=4|8
+ *   CU_SPLIT=chain,cone  NO_CU_MASK  SSRN_PREC / CONE_PREC / TEXTENC_PREC = 0|1|2 (oph_set_precision's codes)  RUN_STAMPS
+ * An unknown name is OPH_ERR_INVALID (oph_last_error(NULL) names it).  The ablation switches of the measurement scripts under
+ * profiles/ (SKIP_CONE, LOOP_ALONE, LOOP_DBG: wrong or unused results) exist only in -DOPH_ABLATE builds. */
+int oph_create_opts(const oph_dims* dims, int device, const char* options, oph_handle** out);
 int oph_destroy(oph_handle* h);
 const char* oph_last_error(const oph_handle* h);   /* h may be NULL: last create error */
 
@@ -142,11 +153,12 @@ int oph_set_streaming(oph_handle* h, int on);
 int oph_set_mag_destination(oph_handle* h, float* Z);
 /* What the pipeline did since oph_create, out[0..n): [0] TextEnc evaluations, [1] runs whose K,V had been pre-encoded under
  * the previous decode, [2] SSRN chunks launched while a decode was running, [3] whole-decode launches, [4] fall-backs from the
- * whole-decode launch to two launches per step, [5] tiles resumed to their batch's stop step, [6] persistent cone launches,
+ * whole-decode launch to two launches per step, [5] tiles resumed to their batch's stop step, [6] 0 (reserved),
  * [7] fp16 range guard: bit 0 SSRN, bit 1 cone, bit 2 TextEnc -- a weight of that net exceeds fp16's range (|w| > 6e4), so its
  *     split-fp16 contractions are pinned to the fp32-operand MFMA,
- * [8] 1 if this handle holds the device's CU-masked streams (one handle per device and process at a time: the three partitions
- *     chain | cone | SSRN are created once per process and lent out), 0 if it runs on ordinary streams (no whole-decode launch),
+ * [8] 1 if this handle runs on the device's CU-masked streams (the three partitions chain | cone | SSRN are created once per process
+ *     and device and shared by the handles of that device, whose calls take turns under the device's lock), 0 if it runs on ordinary
+ *     streams (no whole-decode launch: another partition than the process's first was asked for, or masking is unavailable),
  * [9] decodes in which an in-kernel wait timed out (workgroups of a launch not co-resident) and the affected steps were redone on
  *     the per-step launch path,
  * [10] decodes this handle will still run on the reduced launch paths after such a recovery (0 = the default launches are armed):

@@ -11,11 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libophelia_hip.so")
-SOURCES = ["oph_kernels.hip", "oph_planegemm.hip", "oph_decrun.hip", "oph_decchain.hip", "oph_hcfused.hip", "oph_conehead.hip", "oph_coneloop.hip",
-           "oph_pack.hip", "oph_model.hip", "oph_nets.hip", "oph_cone.hip", "oph_decode.hip", "oph_api.hip", "oph_ops.hip", "oph_aql.hip"]
-# the cone's kernels once more as a code object of their own: the AQL queue (csrc/oph_aql.h) loads it with the HSA loader
-CONE_CO_PATH = os.path.join(LIBDIR, "oph_cone_kernels.co")
-CONE_CO_SOURCES = ["oph_cone_co.hip", "oph_conehead.hip", "oph_hcfused.hip"]      # the first is the translation unit, the others its includes
+SOURCES = ["oph_kernels.hip", "oph_planegemm.hip", "oph_decrun.hip", "oph_decchain.hip", "oph_hcfused.hip", "oph_conehead.hip",
+           "oph_pack.hip", "oph_model.hip", "oph_nets.hip", "oph_cone.hip", "oph_decode.hip", "oph_api.hip", "oph_ops.hip"]
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
@@ -42,6 +39,7 @@ STOP_REFERENCE, STOP_NEVER = 0, 1
 SIGNATURES = {
     "oph_abi_version": (C.c_int, []),
     "oph_create": (C.c_int, [C.POINTER(OphDims), C.c_int, C.POINTER(C.c_void_p)]),
+    "oph_create_opts": (C.c_int, [C.POINTER(OphDims), C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
     "oph_destroy": (C.c_int, [C.c_void_p]),
     "oph_last_error": (C.c_char_p, [C.c_void_p]),
     "oph_num_weights": (C.c_int, [C.c_void_p]),
@@ -161,34 +159,14 @@ def _hipcc_shared(out, srcs, deps, extra, verbose):
     return out
 
 
-def _hipcc_code_object(out, src, deps, verbose):
-    """One translation unit compiled for the device only, as a bare gfx950 code object (an ELF the HSA loader takes)."""
-    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
-        return out
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    tmp = "%s.%d.tmp" % (out, os.getpid())
-    cmd = [hipcc, "--offload-arch=gfx950", "--cuda-device-only", "--no-gpu-bundle-output", "-O3", "-std=c++17",
-           "-Wno-unused-value", "-Wno-unused-result", src] + ["-o", tmp]
-    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if verbose or res.returncode != 0:
-        print(res.stdout)
-    if res.returncode != 0:
-        if os.path.exists(tmp):
-            os.remove(tmp)
-        raise OpheliaHipError("hipcc failed building %s" % os.path.basename(out))
-    os.replace(tmp, out)
-    return out
-
-
 def build(verbose=False):
     """Compile the HIP extensions for gfx950 in-tree (cross-compiles without a GPU)."""
     os.makedirs(LIBDIR, exist_ok=True)
     inc = os.path.join(os.path.dirname(HERE), "include")
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     hdrs = [os.path.join(CSRC, "oph_internal.h"), os.path.join(CSRC, "oph_device.h"), os.path.join(CSRC, "oph_loopdev.h"), os.path.join(CSRC, "oph_host.h"),
-            os.path.join(CSRC, "oph_aql.h"), os.path.join(inc, "ophelia_hip.h")]
-    _hipcc_shared(libpath(), srcs, srcs + hdrs, ["-fvisibility=hidden", "-L/opt/rocm/lib", "-lhsa-runtime64", "-ldl", "-Wl,-rpath,/opt/rocm/lib"], verbose)
-    _hipcc_code_object(CONE_CO_PATH, os.path.join(CSRC, CONE_CO_SOURCES[0]), [os.path.join(CSRC, f) for f in CONE_CO_SOURCES] + hdrs, verbose)
+            os.path.join(inc, "ophelia_hip.h")]
+    _hipcc_shared(libpath(), srcs, srcs + hdrs, ["-fvisibility=hidden"], verbose)
     vsrcs = [os.path.join(CSRC, s) for s in VOCODER_SOURCES]
     _hipcc_shared(VOCODER_LIBPATH, vsrcs, vsrcs + [os.path.join(inc, "ophelia_vocoder.h")],
                   ["-L/opt/rocm/lib", "-lhipfft", "-Wl,-rpath,/opt/rocm/lib"], verbose)

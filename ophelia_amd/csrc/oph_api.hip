@@ -23,114 +23,37 @@ int oph_abi_version(void) { return OPH_ABI_VERSION; }
 
 const char* oph_last_error(const oph_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
-constexpr int OPH_AQL_DEFAULT = 0;      // (see oph_host.h: aql_mode; DESIGN.md section 12 has the measurements behind the default)
 // The CU-masked streams of a device, process-wide: created on first use, never destroyed (see oph_create).
 namespace {
-struct MaskedSet { std::vector<uint32_t> key; hipStream_t s[3] = {nullptr, nullptr, nullptr}; int users = 0; AqlQueue* aql = nullptr; bool aql_tried = false; };
+struct MaskedSet { std::vector<uint32_t> key; hipStream_t s[3] = {nullptr, nullptr, nullptr}; int users = 0; };
 std::mutex g_masked_mutex;
 std::map<int, std::vector<MaskedSet>> g_masked;       // device -> sets (one per distinct partition; normally one)
 std::map<int, std::recursive_mutex> g_device_mutex;   // device -> the lock under which the handles of a device share its masked streams
 // Handles of one device SHARE the masked streams (a second set would put six masked queues on the device: time-slicing): whatever a
 // call enqueues on them goes in under the device's lock (DevGuard at the API entry points), so the launches of two handles never
 // interleave inside a decode -- each call's work is one contiguous run in stream order.  A handle that asks for a different CU
-// partition than the one alive (OPH_CU_SPLIT sweeps) gets ordinary streams.
+// partition than the process's first (CU_SPLIT sweeps) gets ordinary streams.
 bool masked_streams_acquire(int device, int words, const uint32_t* m_dec, const uint32_t* m_conep, const uint32_t* m_ssrn,
                             hipStream_t* sdec, hipStream_t* scone, hipStream_t* sssrn) {
     std::lock_guard<std::mutex> lock(g_masked_mutex);
     std::vector<uint32_t> key;
     for (const uint32_t* m : {m_dec, m_conep, m_ssrn}) key.insert(key.end(), m, m + words);
     std::vector<MaskedSet>& sets = g_masked[device];
-    for (MaskedSet& q : sets)
-        if (q.key == key) { q.users++; *sdec = q.s[0]; *scone = q.s[1]; *sssrn = q.s[2]; return true; }
-    for (MaskedSet& q : sets)
-        if (q.users > 0) return false;               // a different partition is in use on this device
-    MaskedSet q;
-    q.key = key;
+    // ONE set per device and process, for the process's life: masked queues are never destroyed (see oph_create), so a second set would
+    // leave six of them on the device.  A handle that asks for another partition than the set's gets ordinary streams.
+    if (sets.empty()) { sets.emplace_back(); sets[0].key = key; }
+    MaskedSet& q = sets[0];
+    if (q.key != key) return false;
     const uint32_t* masks[3] = {m_dec, m_conep, m_ssrn};
     for (int i = 0; i < 3; ++i)
-        if (hipExtStreamCreateWithCUMask(&q.s[i], words, masks[i]) != hipSuccess) {
+        if (!q.s[i] && hipExtStreamCreateWithCUMask(&q.s[i], words, masks[i]) != hipSuccess) {
             (void)hipGetLastError();
-            return false;                            // (streams created so far stay allocated but unused: never destroyed by design)
+            q.s[i] = nullptr;
+            return false;                            // (the streams created so far are kept in the set and used by the next attempt)
         }
-    q.users = 1;
-    sets.push_back(q);
+    q.users++;
     *sdec = q.s[0]; *scone = q.s[1]; *sssrn = q.s[2];
     return true;
-}
-// The cone partition's AQL queue of the set that owns `sdec` (created on first use, once per process like the streams; nullptr when
-// the HSA side is not available -- the cone then runs on the masked HIP stream as before).  OPH_NO_AQL=1 switches it off.
-AqlQueue* masked_set_aql(int device, hipStream_t sdec, int words, const uint32_t* m_conep, std::string* why) {
-    std::lock_guard<std::mutex> lock(g_masked_mutex);
-    for (MaskedSet& q : g_masked[device]) {
-        if (q.s[0] != sdec) continue;
-        if (!q.aql_tried) {
-            q.aql_tried = true;
-            Dl_info info;
-            std::string path;
-            if (dladdr((const void*)&oph_create, &info) && info.dli_fname) {
-                path = info.dli_fname;
-                const size_t slash = path.rfind('/');
-                path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/oph_cone_kernels.co";
-            }
-            std::string err;
-            const int want = getenv("OPH_AQL_LANES") ? std::max(1, std::min(3, atoi(getenv("OPH_AQL_LANES")))) : 2;
-            q.aql = path.empty() ? nullptr : aql_create(device, m_conep, words, path.c_str(), 4096, 4, &err);
-            if (!q.aql && why) *why = err.empty() ? "library path unknown" : err;
-            if (q.aql) {
-                // Which of the four hardware queues run freely beside the two HIP streams that are busy for a whole decode (the chain's and
-                // SSRN's)?  A 150 us spin on the stream, a stamp launch on the lane: on a shared pipe the stamp comes ~8 us late (oph_aql.h).
-                AqlKernel kst;
-                long long* d_st = nullptr;
-                double late[4] = {0, 0, 0, 0};
-                if (aql_kernel(q.aql, "oph_probe_stamp", &kst, &err) && hipMalloc((void**)&d_st, 4096) == hipSuccess) {
-                    // 16 stamp launches back to back on the lane while the stream's spin runs: ~1 us per launch on a pipe of its own, the pipe's
-                    // rotation period (~8 us) per launch on a shared one
-                    constexpr int NST = 16;
-                    long long* h_args[NST * 2];
-                    for (int i = 0; i < NST; ++i) { h_args[2 * i] = d_st + 8 + i; h_args[2 * i + 1] = nullptr; }
-                    long long** d_arg = (long long**)(d_st + 64);
-                    for (int lane = 0; lane < aql_lanes(q.aql); ++lane) {
-                        const int one[1] = {lane};
-                        aql_use_lanes(q.aql, 1, one);
-                        for (int si : {0, 2}) {
-                            double best = 1e30;
-                            for (int rep = 0; rep < 2; ++rep) {
-                                hipMemset(d_st, 0, 512);
-                                hipMemcpy(d_arg, h_args, sizeof h_args, hipMemcpyHostToDevice);
-                                hipDeviceSynchronize();
-                                launch_probe_spin(40000, d_st, q.s[si]);                          // 400 us
-                                struct timespec ts = {0, 50000}; nanosleep(&ts, nullptr);        // (the spin has started)
-                                for (int i = 0; i < NST; ++i) aql_dispatch(q.aql, 0, kst, 1, 64, 0, d_arg + 2 * i, false);
-                                aql_ring(q.aql);
-                                (void)aql_wait_idle(q.aql, 2.0);
-                                hipStreamSynchronize(q.s[si]);
-                                long long hst[8 + NST];
-                                hipMemcpy(hst, d_st, sizeof hst, hipMemcpyDeviceToHost);
-                                best = std::min(best, (double)(hst[8 + NST - 1] - hst[8]) * 0.01 / (NST - 1));
-                            }
-                            late[lane] = std::max(late[lane], best);
-                        }
-                    }
-                    hipFree(d_st);
-                    (void)hipGetLastError();
-                    int pick[4], np = 0;
-                    for (int lane = 0; lane < aql_lanes(q.aql) && np < want; ++lane) if (late[lane] < 3.0) pick[np++] = lane;
-                    TRACE("AQL lanes: us per launch beside the busy streams %.2f %.2f %.2f %.2f -> using %d lane(s)", late[0], late[1], late[2], late[3], np);
-                    if (np == 0) { pick[0] = 0; np = 1; }
-                    if (const char* e = getenv("OPH_AQL_PICK")) {      // experiments: which hardware queues serve as lanes 0 and 1
-                        int a_ = 0, b_ = 1;
-                        if (sscanf(e, "%d%*[,:-]%d", &a_, &b_) == 2 && a_ >= 0 && b_ >= 0 && a_ < aql_lanes(q.aql) && b_ < aql_lanes(q.aql) && a_ != b_) { pick[0] = a_; pick[1] = b_; np = 2; }
-                    }
-                    aql_use_lanes(q.aql, np == 3 ? 3 : (np >= 2 ? 2 : 1), pick);
-                } else {
-                    const int ident[2] = {0, 1};
-                    aql_use_lanes(q.aql, want >= 2 ? 2 : 1, ident);
-                }
-            }
-        }
-        return q.aql;
-    }
-    return nullptr;
 }
 void masked_streams_release(int device, hipStream_t sdec) {
     std::lock_guard<std::mutex> lock(g_masked_mutex);
@@ -147,7 +70,9 @@ struct DevGuard {
 };
 }  // namespace
 
-int oph_create(const oph_dims* dims, int device, oph_handle** out) {
+int oph_create(const oph_dims* dims, int device, oph_handle** out) { return oph_create_opts(dims, device, nullptr, out); }
+
+int oph_create_opts(const oph_dims* dims, int device, const char* options, oph_handle** out) {
     if (!dims || !out) { g_create_error = "null argument"; return OPH_ERR_INVALID; }
     *out = nullptr;
     int ndev = 0;
@@ -172,7 +97,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
     oph_handle* h = new oph_handle();
     h->dm = m;
     h->device = device;
-    h->opt.read();
+    { std::string why; if (!h->opt.read(options, &why)) { g_create_error = why; delete h; return OPH_ERR_INVALID; } }
     static const char* names[PC_COUNT] = {"conv_gemm_f32<128,128>", "conv_gemm_f32<64,64>", "conv_gemm_bf16x3", "ln_rows", "dec_layer16", "row_chain", "attn_rows", "misc", "dec_run", "dec_loop", "cone_head", "hc_fused", "plane_gemm"};
     for (int i = 0; i < PC_COUNT; ++i) h->prof[i].name = names[i];
     // CU partition for the decode loop (MI355X: 256 CUs, mask bit i -> XCD i%8): the dependent layers of a step get a
@@ -203,20 +128,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
             // All three or none.
             h->mask_words = words;
             if (!masked_streams_acquire(device, words, m_dec, m_conep, m_ssrn, &h->sdec, &h->scone, &h->sssrn)) { h->sdec = h->scone = h->sssrn = nullptr; h->mask_words = 0; }
-            else {
-                h->masked_borrowed = true;
-                h->aql_mode = getenv("OPH_AQL") ? std::max(0, std::min(3, atoi(getenv("OPH_AQL")))) : OPH_AQL_DEFAULT;
-                if (getenv("OPH_NO_AQL")) h->aql_mode = 0;
-                if (h->aql_mode) {
-                    std::string why;
-                    h->aql = masked_set_aql(device, h->sdec, words, m_conep, &why);
-                    std::string e1, e2;
-                    if (h->aql && !(aql_kernel(h->aql, "oph_cone_head_coh", &h->aql_k[0], &e1) && aql_kernel(h->aql, "oph_hc_fused_coh", &h->aql_k[1], &e2) &&
-                                    aql_kernel(h->aql, "oph_cone_head_plain", &h->aql_k[2], &e1) && aql_kernel(h->aql, "oph_hc_fused_plain", &h->aql_k[3], &e2) &&
-                                    aql_kernel(h->aql, "oph_gate", &h->aql_k[4], &e1))) { why = e1 + " " + e2; h->aql = nullptr; }
-                    if (!h->aql) TRACE("pipelined cone off (no AQL queue: %s): the cone's launches go through the HIP stream", why.c_str());
-                }
-            }
+            else h->masked_borrowed = true;
             h->ndec_cus = h->mask_words ? ndec : ncu;
         } else h->ndec_cus = ncu;
         (void)hipGetLastError();
@@ -239,6 +151,7 @@ int oph_create(const oph_dims* dims, int device, oph_handle** out) {
         hipEventCreateWithFlags(&h->ev_cone, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
         g_create_error = "stream/event creation failed";
+        if (h->masked_borrowed) { masked_streams_release(h->device, h->sdec); h->sdec = h->scone = h->sssrn = nullptr; }
         delete h;
         return OPH_ERR_DEVICE;
     }
@@ -272,9 +185,6 @@ int oph_destroy(oph_handle* h) {
     hipSetDevice(h->device);
     TRACE("destroy: sync streams");
     for (hipStream_t st : {h->stream, h->sdec, h->scone, h->sssrn, h->scopy}) if (st) hipStreamSynchronize(st);
-    if (h->aql && h->aql_used) { (void)aql_wait_idle(h->aql, 10.0); h->aql_used = false; }
-    if (h->aql_store.stage) hipHostFree(h->aql_store.stage);
-    for (void* p_ : {(void*)h->d_kernarg, (void*)h->d_lvl_count}) if (p_) hipFree(p_);
     for (auto& pc : h->prof)
         for (auto& e : pc.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (hipEvent_t e : {h->ev0, h->ev1, h->ev_attn, h->ev_cone, h->ev_in, h->ev_out, h->ev_dec_done, h->ev_ssrn_done[0], h->ev_ssrn_done[1], h->ev_preenc, h->ev_copy, h->ev_chunk, h->ev_cs, h->ev_ce})
@@ -485,7 +395,7 @@ int oph_set_precision(oph_handle* h, int which, int mode) {
     }
     if (which == 0) { h->ssrn_prec = mode; h->chunk_ms = 0.f; return OPH_OK; }
     if (which == 1) {
-        if (mode == 1 && !(h->n_hc_dec > 1 && h->audiodec[h->dec_pre].Wh)) { h->fail("the cone's bf16 planes were not built (create the handle under OPH_CONE_PREC=1)"); return OPH_ERR_STATE; }
+        if (mode == 1 && !(h->n_hc_dec > 1 && h->audiodec[h->dec_pre].Wh)) { h->fail("the cone's bf16 planes were not built (create the handle with the option CONE_PREC=1)"); return OPH_ERR_STATE; }
         h->cone_prec = mode; return OPH_OK;
     }
     if (which == 2 && mode != 1) { h->textenc_prec = mode; return OPH_OK; }
@@ -497,7 +407,7 @@ int oph_set_precision(oph_handle* h, int which, int mode) {
 // [3] whole-decode launches  [4] fallbacks from the whole-decode launch to two launches per step  [5] tiles resumed to the batch's stop step
 int oph_get_counters(oph_handle* h, int64_t* out, int n) {
     if (!h || !out) return OPH_ERR_INVALID;
-    const long long v[11] = {h->n_textenc, h->n_preenc_used, h->n_chunks_streamed, h->n_loop_decodes, h->n_loop_fallbacks, h->n_tile_resumes, h->n_cone_loops,
+    const long long v[11] = {h->n_textenc, h->n_preenc_used, h->n_chunks_streamed, h->n_loop_decodes, h->n_loop_fallbacks, h->n_tile_resumes, 0LL /* (was: persistent cone launches; removed in round 6) */,
                              (long long)((h->guard_ssrn ? 1 : 0) | (h->guard_cone ? 2 : 0) | (h->guard_text ? 4 : 0)),
                              h->mask_words > 0 ? 1 : 0, h->n_recoveries, h->degraded_left};
     for (int i = 0; i < n && i < 11; ++i) out[i] = v[i];

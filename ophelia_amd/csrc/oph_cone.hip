@@ -64,7 +64,7 @@ void launch_cone(oph_handle* h, int t) {
         const bool spk_next = pre > 1 && h->audiodec[1].ccat > 0;
         if (spk_next) { ch.Y = h->coneTmp; ch.ldy = h->audiodec[1].kc; ch.spk_table = h->emb_spk; ch.spk_ids = h->d_spk; ch.spk_dim = h->audiodec[1].ccat; }
         else { ch.Y = cone[0]; ch.ldy = h->audiodec[pre].kc; }
-        ch.ctl = h->d_ctl; ch.t = t; ch.lvl_out = -1;
+        ch.ctl = h->d_ctl; ch.t = t;
         const bool fused = h->cone_fused_ok && !spk_next && h->cone_prec == 2 && h->hcf_capacity != 0;
         if (fused) { ch.Yh = h->coneH[t & 1][0]; ch.Yl = h->coneL[t & 1][0]; }
         ch.wait_sig = ar.wait_sig; ch.wait_val = ar.wait_val;
@@ -80,29 +80,9 @@ void launch_cone(oph_handle* h, int t) {
             ch.done_sig = h->d_sig + LOOP_SIG_LEVEL0; ch.done_val = h->cone_done_val; ch.done_count = h->d_cone_count; ch.done_target = h->cone_done_total[0];
             ch.done_stamp = stamp_of(0);
         }
-        int head_wgs = 0;          // (pipelined cone: the head's launch has this many workgroups, each counts into shard blockIdx & 7)
-        if (h->aql_rec && fused && ch.i_new < 0) {
-            // the pipelined cone (oph_aql.h): the launch is recorded as an AQL packet instead of being launched on the HIP stream
-            ch.rb = 4;
-            if (h->aql_rec->pipelined) { ch.lvl_count = h->d_lvl_count; ch.lvl_out = 0; ch.lvl_nth = (short)h->aql_rec->nth; }
-            // (4 rows per workgroup, 4 waves: small enough to be placed beside a resident hc_fused workgroup -- a 16-wave workgroup needs a
-            //  CU to itself and is starved by the next level's waiting workgroups: measured, 2 s time-outs)
-            head_wgs = (ch.npos * ch.Bpad + 3) / 4;
-            // split mode: the head of step t starts behind a packet-processor dependency on the chain's per-step signal (2 t + 1), not as
-            // a resident launch that spins (the in-kernel wait stays: it finds its word set)
-            // split mode: the head of step t starts behind a one-wave gate that waits for the chain's attention word (the head's own
-            // wait then finds the word set): a resident head spinning for the chain would hold the wave slots the previous step's
-            // small levels (second lane) need -- and the chain waits for those
-            if (h->aql_rec->split > 0 && ch.wait_sig && ch.wait_val != 0u) {
-                GateArgs ga{}; ga.w32 = ch.wait_sig; ga.want = ch.wait_val; ga.ctl = h->d_ctl; ga.t = t;
-                h->aql_rec->add(4, 1, 64, 0, &ga, sizeof ga, 0);
-            }
-            h->aql_rec->add(h->aql_rec->pipelined ? 0 : 2, (uint32_t)head_wgs, 256, 0, &ch, sizeof ch, 0);
-        } else {
-            h->pbegin(PC_CONEHEAD);
-            launch_cone_head(ch, g_cur);
-            h->pend(PC_CONEHEAD, ((double)n0 * B * (3.0 * d + 2.0 * m.attention_win_size * d) + (double)d * d) * 4.0, (double)n0 * B * 4.0 * m.attention_win_size * d + 2.0 * B * d * d);
-        }
+        h->pbegin(PC_CONEHEAD);
+        launch_cone_head(ch, g_cur);
+        h->pend(PC_CONEHEAD, ((double)n0 * B * (3.0 * d + 2.0 * m.attention_win_size * d) + (double)d * d) * 4.0, (double)n0 * B * 4.0 * m.attention_win_size * d + 2.0 * B * d * d);
         pre_first = 1;
         if (fused) {
             // levels 1 .. nh-1: one hc_fused launch each (contraction on the planes + LayerNorm x 2 + gate + mix)
@@ -116,10 +96,6 @@ void launch_cone(oph_handle* h, int t) {
                     hipMemsetAsync(h->d_hcf_stats, 0, (size_t)2 * nh * h->hcf_stats_stride * sizeof(unsigned long long), g_cur);
                     h->hcf_epoch = 0;
                 }
-                // (opt-in, OPH_HC_PAIR) the last two levels as ONE launch (hc_fused_pair) when each is a single row block and the launches go through the HIP stream
-                const bool pair = h->opt.hc_pair && !h->aql_rec && nh >= 3 && h->d_hcpair && h->d_hcpair_sync &&
-                                  (int)h->Hset[nh - 2].size() * Bpad <= 64 && (int)h->Hset[nh - 1].size() * Bpad <= 64;
-                HcFusedArgs pair_f[2];
                 for (int k = 0; k + 1 < nh; ++k) {
                     const Layer& l = h->audiodec[pre + k];
                     const int n_out = (int)h->Hset[k + 1].size();
@@ -128,9 +104,9 @@ void launch_cone(oph_handle* h, int t) {
                     f.tab = h->d_tab[k]; f.need = h->d_need[k]; f.n_out = n_out; f.j = t; f.Bpad = Bpad; f.M = n_out * Bpad;
                     f.Wh = l.Wph; f.Wl = l.Wpl; f.bias = l.bias_p; f.g1 = l.g1; f.b1 = l.b1; f.g2 = l.g2; f.b2 = l.b2;
                     f.Y = cone[k + 1]; f.Yh = h->coneH[t & 1][k + 1]; f.Yl = h->coneL[t & 1][k + 1];
-                    // (the statistics regions alternate with the step parity: consecutive steps' launches of a level may overlap in the pipelined cone)
+                    // (the statistics regions alternate with the step parity)
                     f.stats = h->d_hcf_stats + ((size_t)k * 2 + (t & 1)) * h->hcf_stats_stride; f.epoch = ++h->hcf_epoch; f.ctl = h->d_ctl; f.zeros = h->d_zeros;
-                    f.t = t; f.lvl_io = 0xffu | 0xffu << 8;
+                    f.t = t;
                     if (h->cone_inline_sig && k + 1 < LOOP_MAX_LEVELS) {
                         const Layer& tl = h->audiodec[pre + k + 1];
                         f.coh0 = idx_of(h->Hset[k + 1], -tl.off[0]); f.coh1 = idx_of(h->Hset[k + 1], -tl.off[1]);
@@ -139,56 +115,6 @@ void launch_cone(oph_handle* h, int t) {
                         f.done_stamp = stamp_of(k + 1);
                     }
                     if (h->d_cldbg && t == m.max_T / 2) f.dbg = h->d_cldbg + 8 * k;
-                    if (h->aql_rec && head_wgs > 0) {
-                        // wait for every workgroup of the producing launch (level k: the head, or the previous hc_fused: 8 column tiles per row block)
-                        const int in_units = k == 0 ? head_wgs : (f.in_rows + 63) / 64, in_mult = k == 0 ? 1 : 8;
-                        if (h->aql_rec->pipelined) {
-                            f.lvl_count = h->d_lvl_count;
-                            f.lvl_io = (unsigned)k | (unsigned)(k + 1) << 8 | (unsigned)in_mult << 16;
-                            f.lvl_n = (unsigned)in_units | (unsigned)h->aql_rec->nth << 16;
-                        }
-                        {
-                            // split mode: level k + 1 is produced on lane 1 from `split` on; the first such launch of a step waits for the
-                            // launch before it (lane 0) through the step's signal
-                            const int sp = h->aql_rec->split, lvl = k + 1, sig = t;
-                            const bool tail = sp > 0 && lvl >= sp;
-                            if (sp > 0 && lvl == sp) {
-                                // the second lane's step begins with a gate on the completion signal of level sp - 1's launch (first lane)
-                                GateArgs ga{}; ga.w64 = aql_signal_value_ptr(h->aql, sig); ga.ctl = h->d_ctl; ga.t = t;
-                                h->aql_rec->add(4, 1, 64, 0, &ga, sizeof ga, 1);
-                            }
-                            h->aql_rec->add(h->aql_rec->pipelined ? 1 : 3, (uint32_t)hc_fused_grid(f.M), 512, (uint32_t)hc_fused_lds_bytes(), &f, sizeof f,
-                                            tail ? 1 : 0, -1, (sp > 0 && lvl + 1 == sp) ? sig : -1);
-                        }
-                        continue;
-                    }
-                    if (pair && k + 3 >= nh) {
-                        pair_f[k + 3 - nh] = f;
-                        if (k + 2 < nh) continue;               // (the pair is launched when its second level's arguments are there)
-                        const int q = t & 1;
-                        if (!h->hcpair_ready[q]) {
-                            // the step-independent part, once per step parity (ctl, t, epoch, the completion values and the stamps are patched in by the launch)
-                            // (in stream order on the cone's stream: a null-stream copy would wait for the running whole-decode launch, which waits for this cone)
-                            memcpy(h->hcpair_host + 2 * q, pair_f, sizeof pair_f);
-                            if (hipMemcpyAsync(h->d_hcpair + 2 * q, h->hcpair_host + 2 * q, sizeof pair_f, hipMemcpyHostToDevice, g_cur) != hipSuccess) { (void)hipGetLastError(); h->hcf_capacity = 0; g_cur = saved; return; }
-                            h->hcpair_ready[q] = true;
-                        }
-                        if (h->hcpair_syncs > 0xF0000000u) { hipStreamSynchronize(h->scone); hipMemsetAsync(h->d_hcpair_sync, 0, 64 * sizeof(unsigned), g_cur); h->hcpair_syncs = 0; }
-                        HcPairArgs pa{};
-                        pa.lv = h->d_hcpair + 2 * q; pa.sync = h->d_hcpair_sync; pa.ctl = h->d_ctl; pa.t = t;
-                        h->hcpair_syncs += 8u; pa.sync_target = h->hcpair_syncs;
-                        pa.epoch0 = pair_f[0].epoch; pa.epoch1 = pair_f[1].epoch; pa.done_val = pair_f[1].done_val;
-                        pa.done_target0 = pair_f[0].done_target; pa.done_target1 = pair_f[1].done_target;
-                        pa.done_sig0 = pair_f[0].done_sig; pa.done_sig1 = pair_f[1].done_sig; pa.done_count0 = pair_f[0].done_count; pa.done_count1 = pair_f[1].done_count;
-                        pa.coh00 = pair_f[0].coh0; pa.coh01 = pair_f[0].coh1; pa.coh10 = pair_f[1].coh0; pa.coh11 = pair_f[1].coh1;
-                        pa.done_stamp0 = pair_f[0].done_stamp; pa.done_stamp1 = pair_f[1].done_stamp; pa.dbg0 = pair_f[0].dbg; pa.dbg1 = pair_f[1].dbg;
-                        h->pbegin(PC_HCFUSED);
-                        launch_hc_fused_pair(pa, g_cur);
-                        { const hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { TRACE("hc_fused_pair launch failed: %s", hipGetErrorString(e_)); h->hcf_capacity = 0; } }
-                        const Layer& l0 = h->audiodec[pre + k - 1];
-                        h->pend(PC_HCFUSED, ((double)(pair_f[0].M + pair_f[1].M) * (3.0 * l.cin + l.cout) + (double)(l.N + l0.N) * 3.0 * l.cin) * 4.0, 2.0 * (pair_f[0].M + pair_f[1].M) * l.N * 3.0 * l.cin);
-                        continue;
-                    }
                     h->pbegin(PC_HCFUSED);
                     launch_hc_fused(f, g_cur);
                     h->pend(PC_HCFUSED, ((double)f.M * 3.0 * l.cin + (double)f.M * l.cout + (double)l.N * 3.0 * l.cin) * 4.0, 2.0 * f.M * l.N * 3.0 * l.cin);

@@ -1,5 +1,5 @@
 // cone_head: level 0 of the AudioDec history cone of one decode step in one launch (ConeHeadArgs, oph_internal.h) -- moved out of
-// oph_kernels.hip in round 5 so that it can also be compiled into the cone's own code object (oph_cone_co.hip, oph_aql.h).
+// oph_kernels.hip in round 5.
 #include "oph_internal.h"
 #include "oph_device.h"
 
@@ -13,7 +13,7 @@ namespace oph {
 // WF: window positions handled (4: every request of the row -- Q, the window's K rows, its V . Wc rows, gamma, beta -- is issued
 // before the first use, rows past the window clamped and masked out of the arithmetic; as loads under `if (w < nwin)` they were
 // 2 win + 3 dependent round trips per row, most of this launch's 8-11 us.  8: the general form, windows of 5..8 keys)
-template <int WF, bool COH>
+template <int WF>
 static __device__ __forceinline__ void cone_head_row(const ConeHeadArgs& a, int i, int b, int tq, const f32x4& qw, int lane, int p) {
     const int d = a.d, c = lane * 4;
     const bool cok = c < d;
@@ -79,8 +79,7 @@ static __device__ __forceinline__ void cone_head_row(const ConeHeadArgs& a, int 
         f32x4 o;
 #pragma unroll
         for (int n = 0; n < 4; ++n) o[n] = h[n] * rstd * g[n] + bt[n];
-        // (pipelined: the next level's launch is already running and reads these rows past its L1 -- everything leaves write-through)
-        if (COH || (a.done_sig && (i == a.coh0 || i == a.coh1))) st_coherent(y + c, o);
+        if ((a.done_sig && (i == a.coh0 || i == a.coh1))) st_coherent(y + c, o);       // a row the RUNNING chain reads
         else *(f32x4*)(y + c) = o;
         if (a.Yh) {
             typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -88,14 +87,8 @@ static __device__ __forceinline__ void cone_head_row(const ConeHeadArgs& a, int 
 #pragma unroll
             for (int n = 0; n < 4; ++n) { hi[n] = (_Float16)o[n]; lo[n] = (_Float16)(o[n] - (float)hi[n]); }
             const size_t po = ((size_t)(c >> 6) * a.nrows + (size_t)i * a.Bpad + b) * 64 + (c & 63);
-            if (COH) {
-                typedef unsigned long long u64_;
-                __hip_atomic_store((u64_*)((_Float16*)a.Yh + po), __builtin_bit_cast(u64_, hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store((u64_*)((_Float16*)a.Yl + po), __builtin_bit_cast(u64_, lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                *(h4*)((_Float16*)a.Yh + po) = hi;
-                *(h4*)((_Float16*)a.Yl + po) = lo;
-            }
+            *(h4*)((_Float16*)a.Yh + po) = hi;
+            *(h4*)((_Float16*)a.Yl + po) = lo;
         }
     }
     int ctot = d;
@@ -106,7 +99,6 @@ static __device__ __forceinline__ void cone_head_row(const ConeHeadArgs& a, int 
     }
     for (int c2 = ctot + lane; c2 < a.ldy; c2 += 64) y[c2] = 0.f;
 }
-template <bool COH>
 static __device__ __forceinline__ void cone_head_body(const ConeHeadArgs& a) {
     __shared__ float ps[16][256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -177,7 +169,7 @@ static __device__ __forceinline__ void cone_head_body(const ConeHeadArgs& a) {
                     *(f32x4*)(a.QW + qrow + c) = qw;          // cached: every later step reads this position's term
                 }
                 const int pb = a.p[b];
-                if (a.win <= 4) cone_head_row<4, COH>(a, a.i_new, b, tq, qw, lane, pb); else cone_head_row<ATT_WMAX, COH>(a, a.i_new, b, tq, qw, lane, pb);
+                if (a.win <= 4) cone_head_row<4>(a, a.i_new, b, tq, qw, lane, pb); else cone_head_row<ATT_WMAX>(a, a.i_new, b, tq, qw, lane, pb);
             }
         }
     } else if (live) {
@@ -188,7 +180,7 @@ static __device__ __forceinline__ void cone_head_body(const ConeHeadArgs& a) {
             if (tq >= 0) {
                 const int c = lane * 4;
                 const f32x4 qw = c < d ? *(const f32x4*)(a.QW + ((size_t)tq * a.Bpad + b) * d + c) : zero4;
-                if (a.win <= 4) cone_head_row<4, COH>(a, i, b, tq, qw, lane, pb); else cone_head_row<ATT_WMAX, COH>(a, i, b, tq, qw, lane, pb);
+                if (a.win <= 4) cone_head_row<4>(a, i, b, tq, qw, lane, pb); else cone_head_row<ATT_WMAX>(a, i, b, tq, qw, lane, pb);
             }
         }
     }
@@ -203,56 +195,9 @@ static __device__ __forceinline__ void cone_head_body(const ConeHeadArgs& a) {
             }
         }
     }
-    // pipelined cone: every workgroup counts in when its rows have left (the next level's launch waits for all of them)
-    if (COH && a.lvl_count) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int sh = (int)blockIdx.x & 7, nwg = (a.npos * a.Bpad + a.rb - 1) / a.rb;      // (pipelined launches have no special workgroups: i_new < 0)
-            level_count_in(a.lvl_count, a.lvl_out, sh, (unsigned)a.lvl_nth * (unsigned)((nwg + 7 - sh) >> 3), (unsigned)a.lvl_nth, (unsigned)min(nwg, 8));
-        }
-    }
 }
-__global__ __launch_bounds__(1024) void cone_head(ConeHeadArgs a) { cone_head_body<false>(a); }
-// the pipelined form, dispatched through the AQL queue (oph_aql.h) by its unmangled name
-extern "C" __global__ __launch_bounds__(1024) void oph_cone_head_coh(ConeHeadArgs a) { cone_head_body<true>(a); }
-extern "C" __global__ __launch_bounds__(1024) void oph_cone_head_plain(ConeHeadArgs a) { cone_head_body<false>(a); }
+__global__ __launch_bounds__(1024) void cone_head(ConeHeadArgs a) { cone_head_body(a); }
 
-// Split cone (OPH_AQL=3, oph_aql.h): ONE wave that holds its lane until a word another launch writes has the wanted value -- the
-// chain's attention word in front of a head (w32), or the completion signal of the launch that produced the lane's input (w64: the
-// packet processor clears it when that launch has completed and released its stores).  A waiting head or hc_fused launch holds
-// hundreds of wave slots and starves the launches of the other lane that its own producer waits for (measured: 2 s time-outs); a
-// packet-processor dependency (barrier-AND packet) costs ~30 us per hop (measured: 143 us per step).  Bounded like every wait.
-extern "C" __global__ void oph_gate(GateArgs a) {
-    if (threadIdx.x != 0) return;
-    long long t0 = 0;
-    for (int it = 0;; ++it) {
-        const bool ok = a.w32 ? (int)(__hip_atomic_load(a.w32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.want) >= 0
-                              : __hip_atomic_load(a.w64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) <= 0;
-        if (ok) break;
-        if (a.w32) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(16);
-        if ((it & 127) == 127) {
-            const long long now = wall_clock64();
-            if (t0 == 0) t0 = now;
-            if (now - t0 > 200000000LL || __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                __hip_atomic_store(a.ctl + 2, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
-}
-
-// lane calibration (oph_api.hip): the constant clock when this launch started
-extern "C" __global__ void oph_probe_stamp(long long* out) { if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = wall_clock64(); }
-// ... and a launch that keeps a HIP stream's queue busy for `ticks` of that clock
-__global__ void probe_spin(long long ticks, long long* out) {
-    const long long t0 = wall_clock64();
-    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t0;
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
-}
-
-#ifndef OPH_DEVICE_CODE_OBJECT
-void launch_probe_spin(long long ticks, long long* out, hipStream_t s) { hipLaunchKernelGGL(probe_spin, dim3(1), dim3(64), 0, s, ticks, out); }
 void launch_cone_head(const ConeHeadArgs& a, hipStream_t s) {
     ConeHeadArgs c = a;
     if (a.i_new < 0) { c.rb = 4; hipLaunchKernelGGL(cone_head, dim3((a.npos * a.Bpad + 3) / 4), dim3(256), 0, s, c); return; }
@@ -260,6 +205,5 @@ void launch_cone_head(const ConeHeadArgs& a, hipStream_t s) {
     c.rb = 16;
     hipLaunchKernelGGL(cone_head, dim3(a.B + (others + 15) / 16), dim3(1024), 0, s, c);
 }
-#endif
 
 }  // namespace oph

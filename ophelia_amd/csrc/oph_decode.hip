@@ -157,16 +157,7 @@ int ensure_decode_state(oph_handle* h, int B) {
         h->hcf_stats_stride = (size_t)((maxrows * Bpad + 63) / 64) * 2 * 2 * 32 * 8 * 2;      // granules per level: [row block][2][2][32 rows][8 tiles][2 values]
         h->d_hcf_stats = h->dalloc<unsigned long long>((size_t)2 * nh * h->hcf_stats_stride);      // two per level: alternating with the step parity
         h->hcf_epoch = 0;
-        h->d_hcpair = h->dalloc<HcFusedArgs>(4); h->d_hcpair_sync = h->dalloc<unsigned>(64);      // (zero-filled pool)
-        h->hcpair_ready[0] = h->hcpair_ready[1] = false; h->hcpair_syncs = 0;
-        if (!h->d_hcf_stats || !h->d_hcpair || !h->d_hcpair_sync) { h->fail("out of device memory for decode state"); return OPH_ERR_DEVICE; }
-    }
-    if (h->cone_loop_ok) {
-        bool fits = nh <= CL_MAX_LEVELS;
-        for (int k = 0; k < nh; ++k) fits = fits && (int)h->Hset[k].size() <= CL_MAX_POS;
-        h->d_cl_flags = fits ? h->dalloc<unsigned>((size_t)2 * CL_MAX_LEVELS * CL_MAX_POS + 2 * CL_MAX_LEVELS + 8 * 16) : nullptr;      // flags | level counters | task queues
-        h->d_cl_stats = fits ? h->dalloc<unsigned long long>((size_t)2 * CL_MAX_LEVELS * CL_MAX_POS * 8 * 64) : nullptr;
-        h->cl_epoch = 0;
+        if (!h->d_hcf_stats) { h->fail("out of device memory for decode state"); return OPH_ERR_DEVICE; }
     }
     // ---- per-tile state
     h->tiles.assign(ntiles, Tile());
@@ -517,19 +508,18 @@ int build_loop_layers(oph_handle* h) {
 }
 
 // diagnostics (OPH_TRACE) at the moment a decode's wait timed out: the level words, the levels' arrival counters against their
-// targets, hc_fused_pair's word, the tile's control words
+// targets, the tile's control words
 static void trace_cone_state(oph_handle* h) {
     if (!g_trace || !h->d_sig || !h->d_cone_count) return;
-    unsigned sg[LOOP_SIG_LEVEL0 + 16 * 8], cc[LOOP_MAX_LEVELS], ps[1] = {0};
+    unsigned sg[LOOP_SIG_LEVEL0 + 16 * 8], cc[LOOP_MAX_LEVELS];
     int ctl[4] = {0, 0, 0, 0};
     hipMemcpy(sg, h->d_sig, sizeof sg, hipMemcpyDeviceToHost); hipMemcpy(cc, h->d_cone_count, sizeof cc, hipMemcpyDeviceToHost);
     hipMemcpy(ctl, h->d_ctl, sizeof ctl, hipMemcpyDeviceToHost);
-    if (h->d_hcpair_sync) hipMemcpy(ps, h->d_hcpair_sync, sizeof ps, hipMemcpyDeviceToHost);
     (void)hipGetLastError();
-    TRACE("  sig_base %u: attention word %u; level words %u %u %u %u %u %u; arrivals %u/%u %u/%u %u/%u %u/%u %u/%u %u/%u; pair word %u of %u; ctl %d %d %d %d", h->sig_base, sg[0],
+    TRACE("  sig_base %u: attention word %u; level words %u %u %u %u %u %u; arrivals %u/%u %u/%u %u/%u %u/%u %u/%u %u/%u; ctl %d %d %d %d", h->sig_base, sg[0],
           sg[LOOP_SIG_LEVEL0], sg[LOOP_SIG_LEVEL0 + 16], sg[LOOP_SIG_LEVEL0 + 32], sg[LOOP_SIG_LEVEL0 + 48], sg[LOOP_SIG_LEVEL0 + 64], sg[LOOP_SIG_LEVEL0 + 80],
           cc[0], h->cone_done_total[0], cc[1], h->cone_done_total[1], cc[2], h->cone_done_total[2], cc[3], h->cone_done_total[3], cc[4], h->cone_done_total[4], cc[5], h->cone_done_total[5],
-          ps[0], h->hcpair_syncs, ctl[0], ctl[1], ctl[2], ctl[3]);
+          ctl[0], ctl[1], ctl[2], ctl[3]);
 }
 
 // The decode loop as ONE launch on the critical stream + the per-step cones on the side stream, chained by device words
@@ -581,18 +571,6 @@ int decode_loop(oph_handle* h, int t_begin, int t_end, int stop_mode) {
     }
     // the generic kernel when stamps or ablation bits other than "no side stream" are asked for (they live there)
     const bool use_chain = h->chain_ok && !h->fixed_att && a.QW != nullptr && (dbg & ~32) == 0 && h->d_vbuf;
-    // Split cone (OPH_AQL=3, oph_aql.h): the cone's small levels of step t on a second lane, beside the head and the large levels of
-    // step t + 1; the lanes meet through a completion signal per step (armed here, before anything can clear it)
-    int aql_split = 0;
-    if (use_chain && h->aql && h->aql_mode == 3 && h->n_hc_dec >= 3 && h->qw_from_loop && h->cone_fused_ok && h->cone_head_ok && h->cone_prec == 2 && !h->opt.skip_cone &&
-        !(dbg & 32) && !(h->cone_loop_ok && !h->opt.no_cone_loop) && !(h->audiodec.size() > 1 && h->dec_pre > 1 && h->audiodec[1].ccat > 0) && t_end > std::max(1, t_begin) &&
-        hcf_fits(h) && *aql_error(h->aql) == 0 && aql_signals(h->aql, m.max_T + 2) && aql_signal_value_ptr(h->aql, 0)) {
-        const int sp = h->opt.aql_split > 0 ? h->opt.aql_split : (h->n_hc_dec + 1) / 2;      // 6 levels: 0..2 | 3..5
-        if (sp >= 2 && sp < h->n_hc_dec) {
-            aql_split = sp;
-            for (int t = std::max(1, t_begin); t < t_end; ++t) aql_signal_arm(h->aql, t);
-        }
-    }
     if (use_chain) {
         // every hand-off slot starts as the sentinel (what the previous launch left in them is stale)
         a.vbuf = h->d_vbuf;
@@ -612,168 +590,7 @@ int decode_loop(oph_handle* h, int t_begin, int t_end, int stop_mode) {
     g_cur = h->scone;
     const auto t_host0 = std::chrono::steady_clock::now();
     const bool stream_ssrn = h->spec_ssrn && h->opt.ssrn_chunk > 0 && !h->opt.no_stream_ssrn;
-    // ---- the cone of every step as ONE persistent launch (cone_loop) where the model fits it and its workgroups can all be resident
-    bool cone_in_loop = false;
-    if (h->cone_loop_ok && h->qw_from_loop && h->d_cl_flags && h->d_cl_stats && !h->opt.skip_cone && !(dbg & 32) && t_end > 1 && t_begin == 0) {
-        if (h->cone_loop_wgs < 0) {
-            int ncu = 0;
-            for (int i = 0; i < h->mask_words; ++i) ncu += __builtin_popcount(h->m_conep[i]);
-            h->cone_loop_wgs = std::min(h->opt.cl_wgs_per_cu, cone_loop_blocks_per_cu()) * ncu / 8 * 8;
-        }
-        cone_in_loop = h->cone_loop_wgs >= 64;
-    }
-    if (cone_in_loop) {
-        const int pre = h->dec_pre, nh = h->n_hc_dec;
-        if ((uint64_t)h->cl_epoch + (uint64_t)(m.max_T + 2) * CL_MAX_LEVELS > 0xF0000000ull) {
-            hipStreamSynchronize(h->scone);
-            hipMemsetAsync(h->d_cl_stats, 0, (size_t)2 * CL_MAX_LEVELS * CL_MAX_POS * 8 * 64 * 8, h->scone);
-            h->cl_epoch = 0;
-        }
-        ConeLoopArgs c{};
-        c.nlevels = nh; c.t_begin = std::max(1, t_begin); c.t_end = t_end; c.B = h->B; c.d = m.d;
-        c.npos0 = (int)h->Hset[0].size(); c.off0 = h->d_off0; c.rows0[0] = h->cone[0][0]; c.rows0[1] = h->cone[1][0];
-        const Layer& tl0 = h->audiodec[pre];
-        c.sig0_pos0 = idx_of(h->Hset[0], -tl0.off[0]); c.sig0_pos1 = idx_of(h->Hset[0], -tl0.off[1]);
-        c.Q = h->Qhist; c.QW = h->QWhist; c.KV = h->KV; c.VW = h->VW; c.ldvw = h->ldvw; c.N_keys = m.max_N; c.win = m.attention_win_size;
-        c.gamma0 = h->audiodec[0].g1; c.beta0 = h->audiodec[0].b1;
-        c.p = h->d_p;
-        for (int k = 1; k < nh; ++k) {
-            const Layer& l = h->audiodec[pre + k - 1];       // the highway layer that produces level k from level k-1
-            const Layer& tl = h->audiodec[pre + k];           // the chain layer whose taps read level k
-            ConeLoopLevel& L = c.L[k];
-            L.npos = (int)h->Hset[k].size(); L.Wsw = l.Wsw_cone; L.bias = l.bias; L.g1 = l.g1; L.b1 = l.b1; L.g2 = l.g2; L.b2 = l.b2;
-            L.tab = h->d_tab[k - 1]; L.need = h->d_need[k - 1];
-            L.rows[0] = h->cone[0][k]; L.rows[1] = h->cone[1][k];
-            L.sig_pos0 = idx_of(h->Hset[k], -tl.off[0]); L.sig_pos1 = idx_of(h->Hset[k], -tl.off[1]);
-        }
-        c.flags = h->d_cl_flags; c.levelcnt = h->d_cl_flags + (size_t)2 * CL_MAX_LEVELS * CL_MAX_POS; c.stats = h->d_cl_stats;
-        c.epoch0 = h->cl_epoch; h->cl_epoch += (uint32_t)(m.max_T + 2) * CL_MAX_LEVELS;
-        c.sig = h->d_sig; c.sig_base = h->sig_base; c.ctl = h->d_ctl;
-        c.dbg = h->opt.cl_dbg;
-        if (h->d_cldbg) { c.stamps = h->d_cldbg; hipMemsetAsync(h->d_cldbg, 0, ((size_t)(2 * m.max_T + 4) * 8 + 512) * sizeof(long long), h->scone); }
-        hipMemsetAsync(h->d_cl_flags, 0, ((size_t)2 * CL_MAX_LEVELS * CL_MAX_POS + 2 * CL_MAX_LEVELS + 8 * 16) * sizeof(unsigned), h->scone);
-        launch_cone_loop(c, h->cone_loop_wgs, h->scone);
-        h->n_cone_loops++;
-        // the host has nothing to enqueue per step: it only watches the progress word for the SSRN chunks
-        auto t_prog = std::chrono::steady_clock::now();
-        int last_prog = -2;
-        while (stream_ssrn) {
-            const int prog = h->host_prog[0], stopped_at = h->host_prog[1];
-            if (stopped_at != INT_MAX || prog >= t_end - 1) break;
-            Tile& tl = h->tiles[h->tile];
-            if (tl.ssrn_done + h->opt.ssrn_chunk >= m.max_T) break;          // only the final chunk is left
-            { const int rc = ssrn_stream_chunks(h, prog, false); if (rc) return rc; }
-            if (prog != last_prog) { last_prog = prog; t_prog = std::chrono::steady_clock::now(); }
-            else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_prog).count() > 10.0) {
-                h->fail("decode loop kernel made no progress for 10 s (step %d)", prog);
-                return OPH_ERR_DEVICE;
-            }
-            struct timespec ts = {0, 50000};         // 50 us: a chunk boundary comes every few milliseconds
-            nanosleep(&ts, nullptr);
-        }
-    }
-    // ---- the pipelined cone (oph_aql.h): every launch of every step as an AQL packet without the barrier bit.  The launches order
-    // themselves on the device (attention signal -> head; level counters -> each hc_fused), so the host is not on the path at all: a
-    // fixed-length decode is written out in one go, a decode that may stop early in chunks of `lookahead` steps behind the chain's
-    // progress word (what is queued beyond the stop step early-outs on the device).
-    bool cone_aql = false;
-    if (h->aql && !cone_in_loop && h->qw_from_loop && h->cone_fused_ok && h->cone_head_ok && h->cone_prec == 2 && !h->opt.skip_cone && !(dbg & 32) &&
-        !(h->audiodec.size() > 1 && h->dec_pre > 1 && h->audiodec[1].ccat > 0) && t_end > std::max(1, t_begin) && hcf_fits(h) && *aql_error(h->aql) == 0) {
-        AqlRecorder& rec = h->aql_store;
-        const size_t need = (size_t)(m.max_T + 1) * (size_t)(h->n_hc_dec + 3) * 256;      // (head + levels + the split mode's two gates)
-        if (rec.stage_cap < need) {
-            if (rec.stage) hipHostFree(rec.stage);
-            rec.stage = nullptr; rec.stage_cap = 0;
-            void* p_ = nullptr;
-            if (hipHostMalloc(&p_, need, hipHostMallocDefault) == hipSuccess) { rec.stage = (char*)p_; rec.stage_cap = need; } else (void)hipGetLastError();
-        }
-        if (h->kernarg_cap < need) {
-            if (h->d_kernarg) hipFree(h->d_kernarg);
-            h->d_kernarg = nullptr; h->kernarg_cap = 0;
-            void* p_ = nullptr;
-            if (hipMalloc(&p_, need) == hipSuccess) { h->d_kernarg = (char*)p_; h->kernarg_cap = need; } else (void)hipGetLastError();
-        }
-        if (!h->d_lvl_count) {
-            void* p_ = nullptr;
-            if (hipMalloc(&p_, (size_t)LOOP_MAX_LEVELS * 9 * 16 * sizeof(unsigned)) == hipSuccess) h->d_lvl_count = (unsigned*)p_; else (void)hipGetLastError();
-        }
-        cone_aql = rec.stage && h->d_kernarg && h->d_lvl_count;
-    }
-    if (cone_aql) {
-        AqlRecorder& rec = h->aql_store;
-        if (h->aql_used) { if (!aql_wait_idle(h->aql, 10.0)) { h->fail("the cone's AQL queue did not drain: %s", aql_error(h->aql)); return OPH_ERR_DEVICE; } h->aql_used = false; }
-        rec.pk.clear(); rec.used = 0; rec.nth = 0; rec.overflow = false; rec.pipelined = h->aql_mode == 2;
-        rec.split = aql_split;
-        hipMemsetAsync(h->d_lvl_count, 0, (size_t)LOOP_MAX_LEVELS * 9 * 16 * sizeof(unsigned), h->scopy);
-        const int t_first = std::max(1, t_begin);
-        const int chunk = stop_mode == OPH_STOP_NEVER ? (t_end - t_first) : std::max(4, 2 * lookahead);
-        int t_next = t_first;
-        size_t pk_done = 0;
-        auto submit = [&](int t1) -> int {
-            const size_t arg0 = rec.used;
-            for (int t = t_next; t < t1; ++t) {
-                rec.nth++;
-                h->cone_inline_sig = true; h->cone_wait_val = (t == t_begin) ? 0u : h->sig_base + (uint32_t)t; h->cone_done_val = h->sig_base + (uint32_t)t;
-                h->aql_rec = &rec;
-                launch_cone(h, t);
-                h->aql_rec = nullptr;
-                h->cone_inline_sig = false;
-            }
-            t_next = t1;
-            if (rec.overflow || rec.pk.size() == pk_done) { h->fail("internal: the pipelined cone's launches could not be recorded"); return OPH_ERR_STATE; }
-            // the arguments go to device memory in one copy (the launches read them there at full speed), then the packets are written
-            if (hipMemcpyAsync(h->d_kernarg + arg0, rec.stage + arg0, rec.used - arg0, hipMemcpyHostToDevice, h->scopy) != hipSuccess ||
-                hipStreamSynchronize(h->scopy) != hipSuccess) { h->fail("kernel-argument upload failed"); return OPH_ERR_DEVICE; }
-            for (; pk_done < rec.pk.size(); ++pk_done) {
-                const AqlPacketRec& r = rec.pk[pk_done];
-                if (r.wait_sig >= 0 && !aql_wait_signal(h->aql, r.lane, r.wait_sig)) { h->fail("AQL dependency packet failed: %s", aql_error(h->aql)); return OPH_ERR_DEVICE; }
-                if (!aql_dispatch(h->aql, rec.pipelined ? (int)pk_done : r.lane, h->aql_k[r.kernel], r.grid, r.block, r.lds, h->d_kernarg + r.arg_off, !rec.pipelined, r.done_sig)) { h->fail("AQL dispatch failed: %s", aql_error(h->aql)); return OPH_ERR_DEVICE; }
-            }
-            aql_ring(h->aql);
-            h->aql_used = true;
-            return OPH_OK;
-        };
-        { const int rc = submit(std::min(t_end, t_first + chunk)); if (rc) return rc; }
-        h->n_aql_decodes++;
-        auto t_prog = std::chrono::steady_clock::now();
-        int last_prog = -2;
-        for (;;) {
-            const int prog = h->host_prog[0], stopped_at = h->host_prog[1];
-            if (stopped_at != INT_MAX || prog >= t_end - 1) break;
-            if (t_next < t_end && prog >= t_next - 1 - lookahead) { const int rc = submit(std::min(t_end, t_next + chunk)); if (rc) return rc; }
-            bool more_chunks = false;
-            if (stream_ssrn) {
-                Tile& tl = h->tiles[h->tile];
-                more_chunks = tl.ssrn_done + h->opt.ssrn_chunk < m.max_T;
-                if (more_chunks) { const int rc = ssrn_stream_chunks(h, prog, false); if (rc) return rc; }
-            }
-            static const bool aql_state_dbg = getenv("OPH_AQL_STATE") != nullptr;
-            if (aql_state_dbg) {       // diagnostics: where the lanes stand when the chain stops making progress
-                static int dumped = 0;
-                if (prog != last_prog) { last_prog = prog; t_prog = std::chrono::steady_clock::now(); }
-                else if (dumped < 3 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_prog).count() > 0.3) {
-                    ++dumped;
-                    unsigned sg[LOOP_SIG_LEVEL0 + 16 * 8];
-                    hipMemcpyAsync(sg, h->d_sig, sizeof sg, hipMemcpyDeviceToHost, h->scopy); hipStreamSynchronize(h->scopy);
-                    TRACE("no progress at step %d (sig_base %u): attention word %u, level words %u %u %u %u %u %u; %s", prog, h->sig_base, sg[0], sg[LOOP_SIG_LEVEL0], sg[LOOP_SIG_LEVEL0 + 16],
-                          sg[LOOP_SIG_LEVEL0 + 32], sg[LOOP_SIG_LEVEL0 + 48], sg[LOOP_SIG_LEVEL0 + 64], sg[LOOP_SIG_LEVEL0 + 80], aql_state(h->aql).c_str());
-                    t_prog = std::chrono::steady_clock::now();
-                }
-                struct timespec ts = {0, 50000};
-                nanosleep(&ts, nullptr);
-                continue;
-            }
-            if (t_next >= t_end && !more_chunks) break;          // nothing left for the host to do while the decode runs
-            if (prog != last_prog) { last_prog = prog; t_prog = std::chrono::steady_clock::now(); }
-            else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_prog).count() > 10.0) {
-                h->fail("decode loop kernel made no progress for 10 s (step %d)", prog);
-                return OPH_ERR_DEVICE;
-            }
-            struct timespec ts = {0, 50000};
-            nanosleep(&ts, nullptr);
-        }
-    }
-    for (int t = std::max(1, t_begin); t < t_end && !(dbg & 32) && !cone_in_loop && !cone_aql; ++t) {
+    for (int t = std::max(1, t_begin); t < t_end && !(dbg & 32); ++t) {
         // bounded run-ahead, so that an early stop leaves at most `lookahead` queued cones (they early-out on the device)
         auto t_wait0 = std::chrono::steady_clock::now();
         while (h->host_prog[0] < t - 1 - lookahead && h->host_prog[1] == INT_MAX) {
@@ -942,7 +759,6 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode) {
 // CUs) the cross-stream words and counters are out of step: bring them back to a quiet state so that the handle stays usable.
 void recover_loop_state(oph_handle* h) {
     for (hipStream_t st : {h->sdec, h->scone, h->sssrn, h->stream}) if (st) hipStreamSynchronize(st);
-    if (h->aql && h->aql_used) { (void)aql_wait_idle(h->aql, 10.0); h->aql_used = false; }
     (void)hipGetLastError();
     hipMemsetAsync(h->d_sig, 0, LOOP_SIG_WORDS * sizeof(uint32_t), h->stream);
     hipMemsetAsync(h->d_cone_count, 0, LOOP_MAX_LEVELS * sizeof(unsigned), h->stream);
@@ -1084,31 +900,6 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
                     TRACE("step %d: level 0 of the next cone complete at %.2f us", m.max_T / 2, (lv[(size_t)(m.max_T / 2 + 1) * 8] - z) * 0.01);
                 }
             }
-            if (loop_mode && h->d_cldbg && !h->cone_fused_ok) {
-                std::vector<long long> cd((size_t)(2 * m.max_T + 4) * 8 + 512);
-                hipMemcpy(cd.data(), h->d_cldbg, cd.size() * 8, hipMemcpyDeviceToHost);
-                {   // on which XCD did the workgroups of each column group (block % 8) run?
-                    char line[256]; int n = 0;
-                    for (int c8 = 0; c8 < 8; ++c8) {
-                        unsigned mask = 0;
-                        for (int b = c8; b < h->cone_loop_wgs && b < 512; b += 8) mask |= 1u << (unsigned)cd[(size_t)(2 * last + 4) * 8 + b];
-                        n += snprintf(line + n, sizeof line - n, " %d:0x%x", c8, mask);
-                    }
-                    TRACE("cone_loop: XCD mask per column group (block %% 8):%s", line);
-                }
-                for (int t : {50, 100, 150}) {
-                    if (t >= last) continue;
-                    const long long* q = &cd[(size_t)(last + 1 + t) * 8];
-                    if (q[0]) TRACE("cone_loop step %d, sample task (level 4): wait deps %.2f  gather %.2f  mfma %.2f  local stats %.2f  exchange %.2f  normalise %.2f  store+flag %.2f us", t,
-                                    (q[1] - q[0]) * 0.01, (q[2] - q[1]) * 0.01, (q[3] - q[2]) * 0.01, (q[4] - q[3]) * 0.01, (q[5] - q[4]) * 0.01, (q[6] - q[5]) * 0.01, (q[7] - q[6]) * 0.01);
-                }
-                for (int t : {50, 51, 100, 101, 150}) {
-                    if (t >= m.max_T) continue;
-                    const long long* q = &cd[(size_t)t * 8];
-                    if (q[0]) TRACE("cone_loop step %d: levels 0..5 written %.2f %.2f %.2f %.2f %.2f %.2f us after its release", t,
-                                    (q[1] - q[0]) * 0.01, (q[2] - q[0]) * 0.01, (q[3] - q[0]) * 0.01, (q[4] - q[0]) * 0.01, (q[5] - q[0]) * 0.01, (q[6] - q[0]) * 0.01);
-                }
-            }
             if (loop_mode) {
                 const long long* q = &st[(size_t)(LOOP_MAX_LAYERS - 1) * 8];
                 if (q[1] > q[0]) TRACE("stamped step: %.2f us, shader clock %.0f MHz", (double)(q[1] - q[0]) * 0.01, (double)(q[3] - q[2]) / ((double)(q[1] - q[0]) * 0.01));
@@ -1135,14 +926,6 @@ int decode_range(oph_handle* h, int t_begin, int t_end, int stop_mode, int32_t* 
         }
     }
     // join: the API stream continues (SSRN, fetches) only after both decode streams drained
-    if (h->aql && h->aql_used) {
-        // (the chain's last step waited for the last cone it needs; what is left in the queue are launches beyond a stop step, which
-        //  early-out -- they must be gone before the tile's state is reset for the next decode)
-        hipStreamSynchronize(h->sdec);
-        if (g_trace && getenv("OPH_AQL_STATE")) TRACE("AQL queues when the chain ended: %s", aql_state(h->aql).c_str());
-        if (!aql_wait_idle(h->aql, 10.0)) { h->fail("the cone's AQL queue did not drain: %s", aql_error(h->aql)); recover_loop_state(h); return OPH_ERR_DEVICE; }
-        h->aql_used = false;
-    }
     hipEventRecord(h->ev_out, h->sdec);
     hipStreamWaitEvent(h->stream, h->ev_out, 0);
     hipEventRecord(h->ev_out, h->scone);
@@ -1207,13 +990,6 @@ int decode_batch(oph_handle* h, int t_end, int stop_mode, int32_t* steps_run) {
             else if (h->use_run) { h->use_run = false; what = "one launch per layer"; }
             else break;
             TRACE("decode failed (%s): redoing the tile with %s", h->err.c_str(), what);
-            if (g_trace && h->d_lvl_count) {       // the pipelined cone's completion counters at the time of the failure
-                std::vector<unsigned> lc((size_t)LOOP_MAX_LEVELS * 9 * 16);
-                hipMemcpy(lc.data(), h->d_lvl_count, lc.size() * 4, hipMemcpyDeviceToHost);
-                for (int k = 0; k < h->n_hc_dec; ++k)
-                    TRACE("  level %d: shard counters %u %u %u %u %u %u %u %u; steps complete %u, shards complete %u", k, lc[(k * 8 + 0) * 16], lc[(k * 8 + 1) * 16], lc[(k * 8 + 2) * 16],
-                          lc[(k * 8 + 3) * 16], lc[(k * 8 + 4) * 16], lc[(k * 8 + 5) * 16], lc[(k * 8 + 6) * 16], lc[(k * 8 + 7) * 16], lc[(LOOP_MAX_LEVELS * 8 + k) * 16], lc[(LOOP_MAX_LEVELS * 8 + k) * 16 + 1]);
-            }
             h->last_wait_err = 0;
             h->n_recoveries++;
             h->degraded_left = h->degraded_next; h->degraded_next = std::min(h->degraded_next * 4, 256);

@@ -69,19 +69,6 @@ static __device__ __forceinline__ void st_sc1_b128(float* base, unsigned byte_of
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_, v), r, (int)byte_off, 0, 16 /* sc1 */);
 }
-// Completion counting of the pipelined cone's launches (oph_aql.h), two stages so that the consumers have ONE word to poll:
-// counters [level][8 shards][16 words] (monotonic since the decode's start), then [LOOP_MAX_LEVELS * 8 + level][16 words]: word 0 =
-// steps of this level that are complete, word 1 = shards that have completed (monotonic).  The workgroup that brings its shard to
-// `shard_total` (= nth * the shard's workgroups per launch) counts the shard in; the one that brings the shard count to nth * nshards
-// raises word 0 to nth.  Every store of the counted workgroup has been acknowledged before it counts (s_waitcnt vmcnt(0) by the caller).
-static __device__ __forceinline__ void level_count_in(unsigned* lvl_count, int level, int shard, unsigned shard_total, unsigned nth, unsigned nshards) {
-    const unsigned old = __hip_atomic_fetch_add(lvl_count + (level * 8 + shard) * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old + 1u == shard_total) {
-        unsigned* top = lvl_count + (LOOP_MAX_LEVELS * 8 + level) * 16;
-        const unsigned o2 = __hip_atomic_fetch_add(top + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (o2 + 1u == nth * nshards) __hip_atomic_fetch_max(top, nth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
 static __device__ __forceinline__ bool stopped(const int* stop_after, int t) {
     return stop_after != nullptr && t > *stop_after;
 }

@@ -36,13 +36,6 @@ constexpr long long HF_TIMEOUT_TICKS = 200000000LL;      // 2 s of the 100 MHz c
 // (Round 4 also ran the small levels 3..5 on a second, unmasked stream -- level 2 handed over through a device word, write-through
 // rows, sc1 loads -- so that they would overlap the next step's large levels: with a fourth queue busy beside the three CU-masked
 // ones the queues time-slice, 50 ms per decode instead of 20.4; removed.)
-// COH (round 5, oph_aql.h): the pipelined form.  The launch is dispatched while its predecessor level is still running: it requests
-// what does not depend on that level (tables, bias, the first K-steps of the weights' planes), then waits until every workgroup of
-// the producing launch has counted in (8 sharded counters, one lane each), reads the level's planes and residual rows past its L1
-// (sc1: the producer stored write-through), stores everything write-through itself and counts in when its stores have drained.
-// CIN / COUT (round 5, hc_fused_pair): the coherent reads (level k-1 was written by workgroups that are still running) and the
-// write-through stores on their own, without the pipelined form's wait and count-in.
-template <bool COH, bool CIN = COH, bool COUT = COH>
 static __device__ __forceinline__ void hc_fused_body(const HcFusedArgs& a) {
     // Every output row must get the SAME arithmetic whatever register or lane holds it (an utterance's result may not depend on its
     // row of the tile: tests/test_gpu_properties.py).  With contraction left to the compiler the unrolled epilogue got v_fma for some
@@ -121,34 +114,25 @@ static __device__ __forceinline__ void hc_fused_body(const HcFusedArgs& a) {
                 for (int e = 0; e < 16; ++e) {
                     const int b = (e & 3) + 4 * kh + 8 * ((e >> 2) & 1);
                     const float* px = a.Xres + (size_t)((e >> 3) ? rb + b : ra + b) * HF_C + colh;
-                    xres[e] = CIN ? __hip_atomic_load(px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *px;
+                    xres[e] = *px;
                 }
             }
         };
-        if (!COH) load_xres();
+        load_xres();
         // Operand planes: global -> registers -> LDS (16 bytes per lane and request; a wave's request covers 8 whole cache lines).
         // (Measured first, round 4: the same chunks through global_load_lds -- 39 GB/s per CU whatever the ring depth or the K-step
         // width, the LDS-DMA path's own limit; plain loads stream 2-3x that from L2 / MALL.)  Software pipeline, prefetch distance 2:
         // while step s is multiplied out of LDS buffer s & 1, step s + 1 sits in one register set and step s + 2 is in flight.
         typedef int i32x4 __attribute__((ext_vector_type(4)));
         struct Regs { i32x4 ah[1], al[1], bh[1], bl[1]; };
-        const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc((void*)a.Xh, 0, 0x7fffffff, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc((void*)a.Xl, 0, 0x7fffffff, 0x00020000);
         auto load_a = [&](int s, Regs& q) {
             const int tap = s >> 2;
             const size_t kb = (size_t)(s & 3) * a.in_rows * HF_BK;        // planes are K-blocked: [channel / 64][row][64]
             const int so = asrc[tap];
-            if (CIN) {
-                const i32x4 z = {0, 0, 0, 0};
-                const int bo = (int)(((size_t)(so >= 0 ? so : 0) + kb) * 2);
-                q.ah[0] = so >= 0 ? __builtin_amdgcn_raw_buffer_load_b128(rxh, bo, 0, 16 /* sc1 */) : z;
-                q.al[0] = so >= 0 ? __builtin_amdgcn_raw_buffer_load_b128(rxl, bo, 0, 16 /* sc1 */) : z;
-            } else {
-                const h16* gh = so >= 0 ? Xh + so + kb : zrow;
-                const h16* gl = so >= 0 ? Xl + so + kb : zrow;
-                q.ah[0] = *(const i32x4*)gh;
-                q.al[0] = *(const i32x4*)gl;
-            }
+            const h16* gh = so >= 0 ? Xh + so + kb : zrow;
+            const h16* gl = so >= 0 ? Xl + so + kb : zrow;
+            q.ah[0] = *(const i32x4*)gh;
+            q.al[0] = *(const i32x4*)gl;
         };
         auto load_b = [&](int s, Regs& q) {
             const size_t bo = (((size_t)jt * (HF_K / HF_BK) + s) * HF_BN + rq0) * HF_BK + gp;      // [column tile][K-step][64 columns][64]
@@ -188,47 +172,8 @@ static __device__ __forceinline__ void hc_fused_body(const HcFusedArgs& a) {
         // prefetch distance HF_AHEAD: step s + 1 waits in registers, steps s + 2 .. s + HF_AHEAD are in flight (the loop is fully
         // unrolled: every register-set index is a constant)
         Regs q[HF_AHEAD];
-        if (COH) {
-            // the weights' first K-steps are on their way while this workgroup waits for the producing level
 #pragma unroll
-            for (int s = 0; s < HF_AHEAD; ++s) load_b(s, q[s]);
-            const int lvl_in = (int)(a.lvl_io & 0xff) == 0xff ? -1 : (int)(a.lvl_io & 0xff);
-            if (lvl_in >= 0) {
-                if (w8 == 0) {
-                    // ONE word per level and step to poll (the producers count in two stages: shard counters, the last of a shard counts
-                    // the shard in, the last shard raises the word): a launch's waiting workgroups are up to 168 pollers -- on eight
-                    // counters, every lane polling, they took the memory channels of those lines away from the producers
-                    const unsigned nth = a.lvl_n >> 16;
-                    const unsigned* word = a.lvl_count + (LOOP_MAX_LEVELS * 8 + lvl_in) * 16;
-                    long long t0 = 0;
-                    for (int it = 0;; ++it) {
-                        const unsigned v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((int)(v - nth) >= 0) break;
-                        __builtin_amdgcn_s_sleep(16);
-                        if ((it & 127) == 127) {
-                            const long long now = wall_clock64();
-                            if (t0 == 0) t0 = now;
-                            if (now - t0 > HF_TIMEOUT_TICKS || __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                                if (lane == 0) __hip_atomic_store(a.ctl + 2, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                break;
-                            }
-                        }
-                    }
-                    // (this launch was dispatched long before its step: the decode may have stopped meanwhile)
-                    if (lane == 0) live_s = !(a.t > __hip_atomic_load(a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                }
-                __syncthreads();
-            }
-        }
-        if (!COH || live_s != 0) {
-        if (COH) {
-            load_xres();
-#pragma unroll
-            for (int s = 0; s < HF_AHEAD; ++s) load_a(s, q[s]);
-        } else {
-#pragma unroll
-            for (int s = 0; s < HF_AHEAD; ++s) load_step(s, q[s]);
-        }
+        for (int s = 0; s < HF_AHEAD; ++s) load_step(s, q[s]);
         store_step(0, q[0]);
         __syncthreads();
 #pragma unroll
@@ -361,7 +306,7 @@ static __device__ __forceinline__ void hc_fused_body(const HcFusedArgs& a) {
                 const f32x4 y0 = *(const f32x4*)(ys + rt * 36 + c8), y1 = *(const f32x4*)(ys + rt * 36 + c8 + 4);
                 const size_t o = (size_t)m * HF_C + jt * 32 + c8;
                 const int pos_m = m >> 4;
-                if (COUT || (a.done_sig && (pos_m == a.coh0 || pos_m == a.coh1))) { st_coherent(a.Y + o, y0); st_coherent(a.Y + o + 4, y1); }     // a row a RUNNING kernel reads
+                if (a.done_sig && (pos_m == a.coh0 || pos_m == a.coh1)) { st_coherent(a.Y + o, y0); st_coherent(a.Y + o + 4, y1); }     // a row a RUNNING kernel reads
                 else { *(f32x4*)(a.Y + o) = y0; *(f32x4*)(a.Y + o + 4) = y1; }
                 h16x8 hi, lo;
 #pragma unroll
@@ -371,16 +316,10 @@ static __device__ __forceinline__ void hc_fused_body(const HcFusedArgs& a) {
                 }
                 const int ch = jt * 32 + c8;
                 const size_t po = ((size_t)(ch >> 6) * a.M + m) * HF_BK + (ch & 63);
-                if (COUT) {
-                    st_sc1_b128((float*)a.Yh, (unsigned)(po * 2), __builtin_bit_cast(f32x4, hi));
-                    st_sc1_b128((float*)a.Yl, (unsigned)(po * 2), __builtin_bit_cast(f32x4, lo));
-                } else {
-                    *(h16x8*)((h16*)a.Yh + po) = hi;
-                    *(h16x8*)((h16*)a.Yl + po) = lo;
-                }
+                *(h16x8*)((h16*)a.Yh + po) = hi;
+                *(h16x8*)((h16*)a.Yl + po) = lo;
             }
         }
-        }       // live after the wait
     }
     if (dbg) dbg[4] = wall_clock64();
     // ---- completion of a cone level: the tap rows have left (write-through), one lane raises the level's word (as ln_rows does)
@@ -399,74 +338,9 @@ static __device__ __forceinline__ void hc_fused_body(const HcFusedArgs& a) {
             }
         }
     }
-
-    // pipelined cone: every workgroup that belongs to the level counts in when its rows have left, whether or not it stored any
-    if (COH && a.lvl_count && active) {
-        const int lvl_out = (int)((a.lvl_io >> 8) & 0xff);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            // this launch has out_units row blocks of 8 column tiles; row block u counts into shard u & 7 (= xcd)
-            const unsigned nth = a.lvl_n >> 16;
-            const unsigned shard_total = nth * (unsigned)(((MT + 7 - xcd) >> 3) * HF_NT);
-            level_count_in(a.lvl_count, lvl_out, xcd, shard_total, nth, (unsigned)min(MT, 8));
-        }
-    }
 }
-__global__ __launch_bounds__(512) void hc_fused(HcFusedArgs a) { hc_fused_body<false>(a); }
+__global__ __launch_bounds__(512) void hc_fused(HcFusedArgs a) { hc_fused_body(a); }
 
-// hc_fused_pair (round 5): the cone's LAST TWO levels (64 and 32 rows at the shipped geometry: one row block each) in one launch.
-// A small level costs ~13 us as a launch of its own whatever its row count -- 1.5 us between two launches, ~3 us of prologue
-// (arguments, tables, first operand round trip), ~4 us of K loop, ~3 us of statistics exchange, ~1.3 us of stores -- and the eight
-// workgroups that do the work are the same eight (column tiles 0..7 of row block 0: one XCD) in both levels.  Here they run level A,
-// store its rows write-through (fp32 and planes), count in on one word once their stores have been acknowledged, and go on with
-// level B as soon as all eight have (reads of level A's rows past the L1: the producers sit on the same XCD, the lines are in its
-// L2).  The arguments of the two levels that do not change from step to step live in device memory (p.lv, per step parity); the
-// launch carries the per-step scalars.  Same arithmetic, same order as two hc_fused launches: bitwise the same rows.
-__global__ __launch_bounds__(512) void hc_fused_pair(HcPairArgs p) {
-    const int tid = threadIdx.x;
-    {
-        HcFusedArgs a = p.lv[0];
-        a.ctl = p.ctl; a.t = p.t; a.j = p.t; a.epoch = p.epoch0; a.done_val = p.done_val; a.done_target = p.done_target0; a.done_stamp = p.done_stamp0; a.dbg = p.dbg0;
-        a.done_sig = p.done_sig0; a.done_count = p.done_count0; a.coh0 = p.coh00; a.coh1 = p.coh01;
-        // (plain stores: the readers of these rows are the same eight workgroups' level B -- the same XCD, whose L2 is the point of coherence
-        //  for its CUs -- and the two tap positions the chain reads leave write-through as in every level)
-        hc_fused_body<false, false, false>(a);
-    }
-    // every store of this workgroup has been acknowledged by the XCD's L2 -> count in; the eight
-    // active workgroups (blockIdx & 7 == 0, row block 0) wait for each other, bounded like every wait of the cone
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (((int)blockIdx.x & 7) == 0 && ((int)blockIdx.x >> 6) == 0) {
-        if (tid == 0) {
-            __hip_atomic_fetch_add(p.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            long long t0 = 0;
-            for (int it = 0; (int)(__hip_atomic_load(p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.sync_target) < 0; ++it) {
-                __builtin_amdgcn_s_sleep(1);
-                if ((it & 255) == 255) {
-                    const long long now = wall_clock64();
-                    if (t0 == 0) t0 = now;
-                    if (now - t0 > HF_TIMEOUT_TICKS || __hip_atomic_load(p.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                        __hip_atomic_store(p.ctl + 2, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    {
-        HcFusedArgs b = p.lv[1];
-        b.ctl = p.ctl; b.t = p.t; b.j = p.t; b.epoch = p.epoch1; b.done_val = p.done_val; b.done_target = p.done_target1; b.done_stamp = p.done_stamp1; b.dbg = p.dbg1;
-        b.done_sig = p.done_sig1; b.done_count = p.done_count1; b.coh0 = p.coh10; b.coh1 = p.coh11;
-        hc_fused_body<false, true, false>(b);
-    }
-}
-// the pipelined form, dispatched through the AQL queue (oph_aql.h) by its unmangled name
-extern "C" __global__ __launch_bounds__(512) void oph_hc_fused_coh(HcFusedArgs a) { hc_fused_body<true>(a); }
-extern "C" __global__ __launch_bounds__(512) void oph_hc_fused_plain(HcFusedArgs a) { hc_fused_body<false>(a); }
-
-#ifndef OPH_DEVICE_CODE_OBJECT
 size_t hc_fused_lds_bytes() { return (size_t)2 * (2 * HF_BM + 2 * HF_BN) * HF_BK * 2; }      // (the epilogue's 18.2 KB alias the operand buffers)
 
 // number of workgroups the launch will have / of those that do work (one per (row block, column tile))
@@ -490,14 +364,6 @@ void launch_hc_fused(const HcFusedArgs& a, hipStream_t s) {
     if (!done[dev]) { (void)hipFuncSetAttribute((const void*)hc_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done[dev] = true; }
     hipLaunchKernelGGL(hc_fused, dim3(hc_fused_grid(a.M)), dim3(512), lds, s, a);
 }
-void launch_hc_fused_pair(const HcPairArgs& p, hipStream_t s) {
-    static thread_local std::map<int, bool> done;
-    const size_t lds = hc_fused_lds_bytes();
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!done[dev]) { (void)hipFuncSetAttribute((const void*)hc_fused_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done[dev] = true; }
-    hipLaunchKernelGGL(hc_fused_pair, dim3(64), dim3(512), lds, s, p);       // (both levels: one row block -> hc_fused_grid = 64)
-}
 // workgroups of a launch that can be resident per CU
 int hc_fused_blocks_per_cu(int M) {
     (void)M;
@@ -507,7 +373,5 @@ int hc_fused_blocks_per_cu(int M) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)hc_fused, 512, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return n;
 }
-
-#endif
 
 }  // namespace oph

@@ -9,7 +9,6 @@
 //   oph_ops.hip     per-operator entry points (unit parity) and the conv1d_transpose timing probe
 #pragma once
 #include "oph_internal.h"
-#include "oph_aql.h"
 #pragma GCC visibility push(default)      // the library is built with -fvisibility=hidden: only the C ABI is exported
 #include "../../include/ophelia_hip.h"
 #pragma GCC visibility pop
@@ -76,7 +75,6 @@ struct Layer {
     void *Wh = nullptr, *Wl = nullptr, *Wh2 = nullptr, *Wl2 = nullptr;   // SSRN layers: Wt / Wt2 split into hi + lo bf16 planes (conv_gemm_bf16x3)
     void *Wh16 = nullptr, *Wl16 = nullptr, *Wh2_16 = nullptr, *Wl2_16 = nullptr;   // the same as fp16 planes (split-fp16 x3: fp32-class accuracy)
     void *Wkh = nullptr, *Wkl = nullptr, *Wkh2 = nullptr, *Wkl2 = nullptr;         // the fp16 planes K-blocked [ntaps kc / 32][Nalloc][32] (plane_gemm)
-    float* Wsw_cone = nullptr;                   // AudioDec highway layers: kernel in cone_loop's fragment order (oph_coneloop.hip)
     void *Wph = nullptr, *Wpl = nullptr; float* bias_p = nullptr;   // AudioDec highway layers: kernel as fp16 planes [2C][3 kc] with the columns
                                                                      // permuted per 64-tile to [32 H1 | the same 32 channels of H2] (hc_fused)
     float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
@@ -96,70 +94,88 @@ constexpr int TEXTENC_PREC_DEFAULT = 2;   // TextEnc contractions when OPH_TEXTE
 constexpr int CONE_PREC_DEFAULT = 2;      // arithmetic of the cone's two many-row contractions when OPH_CONE_PREC is not set (see oph_finalize_weights)
 constexpr int CONE_KSPLIT = 4;   // split-K of the latency-bound decoder-cone GEMMs (partials summed by ln_rows); buffers are sized for it
 
-// The OPH_* environment switches (debugging / measurement knobs, README.md lists them), read ONCE per handle in
-// oph_create -- nothing on a launch path calls getenv.
+// Launch-path and arithmetic options of a handle.  They are NOT read from the environment: a production build takes them only from
+// the option string of oph_create_opts ("NAME=value NAME ...", names below without any prefix; oph_create = no options), so an
+// inherited environment variable cannot change what a handle computes or how fast.  Every option here selects a launch path the
+// library also takes by itself (non-standard geometries, the recovery ladder) or an arithmetic flavour of oph_set_precision: results
+// stay within the cross-flavour bar (tests/test_gpu_decode_modes.py).  Measurement builds (-DOPH_ABLATE, ophelia_amd/_lib.py with
+// OPH_HIPCC_FLAGS) additionally accept the ablation options -- SKIP_CONE, LOOP_ALONE, LOOP_DBG: wrong or unused results -- and read
+// OPH_<NAME> from the environment for every name; a production build refuses the ablation names and never calls getenv for options.
 struct Options {
-    int decode = 0;                  // OPH_DECODE = loop (0, default where possible) | runs (1: two launches per step) | layers (2: one launch per layer)
-    int run_rows = 8;                // OPH_RUN_ROWS: utterance rows per workgroup of dec_loop (8 or 4)
+    int decode = 0;                  // DECODE = loop (0, default where possible) | runs (1: two launches per step) | layers (2: one launch per layer)
+    int run_rows = 8;                // RUN_ROWS: utterance rows per workgroup of dec_loop (8 or 4)
     // split-K of the cone GEMMs: many-row levels have enough tiles to fill the cone's CUs with less splitting (fewer partials
-    // to write and re-read).  OPH_CONE_KSPLIT="big,small", each 1..4; measured (profiles/r02): 3,4 best
+    // to write and re-read).  CONE_KSPLIT="big,small", each 1..4; measured (profiles/r02): 3,4 best
     int ksplit_big = 3, ksplit_small = CONE_KSPLIT;
-    int fc_rows = -1, fc_insplit = 2;   // OPH_CONE_FC_ROWS (cone levels of at most this many rows run as cone_fc16), OPH_CONE_FC_INSPLIT
-    int lookahead = 8;               // OPH_LOOP_LOOKAHEAD: cones the host may queue ahead of the loop kernel's progress
-    int loop_dbg = 0;                // OPH_LOOP_ALONE -> 32: the whole-decode launch without its side stream (counter passes; mel unused).
-                                     // The other ablation bits of dec_loop (OPH_LOOP_DBG) exist only in -DOPH_ABLATE builds
-    int cu_dec = 0, cu_cone = 0;     // OPH_CU_SPLIT="chain,cone" CUs of the three partitions (rest: SSRN)
-    bool no_cu_mask = false;         // OPH_NO_CU_MASK
-    bool no_cone_head = false, no_loop_qw = false, no_preencode = false, no_stream_ssrn = false, no_cone_loop = false;
-    int cone_prec = -1;              // OPH_CONE_PREC: the two many-row cone contractions: 0 fp32 MFMA, 1 split-bf16 x3 (experiment), 2 split-fp16 x3; -1 = the default
-    int ssrn_prec = -1;              // OPH_SSRN_PREC: 0 fp32 MFMA, 1 split-bf16 x3, 2 split-fp16 x3; -1 = the default (OPH_SSRN_FP32 = 0)
-    int textenc_prec = -1;           // OPH_TEXTENC_PREC: 0 fp32 MFMA, 2 split-fp16 x3; -1 = the default
-    bool ssrn_fp32 = false;          // OPH_SSRN_FP32
-    bool skip_cone = false;          // OPH_SKIP_CONE: timing experiments only, results are wrong
-    bool stream_value = false;       // OPH_STREAM_VALUE: per-step launch paths chain their two streams with stream value operations
-    bool run_stamps = false;         // OPH_RUN_STAMPS: clock stamps of the decode kernels' phases (printed under OPH_TRACE)
-    int ssrn_chunk = 40;             // OPH_SSRN_CHUNK: mel frames per streamed SSRN chunk (0 = SSRN only after the decode)
-    int ssrn_last = 0;               // OPH_SSRN_LAST: frames of the final piece (0 = whatever the chunks leave: max_T mod chunk, or a whole chunk)
-    int cl_wgs_per_cu = 2, cl_dbg = 0;   // OPH_CL_WGS_PER_CU (cone_loop workgroups per CU: 1 or 2), OPH_CL_DBG
-    bool hc_pair = false;            // OPH_HC_PAIR: the cone's last two levels as one hc_fused_pair launch (opt-in: measured 0.6 - 1.8 % slower than two
-                                     // hc_fused launches, profiles/r05_pair.txt -- a launch boundary costs less than an in-launch hand-off)
-    bool no_fused_cone = false;      // OPH_NO_FUSED_CONE: the cone's levels as contraction + ln_rows launches instead of hc_fused
-    int pg_waves = 0;                // OPH_PG_WAVES=4|8: the transposed convolution's plane_gemm form forced (64 channels per workgroup on 4 waves | 128 on 8;
+    int fc_rows = -1, fc_insplit = 2;   // CONE_FC_ROWS (cone levels of at most this many rows run as cone_fc16), CONE_FC_INSPLIT
+    int lookahead = 8;               // LOOP_LOOKAHEAD: cones the host may queue ahead of the loop kernel's progress
+    int loop_dbg = 0;                // -DOPH_ABLATE only: LOOP_ALONE -> 32 (the whole-decode launch without its side stream: counter passes; mel unused),
+                                     // LOOP_DBG = the other ablation bits of dec_loop
+    int cu_dec = 0, cu_cone = 0;     // CU_SPLIT="chain,cone" CUs of the three partitions (rest: SSRN)
+    bool no_cu_mask = false;         // NO_CU_MASK
+    bool no_cone_head = false, no_loop_qw = false, no_preencode = false, no_stream_ssrn = false;
+    int cone_prec = -1;              // CONE_PREC: the two many-row cone contractions: 0 fp32 MFMA, 1 split-bf16 x3 (experiment), 2 split-fp16 x3; -1 = the default
+    int ssrn_prec = -1;              // SSRN_PREC: 0 fp32 MFMA, 1 split-bf16 x3, 2 split-fp16 x3; -1 = the default
+    int textenc_prec = -1;           // TEXTENC_PREC: 0 fp32 MFMA, 2 split-fp16 x3; -1 = the default
+    bool skip_cone = false;          // -DOPH_ABLATE only: SKIP_CONE: timing experiments, results are wrong
+    bool stream_value = false;       // STREAM_VALUE: per-step launch paths chain their two streams with stream value operations
+    bool run_stamps = false;         // RUN_STAMPS: clock stamps of the decode kernels' phases (printed under OPH_TRACE); takes dec_loop
+    int ssrn_chunk = 40;             // SSRN_CHUNK: mel frames per streamed SSRN chunk (0 = SSRN only after the decode)
+    bool no_fused_cone = false;      // NO_FUSED_CONE: the cone's levels as contraction + ln_rows launches instead of hc_fused
+    int pg_waves = 0;                // PG_WAVES=4|8: the transposed convolution's plane_gemm form forced (64 channels per workgroup on 4 waves | 128 on 8;
                                      // 0 = the launcher's choice); in -DOPH_ABLATE builds 8 also selects the 8-wave forms of the other layers
-    bool no_plane_gemm = false;      // OPH_NO_PLANE_GEMM: the batched nets' split-fp16 contractions on fp32 rows (conv_gemm_bf16x3) instead of planes (plane_gemm)
-    int aql_split = 0;               // OPH_AQL_SPLIT: first cone level of the second lane in OPH_AQL=3 (0 = the middle: 3 of 6)
-    bool no_chain = false;           // OPH_NO_CHAIN: the whole-decode launch as dec_loop (generic) even where dec_chain (specialised) fits
-    void read() {
-        auto flag = [](const char* n) { return getenv(n) != nullptr; };
-        auto num = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
-        if (const char* m = getenv("OPH_DECODE")) decode = !strcmp(m, "runs") ? 1 : (!strcmp(m, "layers") ? 2 : 0);
-        if (flag("OPH_NO_DECRUN")) decode = 2;
-        else if (flag("OPH_NO_DECLOOP") && decode == 0) decode = 1;
-        run_rows = num("OPH_RUN_ROWS", 8) == 4 ? 4 : 8;
-        if (const char* e = getenv("OPH_CONE_KSPLIT")) { int a_ = 0, b_ = 0; if (sscanf(e, "%d,%d", &a_, &b_) == 2 && a_ >= 1 && a_ <= CONE_KSPLIT && b_ >= 1 && b_ <= CONE_KSPLIT) { ksplit_big = a_; ksplit_small = b_; } }
-        fc_rows = num("OPH_CONE_FC_ROWS", -1); fc_insplit = std::max(1, num("OPH_CONE_FC_INSPLIT", 2));
-        lookahead = num("OPH_LOOP_LOOKAHEAD", 8);
-        loop_dbg = flag("OPH_LOOP_ALONE") ? 32 : 0;
+    bool no_plane_gemm = false;      // NO_PLANE_GEMM: the batched nets' split-fp16 contractions on fp32 rows (conv_gemm_bf16x3) instead of planes (plane_gemm)
+    bool no_chain = false;           // NO_CHAIN: the whole-decode launch as dec_loop (generic) even where dec_chain (specialised) fits
+    // spec: the option string or NULL.  Returns false (and says why) on a name this build does not know.
+    bool read(const char* spec, std::string* why) {
+        static const char* const known[] = {"DECODE", "RUN_ROWS", "CONE_KSPLIT", "CONE_FC_ROWS", "CONE_FC_INSPLIT", "LOOP_LOOKAHEAD", "CU_SPLIT", "NO_CU_MASK", "NO_CONE_HEAD",
+                                            "NO_LOOP_QW", "NO_PREENCODE", "NO_STREAM_SSRN", "CONE_PREC", "SSRN_PREC", "TEXTENC_PREC", "STREAM_VALUE", "RUN_STAMPS", "SSRN_CHUNK",
+                                            "NO_FUSED_CONE", "PG_WAVES", "NO_PLANE_GEMM", "NO_CHAIN",
 #ifdef OPH_ABLATE
-        loop_dbg = num("OPH_LOOP_DBG", loop_dbg);
+                                            "SKIP_CONE", "LOOP_ALONE", "LOOP_DBG",
 #endif
-        if (const char* sp = getenv("OPH_CU_SPLIT")) { int a_ = 0, b_ = 0; if (sscanf(sp, "%d,%d", &a_, &b_) == 2 && a_ > 0 && b_ > 0) { cu_dec = a_; cu_cone = b_; } }
-        no_cu_mask = flag("OPH_NO_CU_MASK");
-        no_cone_head = flag("OPH_NO_CONE_HEAD"); no_loop_qw = flag("OPH_NO_LOOP_QW"); no_preencode = flag("OPH_NO_PREENCODE");
-        no_stream_ssrn = flag("OPH_NO_STREAM_SSRN");
-        // the cone as one persistent launch (cone_loop) is opt-in: measured 25.5-26.1 ms per batch against 25.0 ms with the nine
-        // launches per step; it frees the host thread from enqueuing, which matters with 8 ranks on one node
-        no_cone_loop = !flag("OPH_CONE_LOOP") || flag("OPH_NO_CONE_LOOP");
-        ssrn_fp32 = flag("OPH_SSRN_FP32"); skip_cone = flag("OPH_SKIP_CONE");
-        cone_prec = num("OPH_CONE_PREC", flag("OPH_CONE_BF16X3") ? 1 : -1); if (cone_prec > 2) cone_prec = -1;
-        ssrn_prec = num("OPH_SSRN_PREC", ssrn_fp32 ? 0 : -1); if (ssrn_prec > 2) ssrn_prec = -1;
-        textenc_prec = num("OPH_TEXTENC_PREC", -1); if (textenc_prec != 0 && textenc_prec != 2) textenc_prec = -1;
-        { const char* sv = getenv("OPH_STREAM_VALUE"); stream_value = sv && atoi(sv) != 0; }
-        run_stamps = flag("OPH_RUN_STAMPS");
-        ssrn_chunk = std::max(0, num("OPH_SSRN_CHUNK", 40)); ssrn_last = std::max(0, num("OPH_SSRN_LAST", 0));
-        cl_wgs_per_cu = num("OPH_CL_WGS_PER_CU", 2) == 1 ? 1 : 2; cl_dbg = num("OPH_CL_DBG", 0);
-        aql_split = num("OPH_AQL_SPLIT", 0);
-        no_chain = flag("OPH_NO_CHAIN"); no_fused_cone = flag("OPH_NO_FUSED_CONE"); hc_pair = flag("OPH_HC_PAIR"); no_plane_gemm = flag("OPH_NO_PLANE_GEMM"); pg_waves = num("OPH_PG_WAVES", 0); if (pg_waves != 4 && pg_waves != 8) pg_waves = 0;
+        };
+        std::map<std::string, std::string> kv;
+        for (const char* p = spec ? spec : ""; *p;) {
+            while (*p == ' ' || *p == ';' || *p == '\t' || *p == '\n') ++p;
+            const char* e = p;
+            while (*e && *e != ' ' && *e != ';' && *e != '\t' && *e != '\n') ++e;
+            if (e == p) break;
+            std::string tok(p, e);
+            const size_t eq = tok.find('=');
+            const std::string name = tok.substr(0, eq), val = eq == std::string::npos ? std::string("1") : tok.substr(eq + 1);
+            bool ok = false;
+            for (const char* k : known) ok = ok || name == k;
+            if (!ok) { if (why) *why = "unknown option '" + name + "' (oph_create_opts)"; return false; }
+            kv[name] = val;
+            p = e;
+        }
+#ifdef OPH_ABLATE
+        for (const char* k : known)
+            if (!kv.count(k)) { const std::string en = std::string("OPH_") + k; if (const char* e = getenv(en.c_str())) kv[k] = e; }
+#endif
+        auto str = [&](const char* n) -> const char* { auto it = kv.find(n); return it == kv.end() ? nullptr : it->second.c_str(); };
+        auto flag = [&](const char* n) { return str(n) != nullptr; };
+        auto num = [&](const char* n, int dflt) { const char* e = str(n); return e ? atoi(e) : dflt; };
+        if (const char* m = str("DECODE")) decode = !strcmp(m, "runs") ? 1 : (!strcmp(m, "layers") ? 2 : 0);
+        run_rows = num("RUN_ROWS", 8) == 4 ? 4 : 8;
+        if (const char* e = str("CONE_KSPLIT")) { int a_ = 0, b_ = 0; if (sscanf(e, "%d,%d", &a_, &b_) == 2 && a_ >= 1 && a_ <= CONE_KSPLIT && b_ >= 1 && b_ <= CONE_KSPLIT) { ksplit_big = a_; ksplit_small = b_; } }
+        fc_rows = num("CONE_FC_ROWS", -1); fc_insplit = std::max(1, num("CONE_FC_INSPLIT", 2));
+        lookahead = num("LOOP_LOOKAHEAD", 8);
+        loop_dbg = num("LOOP_DBG", flag("LOOP_ALONE") ? 32 : 0);        // (names a production build has refused above)
+        skip_cone = flag("SKIP_CONE");
+        if (const char* sp = str("CU_SPLIT")) { int a_ = 0, b_ = 0; if (sscanf(sp, "%d,%d", &a_, &b_) == 2 && a_ > 0 && b_ > 0) { cu_dec = a_; cu_cone = b_; } }
+        no_cu_mask = flag("NO_CU_MASK");
+        no_cone_head = flag("NO_CONE_HEAD"); no_loop_qw = flag("NO_LOOP_QW"); no_preencode = flag("NO_PREENCODE");
+        no_stream_ssrn = flag("NO_STREAM_SSRN");
+        cone_prec = num("CONE_PREC", -1); if (cone_prec > 2) cone_prec = -1;
+        ssrn_prec = num("SSRN_PREC", -1); if (ssrn_prec > 2) ssrn_prec = -1;
+        textenc_prec = num("TEXTENC_PREC", -1); if (textenc_prec != 0 && textenc_prec != 2) textenc_prec = -1;
+        stream_value = num("STREAM_VALUE", 0) != 0;
+        run_stamps = flag("RUN_STAMPS");
+        ssrn_chunk = std::max(0, num("SSRN_CHUNK", 40));
+        no_chain = flag("NO_CHAIN"); no_fused_cone = flag("NO_FUSED_CONE"); no_plane_gemm = flag("NO_PLANE_GEMM"); pg_waves = num("PG_WAVES", 0); if (pg_waves != 4 && pg_waves != 8) pg_waves = 0;
+        return true;
     }
     int cone_ksplit(int M) const { return M >= 512 ? ksplit_big : ksplit_small; }
 };
@@ -180,28 +196,6 @@ struct Tile {
                                             // <= ssrn_done: chunks computed while no destination was set (a resumed decode) are not copied
 };
 
-// The pipelined cone's launches of a run of decode steps, recorded by launch_cone instead of being launched on the HIP stream:
-// kernel arguments in a pinned staging area (one 256-byte slot per launch), one record per AQL packet (oph_aql.h)
-struct AqlPacketRec { int kernel; uint32_t grid, block, lds; size_t arg_off; int lane, wait_sig, done_sig; };
-struct AqlRecorder {
-    std::vector<AqlPacketRec> pk;
-    char* stage = nullptr; size_t stage_cap = 0, used = 0;
-    int nth = 0;                        // cone steps recorded since the level counters were zeroed (1-based while a step is being recorded)
-    bool overflow = false;
-    bool pipelined = false;             // the launches order themselves on the device (hc_fused<true> / cone_head<true> on alternating lanes); else
-                                        // the plain kernels on one lane with the barrier bit: what the HIP stream did, without its host cost
-    int split = 0;                      // > 0 (OPH_AQL=3): the cone's levels >= split run on a second lane, behind a packet-processor dependency on
-                                        // the launch of level split - 1 (a device-only signal per step): the small levels of step t overlap the head
-                                        // and the large levels of step t + 1.  Plain kernels, barrier bits within a lane.
-    // lane / wait_sig / done_sig: split mode only (wait_sig >= 0: a barrier-AND packet on that signal goes in front of the launch)
-    void add(int kernel, uint32_t grid, uint32_t block, uint32_t lds, const void* args, size_t bytes, int lane = 0, int wait_sig = -1, int done_sig = -1) {
-        if (used + 256 > stage_cap || bytes > 256) { overflow = true; return; }
-        memcpy(stage + used, args, bytes);
-        pk.push_back({kernel, grid, block, lds, used, lane, wait_sig, done_sig});
-        used += 256;
-    }
-};
-
 struct oph_handle {
     oph_dims dm{};
     Options opt;
@@ -220,15 +214,6 @@ struct oph_handle {
     bool ssrn_inflight[2] = {false, false};
     int buf = 0; bool pipelined = false;
     uint32_t m_cone[16] = {0}, m_conep[16] = {0}, m_ssrn[16] = {0}; int mask_words = 0;   // CU partitions (0 words = no masking)
-    // pipelined cone (oph_aql.h): an AQL queue of our own on the cone partition's CUs, lent with the masked streams
-    AqlQueue* aql = nullptr; AqlKernel aql_k[5];        // [0] oph_cone_head_coh, [1] oph_hc_fused_coh, [2] oph_cone_head_plain, [3] oph_hc_fused_plain, [4] oph_gate
-    int aql_mode = 0;                                   // OPH_AQL: 0 off (HIP stream), 1 one lane + barrier bits + plain kernels, 2 pipelined on two lanes,
-                                                        // 3 split: head + large levels on lane 0, the small levels on lane 1 behind a signal dependency
-    AqlRecorder aql_store; AqlRecorder* aql_rec = nullptr;      // aql_rec != null while launch_cone records instead of launching
-    char* d_kernarg = nullptr; size_t kernarg_cap = 0;  // device copy of the recorded kernel arguments
-    unsigned* d_lvl_count = nullptr;                    // completion counters [LOOP_MAX_LEVELS][8 shards][16 words]
-    bool aql_used = false;                              // packets were submitted since the queue was last seen idle
-    long long n_aql_decodes = 0;
     bool masked_borrowed = false;      // sdec / scone / sssrn are the device's process-wide CU-masked streams (oph_api.hip): returned, not destroyed
     int ssrn_prec = 2;                 // SSRN contractions: 2 = split-fp16 x3 (fp32 accumulate, fp32-class accuracy), 1 = split-bf16 x3, 0 = fp32 MFMA
     hipEvent_t ev_attn = nullptr, ev_cone = nullptr;
@@ -336,13 +321,7 @@ struct oph_handle {
     // dec_loop mode: the cone waits / signals inside its own first / last launch
     bool cone_inline_sig = false; uint32_t cone_wait_val = 0, cone_done_val = 0, cone_done_total[LOOP_MAX_LEVELS] = {0};     // per cone level: arrivals so far
     unsigned* d_cone_count = nullptr;
-    // the cone as ONE persistent launch beside dec_loop (cone_loop, oph_coneloop.hip)
-    bool cone_loop_ok = false;          // this model's geometry fits it (d = 256, no speaker concat / LCC / nonorm in AudioDec)
-    int cone_loop_wgs = -1;             // its grid: workgroups that are resident at once on the cone partition (multiple of 8; -1: not asked yet)
-    unsigned* d_cl_flags = nullptr; unsigned long long* d_cl_stats = nullptr;     // [flags | level counters], statistics granules
-    uint32_t cl_epoch = 0;
-    long long* d_cldbg = nullptr;       // OPH_RUN_STAMPS: cone_loop's per-step stamps
-    long long n_cone_loops = 0;
+    long long* d_cldbg = nullptr;       // OPH_RUN_STAMPS: hc_fused's phase stamps of workgroup 0, [level][8]
     float *coneR = nullptr, *coneRaw = nullptr, *coneTmp = nullptr;
     // the cone's levels as one launch each (hc_fused): every level also as fp16 hi / lo planes, the LayerNorm exchange granules
     bool cone_fused_ok = false;         // weights packed for it (standard geometry)
@@ -351,8 +330,6 @@ struct oph_handle {
     size_t hcf_stats_stride = 0;        // granules of one level's statistics region
     // hc_fused_pair (the cone's last two levels in one launch): the two levels' step-independent arguments per step parity, the word
     // their workgroups count into between the levels, how often they have (8 per launch)
-    HcFusedArgs hcpair_host[4];         // (the upload's source: alive for as long as the asynchronous copy may read it)
-    HcFusedArgs* d_hcpair = nullptr; unsigned* d_hcpair_sync = nullptr; bool hcpair_ready[2] = {false, false}; uint32_t hcpair_syncs = 0;
     int ldy = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

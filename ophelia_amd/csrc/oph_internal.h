@@ -166,10 +166,6 @@ struct ConeHeadArgs {
     const unsigned* wait_sig;
     unsigned* done_sig; unsigned* done_count;          // as EpiArgs: cone level 0 written
     long long* done_stamp;
-    unsigned* lvl_count;                // pipelined cone (oph_aql.h): completion counters [level][8 shards][16 words]; every workgroup of a
-                                        // launch counts into (level lvl_out, shard blockIdx & 7) when its rows have left (write-through)
-    short lvl_out;                      // -1: not pipelined (a HIP stream orders the launches)
-    short lvl_nth;                      // this is the nth cone step since the counters were zeroed (1-based)
     int d, N_keys, win, ldvw, ldn, nonorm;
     int B, Bpad, nrows, j;
     int npos; int i_new;                // positions (nrows = npos * Bpad); index of the newest one (smallest offset)
@@ -179,7 +175,6 @@ struct ConeHeadArgs {
 };
 static_assert(sizeof(ConeHeadArgs) <= 256, "cone_head's kernel arguments: four 64-byte lines");
 void launch_cone_head(const ConeHeadArgs& a, hipStream_t s);
-void launch_probe_spin(long long ticks, long long* out, hipStream_t s);
 
 // ---- hc_fused: a level of the AudioDec history cone as ONE launch (oph_hcfused.hip): split-fp16 x3 contraction with both operands
 // as fp16 hi / lo planes through global_load_lds, then LayerNorm x 2 + gate + highway mix in the same kernel -- the 8 column tiles of
@@ -199,11 +194,6 @@ struct HcFusedArgs {
     unsigned* done_sig; unsigned* done_count;           // as EpiArgs
     long long* done_stamp;
     long long* dbg;                                     // diagnostics: phase stamps of workgroup 0 [8], or null
-    unsigned* lvl_count;                                // pipelined cone (hc_fused<true>, oph_aql.h): completion counters [level][8 shards][16 words]
-    unsigned lvl_io;                                    // ... lvl_in | lvl_out << 8 | in_mult << 16: wait until every workgroup of level lvl_in's launch
-                                                        // of this step has counted in, count into lvl_out when this workgroup's rows have left
-    unsigned lvl_n;                                     // ... in_units | nth << 16: the producer's launch has in_mult workgroups per unit, unit u in shard
-                                                        // u & 7; this is the nth cone step since the counters were zeroed
     int in_rows, n_out, j;
     int Bpad, M;                                        // M = n_out * Bpad output rows
     unsigned epoch;                                     // tag of this launch's granules (never reused)
@@ -211,18 +201,6 @@ struct HcFusedArgs {
     unsigned done_val, done_target; int coh0, coh1;
 };
 static_assert(sizeof(HcFusedArgs) <= 256, "hc_fused's kernel arguments: four 64-byte lines");
-// hc_fused_pair: two consecutive one-row-block levels in one launch (oph_hcfused.hip)
-struct HcPairArgs {
-    const HcFusedArgs* lv;              // device memory: [2] the two levels' arguments as a launch of their own would get them; the fields below are patched in
-    unsigned* sync; int* ctl;           // the word the eight active workgroups count into between the levels; the tile's control words
-    long long* done_stamp0; long long* done_stamp1; long long* dbg0; long long* dbg1;
-    unsigned* done_sig0; unsigned* done_sig1; unsigned* done_count0; unsigned* done_count1;      // (null on launch paths that order the cone by stream operations)
-    unsigned sync_target; int t;
-    unsigned epoch0, epoch1, done_val, done_target0, done_target1;
-    int coh00, coh01, coh10, coh11;
-};
-static_assert(sizeof(HcPairArgs) <= 256, "hc_fused_pair's kernel arguments: four 64-byte lines");
-void launch_hc_fused_pair(const HcPairArgs& p, hipStream_t s);
 void launch_hc_fused(const HcFusedArgs& a, hipStream_t s);
 size_t hc_fused_lds_bytes();
 int hc_fused_grid(int M);
@@ -357,8 +335,6 @@ constexpr int LOOP_DESC_WORDS = 20, LOOP_DESC_STRIDE = 32;
 // modes); sig[LOOP_SIG_LEVEL0 + 16 k] level k of the cone of step t written (dec_loop: the layer whose taps read level k
 // waits for that word only -- the cone's later levels are still being computed while the chain's first tap layers run).
 constexpr int LOOP_SIG_LEVEL0 = 32, LOOP_SIG_WORDS = 256, LOOP_MAX_LEVELS = 8;
-// oph_gate (oph_conehead.hip): one wave spins until *w32 >= want (w32 non-null) or *w64 <= 0
-struct GateArgs { const unsigned* w32; const long long* w64; int* ctl; unsigned want; int t; };
 struct LoopArgs {
     int nlayers; int B; int Bpad; int t_begin, t_end; int stop_mode;      // steps [t_begin, t_end)
     int attn_layer;                     // index of the RUN_ATTN layer
@@ -393,47 +369,12 @@ int dec_loop_blocks_per_cu(int rows_per_group, int kmax);
 void launch_dec_chain(const LoopArgs& a, int col_slices, hipStream_t s);
 int dec_chain_blocks_per_cu();
 
-// ---- the AudioDec history cone of every decode step in ONE persistent launch beside dec_loop (oph_coneloop.hip).
-// Level 0 = the cone head (attention rows through the cached V.Wc / Q.Wq terms + LayerNorm); level k >= 1 = highway layer k-1
-// evaluated at the positions of Hset[k], with LayerNorm x 2 + gate + mix in the same task.  Geometry: d = 256 channels,
-// 3 taps x 256 = 768 K, 16 utterance rows.
-constexpr int CL_MAX_LEVELS = 8, CL_MAX_POS = 96;
-constexpr int CL_NCH = 48;                  // 4-wide k groups per k-quarter: 768 / 4 quarters / 4
-struct ConeLoopLevel {
-    int npos;                               // positions of this level (|Hset[k]|)
-    const float* Wsw;                       // highway layer k-1's kernel in the lanes' fragment order: [8 column groups][4 waves][CL_NCH][64 lanes][4]
-    const float* bias;                      // [2 * 256]
-    const float *g1, *b1, *g2, *b2;         // LayerNorm parameters of H1 / H2
-    const int* tab; const int* need;        // [3][npos]: source position in level k-1 per tap (oldest first); valid iff t >= need
-    float* rows[2];                         // this level's rows [npos][16][256], ping-pong over the step parity
-    int sig_pos0, sig_pos1;                 // the two positions dec_loop's taps read: when both are written the level's word is raised
-};
-struct ConeLoopArgs {
-    int nlevels; int t_begin, t_end; int B; int d;
-    int npos0; const int* off0; float* rows0[2]; int sig0_pos0, sig0_pos1;        // level 0
-    const float* Q; const float* QW; const float* KV; const float* VW; int ldvw; int N_keys; int win;
-    const float* gamma0; const float* beta0;
-    const int* p;                           // prev_max double buffer [2][16]
-    ConeLoopLevel L[CL_MAX_LEVELS];         // [1 .. nlevels)
-    unsigned* flags;                        // [2 parities][CL_MAX_LEVELS][CL_MAX_POS] tasks completed per (level, position); zero at launch
-    unsigned* levelcnt;                     // [2][CL_MAX_LEVELS] arrivals of the tap positions; zero at launch
-    unsigned long long* stats;              // granules [2][CL_MAX_LEVELS][CL_MAX_POS][8][64]
-    unsigned epoch0;                        // statistics tag of (step t, level k) = epoch0 + t * CL_MAX_LEVELS + k, never reused
-    unsigned* sig; unsigned sig_base;       // as LoopArgs
-    int* ctl;                               // [1] stop step  [2] error
-    long long* stamps;                      // diagnostics (OPH_RUN_STAMPS): [max_T][8] clock stamps: cone(t) released, level k's word raised; [7] = misplaced workgroups
-    int dbg;                                // 1: gather with 8-byte atomics (ld_coherent) instead of 16-byte sc1 loads
-};
-void launch_cone_loop(const ConeLoopArgs& a, int nwg, hipStream_t s);     // nwg: multiple of 8, all resident
-int cone_loop_blocks_per_cu();
-
 // weight repacking on the device (oph_pack.hip)
 void launch_pack_conv(const float* k, float* Wt, int size, int cin, int cout, int kc, int Nalloc, hipStream_t s);
 void launch_pack_convT(const float* kt, float* We, float* Wo, int cin, int cout, int kc, int Nalloc, hipStream_t s);
 void launch_pack_wkn(const float* k, float* Wkn, int cin, int N, int kc, int ldn, hipStream_t s);
 void launch_pack_wtc(const float* k, float* Wc, int d, int kc_c, int ldvw, hipStream_t s);
 void launch_pack_hcf(const float* kr, const float* bs, float* wp, float* bp, hipStream_t s);
-void launch_pack_coneloop(const float* kr, float* ws, int nch, hipStream_t s);
 void launch_pack_loop(const float* Wt, int ldw, int rows_have, int nch, int slices, int R, int PF, float* dst, hipStream_t s);
 void launch_pad_copy(const float* src, float* dst, size_t n, size_t npad, int mode, int row0, hipStream_t s);
 void launch_maxabs(const float* x, size_t n, unsigned* out, hipStream_t s);

@@ -435,28 +435,6 @@ static int finalize_weights_impl(oph_handle* h) {
         if (!h->Wt_c || !k) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
         launch_pack_wtc(k, h->Wt_c, d, h->kc_c, h->ldvw, h->stream);
     }
-    // cone_loop: every AudioDec highway layer but the last is re-evaluated over history positions by resident workgroups; its
-    // kernel in the lanes' fragment order: [column group cg][wave w][k group i][lane][4] with
-    //   column = (w >> 1) * C + 32 cg + 16 (w & 1) + (lane & 15)        (wave 0,1: H1 channels of the group, wave 2,3: the same channels of H2)
-    //   k      = 192 (lane >> 4) + 4 i + e                               (k over [tap x[t-2r] | tap x[t-r] | x[t]] x 256 channels)
-    {
-        const int pre = h->dec_pre, nh = h->n_hc_dec, d = h->dm.d;
-        bool ok = !h->opt.no_cone_loop && h->cone_head_ok && pre == 1 && d == 256 && !(h->dm.flags & (OPH_FLAG_LCC | OPH_FLAG_NORM_NONE | OPH_FLAG_NO_MONOTONIC)) &&
-                  h->dm.attention_win_size <= 4 && nh >= 2 && nh <= CL_MAX_LEVELS;      // (opt-in persistent cone; packed on the device like the rest)
-        for (int k = 0; ok && k + 1 < nh; ++k) {
-            const Layer& l = h->audiodec[pre + k];
-            ok = l.kind == K_HC && l.ntaps == 3 && l.kc == 256 && l.cout == 256 && l.cin == 256 && l.ln && !l.lcc && l.ccat == 0 && l.causal;
-        }
-        for (int k = 0; ok && k + 1 < nh; ++k) {
-            Layer& l = h->audiodec[pre + k];
-            const float* kr = dev_tensor(h, l.scope + "/conv1d/kernel");      // (3, 256, 512)
-            float* ws = h->dalloc<float>((size_t)8 * 4 * CL_NCH * 64 * 4);
-            if (kr && ws) launch_pack_coneloop(kr, ws, CL_NCH, h->stream);
-            l.Wsw_cone = (kr && ws) ? ws : nullptr;
-            if (!l.Wsw_cone) { h->fail("out of device memory"); return OPH_ERR_DEVICE; }
-        }
-        h->cone_loop_ok = ok;
-    }
     // hc_fused: the cone's levels as one launch each.  Kernel of AudioDec highway layer k as planes with the output columns permuted
     // per 64-tile to [32 H1 channels | the same 32 channels of H2]
     {

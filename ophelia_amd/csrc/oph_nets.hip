@@ -267,9 +267,6 @@ int ssrn_stream_chunks(oph_handle* h, int frames_ready, bool final, bool side_ta
         if (final) b = m.max_T;
         else {
             b = a + ch;
-            // (the last frames always belong to the final piece; OPH_SSRN_LAST = x > 0 keeps it to x frames: the frames in front of them
-            //  leave as one shorter chunk on the partition as soon as they can)
-            if (b >= m.max_T && h->opt.ssrn_last > 0 && a < m.max_T - h->opt.ssrn_last) b = m.max_T - h->opt.ssrn_last;
             if (b + ahead > frames_ready || b >= m.max_T) break;
             // one chunk in flight on the partition; its measured duration tells whether another one can still finish before
             // the decode does -- if not, those frames are cheaper in the final piece on the whole chip

@@ -230,7 +230,7 @@ int oph_bench_conv1d_transpose(int device, int B, int T, int Cin, int Cout, int 
 #ifdef OPH_ABLATE
         pg_dbg = 1 << (precision - 6); precision = 2;
 #else
-        g_op_error = "precisions 6..9 (ablation builds of plane_gemm) exist only in libraries built with -DOPH_ABLATE"; return OPH_ERR_UNSUPPORTED;
+        g_op_error = "precisions 6..9 (ablation builds of plane_gemm) exist only in measurement builds of the library (ABLATE)"; return OPH_ERR_UNSUPPORTED;
 #endif
     }      // measurement only: plane_gemm without its MFMAs / without its operand stream
     const bool planes = precision == 2;

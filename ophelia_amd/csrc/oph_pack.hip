@@ -60,15 +60,6 @@ __global__ void pack_loop_k(const float* Wt, int ldw, int rows_have, int nch, in
     if (col < rows_have) v = *(const f32x4*)(Wt + (size_t)col * ldw + k);
     *(f32x4*)(dst + i * 4) = v;
 }
-// highway kernel (3, 256, 512) -> cone_loop's lane order [column group cg][wave w][k group i][lane][4]:
-// column = (w >> 1) * 256 + 32 cg + 16 (w & 1) + (lane & 15), k = 192 (lane >> 4) + 4 i + e
-__global__ void pack_coneloop_k(const float* kr, float* ws, int nch) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)8 * 4 * nch * 64 * 4) return;
-    const int e = (int)(i & 3), lane = (int)((i >> 2) & 63), ii = (int)((i >> 8) % nch), w = (int)((i >> 8) / nch % 4), cg = (int)((i >> 8) / ((size_t)nch * 4));
-    const int col = (w >> 1) * 256 + 32 * cg + 16 * (w & 1) + (lane & 15), kk = 192 * (lane >> 4) + 4 * ii + e, tap = kk / 256, c = kk % 256;
-    ws[i] = kr[((size_t)tap * 256 + c) * 512 + col];
-}
 // vectors and tables: dst[i] = i < n ? f(src[i]) : 0; mode 1: learned channel contributions -- sigmoid(x), row 0 of the table reads as
 // zeros (modules.embed zero-pads it, modules.py:38-40)
 __global__ void pad_copy_k(const float* src, float* dst, size_t n, size_t npad, int mode, int row0) {
@@ -112,11 +103,6 @@ void launch_maxabs(const float* x, size_t n, unsigned* out, hipStream_t s) {
 void launch_pack_loop(const float* Wt, int ldw, int rows_have, int nch, int slices, int R, int PF, float* dst, hipStream_t s) {
     const size_t n = (size_t)slices * R * PF * 64;
     hipLaunchKernelGGL(pack_loop_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Wt, ldw, rows_have, nch, slices, R, PF, dst);
-}
-
-void launch_pack_coneloop(const float* kr, float* ws, int nch, hipStream_t s) {
-    const size_t n = (size_t)8 * 4 * nch * 64 * 4;
-    hipLaunchKernelGGL(pack_coneloop_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, kr, ws, nch);
 }
 
 }  // namespace oph

@@ -110,13 +110,20 @@ class Engine(object):
     results) or builds the engine with resident_results=False: every result is then a plain writable array and every input is
     uploaded, exactly the reference's data flow."""
 
-    def __init__(self, hp, device=0, max_N=None, max_T=None, resident_results=None):
+    def __init__(self, hp, device=0, max_N=None, max_T=None, resident_results=None, options=None):
+        """options: launch-path / arithmetic options of oph_create_opts (include/ophelia_hip.h) as a dict {"DECODE": "runs", "NO_CHAIN": 1}
+        or the string itself; default hp.engine_options, else none.  The library reads no environment variable for them."""
         self.lib = _lib.load()
         self.dims = dims_from_hp(hp, max_N, max_T)
         self.hp = hp
         self.device = int(device)
         self._h = C.c_void_p()
-        rc = self.lib.oph_create(C.byref(self.dims), int(device), C.byref(self._h))
+        if options is None:
+            options = getattr(hp, "engine_options", None)
+        if isinstance(options, dict):
+            options = " ".join("%s=%s" % (k, v) for k, v in options.items())
+        self.options = options or ""
+        rc = self.lib.oph_create_opts(C.byref(self.dims), int(device), self.options.encode() or None, C.byref(self._h))
         if rc != 0:
             raise _lib.OpheliaHipError("oph_create failed (%d): %s" % (rc, self.lib.oph_last_error(None).decode()))
         self.multispeaker = bool(self.dims.flags & (_lib.FLAG_SPK_AUDIO_DECODER_INPUT | _lib.FLAG_SPK_TEXT_ENCODER_INPUT |

@@ -76,3 +76,27 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "oph_cpu" not in src, f
+
+
+def test_production_library_reads_no_option_from_the_environment():
+    """the production library's launch paths and arithmetic are chosen through oph_create_opts only.  The one
+    environment variable it reads is OPH_TRACE (diagnostics on stderr): no other OPH_* name may appear in the binary, so an inherited
+    OPH_SKIP_CONE / OPH_LOOP_ALONE / OPH_DECODE cannot change a result or a launch path (the GPU leg is tests/test_gpu_misuse.py)."""
+    import re
+    from ophelia_amd import _lib
+    data = open(_lib.LIBPATH, "rb").read()
+    names = set(m.decode() for m in re.findall(rb"OPH_[A-Z][A-Z0-9_]+", data))
+    assert names <= {"OPH_TRACE"}, names
+    # and the option parser refuses a name it does not know -- the ablation switches among them -- before it touches a device
+    lib = _lib.load()
+    import ctypes as C
+    d = _lib.OphDims()
+    for f, v in (("vocab", 32), ("e", 128), ("d", 256), ("c", 512), ("n_mels", 80), ("full_dim", 1025), ("r", 4), ("max_N", 20), ("max_T", 12),
+                 ("attention_win_size", 3)):
+        setattr(d, f, v)
+    h = C.c_void_p()
+    rc = lib.oph_create_opts(C.byref(d), 0, b"SKIP_CONE=1", C.byref(h))
+    assert rc != 0 and not h.value
+    msg = lib.oph_last_error(None).decode()
+    # (without a GPU the device check comes first; with one, the parser names the option)
+    assert "SKIP_CONE" in msg or "no HIP device" in msg, msg

@@ -101,3 +101,33 @@ def test_wrong_order_and_bad_arguments_are_errors_not_crashes(model):
 
     after = _batch(eng, O, hp)
     assert all(np.array_equal(a, b) for a, b in zip(before, after)), "the handle does not serve the same batch the same way after the errors"
+
+
+def test_inherited_environment_cannot_change_a_result_or_a_launch_path(model, monkeypatch):
+    """OPH_SKIP_CONE ("results are wrong") and OPH_LOOP_ALONE ("mel unused") used to be read by every production
+    build.  Now the launch paths are options of oph_create_opts and the ablation names exist only in -DOPH_ABLATE builds: with the
+    old variables in the environment a fresh handle computes the same bits through the same launches, and asking for an ablation
+    option explicitly is an error."""
+    from ophelia_amd.engine import Engine
+    from ophelia_amd import _lib
+    hp, eng, O = model
+    W = O.random_weights(hp, 9)
+    want = _batch(eng, O, hp, B=16, seed=11)
+    for k, v in (("OPH_SKIP_CONE", "1"), ("OPH_LOOP_ALONE", "1"), ("OPH_LOOP_DBG", "32"), ("OPH_DECODE", "layers"), ("OPH_NO_CHAIN", "1"),
+                 ("OPH_SSRN_PREC", "1"), ("OPH_CONE_PREC", "1"), ("OPH_NO_CU_MASK", "1"), ("OPH_SSRN_CHUNK", "3")):
+        monkeypatch.setenv(k, v)
+    e2 = Engine(hp, device=0)
+    try:
+        e2.load_weights(W)
+        c0 = e2.counters()
+        got = _batch(e2, O, hp, B=16, seed=11)
+        c1 = e2.counters()
+        for a, b, what in zip(got, want, ("Y", "alignments", "Z")):
+            assert np.array_equal(a, b), "%s differs under an inherited OPH_* environment" % what
+        assert c1["loop_decodes"] - c0["loop_decodes"] == 1 and c1["masked_streams"] == 1      # the default launch path ran
+    finally:
+        e2.close()
+    for bad in ("SKIP_CONE=1", "LOOP_ALONE", "LOOP_DBG=32", "NO_SUCH_OPTION=1"):
+        with pytest.raises(_lib.OpheliaHipError) as ei:
+            Engine(hp, device=0, options=bad)
+        assert bad.split("=")[0] in str(ei.value)

@@ -12,9 +12,9 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def _engine(hp, W):
+def _engine(hp, W, options=None):
     from ophelia_amd.engine import Engine
-    eng = Engine(hp, device=0)
+    eng = Engine(hp, device=0, options=options)
     eng.load_weights(W)
     return eng
 
@@ -150,26 +150,15 @@ def test_plane_gemm_wave_forms_and_the_row_kernel_agree(c2):
     """SSRN's split-fp16 contractions run on pre-split fp16 planes (plane_gemm, oph_planegemm.hip).  The transposed convolution has
     a 4-wave form (64 channels of both phases per workgroup) and an 8-wave form (128); they sum every output element in the same
     order -- bitwise equal, whichever the launcher picks (D_4: 4 waves, D_7: 8 at this size) -- and the round-3 kernel on fp32 rows
-    (OPH_NO_PLANE_GEMM: another K order) agrees within the fp32 class."""
-    import os
+    (option NO_PLANE_GEMM: another K order) agrees within the fp32 class."""
     hp, W, L, _ = c2
     Y0 = np.random.default_rng(5).random((16, hp.max_T, hp.n_mels), dtype=np.float32)
     Z0 = O.synth_mel2mag(hp, W, Y0)
     out = {}
-    for name, env in (("default", {}), ("waves4", {"OPH_PG_WAVES": "4"}), ("waves8", {"OPH_PG_WAVES": "8"}), ("rows", {"OPH_NO_PLANE_GEMM": "1"})):
-        saved = {k: os.environ.get(k) for k in ("OPH_PG_WAVES", "OPH_NO_PLANE_GEMM")}
-        for k in saved:
-            os.environ.pop(k, None)
-        os.environ.update(env)
-        try:
-            e = _engine(hp, W)                      # the switches are read once per handle
-            out[name] = e.ssrn(Y0)
-            e.close()
-        finally:
-            for k, v in saved.items():
-                os.environ.pop(k, None)
-                if v is not None:
-                    os.environ[k] = v
+    for name, opts in (("default", None), ("waves4", {"PG_WAVES": 4}), ("waves8", {"PG_WAVES": 8}), ("rows", {"NO_PLANE_GEMM": 1})):
+        e = _engine(hp, W, opts)                    # launch-path options of oph_create_opts
+        out[name] = e.ssrn(Y0)
+        e.close()
     for name, Z in out.items():
         print("%s: max-abs vs oracle %.3e" % (name, np.abs(Z - Z0).max()))
         assert np.abs(Z - Z0).max() < TOL

@@ -202,7 +202,7 @@ def test_soak_of_the_decode_protocol(model):
 def test_resumed_tiles_redo_the_ssrn_rows_that_saw_their_tail(model):
     """A tile that stopped early and is resumed to the batch's stop step gets new frames after its stop: the SSRN chunks that
     were streamed while it first ran (and saw zeros there) must be redone.  Forced here with a tiny chunk size so that
-    chunks do stream before the early stops (child process: the switch is read at handle creation)."""
+    chunks do stream before the early stops (child process: a fresh set of streams)."""
     import os, subprocess, sys
     code = r"""
 import sys, numpy as np
@@ -213,7 +213,7 @@ from ophelia_amd.engine import Engine
 hp = hp_from_snapshot("lj_tutorial.cfg", max_T=120)
 W = O.random_weights(hp, 2)
 L = O.random_text(hp, 24, 41, min_len=6, max_len=36); ends = O.get_text_lengths(L).astype(np.int32)
-eng = Engine(hp, device=0); eng.load_weights(W); eng.set_ssrn_precision(0)
+eng = Engine(hp, device=0, options={"SSRN_CHUNK": 4}); eng.load_weights(W); eng.set_ssrn_precision(0)
 K, V = eng.encode_text(L)
 Y, t_ends, al, steps = eng.text2mel(K, V, ends)
 c = eng.counters()
@@ -223,7 +223,7 @@ Z1 = eng.ssrn(np.array(Y))
 assert np.array_equal(Z, Z1), float(np.abs(Z - Z1).max())
 print("ok", steps, c)
 """
-    env = dict(os.environ, OPH_SSRN_CHUNK="4")
+    env = dict(os.environ)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code, root], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-3000:]
