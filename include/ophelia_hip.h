@@ -65,6 +65,14 @@ typedef struct oph_dims {
 #define OPH_FLAG_SPK_TEXT_ENCODER_INPUT 8  /* 'text_encoder_input' in hp.multispeaker (networks.py:138-144)        */
 #define OPH_FLAG_SPK_TEXT_ENCODER_TOWARDS_END 16 /* 'text_encoder_towards_end' (networks.py:184-199)               */
 #define OPH_FLAG_SPK_AUDIO_ENCODER_INPUT 64 /* 'audio_encoder_input' in hp.multispeaker (networks.py:237-245)         */
+#define OPH_FLAG_NO_CONCAT_QUERY 128       /* hp.concatenate_query False (networks.py:317-321): AudioDec reads the attention context alone;
+                                              Text2Mel/AudioDec/C_1/conv1d/kernel is (1, d, d) instead of (1, 2d, d)                  */
+#define OPH_FLAG_NO_SQUASH_T2M 256         /* hp.squash_output_t2m False (networks.py:430-433): Y = Y_logits, no sigmoid              */
+#define OPH_FLAG_NO_SQUASH_SSRN 512        /* hp.squash_output_ssrn False (networks.py:533-536): Z = Z_logits                         */
+#define OPH_FLAG_SPK_SSRN_INPUT 1024       /* 'ssrn_input' in hp.multispeaker (networks.py:457-465): SSRN/embed_2 + SSRN/C_3 behind C_1.
+                                              The speaker codes reach SSRN through oph_ssrn_speakers, or are those staged with the text
+                                              when SSRN runs on resident frames; plain oph_ssrn(Y != NULL) is an error then -- as the
+                                              reference's sess.run(g.Z, {g.mels: Y}) is without g.speakers (synthesize.py:257)        */
 #define OPH_FLAG_LCC 32                    /* 'learn_channel_contributions' (modules.py:78-88): per-speaker sigmoid
                                               channel gates on every Text2Mel layer that the reference passes lcc= to */
 
@@ -143,6 +151,9 @@ int oph_ssrn(oph_handle* h, const float* Y, int B, int T, float* Z);
 /* oph_ssrn_logits   the same with the fetch surface's second tensor: Z = g.Z and Z_logits = g.Z_logits
  *     (networks.py:527-534: the last conv1d's LayerNorm rows before squash_output_ssrn's sigmoid), both (B, r*T, full_dim). */
 int oph_ssrn_logits(oph_handle* h, const float* Y, int B, int T, float* Z, float* Z_logits);
+/* oph_ssrn_speakers  sess.run([g.Z, g.Z_logits], {g.mels: Y, g.speakers: spk}) on the SSRN graph of a configuration with
+ *     'ssrn_input' in hp.multispeaker (architectures.py:142, networks.py:457-465): spk (B) speaker codes; Z_logits may be NULL. */
+int oph_ssrn_speakers(oph_handle* h, const float* Y, const int32_t* spk, int B, int T, float* Z, float* Z_logits);
 /* Speculative SSRN during oph_text2mel (default on): chunks of mel frames go through SSRN on their own CU partition as
  * soon as the decoder has produced them (SSRN's receptive field is +-9 mel frames), for oph_ssrn(Y = NULL) to pick up.
  * on: 0 off, 1 on, n >= 2 on with n mel frames per chunk (default 40). */

@@ -33,6 +33,10 @@ FLAG_SPK_TEXT_ENCODER_INPUT = 8
 FLAG_SPK_TEXT_ENCODER_TOWARDS_END = 16
 FLAG_LCC = 32
 FLAG_SPK_AUDIO_ENCODER_INPUT = 64
+FLAG_NO_CONCAT_QUERY = 128
+FLAG_NO_SQUASH_T2M = 256
+FLAG_NO_SQUASH_SSRN = 512
+FLAG_SPK_SSRN_INPUT = 1024
 STOP_REFERENCE, STOP_NEVER = 0, 1
 
 # name -> (restype, argtypes); every symbol declared in include/ophelia_hip.h
@@ -60,6 +64,7 @@ SIGNATURES = {
     "oph_run_host": (C.c_int, [C.c_void_p, C.c_int, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_i32p]),
     "oph_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "oph_host_free": (C.c_int, [C.c_void_p]),
+    "oph_ssrn_speakers": (C.c_int, [C.c_void_p, c_f32p, c_i32p, C.c_int, C.c_int, c_f32p, c_f32p]),
     "oph_ssrn_logits": (C.c_int, [C.c_void_p, c_f32p, C.c_int, C.c_int, c_f32p, c_f32p]),
     "oph_set_streaming": (C.c_int, [C.c_void_p, C.c_int]),
     "oph_set_mag_destination": (C.c_int, [C.c_void_p, c_f32p]),

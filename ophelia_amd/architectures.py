@@ -14,6 +14,10 @@ from . import tf_checkpoint
 from . import weights as WT
 
 
+class InvalidArgumentError(ValueError):
+    """tf.errors.InvalidArgumentError's place in this session: a fetch that needs a placeholder the feed dict lacks."""
+
+
 class Tensor(object):
     """A named graph tensor handle: what the reference's code holds as `g.K`, `g.mels`, ... and passes to
     sess.run as a fetch or as a feed-dict key (identity-hashed, like a tf.Tensor)."""
@@ -136,7 +140,15 @@ class Session(object):
         if isinstance(g, SSRNGraph):
             if "mels" not in fed:
                 raise ValueError("SSRN graph: feed g.mels")
-            if any(t.name == "Z_logits" for t in fl):
+            if "ssrn_input" in (hp.multispeaker or []):
+                # networks.py:457-465 reads g.speakers: TensorFlow refuses the run when the placeholder is not fed -- which is what
+                # happens to the reference's own synth_mel2mag (synthesize.py:257 feeds g.mels alone)
+                if "speakers" not in fed:
+                    raise InvalidArgumentError("You must feed a value for placeholder tensor 'speakers' ('ssrn_input' in hp.multispeaker)")
+                want = any(t.name == "Z_logits" for t in fl)
+                r = eng.ssrn(fed["mels"], speaker_data=fed["speakers"], logits=want)
+                vals = {"Z": r[0], "Z_logits": r[1]} if want else {"Z": r}
+            elif any(t.name == "Z_logits" for t in fl):
                 Z, Zl = eng.ssrn_logits(fed["mels"])         # the device's own pre-squash rows (networks.py:527-534)
                 vals = {"Z": Z, "Z_logits": Zl}
             else:

@@ -88,7 +88,7 @@ int oph_create_opts(const oph_dims* dims, int device, const char* options, oph_h
         g_create_error = "dimensions outside the supported hot path (d<=256, c<=512, n_mels<=256, full_dim<=1280, win<=8)";
         return OPH_ERR_UNSUPPORTED;
     }
-    if ((m.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_TOWARDS_END | OPH_FLAG_LCC | OPH_FLAG_SPK_AUDIO_ENCODER_INPUT)) &&
+    if ((m.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_TOWARDS_END | OPH_FLAG_LCC | OPH_FLAG_SPK_AUDIO_ENCODER_INPUT | OPH_FLAG_SPK_SSRN_INPUT)) &&
         (m.nspeakers < 1 || m.speaker_embedding_size < 1 || m.speaker_embedding_size % 4)) {
         g_create_error = "multispeaker flag set but nspeakers/speaker_embedding_size invalid";
         return OPH_ERR_INVALID;
@@ -224,7 +224,7 @@ static int check_ready(oph_handle* h, int B) {
     return OPH_OK;
 }
 static bool model_is_multispeaker(const oph_handle* h) {
-    return h->dm.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_TOWARDS_END | OPH_FLAG_LCC | OPH_FLAG_SPK_AUDIO_ENCODER_INPUT);
+    return h->dm.flags & (OPH_FLAG_SPK_AUDIO_DECODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_INPUT | OPH_FLAG_SPK_TEXT_ENCODER_TOWARDS_END | OPH_FLAG_LCC | OPH_FLAG_SPK_AUDIO_ENCODER_INPUT | OPH_FLAG_SPK_SSRN_INPUT);
 }
 // ends = get_text_lengths(L) (synthesize.py:242-247): a key position of the text, 0 ... max_N
 static int check_ends(oph_handle* h, const int32_t* ends, int B) {
@@ -708,7 +708,7 @@ int oph_text2mel_graph(oph_handle* h, const float* K, const float* V, const floa
     dlogits = h->raw + (h->raw_elems - (size_t)B * T * ldn);
     io.final_logits = dlogits;
     std::vector<Layer> dec = h->audiodec;
-    dec.back().act = ACT_SIGMOID;                   // squash_output_t2m (networks.py:430-431)
+    dec.back().act = (m.flags & OPH_FLAG_NO_SQUASH_T2M) ? ACT_NONE : ACT_SIGMOID;                   // squash_output_t2m (networks.py:430-433)
     float* dY = run_batched(h, dec, dR, 2 * d, B, T, 0, 0, nullptr, 0, 0, &ldl, nullptr, io);
     if (Y) HIPCHK(h, hipMemcpy2DAsync(Y, (size_t)m.n_mels * 4, dY, (size_t)ldl * 4, (size_t)m.n_mels * 4, (size_t)B * T, hipMemcpyDeviceToHost, h->stream));
     if (Y_logits) HIPCHK(h, hipMemcpy2DAsync(Y_logits, (size_t)m.n_mels * 4, dlogits, (size_t)ldl * 4, (size_t)m.n_mels * 4, (size_t)B * T, hipMemcpyDeviceToHost, h->stream));
@@ -723,12 +723,15 @@ int oph_text2mel_graph(oph_handle* h, const float* K, const float* V, const floa
 
 // oph_ssrn / oph_ssrn_logits.  Y == NULL: the mel frames the last decode call left in HBM (B and T must be that batch's);
 // whatever its streamed SSRN has not covered yet is computed now.
-static int ssrn_common(oph_handle* h, const float* Y, int B, int T, float* Z, float* Z_logits) {
+static int ssrn_common(oph_handle* h, const float* Y, int B, int T, float* Z, float* Z_logits, const int32_t* spk = nullptr) {
     DevGuard dev_guard(h);
     int rc = check_ready(h, B);
     if (rc) return rc;
     if (!Z || T < 1) { h->fail("bad argument"); return OPH_ERR_INVALID; }
     const oph_dims& m = h->dm;
+    if (spk && !(m.flags & OPH_FLAG_SPK_SSRN_INPUT)) { h->fail("speaker codes given, but 'ssrn_input' is not in this configuration's multispeaker positions"); return OPH_ERR_INVALID; }
+    if (Y && !spk && (m.flags & OPH_FLAG_SPK_SSRN_INPUT)) { h->fail("'ssrn_input': the SSRN graph needs the speaker codes (oph_ssrn_speakers) -- g.speakers is not fed"); return OPH_ERR_INVALID; }
+    if (spk) for (int i = 0; i < B; ++i) if (spk[i] < 0 || spk[i] >= m.nspeakers) { h->fail("speaker id %d out of range", spk[i]); return OPH_ERR_INVALID; }
     if (T > m.max_T) { h->fail("T=%d exceeds max_T=%d", T, m.max_T); return OPH_ERR_INVALID; }
     if (!Y && !Z_logits) {
         if (!h->y_resident || B != h->nB || T != m.max_T) { h->fail("Y = NULL asks for the mel frames the last decode left in HBM, but there are none for B=%d, T=%d", B, T); return OPH_ERR_STATE; }
@@ -754,14 +757,16 @@ static int ssrn_common(oph_handle* h, const float* Y, int B, int T, float* Z, fl
     const int ldy = round_up(m.n_mels, 32);
     float* dY = nullptr; float* dZ = nullptr; float* dZl = nullptr;
     const size_t zn = (size_t)B * T * m.r * m.full_dim;
-    HIPCHK(h, hipMalloc((void**)&dY, (size_t)B * T * m.n_mels * 4));
+    HIPCHK(h, hipMalloc((void**)&dY, (size_t)B * T * m.n_mels * 4 + (spk ? (size_t)B * 4 : 0)));      // (+ the speaker codes behind the frames)
+    int* dSpk = spk ? (int*)(dY + (size_t)B * T * m.n_mels) : nullptr;
     if (hipMalloc((void**)&dZ, zn * 4) != hipSuccess || (Z_logits && hipMalloc((void**)&dZl, zn * 4) != hipSuccess)) {
         hipFree(dY); if (dZ) hipFree(dZ); (void)hipGetLastError(); h->fail("out of device memory for the SSRN output"); return OPH_ERR_DEVICE;
     }
     hipError_t e = hipMemcpyAsync(dY, Y, (size_t)B * T * m.n_mels * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && spk) e = hipMemcpyAsync(dSpk, spk, (size_t)B * 4, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) {
         launch_pad_rows(dY, m.n_mels, h->actB, ldy, (long long)B * T, m.n_mels, h->stream);
-        rc = run_ssrn_on(h, h->actB, ldy, B, T, dZ, 0, dZl);
+        rc = run_ssrn_on(h, h->actB, ldy, B, T, dZ, 0, dZl, dSpk);
         e = hipMemcpyAsync(Z, dZ, zn * 4, hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess && Z_logits) e = hipMemcpyAsync(Z_logits, dZl, zn * 4, hipMemcpyDeviceToHost, h->stream);
     }
@@ -771,6 +776,10 @@ static int ssrn_common(oph_handle* h, const float* Y, int B, int T, float* Z, fl
     return rc;
 }
 int oph_ssrn(oph_handle* h, const float* Y, int B, int T, float* Z) { return ssrn_common(h, Y, B, T, Z, nullptr); }
+int oph_ssrn_speakers(oph_handle* h, const float* Y, const int32_t* spk, int B, int T, float* Z, float* Z_logits) {
+    if (h && (!Y || !spk)) { h->fail("null argument"); return OPH_ERR_INVALID; }
+    return ssrn_common(h, Y, B, T, Z, Z_logits, spk);
+}
 int oph_ssrn_logits(oph_handle* h, const float* Y, int B, int T, float* Z, float* Z_logits) {
     if (h && !Z_logits) { h->fail("null argument"); return OPH_ERR_INVALID; }
     return ssrn_common(h, Y, B, T, Z, Z_logits);

@@ -362,7 +362,7 @@ bool run_supported(const oph_handle* h) {
     const oph_dims& m = h->dm;
     if (h->opt.decode == 2) return false;
     if (h->n_hc_dec > LOOP_MAX_LEVELS || h->n_hc_dec >= 15) return false;      // one completion word per cone level; 4-bit level fields in the packed descriptors
-    if (m.flags & (OPH_FLAG_LCC | OPH_FLAG_NO_MONOTONIC)) return false;       // variants served by the per-layer kernels
+    if (m.flags & (OPH_FLAG_LCC | OPH_FLAG_NO_MONOTONIC | OPH_FLAG_NO_SQUASH_T2M)) return false;       // variants served by the per-layer kernels
     if ((int)h->audioenc.size() + h->dec_pre > RUN_MAX_LAYERS || (int)h->audiodec.size() - h->dec_pre + 1 > RUN_MAX_LAYERS) return false;
     for (const auto* net : {&h->audioenc, &h->audiodec})
         for (const Layer& l : *net) {
@@ -748,7 +748,7 @@ void decode_step(oph_handle* h, int t, int t_last, int stop_mode) {
         a.lcc_pro = prev->lcc_gate;
         a.nlayers = (int)h->audiodec.size() - pre - nh;
         for (int i = 0; i < a.nlayers; ++i) a.L[i] = row_layer(h->audiodec[pre + nh + i]);
-        a.L[a.nlayers - 1].act = ACT_SIGMOID;           // squash_output_t2m (networks.py:430-431)
+        a.L[a.nlayers - 1].act = (m.flags & OPH_FLAG_NO_SQUASH_T2M) ? ACT_NONE : ACT_SIGMOID;           // squash_output_t2m (networks.py:430-433)
         a.emit = 1; a.Yout = h->Yout; a.ldy = h->ldy; a.Ytm = h->Ytm; a.ldtm = h->ldy; a.max_T = m.max_T;
         a.B = B; a.Bpad = Bpad; a.stop_after = stop_after; a.t = t; a.d = d;
         run_row_chain(h, a, 0);

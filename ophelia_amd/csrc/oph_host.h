@@ -61,6 +61,8 @@ struct Layer {
     bool causal = false;
     int act = ACT_NONE;
     int ccat = 0;                // speaker-embedding channels concatenated to the input (cin includes them)
+    int cin_var = 0;             // > 0: input channels of the TF VARIABLE when fewer than cin -- hp.concatenate_query False: AudioDec C_1's kernel is
+                                 // (1, d, d) and is packed into the first d of the layer's 2d input channels (the query half multiplies zeros)
     bool ln = true;              // false: hp.norm None -> no gamma/beta variables, normalisation is the identity
     std::string cat_scope;       // TextEnc layers with ccat: TF scope of the speaker lookup table concatenated to the input
     float* cat_table = nullptr;
@@ -431,7 +433,7 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
 int ensure_batched_capacity(oph_handle* h, int B);
 int run_encode_into(oph_handle* h, const int* dL, const int* dSpk, int B, float* KVdst, hipStream_t stream, int wsi);
 int run_encode(oph_handle* h);
-int run_ssrn_on(oph_handle* h, const float* Yrows, int ldy, int B, int T, float* Zout, int wsi = 0, float* Zlogits = nullptr);
+int run_ssrn_on(oph_handle* h, const float* Yrows, int ldy, int B, int T, float* Zout, int wsi = 0, float* Zlogits = nullptr, const int* dSpk = nullptr);
 void ssrn_margins(const oph_handle* h, int* back, int* ahead);
 int copy_mag_rows(oph_handle* h, int a, int b, hipStream_t after);
 int run_ssrn_chunk(oph_handle* h, int a, int b, hipStream_t st, int wsi);

@@ -65,6 +65,9 @@ void build_networks(oph_handle* h) {
         const char* n = "Text2Mel/AudioDec";
         int i = 1;
         add_conv(h->audiodec, sc(n, "C", i++), 2 * d, d, true, ACT_NONE);
+        // hp.concatenate_query False (networks.py:317-321): R = the context alone and C_1's kernel has d input rows.  The device keeps
+        // R' = [ctx | Q] and packs zeros for the Q rows: every kernel of the decode path is unchanged, ctx . Wc + 0 is exact
+        if (m.flags & OPH_FLAG_NO_CONCAT_QUERY) h->audiodec.back().cin_var = d;
         h->dec_pre = 1;
         if (m.flags & OPH_FLAG_SPK_AUDIO_DECODER_INPUT) {
             i++;                                      // embed_2
@@ -82,6 +85,11 @@ void build_networks(oph_handle* h) {
         const char* n = "SSRN";
         int i = 1;
         add_conv(h->ssrn, sc(n, "C", i++), m.n_mels, c, false, ACT_NONE);
+        if (m.flags & OPH_FLAG_SPK_SSRN_INPUT) {                  // networks.py:457-465: embed_2, concat, C_3 (no activation)
+            const std::string es = sc(n, "embed", i++);
+            add_conv(h->ssrn, sc(n, "C", i++), c + m.speaker_embedding_size, c, false, ACT_NONE, m.speaker_embedding_size);
+            h->ssrn.back().cat_scope = es;
+        }
         for (int j = 0, r = 1; j < 2; ++j, r *= 3) add_hc(h->ssrn, sc(n, "HC", i++), c, 3, r, false);
         const int ntr = m.r == 4 ? 2 : 3;
         for (int o = 0; o < ntr; ++o) {
@@ -94,7 +102,7 @@ void build_networks(oph_handle* h) {
         for (int o = 0; o < 2; ++o) add_hc(h->ssrn, sc(n, "HC", i++), 2 * c, 3, 1, false);
         add_conv(h->ssrn, sc(n, "C", i++), 2 * c, m.full_dim, false, ACT_NONE);
         for (int o = 0; o < 2; ++o) add_conv(h->ssrn, sc(n, "C", i++), m.full_dim, m.full_dim, false, ACT_RELU);
-        add_conv(h->ssrn, sc(n, "C", i++), m.full_dim, m.full_dim, false, ACT_SIGMOID);   // squash_output_ssrn
+        add_conv(h->ssrn, sc(n, "C", i++), m.full_dim, m.full_dim, false, (m.flags & OPH_FLAG_NO_SQUASH_SSRN) ? ACT_NONE : ACT_SIGMOID);   // squash_output_ssrn (networks.py:533-536)
     }
     // hp.norm None concerns Text2Mel only: synthesize() sets hp.norm = 'layer' while it builds SSRNGraph and restores None
     // afterwards (synthesize.py:513-534), so the SSRN of such a config is normalised like any other and its checkpoint
@@ -115,7 +123,7 @@ void build_networks(oph_handle* h) {
         for (const Layer& l : v) {
             if (!l.cat_scope.empty()) inv(l.cat_scope + "/lookup_table", {m.nspeakers, m.speaker_embedding_size});
             if (l.kind == K_CONV) {
-                inv(l.scope + "/conv1d/kernel", {1, l.cin, l.cout});
+                inv(l.scope + "/conv1d/kernel", {1, l.cin_var > 0 ? l.cin_var : l.cin, l.cout});
                 inv(l.scope + "/conv1d/bias", {l.cout});
                 if (l.ln) {
                     inv(l.scope + "/normalize/beta", {l.cout});
@@ -243,12 +251,13 @@ int pack_layer(oph_handle* h, Layer& l) {
         const float* k = dev_tensor(h, l.scope + "/conv1d/kernel");
         l.Wt = h->dalloc<float>((size_t)l.Nalloc * l.size * l.kc);
         if (!k || !l.Wt) return -1;
-        launch_pack_conv(k, l.Wt, l.size, l.cin, l.N, l.kc, l.Nalloc, h->stream);
+        const int cin_k = l.cin_var > 0 ? l.cin_var : l.cin;      // rows the variable has; the packed copies are zero beyond them
+        launch_pack_conv(k, l.Wt, l.size, cin_k, l.N, l.kc, l.Nalloc, h->stream);
         if (l.kind == K_CONV && l.size == 1 && l.N <= 256) {
             l.ldn = round_up(l.N, 4);
             l.Wkn = h->dalloc<float>((size_t)l.kc * l.ldn);
             if (!l.Wkn) return -1;
-            launch_pack_wkn(k, l.Wkn, l.cin, l.N, l.kc, l.ldn, h->stream);
+            launch_pack_wkn(k, l.Wkn, cin_k, l.N, l.kc, l.ldn, h->stream);
         }
     }
     l.bias = dev_padded(h, l.scope + "/conv1d/bias", l.Nalloc);

@@ -184,10 +184,11 @@ int run_encode_into(oph_handle* h, const int* dL, const int* dSpk, int B, float*
 // the whole staged batch, on the API stream
 int run_encode(oph_handle* h) { return run_encode_into(h, h->bL[h->txt], h->bSpk[h->txt], h->nB, h->bKV[h->kv_cur], h->stream, 0); }
 
-int run_ssrn_on(oph_handle* h, const float* Yrows, int ldy, int B, int T, float* Zout, int wsi, float* Zlogits) {
+int run_ssrn_on(oph_handle* h, const float* Yrows, int ldy, int B, int T, float* Zout, int wsi, float* Zlogits, const int* dSpk) {
     const oph_dims& m = h->dm;
     BatchedIO io{};
     io.final_logits = Zlogits;
+    io.spk = dSpk;                    // 'ssrn_input' (networks.py:457-465); null: the staged batch's codes
     run_batched(h, h->ssrn, const_cast<float*>(Yrows), ldy, B, T, wsi, h->ssrn_prec, Zout, m.full_dim, m.full_dim, nullptr, nullptr, io);
     HIPCHK(h, hipGetLastError());
     return OPH_OK;
@@ -239,6 +240,7 @@ int run_ssrn_chunk(oph_handle* h, int a, int b, hipStream_t st, int wsi) {
     BatchedIO io{};
     io.out_T = Tc * m.r; io.keep_lo = (a - lo) * m.r; io.keep_hi = (b - lo) * m.r;
     io.out_bs = (long long)m.max_T * m.r; io.out_t0 = lo * m.r;
+    io.spk = h->d_spk;                // this tile's slice of the staged speaker codes ('ssrn_input')
     run_batched(h, h->ssrn, ws, h->ldy, h->B, Tc, wsi, h->ssrn_prec, h->Z, m.full_dim, m.full_dim, nullptr, nullptr, io);
     g_cur = saved;
     if (h->z_host) {

@@ -78,7 +78,10 @@ def load_data(hp, mode="synthesis"):
             assert len(fields) >= 4, fields
             spk_code = ""
             if "speaker_dependent_phones" in hp.multispeaker:
-                raise NotImplementedError("speaker_dependent_phones is outside the hot-path scope")
+                # data_load.py:153-154 takes `speaker_code = speaker`, but in mode='synthesis' get_speaker_codes is False (:80-81) and
+                # `speaker` was never assigned (:145-149): the reference dies here with this very exception.  load_vocab above has built
+                # the speaker-dependent vocabulary (data_load.py:42-46) exactly as the reference does before it gets here.
+                raise UnboundLocalError("local variable 'speaker' referenced before assignment")
             ids = [char2idx[p] for p in phones_normalize(fields[3], char2idx, speaker_code=spk_code)]
         elif hp.input_type == "letters":
             ids = [char2idx[ch] for ch in text_normalize(norm_text, hp) + "E"]      # E: EOS

@@ -69,7 +69,10 @@ def dims_from_hp(hp, max_N=None, max_T=None):
                  "text_encoder_input": _lib.FLAG_SPK_TEXT_ENCODER_INPUT,
                  "text_encoder_towards_end": _lib.FLAG_SPK_TEXT_ENCODER_TOWARDS_END,
                  "learn_channel_contributions": _lib.FLAG_LCC,
-                 "audio_encoder_input": _lib.FLAG_SPK_AUDIO_ENCODER_INPUT}
+                 "audio_encoder_input": _lib.FLAG_SPK_AUDIO_ENCODER_INPUT,
+                 "ssrn_input": _lib.FLAG_SPK_SSRN_INPUT,
+                 # host-side only (data_load.load_vocab / phones_normalize, data_load.py:42-46, 61-64): the graphs do not change
+                 "speaker_dependent_phones": 0}
     unsupported = [p for p in ms if p not in positions]
     if unsupported:
         raise NotImplementedError("multispeaker positions %s are not supported (supported: %s)"
@@ -77,10 +80,9 @@ def dims_from_hp(hp, max_N=None, max_T=None):
     norm = getattr(hp, "norm", "layer")
     if norm not in ("layer", None):
         raise NotImplementedError("hp.norm=%r is not supported ('layer' or None)" % (norm,))
+    # SURVEY.md section 2 OUT-OF-SCOPE: the Merlin-label text encoder, the alternative history types and label inputs
     for attr, want in (("text_encoder_type", "DCTTS_standard"),
-                       ("history_type", "DCTTS_standard"), ("merlin_label_dir", ""),
-                       ("concatenate_query", True),
-                       ("squash_output_t2m", True), ("squash_output_ssrn", True)):
+                       ("history_type", "DCTTS_standard"), ("merlin_label_dir", "")):
         if getattr(hp, attr, want) != want:
             raise NotImplementedError("hp.%s=%r is outside the hot-path scope" % (attr, getattr(hp, attr)))
     d = _lib.OphDims()
@@ -93,6 +95,12 @@ def dims_from_hp(hp, max_N=None, max_T=None):
     d.nspeakers = getattr(hp, "nspeakers", 0) if ms else 0
     d.speaker_embedding_size = getattr(hp, "speaker_embedding_size", 0) if ms else 0
     d.flags = (_lib.FLAG_NORM_NONE if norm is None else 0)
+    if not getattr(hp, "concatenate_query", True):
+        d.flags |= _lib.FLAG_NO_CONCAT_QUERY            # networks.py:317-321
+    if not getattr(hp, "squash_output_t2m", True):
+        d.flags |= _lib.FLAG_NO_SQUASH_T2M              # networks.py:430-433
+    if not getattr(hp, "squash_output_ssrn", True):
+        d.flags |= _lib.FLAG_NO_SQUASH_SSRN             # networks.py:533-536
     if getattr(hp, "turn_off_monotonic_for_synthesis", False):
         if d.max_N > 256:
             raise NotImplementedError("turn_off_monotonic_for_synthesis is supported up to max_N = 256")
@@ -318,7 +326,23 @@ class Engine(object):
                                               _lib.fptr(out["Y"]), _lib.fptr(out["alignments"]), _lib.iptr(out["max_attentions"])))
         return out
 
-    def ssrn(self, Y):
+    def ssrn(self, Y, speaker_data=None, logits=False):
+        """Z = g.Z of the SSRN graph at g.mels = Y.  speaker_data (B,) / (B, 1): g.speakers, for configurations with 'ssrn_input'
+        in hp.multispeaker (networks.py:457-465) -- the reference's synth_mel2mag cannot feed them (synthesize.py:257); this is
+        the graph surface.  logits=True returns (Z, Z_logits)."""
+        if speaker_data is not None:
+            Y = np.ascontiguousarray(Y, dtype=np.float32)
+            B, T, nm = Y.shape
+            assert nm == self.dims.n_mels
+            spk = np.ascontiguousarray(np.asarray(speaker_data).reshape(B), dtype=np.int32)
+            Z = PINNED.empty((B, T * self.dims.r, self.dims.full_dim))
+            Zl = PINNED.empty((B, T * self.dims.r, self.dims.full_dim)) if logits else None
+            self._kv_token = self._y_token = None
+            self._drop_spec()
+            self._chk(self.lib.oph_ssrn_speakers(self._h, _lib.fptr(Y), _lib.iptr(spk), B, T, _lib.fptr(Z), None if Zl is None else _lib.fptr(Zl)))
+            return (Z, Zl) if logits else Z
+        if logits:
+            return self.ssrn_logits(Y)
         resident = self.is_resident_mel(Y)
         if not resident:
             Y = np.ascontiguousarray(Y, dtype=np.float32)

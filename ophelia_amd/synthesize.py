@@ -125,6 +125,13 @@ def synth_text2mel(hp, L, g, sess, speaker_data=None, duration_data=None, labels
 
 
 def synth_mel2mag(hp, Y, g, sess, batchsize=128):
+    if hp is not None and "ssrn_input" in (getattr(hp, "multispeaker", None) or []):
+        # The reference's function feeds {g.mels: Y_batch} alone (synthesize.py:257, "#assert speaker_data==None ## TODO"): with the
+        # speaker embedding wired into SSRN (networks.py:457-465) TensorFlow ends the run here.  Same place, same kind of error;
+        # the speaker-conditioned SSRN itself is reachable through sess.run(g.Z, {g.mels: Y, g.speakers: codes}).
+        from .architectures import InvalidArgumentError
+        raise InvalidArgumentError("You must feed a value for placeholder tensor 'speakers' ('ssrn_input' in hp.multispeaker; "
+                                   "synth_mel2mag feeds g.mels only, synthesize.py:257)")
     eng = sess.ensure_ready()
     if getattr(eng, "is_resident_mel", lambda y: False)(Y):
         # the very array synth_codedtext2mel returned: its frames are still in HBM and SSRN has been running over them

@@ -285,10 +285,16 @@ def audio_dec(hp, R, W, speakers=None, scope="Text2Mel/AudioDec"):
     return logits, Y
 
 
-def ssrn(hp, Y, W, scope="SSRN"):
-    """networks.py:437-537 (no 'ssrn_input' speaker hook: unused by BASELINE configs)."""
+def ssrn(hp, Y, W, scope="SSRN", speakers=None):
+    """networks.py:437-537.  `speakers` (B,1) int only when 'ssrn_input' in hp.multispeaker (networks.py:457-465: no shipped
+    config sets it, and the reference's own synth_mel2mag does not feed g.speakers -- synthesize.py:250-260 -- so it is reachable
+    through the graph surface only)."""
     i = 1
     t = conv1d(Y, W, "%s/C_%d" % (scope, i)); i += 1
+    if "ssrn_input" in hp.multispeaker:
+        reps = _speaker_reps(speakers, t.shape[1], W["%s/embed_%d/lookup_table" % (scope, i)]); i += 1
+        t = np.concatenate((t, reps), -1)
+        t = conv1d(t, W, "%s/C_%d" % (scope, i)); i += 1
     for j in range(2):
         t = hc(t, W, "%s/HC_%d" % (scope, i), rate=3 ** j); i += 1
     n_transposes = {4: 2, 8: 3}[hp.r]
@@ -488,15 +494,16 @@ def synth_codedtext2mel_incremental(hp, W, K, V, ends, speakers=None, stop=True,
     return Y, t_ends.tolist(), alignments
 
 
-def synth_mel2mag(hp, W, Y, batchsize=128):
+def synth_mel2mag(hp, W, Y, batchsize=128, speakers=None):
     """synthesize.py:250-260.  nbatches = max(1, len(Y) / batchsize) is Python-2
-    integer division."""
+    integer division.  (speakers: only for 'ssrn_input', which the reference's function cannot feed -- see ssrn.)"""
     if batchsize > 0:
         nbatches = max(1, len(Y) // batchsize)
         batches = np.array_split(Y, nbatches)
+        spk = [None] * nbatches if speakers is None else np.array_split(np.asarray(speakers), nbatches)
     else:
-        batches = [Y]
-    return np.concatenate([ssrn(hp, Yb, W)[1] for Yb in batches])
+        batches, spk = [Y], [speakers]
+    return np.concatenate([ssrn(hp, Yb, W, speakers=sb)[1] for Yb, sb in zip(batches, spk)])
 
 
 # --------------------------------------------------------------------------
@@ -554,7 +561,7 @@ def variable_shapes(hp):
     for _ in range(10):
         hcl("%s/HC_%d" % (s, i), d, 3); i += 1
     s = "Text2Mel/AudioDec"; i = 1
-    conv("%s/C_%d" % (s, i), 2 * d, d, lcc=False); i += 1
+    conv("%s/C_%d" % (s, i), 2 * d if getattr(hp, "concatenate_query", True) else d, d, lcc=False); i += 1      # networks.py:317-321: R = [ctx | Q] or ctx alone
     if "audio_decoder_input" in hp.multispeaker:
         out["%s/embed_%d/lookup_table" % (s, i)] = (hp.nspeakers, hp.speaker_embedding_size); i += 1
         conv("%s/C_%d" % (s, i), d + hp.speaker_embedding_size, d, lcc=False); i += 1
@@ -569,6 +576,9 @@ def variable_shapes(hp):
     ln = True
     s = "SSRN"; i = 1
     conv("%s/C_%d" % (s, i), hp.n_mels, c); i += 1
+    if "ssrn_input" in hp.multispeaker:              # networks.py:457-465
+        out["%s/embed_%d/lookup_table" % (s, i)] = (hp.nspeakers, hp.speaker_embedding_size); i += 1
+        conv("%s/C_%d" % (s, i), c + hp.speaker_embedding_size, c); i += 1
     for _ in range(2):
         hcl("%s/HC_%d" % (s, i), c, 3); i += 1
     for _ in range({4: 2, 8: 3}[hp.r]):

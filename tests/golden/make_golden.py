@@ -187,6 +187,19 @@ VARIANTS = {
     # multispeaker ['learn_channel_contributions'] (config/vctk_03_lcc.cfg, nancyplusnick_04_lcc.cfg)
     "vctk03_lcc": dict(cfg="vctk_03_lcc.cfg", B=3, max_N=16, max_T=12, wseed=49, tseed=50, min_len=8, max_len=15,
                        stop=True, speaker_ix=3),
+    # hp.concatenate_query = False (networks.py:317-321: AudioDec reads the context alone, C_1's kernel is (1, d, d)); no shipped
+    # config sets it -- lj_tutorial.cfg with the attribute overridden
+    "lj_noconcat": dict(cfg="lj_tutorial.cfg", B=3, max_N=14, max_T=16, wseed=55, tseed=56, min_len=3, max_len=9,
+                        stop=True, override={"concatenate_query": False}),
+    # hp.squash_output_t2m = hp.squash_output_ssrn = False (networks.py:430-433, 533-536: Y = Y_logits, Z = Z_logits)
+    "lj_nosquash": dict(cfg="lj_tutorial.cfg", B=3, max_N=14, max_T=16, wseed=57, tseed=58, min_len=3, max_len=9,
+                        stop=True, override={"squash_output_t2m": False, "squash_output_ssrn": False}),
+    # 'ssrn_input' in hp.multispeaker (networks.py:457-465).  The reference's synth_mel2mag feeds g.mels only (synthesize.py:257), so
+    # under TensorFlow this configuration dies there with "You must feed a value for placeholder tensor" (g.speakers); the eager
+    # stand-in's session hands the SSRN graph the speaker codes of the Text2Mel run, i.e. the Z stored here is
+    # sess.run(g.Z, {g.mels: Y, g.speakers: codes}) -- the graph-surface value
+    "vctk_spk_ssrn": dict(cfg="vctk_01.cfg", B=2, max_N=14, max_T=12, wseed=59, tseed=60, min_len=6, max_len=13,
+                          stop=True, speaker_ix=4, override={"multispeaker": ["audio_decoder_input", "ssrn_input"]}),
 }
 
 

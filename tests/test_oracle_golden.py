@@ -13,7 +13,9 @@ CASES = ["lj_free", "lj_stop", "vctk_spk",
          # ... and external durations (FixedAttention)
          "proj_nomono", "g1abc_nonorm", "nn_spk_in", "vctk02_spk_end", "vctk03_lcc", "g1ab_extdur",
          # ... and the speaker embedding at the audio-encoder input (synthetic variant of vctk_01.cfg)
-         "vctk_spk_audioenc"]
+         "vctk_spk_audioenc",
+         # ... concatenate_query = False, squash_output_t2m / squash_output_ssrn = False, 'ssrn_input' (VERDICT r05 f-4 leftovers)
+         "lj_noconcat", "lj_nosquash", "vctk_spk_ssrn"]
 TOL = 2e-5   # fp32 reassociation between numpy-BLAS (oracle) and torch (golden primitives)
 
 
@@ -56,7 +58,8 @@ def test_decode_loop(tag, algo):
     assert np.array_equal(np.array(trace), g["max_attentions_trace"])
     assert t_ends == g["t_ends"].tolist()
     assert len(trace) == int(g["steps_run"])
-    assert np.abs(Y - g["Y"]).max() < TOL
+    # (squash_output_t2m = False: Y is the un-squashed LayerNorm output, |Y| up to ~4 instead of <= 1 -- the bar scales with it)
+    assert np.abs(Y - g["Y"]).max() < TOL * max(1.0, float(np.abs(g["Y"]).max()))
     assert np.abs(al - g["alignments"]).max() < TOL
     # frames after the break step stay zero (synthesize.py:157,225-228)
     assert not Y[:, len(trace):].any() and not al[:, :, len(trace):].any()
@@ -66,9 +69,10 @@ def test_decode_loop(tag, algo):
 def test_ssrn(tag):
     hp, meta, g = load_wiring_case(tag)
     W = O.random_weights(hp, meta["weight_seed"], scopes=("SSRN",))
-    Z = O.synth_mel2mag(hp, W, g["Y"])
+    spk = g.get("speakers") if "ssrn_input" in hp.multispeaker else None      # (the generator's session feeds them: make_golden.py)
+    Z = O.synth_mel2mag(hp, W, g["Y"], speakers=spk)
     assert Z.shape == g["Z"].shape == (len(g["Y"]), hp.max_T * hp.r, hp.full_dim)
-    assert np.abs(Z - g["Z"]).max() < TOL
+    assert np.abs(Z - g["Z"]).max() < TOL * max(1.0, float(np.abs(g["Z"]).max()))
 
 
 def test_mask_is_global_over_time():

@@ -12,7 +12,7 @@ from ophelia_amd import calculate_CDP_Ain_Aout as CDP
 from ophelia_amd import synthesize as S
 
 CASES = ["lj_free", "lj_stop", "vctk_spk", "proj_nomono", "g1abc_nonorm", "nn_spk_in", "vctk02_spk_end", "vctk03_lcc",
-         "g1ab_extdur", "vctk_spk_audioenc"]
+         "g1ab_extdur", "vctk_spk_audioenc", "lj_noconcat", "lj_nosquash", "vctk_spk_ssrn"]
 
 
 @pytest.mark.parametrize("tag", CASES)
