@@ -145,6 +145,26 @@ def frontend_case():
     np.savez_compressed(os.path.join(HERE, "frontend.npz"), **out)
 
 
+def sdp_frontend_case():
+    """'speaker_dependent_phones' in hp.multispeaker (data_load.py:42-46, 61-64, 153-154): the reference's load_vocab on such a
+    configuration, and what its load_data(mode='synthesis') does with it (an exception: `speaker` is only assigned when the speaker
+    is read from the transcript, which synthesis never does, data_load.py:80-81, 145-154)."""
+    hp = ref_configuration.load_config(os.path.join(REF, "config", "lj_tutorial.cfg"))
+    hp.multispeaker = ["speaker_dependent_phones"]
+    hp.speaker_list = ["<PADDING>", "spkA", "spkB"]
+    hp.test_transcript = os.path.join(HERE, "test_transcript_lj_tutorial.csv")
+    c2i, i2c = ref_data_load.load_vocab(hp)
+    raised = None
+    try:
+        with contextlib.redirect_stderr(io.StringIO()), contextlib.redirect_stdout(io.StringIO()):
+            ref_data_load.load_data(hp, mode="synthesis")
+    except BaseException as e:       # noqa: BLE001 (sys.exit included: whatever the reference does is the golden)
+        raised = [type(e).__name__, str(e)]
+    with open(os.path.join(HERE, "frontend_sdp.json"), "w") as f:
+        json.dump({"speaker_list": hp.speaker_list, "char2idx": c2i, "n_vocab": len(i2c), "synthesis_load_data_raises": raised}, f, indent=1, sort_keys=True)
+    print("speaker-dependent phones:", len(i2c), "symbols; load_data(mode='synthesis') ->", raised)
+
+
 def config_snapshot(cfgs, fresh=False):
     """config attribute snapshot (the drop-in config API): every simple-typed attribute"""
     path = os.path.join(HERE, "config_snapshot.json")
@@ -247,6 +267,9 @@ def chunking_case():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "sdp":
+        sdp_frontend_case()
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[1] == "case":           # one variant case, in this (fresh) interpreter
         v = dict(VARIANTS[sys.argv[2]])
         config_snapshot((v["cfg"],))
@@ -255,6 +278,7 @@ if __name__ == "__main__":
         run_case(sys.argv[2], v.pop("cfg"), **v)
         sys.exit(0)
     frontend_case()
+    sdp_frontend_case()
     chunking_case()
     # free-running, no early stop reached within max_T (long texts)
     run_case("lj_free", "lj_tutorial.cfg", B=2, max_N=24, max_T=16, wseed=11, tseed=12,

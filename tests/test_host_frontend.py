@@ -157,14 +157,48 @@ def test_external_durations_front_end_matches_reference():
 
 def test_out_of_scope_configs_fail_loudly():
     from ophelia_amd.engine import dims_from_hp
-    for attr, val in (("multispeaker", ["speaker_dependent_phones"]), ("multispeaker", ["ssrn_input"]),   # (the reference's
-                      # own synth_mel2mag never feeds speakers to the SSRN graph, synthesize.py:250-260)
+    # what SURVEY.md section 2 marks out of scope -- and nothing else
+    for attr, val in (("multispeaker", ["no_such_position"]),
                       ("norm", "batch"), ("merlin_label_dir", "/some/labels"), ("text_encoder_type", "minimal_feedforward"),
-                      ("history_type", "fractional_position_in_phone"), ("squash_output_t2m", False)):
+                      ("history_type", "fractional_position_in_phone")):
         hp = hp_from_snapshot("lj_tutorial.cfg")
         setattr(hp, attr, val)
         with pytest.raises(NotImplementedError):
             dims_from_hp(hp)
+
+
+def test_f4_leftovers_are_configurations_not_refusals():
+    """hp.concatenate_query / squash_output_* False and the 'ssrn_input' / 'speaker_dependent_phones' positions build a handle
+    description (the GPU legs are tests/test_gpu_model.py::test_golden_cases[lj_noconcat | lj_nosquash | vctk_spk_ssrn])"""
+    from ophelia_amd import _lib
+    from ophelia_amd.engine import dims_from_hp
+    assert dims_from_hp(hp_from_snapshot("lj_tutorial.cfg", concatenate_query=False)).flags == _lib.FLAG_NO_CONCAT_QUERY
+    assert dims_from_hp(hp_from_snapshot("lj_tutorial.cfg", squash_output_t2m=False)).flags == _lib.FLAG_NO_SQUASH_T2M
+    assert dims_from_hp(hp_from_snapshot("lj_tutorial.cfg", squash_output_ssrn=False)).flags == _lib.FLAG_NO_SQUASH_SSRN
+    d = dims_from_hp(hp_from_snapshot("vctk_01.cfg", multispeaker=["audio_decoder_input", "ssrn_input"]))
+    assert d.flags == _lib.FLAG_SPK_AUDIO_DECODER_INPUT | _lib.FLAG_SPK_SSRN_INPUT and d.nspeakers > 0
+    d = dims_from_hp(hp_from_snapshot("nancyplusnick_01.cfg", multispeaker=["learn_channel_contributions", "speaker_dependent_phones"]))
+    assert d.flags == _lib.FLAG_LCC               # speaker-dependent phones live in the transcript front-end alone
+
+
+def test_speaker_dependent_phones_front_end_is_the_reference_one(tmp_path):
+    """data_load.py:42-46: the vocabulary becomes [padding] + phone_speaker for every speaker and phone; and the reference's
+    load_data(mode='synthesis') on such a configuration raises UnboundLocalError (`speaker` is only bound when speakers are read
+    from the transcript, which synthesis never does) -- tests/golden/frontend_sdp.json holds what the reference itself did."""
+    import json
+    from ophelia_amd.data_load import load_data, load_vocab, phones_normalize
+    ref = json.load(open(os.path.join(GOLDEN, "frontend_sdp.json")))
+    hp = hp_from_snapshot("lj_tutorial.cfg", multispeaker=["speaker_dependent_phones"])
+    hp.speaker_list = ref["speaker_list"]
+    c2i, i2c = load_vocab(hp)
+    assert c2i == ref["char2idx"] and len(i2c) == ref["n_vocab"]
+    assert phones_normalize("aa ae", c2i, speaker_code="spkB") == ["aa_spkB", "ae_spkB"]
+    hp.test_transcript, hp.waveforms = os.path.join(GOLDEN, "test_transcript_lj_tutorial.csv"), "w"
+    kind, msg = ref["synthesis_load_data_raises"]
+    assert kind == "UnboundLocalError"
+    with pytest.raises(UnboundLocalError) as ei:
+        load_data(hp, mode="synthesis")
+    assert str(ei.value) == msg
 
 
 def test_option_variants_map_to_abi_flags():
