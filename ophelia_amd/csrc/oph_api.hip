@@ -469,13 +469,14 @@ int oph_fetch_mag(oph_handle* h, float* Z) {
     const oph_dims& m = h->dm;
     HIPCHK(h, hipMemcpyAsync(Z, h->bZ[h->buf], (size_t)h->nB * m.max_T * m.r * m.full_dim * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return OPH_OK;
+    return check_convt_ln(h);
 }
 
 int oph_device_mag(oph_handle* h, const float** d_mag, int64_t* utt_stride, int32_t* B) {
     if (!h || !h->bKV[0] || !d_mag) { if (h) h->fail("no staged batch / null"); return OPH_ERR_STATE; }
     if (h->sssrn) HIPCHK(h, hipStreamSynchronize(h->sssrn));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    { const int rc = check_convt_ln(h); if (rc) return rc; }
     const oph_dims& m = h->dm;
     *d_mag = h->bZ[h->buf];
     if (utt_stride) *utt_stride = (int64_t)m.max_T * m.r * m.full_dim;
@@ -542,7 +543,7 @@ int oph_run_host(oph_handle* h, int stop_mode, float* K, float* V, float* Y, int
         auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         TRACE("run_host: text / K,V %.3f ms, decode_batch %.3f ms, finish_ssrn enqueue %.3f ms, final syncs %.3f ms", ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3), ms(tp3, clk::now()));
     }
-    return OPH_OK;
+    return check_convt_ln(h);
 }
 
 // ---- host-buffer session calls ---------------------------------------------------------------
@@ -746,7 +747,7 @@ static int ssrn_common(oph_handle* h, const float* Y, int B, int T, float* Z, fl
             HIPCHK(h, hipStreamSynchronize(h->stream));
             HIPCHK(h, hipStreamSynchronize(h->sssrn));
             HIPCHK(h, hipStreamSynchronize(h->scopy));
-            return OPH_OK;
+            return check_convt_ln(h);
         }
         if ((rc = finish_ssrn(h))) return rc;
         return oph_fetch_mag(h, Z);
@@ -773,7 +774,7 @@ static int ssrn_common(oph_handle* h, const float* Y, int B, int T, float* Z, fl
     const hipError_t es = hipStreamSynchronize(h->stream);
     hipFree(dY); hipFree(dZ); if (dZl) hipFree(dZl);
     if (e != hipSuccess || es != hipSuccess) { h->fail("ssrn failed: %s", hipGetErrorString(e != hipSuccess ? e : es)); return OPH_ERR_DEVICE; }
-    return rc;
+    return rc ? rc : check_convt_ln(h);
 }
 int oph_ssrn(oph_handle* h, const float* Y, int B, int T, float* Z) { return ssrn_common(h, Y, B, T, Z, nullptr); }
 int oph_ssrn_speakers(oph_handle* h, const float* Y, const int32_t* spk, int B, int T, float* Z, float* Z_logits) {

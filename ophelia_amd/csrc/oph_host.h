@@ -128,11 +128,12 @@ struct Options {
                                      // 0 = the launcher's choice); in -DOPH_ABLATE builds 8 also selects the 8-wave forms of the other layers
     bool no_plane_gemm = false;      // NO_PLANE_GEMM: the batched nets' split-fp16 contractions on fp32 rows (conv_gemm_bf16x3) instead of planes (plane_gemm)
     bool no_chain = false;           // NO_CHAIN: the whole-decode launch as dec_loop (generic) even where dec_chain (specialised) fits
+    bool no_fused_convt_ln = false;  // NO_FUSED_CONVT_LN: conv1d_transpose as plane_gemm + ln_rows (two launches, round 5) instead of LayerNorm inside the launch
     // spec: the option string or NULL.  Returns false (and says why) on a name this build does not know.
     bool read(const char* spec, std::string* why) {
         static const char* const known[] = {"DECODE", "RUN_ROWS", "CONE_KSPLIT", "CONE_FC_ROWS", "CONE_FC_INSPLIT", "LOOP_LOOKAHEAD", "CU_SPLIT", "NO_CU_MASK", "NO_CONE_HEAD",
                                             "NO_LOOP_QW", "NO_PREENCODE", "NO_STREAM_SSRN", "CONE_PREC", "SSRN_PREC", "TEXTENC_PREC", "STREAM_VALUE", "RUN_STAMPS", "SSRN_CHUNK",
-                                            "NO_FUSED_CONE", "PG_WAVES", "NO_PLANE_GEMM", "NO_CHAIN",
+                                            "NO_FUSED_CONE", "PG_WAVES", "NO_PLANE_GEMM", "NO_CHAIN", "NO_FUSED_CONVT_LN",
 #ifdef OPH_ABLATE
                                             "SKIP_CONE", "LOOP_ALONE", "LOOP_DBG",
 #endif
@@ -176,6 +177,7 @@ struct Options {
         stream_value = num("STREAM_VALUE", 0) != 0;
         run_stamps = flag("RUN_STAMPS");
         ssrn_chunk = std::max(0, num("SSRN_CHUNK", 40));
+        no_fused_convt_ln = flag("NO_FUSED_CONVT_LN");
         no_chain = flag("NO_CHAIN"); no_fused_cone = flag("NO_FUSED_CONE"); no_plane_gemm = flag("NO_PLANE_GEMM"); pg_waves = num("PG_WAVES", 0); if (pg_waves != 4 && pg_waves != 8) pg_waves = 0;
         return true;
     }
@@ -267,6 +269,9 @@ struct oph_handle {
     size_t act_elems = 0, raw_elems = 0;
     // the activation buffers once more as fp16 hi / lo planes, K-blocked [channel / 32][rows][32] (plane_gemm's operand): [workspace][A | B][hi | lo]
     void* actP[2][2][2] = {{{nullptr, nullptr}, {nullptr, nullptr}}, {{nullptr, nullptr}, {nullptr, nullptr}}};
+    // conv1d_transpose with its LayerNorm inside the launch (plane_gemm<.., LNF>): exchange regions per workspace set (the API stream's
+    // and the SSRN partition's launches may overlap), launch tags, and the error word (pinned: host_prog[8]) a timed-out exchange raises
+    float* d_pg_stats[2] = {nullptr, nullptr}; size_t pg_stats_bytes = 0; unsigned pg_epoch = 0; int* d_pg_err = nullptr; bool pg_ln_off = false;
     long long* d_amax = nullptr;        // oph_text2mel_graph: argmax per (utterance, frame)
     // ---- the staged batch: nB utterances, resident in HBM, utterance-major.  Text is double-buffered so that the NEXT
     // batch can be staged (oph_stage_text_next) and pre-encoded while this one decodes.
@@ -431,6 +436,8 @@ void run_dec(oph_handle* h, const DecArgs& a, const Layer& l);
 float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, int ld_in, int B, int T, int wsi, int prec,
                    float* final_out, int final_ld, int final_pad, int* out_ld, long long* out_rows, const BatchedIO& io = BatchedIO());
 int ensure_batched_capacity(oph_handle* h, int B);
+int check_convt_ln(oph_handle* h);
+bool convt_ln_fits(const oph_handle* h, int wsi);       // after a synchronisation: did a fused conv1d_transpose + LayerNorm launch time out?
 int run_encode_into(oph_handle* h, const int* dL, const int* dSpk, int B, float* KVdst, hipStream_t stream, int wsi);
 int run_encode(oph_handle* h);
 int run_ssrn_on(oph_handle* h, const float* Yrows, int ldy, int B, int T, float* Zout, int wsi = 0, float* Zlogits = nullptr, const int* dSpk = nullptr);

@@ -53,7 +53,17 @@ struct PlaneGemmArgs {
     int convt;
     int waves;                                  // 0: chosen by the launcher; 4 / 8: forced (measurement)
     int dbg;                                    // measurement only: 1 = no MFMAs (operand stream alone), 2 = no operand stream (MFMAs on whatever the LDS holds)
+    // ---- conv1d_transpose with its LayerNorm inside the launch (round 6; ln_gamma != null, N a multiple of 64): the column tiles of a
+    // row tile exchange per-row (mean, M2) partials of their 64-channel groups, every workgroup normalises its own channels and
+    // writes the rows as fp32 (Y, 2 M rows of ldy floats) and, if Yh is set, as the next layer's fp16 hi / lo planes [ldy / 32][2 M][32]
+    const float* ln_gamma; const float* ln_beta;
+    float* Y; int ldy;
+    _Float16* Yh; _Float16* Yl;
+    float* ln_stats;                            // exchange region: [row tile][N / 64 groups][256 = 128 rows x 2 phases] 16-byte granules {mean, M2, epoch, -}
+    unsigned ln_epoch;                          // tag of this launch's granules (never reused on this region)
+    int* ln_err;                                // set to 1 if a partner's granules never arrived (bounded wait: workgroups of the launch not co-resident)
 };
+size_t plane_gemm_ln_stats_bytes(int M, int N);            // size of the exchange region for a launch of M input rows
 void launch_plane_gemm(const PlaneGemmArgs& a, hipStream_t s);
 bool plane_gemm_ok(int ntaps, const int* off, int kc, bool convt);
 void launch_kblock_planes(const void* src, void* dst, int rows, int ld, hipStream_t s);      // 2-byte plane [rows][ld] -> [ld / 32][rows][32]

@@ -77,11 +77,24 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
             g.Wt = l.Wt; g.Wh = f16 ? l.Wh16 : l.Wh; g.Wl = f16 ? l.Wl16 : l.Wl; g.f16 = f16; g.ldw = 2 * l.kc; g.ntaps = 2; g.off[0] = 0; g.off[1] = -1;
             GemmArgs g2 = g;
             g2.Wt = l.Wt2; g2.Wh = f16 ? l.Wh2_16 : l.Wh2; g2.Wl = f16 ? l.Wl2_16 : l.Wl2; g2.ldw = l.kc; g2.ntaps = 1; g2.off[0] = 0; g2.H = wsraw + l.Nalloc;
+            // LayerNorm inside the launch (round 6): the launch writes the normalised rows and the next layer's planes itself
+            const bool fuse_ln = use_planes && !h->opt.no_fused_convt_ln && !h->pg_ln_off && l.ln && !last && l.N % 64 == 0 && l.N <= 1024 && !l.lcc_gate && layers[li + 1].ccat == 0 &&
+                                 h->d_pg_stats[wsi ? 1 : 0] && h->d_pg_err && plane_gemm_ln_stats_bytes(M, l.N) <= h->pg_stats_bytes && convt_ln_fits(h, wsi);
             if (use_planes) {    // both phases as one problem on the planes
                 PlaneGemmArgs pg{};
                 pg.Ah = xh; pg.Al = xl; pg.Wh = (const _Float16*)l.Wkh; pg.Wl = (const _Float16*)l.Wkl; pg.Wh2 = (const _Float16*)l.Wkh2; pg.Wl2 = (const _Float16*)l.Wkl2;
                 pg.bias = l.bias; pg.H = wsraw; pg.M = M; pg.N = l.N; pg.kc = l.kc; pg.T = Tcur; pg.nalloc = l.Nalloc; pg.ldh = 2 * l.Nalloc;
                 pg.ntaps = 2; pg.off[0] = 0; pg.off[1] = -1; pg.convt = 1; pg.waves = h->opt.pg_waves;
+                if (fuse_ln) {
+                    if (h->pg_epoch > 0xF0000000u) {          // tag wrap guard: start over from zeroed regions
+                        hipDeviceSynchronize();
+                        for (float* p_ : h->d_pg_stats) if (p_) hipMemset(p_, 0, h->pg_stats_bytes);
+                        h->pg_epoch = 0;
+                    }
+                    pg.ln_gamma = l.g1; pg.ln_beta = l.b1; pg.Y = y; pg.ldy = ldy;
+                    if (write_planes) { pg.Yh = (_Float16*)h->actP[wsi ? 1 : 0][flip][0]; pg.Yl = (_Float16*)h->actP[wsi ? 1 : 0][flip][1]; }
+                    pg.ln_stats = h->d_pg_stats[wsi ? 1 : 0]; pg.ln_epoch = ++h->pg_epoch; pg.ln_err = h->d_pg_err;
+                }
                 h->pbegin(PC_PLANEGEMM);
                 launch_plane_gemm(pg, g_cur);
                 h->pend(PC_PLANEGEMM, ((double)g.M * l.cin + 2.0 * g.M * g.N + 3.0 * g.N * l.cin) * 4.0, 2.0 * g.M * g.N * 3.0 * l.cin);
@@ -95,7 +108,7 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
             Tcur *= 2;
             e.ldh = l.Nalloc; e.M = B * Tcur; e.C = l.cout; e.mode = PRE_CONV; e.act = ACT_NONE;
             if (write_planes) { e.planes = 1; e.Yh = h->actP[wsi ? 1 : 0][flip][0]; e.Yl = h->actP[wsi ? 1 : 0][flip][1]; }
-            run_epi(h, e);
+            if (!fuse_ln) run_epi(h, e);
         } else {
             const bool f16 = prec >= 2;
             g.nprod = prec == 3 ? 2 : (prec == 4 ? 1 : 3);
@@ -134,6 +147,23 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
     return x;
 }
 
+// Can the column tiles of a row tile of the fused conv1d_transpose + LayerNorm launch be resident together on every XCD of the stream
+// the workspace set `wsi` runs on?  They wait for each other's statistics (up to 8 workgroups of one row tile per XCD, one per CU).
+bool convt_ln_fits(const oph_handle* h, int wsi) {
+    int ncu = 0;
+    if (wsi && h->mask_words > 0) for (int i = 0; i < h->mask_words; ++i) ncu += __builtin_popcount(h->m_ssrn[i]);
+    else { hipDeviceProp_t prop; ncu = hipGetDeviceProperties(&prop, h->device) == hipSuccess ? prop.multiProcessorCount : 0; }
+    return ncu / 8 >= 8;
+}
+int check_convt_ln(oph_handle* h) {
+    if (!h->host_prog || h->host_prog[8] == 0) return OPH_OK;
+    h->host_prog[8] = 0;
+    h->pg_ln_off = true;               // the handle goes on with the two-launch form
+    h->fail("conv1d_transpose + LayerNorm: the column tiles of a row tile never saw each other's statistics (time-out: workgroups of one launch "
+            "were not co-resident); this call's spectrogram is invalid, later calls use the two-launch form");
+    return OPH_ERR_DEVICE;
+}
+
 int ensure_batched_capacity(oph_handle* h, int B) {
     if (B <= h->capB) return 0;
     const oph_dims& m = h->dm;
@@ -154,6 +184,13 @@ int ensure_batched_capacity(oph_handle* h, int B) {
         if (!h->actP[w_][b_][p_]) { h->fail("out of device memory for batch %d", B); return OPH_ERR_DEVICE; }
     }
     if (!h->actA || !h->actB || !h->raw || !h->actA2 || !h->actB2 || !h->raw2) { h->fail("out of device memory for batch %d", B); return OPH_ERR_DEVICE; }
+    {   // exchange regions of the fused conv1d_transpose + LayerNorm launches (the largest: the last transposed layer's input rows)
+        h->pg_stats_bytes = plane_gemm_ln_stats_bytes((int)(rows_ssrn / 2), m.c);
+        for (int w_ = 0; w_ < 2; ++w_) h->d_pg_stats[w_] = (float*)h->dalloc<unsigned char>(h->pg_stats_bytes);      // (zero-filled)
+        void* dp = nullptr;
+        if (h->host_prog && hipHostGetDevicePointer(&dp, (void*)h->host_prog, 0) == hipSuccess) { h->d_pg_err = (int*)dp + 8; h->host_prog[8] = 0; }
+        (void)hipGetLastError();
+    }
     h->capB = B;
     return 0;
 }

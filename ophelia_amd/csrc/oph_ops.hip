@@ -180,6 +180,20 @@ int oph_op_conv1d_transpose_prec(int device, const float* x, int B, int T, int C
             pg.Ah = (const _Float16*)dxh; pg.Al = (const _Float16*)dxl; pg.Wh = (const _Float16*)kweh; pg.Wl = (const _Float16*)kwel;
             pg.Wh2 = (const _Float16*)kwoh; pg.Wl2 = (const _Float16*)kwol; pg.bias = dbias; pg.H = dh; pg.M = M; pg.N = Cout; pg.kc = kc; pg.T = T;
             pg.nalloc = Nalloc; pg.ldh = 2 * Nalloc; pg.ntaps = 2; pg.off[0] = 0; pg.off[1] = -1; pg.convt = 1;
+            if (Cout % 64 == 0 && Cout <= 1024) {       // the SSRN path's launch since round 6: LayerNorm inside (the statistics cross the column tiles)
+                float* dst = (float*)c.alloc<unsigned char>(plane_gemm_ln_stats_bytes(M, Cout));
+                int* derr = c.alloc<int>(1);
+                if (!c.ok) return OPH_ERR_DEVICE;
+                hipMemsetAsync(dst, 0, plane_gemm_ln_stats_bytes(M, Cout), c.s); hipMemsetAsync(derr, 0, 4, c.s);
+                pg.ln_gamma = dg; pg.ln_beta = db; pg.Y = dy; pg.ldy = Cout; pg.ln_stats = dst; pg.ln_epoch = 1; pg.ln_err = derr;
+                launch_plane_gemm(pg, c.s);
+                int herr = 0;
+                hipMemcpyAsync(&herr, derr, 4, hipMemcpyDeviceToHost, c.s);
+                hipMemcpyAsync(y, dy, (size_t)2 * M * Cout * 4, hipMemcpyDeviceToHost, c.s);
+                const int rc = c.finish();
+                if (rc == OPH_OK && herr) { g_op_error = "conv1d_transpose + LayerNorm: statistics exchange timed out"; return OPH_ERR_DEVICE; }
+                return rc;
+            }
             launch_plane_gemm(pg, c.s);
         } else
             launch_conv_gemm_pair(g, g2, precision, c.s);
@@ -246,7 +260,17 @@ int oph_bench_conv1d_transpose(int device, int B, int T, int Cin, int Cout, int 
         launch_kblock_planes(dweh, kweh, Nalloc, 2 * kc, c.s); launch_kblock_planes(dwel, kwel, Nalloc, 2 * kc, c.s);
         launch_kblock_planes(dwoh, kwoh, Nalloc, kc, c.s); launch_kblock_planes(dwol, kwol, Nalloc, kc, c.s);
     }
-    if (precision == 5) precision = 2;
+    // precision 10: the round-5 launches of the default arithmetic (plane_gemm writing raw rows + ln_rows), for comparison with the
+    // fused launch (precision 2 since round 6)
+    const bool two_launch = precision == 10;
+    if (precision == 5 || precision == 10) precision = 2;
+    const bool fused = planes && !two_launch && pg_dbg == 0 && Cout % 64 == 0 && Cout <= 1024;
+    float* dst = nullptr; int* derr = nullptr; unsigned epoch = 0;
+    if (fused) {
+        dst = (float*)c.alloc<unsigned char>(plane_gemm_ln_stats_bytes(M, Cout)); derr = c.alloc<int>(1);
+        if (!c.ok) return OPH_ERR_DEVICE;
+        hipMemsetAsync(dst, 0, plane_gemm_ln_stats_bytes(M, Cout), c.s); hipMemsetAsync(derr, 0, 4, c.s);
+    }
     hipStreamSynchronize(c.s);
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { g_op_error = "event creation failed"; return OPH_ERR_DEVICE; }
@@ -256,6 +280,12 @@ int oph_bench_conv1d_transpose(int device, int B, int T, int Cin, int Cout, int 
             pg.Ah = (const _Float16*)dxh; pg.Al = (const _Float16*)dxl; pg.Wh = (const _Float16*)kweh; pg.Wl = (const _Float16*)kwel;
             pg.Wh2 = (const _Float16*)kwoh; pg.Wl2 = (const _Float16*)kwol; pg.bias = dbias; pg.H = dh; pg.M = M; pg.N = Cout; pg.kc = kc; pg.T = T;
             pg.nalloc = Nalloc; pg.ldh = 2 * Nalloc; pg.ntaps = 2; pg.off[0] = 0; pg.off[1] = -1; pg.convt = 1; pg.dbg = pg_dbg;
+            if (fused) {
+                pg.ln_gamma = dg; pg.ln_beta = db; pg.Y = dy; pg.ldy = Cout; pg.Yh = (_Float16*)dyh; pg.Yl = (_Float16*)dyl;
+                pg.ln_stats = dst; pg.ln_epoch = ++epoch; pg.ln_err = derr;
+                launch_plane_gemm(pg, c.s);
+                return;
+            }
             launch_plane_gemm(pg, c.s);
             EpiArgs e{};
             e.H = dh; e.ldh = Nalloc; e.M = 2 * M; e.C = Cout; e.mode = PRE_CONV; e.act = ACT_NONE; e.g1 = dg; e.b1 = db; e.Y = dy; e.ldy = Cout; e.ypad = round_up(Cout, 32);
@@ -283,6 +313,11 @@ int oph_bench_conv1d_transpose(int device, int B, int T, int Cin, int Cout, int 
     if (er == hipSuccess) er = hipEventElapsedTime(&ms, e0, e1);
     hipEventDestroy(e0); hipEventDestroy(e1);
     if (er != hipSuccess) { g_op_error = hipGetErrorString(er); return OPH_ERR_DEVICE; }
+    if (fused) {
+        int herr = 0;
+        hipMemcpy(&herr, derr, 4, hipMemcpyDeviceToHost);
+        if (herr) { g_op_error = "conv1d_transpose + LayerNorm: statistics exchange timed out"; return OPH_ERR_DEVICE; }
+    }
     *avg_us = (double)ms * 1e3 / iters;
     // per input row Cin*4 B in + 2*Cout*4 B out, + the 3*Cin*Cout weights once per call; 2*3*Cin*Cout flop per input row
     if (alg_bytes) *alg_bytes = ((double)M * Cin + 2.0 * M * Cout + 3.0 * Cin * Cout) * 4.0;

@@ -63,7 +63,15 @@ template <int NT, bool CONVT, int WV> struct PlaneGemmCfg {
     static constexpr size_t LDS_BYTES = (size_t)STAGES * STAGE * 2 > (size_t)128 * LDO * 4 ? (size_t)STAGES * STAGE * 2 : (size_t)128 * LDO * 4;
 };
 
-template <int NT, bool CONVT, int WV = 4, int DBG = 0>        // DBG (measurement only): 1 = no MFMAs, 2 = no operand stream in the loop, 4 = no stores, 8 = three K blocks
+// LNF (round 6, transposed convolution only): the layer's LayerNorm (modules.py:47-75, 252-256) inside the launch.  Until round 5 D_4 / D_7
+// were two launches -- this kernel writing raw rows, ln_rows re-reading them (10 of D_4's 32 us).  Here the column
+// tiles of a row tile (8 x 64 channels, or 4 x 128) sit on ONE XCD with consecutive ids (workgroup b -> XCD b % 8), exchange per-row
+// partial statistics of their 64-channel groups as 16-byte {mean, M2, epoch} granules (write-through stores, sc1 loads, the data is
+// its own flag: hc_fused's exchange), pool them exactly (Chan et al.) in a fixed order, normalise their own channels in the staged
+// output tile and store fp32 rows + the next layer's planes.  The partials are always per 64-channel group, whatever the form
+// (4 or 8 waves): a streamed SSRN chunk (few rows: 4 waves) reproduces the one-piece evaluation (8 waves) bit for bit.
+constexpr long long PG_LN_TIMEOUT_TICKS = 200000000LL;     // 2 s of the 100 MHz clock
+template <int NT, bool CONVT, int WV = 4, int DBG = 0, bool LNF = false>        // DBG (measurement only): 1 = no MFMAs, 2 = no operand stream in the loop, 4 = no stores, 8 = three K blocks
 __global__ __launch_bounds__(64 * WV, 1) void plane_gemm(PlaneGemmArgs a) {      // (one workgroup per CU: two of a k = 1 layer's -- 68 KB each -- measured 115 us against 103)
     static_assert(!CONVT || NT == 2, "transposed convolution: taps x[t], x[t-1]");
     typedef PlaneGemmCfg<NT, CONVT, WV> Cfg;
@@ -75,15 +83,25 @@ __global__ __launch_bounds__(64 * WV, 1) void plane_gemm(PlaneGemmArgs a) {     
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int MT = (a.M + 127) / 128, NTL = (a.N + BNC - 1) / BNC;
     const int ntiles = MT * NTL;
-    int id;
-    {   // XCD-aware bijective remap (workgroups b, b + 8, .. share an XCD / L2): a contiguous chunk of tiles per XCD
-        const int bid = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    int tm, tn;
+    if constexpr (LNF) {
+        // the NTL column tiles of a row tile exchange statistics: ids {8 NTL q + 8 k + x : k} = row tile 8 q + x -- one XCD, consecutive
+        // in that XCD's dispatch order, so the partners of a waiting workgroup are resident or next in line (no dead-lock as long as an
+        // XCD holds NTL workgroups of this launch at a time: plane_gemm_ln_fits)
+        const int bid = blockIdx.x, xcd = bid & 7;
+        tn = (bid >> 3) % NTL; tm = (bid >> 3) / NTL * 8 + xcd;
+        if (tm >= MT) return;                        // (grid padded to whole groups of 8 row tiles)
+    } else {
+        int id;
+        {   // XCD-aware bijective remap (workgroups b, b + 8, .. share an XCD / L2): a contiguous chunk of tiles per XCD
+            const int bid = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
+            id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        }
+        constexpr int GM = 8;                            // 8 row tiles x all column tiles per group: both panels stay in the L2
+        const int width = GM * NTL, g = id / width, first_m = g * GM;
+        const int gsz = min(MT - first_m, GM);
+        tm = first_m + (id % width) % gsz; tn = (id % width) / gsz;
     }
-    constexpr int GM = 8;                            // 8 row tiles x all column tiles per group: both panels stay in the L2
-    const int width = GM * NTL, g = id / width, first_m = g * GM;
-    const int gsz = min(MT - first_m, GM);
-    const int tm = first_m + (id % width) % gsz, tn = (id % width) / gsz;
     const int m0 = tm * 128, n0 = tn * BNC;
 
     // ---- what each lane copies.  A piece = 64 lanes x 16 B = 16 LDS rows of 64 B; lane -> (row lane >> 2, 16-byte position
@@ -301,6 +319,104 @@ __global__ __launch_bounds__(64 * WV, 1) void plane_gemm(PlaneGemmArgs a) {     
             for (int e = 0; e < 16; ++e) Os[(wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh) * LDO + cl] = acc[i][jn][e] + bv;
         }
     __syncthreads();
+    if constexpr (LNF) {
+        static_assert(CONVT, "the fused LayerNorm serves the transposed convolution");
+        // ---- LayerNorm of the 256 output rows of this tile (input row r, phase p -> output row 2 (m0 + r) + p) over all a.N channels
+        constexpr int NG = BNC / 64;                               // 64-channel groups per phase in this workgroup (1: 4 waves, 2: 8 waves)
+        static_assert(64 * WV == 256 * NG, "one (row, phase, group) task per thread");
+        __shared__ float srow[256][2];                             // mean, rstd per (row, phase)
+        const int rp = tid / NG, gq = tid % NG, r = rp >> 1, p = rp & 1;
+        const int ngt = a.N >> 6, gt = (n0 >> 6) + gq;             // groups of a row; this thread's
+        float* const xs = Os + r * LDO + p * BNC + gq * 64;
+        float mean_g, m2_g;
+        {
+            f32x4 v[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) v[c] = *(const f32x4*)(xs + 4 * c);
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+            mean_g = s * (1.0f / 64.0f);
+            float q = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float dl = v[c][e] - mean_g; q = fmaf(dl, dl, q); }
+            m2_g = q;
+        }
+        float* const region = a.ln_stats + (size_t)tm * ngt * 256 * 4;
+        {
+            f32x4 g;
+            g[0] = mean_g; g[1] = m2_g; g[2] = __uint_as_float(a.ln_epoch); g[3] = 0.f;
+            st_sc1_b128(region, (unsigned)((gt * 256 + rp) * 16), g);
+        }
+        // gather the row's ngt partials (its own among them, from memory like the others: the same bits in every form)
+        float mean = 0.f, rstd = 0.f;
+        {
+            long long t0 = 0;
+            for (int it = 0;; ++it) {
+                float gm[16], gq2[16];                       // (N <= 1024: at most 16 groups; constant trip counts keep them in registers)
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (j < ngt) {
+                        const f32x4 g = ld_sc1_b128(region, (unsigned)((j * 256 + rp) * 16));
+                        gm[j] = g[0]; gq2[j] = g[1];
+                        ok = ok && __float_as_uint(g[2]) == a.ln_epoch;
+                    } else { gm[j] = 0.f; gq2[j] = 0.f; }
+                }
+                bool give_up = false;
+                if (!__all(ok) && it >= 64 && (it & 63) == 0) {
+                    const long long now = wall_clock64();
+                    if (t0 == 0) t0 = now;
+                    give_up = now - t0 > PG_LN_TIMEOUT_TICKS || __hip_atomic_load(a.ln_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+                    if (give_up && lane == 0) __hip_atomic_store(a.ln_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (pinned host word)
+                }
+                if (__all(ok) || give_up) {
+                    float sm = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) sm += gm[j];
+                    mean = sm / (float)ngt;
+                    float q = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) q += gq2[j];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) if (j < ngt) { const float dl = gm[j] - mean; q = fmaf(64.0f * dl, dl, q); }
+                    rstd = fast_rsqrt(q / (float)a.N + LN_EPS);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        if (gq == 0) { srow[rp][0] = mean; srow[rp][1] = rstd; }
+        __syncthreads();
+        // ---- normalise, store fp32 rows and the next layer's planes: thread <-> (row, 4 consecutive channels of one phase)
+        constexpr int C4 = NCOLS / 4, ITS = 128 * C4 / (64 * WV), PC4 = BNC / 4;
+        const int c4 = tid % C4;                                   // (64 WV is a multiple of C4: the same columns in every iteration)
+        const int ph = c4 / PC4, ch = n0 + (c4 % PC4) * 4;
+        const f32x4 gv = *(const f32x4*)(a.ln_gamma + ch), bv = *(const f32x4*)(a.ln_beta + ch);
+        const size_t rows2 = (size_t)2 * a.M;
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+            const int idx = it * 64 * WV + tid, row = idx / C4;
+            if (m0 + row >= a.M) continue;
+            f32x4 v = *(const f32x4*)(Os + row * LDO + c4 * 4);
+            const float mu = srow[row * 2 + ph][0], rs = srow[row * 2 + ph][1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (v[e] - mu) * rs * gv[e] + bv[e];
+            const size_t orow = (size_t)2 * (m0 + row) + ph;
+            *(f32x4*)(a.Y + orow * a.ldy + ch) = v;
+            if (a.Yh) {
+                h16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { hi[e] = (h16)v[e]; lo[e] = (h16)(v[e] - (float)hi[e]); }
+                const size_t o = ((size_t)(ch >> 5) * rows2 + orow) * 32 + (ch & 31);
+                *(h16x4*)(a.Yh + o) = hi;
+                *(h16x4*)(a.Yl + o) = lo;
+            }
+        }
+        return;
+    }
     if constexpr (!(DBG & 4)) {
         constexpr int C4 = NCOLS / 4, ITS = 128 * C4 / (64 * WV);      // 16-byte pieces per row; per thread
         auto out = [&](auto guarded) {
@@ -319,7 +435,7 @@ __global__ __launch_bounds__(64 * WV, 1) void plane_gemm(PlaneGemmArgs a) {     
     }
 }
 
-template <int NT, bool CONVT, int WV = 4, int DBG = 0>
+template <int NT, bool CONVT, int WV = 4, int DBG = 0, bool LNF = false>
 static void launch_plane_gemm_t(const PlaneGemmArgs& a, hipStream_t s) {
     typedef PlaneGemmCfg<NT, CONVT, WV> Cfg;
     constexpr size_t lds = Cfg::LDS_BYTES;
@@ -327,12 +443,14 @@ static void launch_plane_gemm_t(const PlaneGemmArgs& a, hipStream_t s) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr_set[dev & 63]) {
-        (void)hipFuncSetAttribute((const void*)plane_gemm<NT, CONVT, WV, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)plane_gemm<NT, CONVT, WV, DBG, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set[dev & 63] = true;
     }
     const int MT = (a.M + 127) / 128, NTL = (a.N + Cfg::BNC - 1) / Cfg::BNC;
-    hipLaunchKernelGGL((plane_gemm<NT, CONVT, WV, DBG>), dim3(MT * NTL), dim3(64 * WV), lds, s, a);
+    const int grid = LNF ? (MT + 7) / 8 * 8 * NTL : MT * NTL;          // (fused LayerNorm: whole groups of 8 row tiles, see the kernel)
+    hipLaunchKernelGGL((plane_gemm<NT, CONVT, WV, DBG, LNF>), dim3(grid), dim3(64 * WV), lds, s, a);
 }
+size_t plane_gemm_ln_stats_bytes(int M, int N) { return (size_t)((M + 127) / 128) * (size_t)(N >> 6) * 256 * 16; }
 // a.convt: conv1d_transpose (taps x[t], x[t-1] on the even phase's planes Wh / Wl, x[t] on the odd phase's Wh2 / Wl2; raw rows
 // interleaved, a.ldh = 2 Nalloc); otherwise a.ntaps = 1 or 3 taps at offsets a.off[] (|offset| <= PLANE_GEMM_HALO).
 // a.waves: 0 = chosen here, 4 / 8 forced (measurement)
@@ -347,6 +465,10 @@ void launch_plane_gemm(const PlaneGemmArgs& a, hipStream_t s) {
 #endif
         // more 64-channel workgroups than CUs would take two rounds at one per CU: 128 channels per workgroup, 8 waves
         const bool wide = a.waves ? a.waves == 8 : (MT * ((a.N + 63) / 64) > 256 && a.N % 128 == 0);
+        if (a.ln_gamma) {          // LayerNorm inside the launch (the caller has checked N % 64 == 0, N <= 1024 and the exchange region)
+            if (wide) launch_plane_gemm_t<2, true, 8, 0, true>(a, s); else launch_plane_gemm_t<2, true, 4, 0, true>(a, s);
+            return;
+        }
         if (wide) launch_plane_gemm_t<2, true, 8>(a, s); else launch_plane_gemm_t<2, true, 4>(a, s);
     } else if (a.ntaps == 1) {
 #ifdef OPH_ABLATE      // (the 8-wave forms of the k = 1 / 3-tap layers measured slower, DESIGN.md section 10.7: measurement builds only)

@@ -27,6 +27,29 @@ def test_bench_spawns_the_requested_ranks():
     assert out["n_gpus"] == 2 and out["max_rank_plus_1"] == 2.0
 
 
+def test_bench_plumbing_at_world_8():
+    """The shape the driver's 8-GPU run has: eight ranks from one command, one line from rank 0, every rank on its
+    own device index and -- where the host has the cores -- on its own slice of them; a node with fewer than two cores per rank
+    is reported (this container has 8)."""
+    res = _run(["--gpus", "8", "--spawn-selftest"], timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["max_rank_plus_1"] == 8.0
+    ranks = sorted(out["ranks"], key=lambda r: r["rank"])
+    assert [r["rank"] for r in ranks] == list(range(8)) and [r["device"] for r in ranks] == [r["local_rank"] for r in ranks] == list(range(8))
+    assert len(set(r["pid"] for r in ranks)) == 8
+    nproc = out["host_nproc"]
+    if nproc >= 8:
+        slices = [tuple(r["cores"]) for r in ranks]
+        assert all(len(s) == nproc // 8 for s in slices)
+        assert len(set(c for s in slices for c in s)) == 8 * (nproc // 8)          # disjoint
+    if nproc < 16:
+        assert out["host_warning"] and "16" in out["host_warning"]
+        assert "host cores for 8 ranks" in res.stderr
+
+
 def test_bench_refuses_a_mismatching_launcher():
     res = _run(["--gpus", "4", "--spawn-selftest"], {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "2",
                                                      "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})

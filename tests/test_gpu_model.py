@@ -189,7 +189,8 @@ def test_plane_gemm_wave_forms_and_the_row_kernel_agree(c2):
     Y0 = np.random.default_rng(5).random((16, hp.max_T, hp.n_mels), dtype=np.float32)
     Z0 = O.synth_mel2mag(hp, W, Y0)
     out = {}
-    for name, opts in (("default", None), ("waves4", {"PG_WAVES": 4}), ("waves8", {"PG_WAVES": 8}), ("rows", {"NO_PLANE_GEMM": 1})):
+    for name, opts in (("default", None), ("waves4", {"PG_WAVES": 4}), ("waves8", {"PG_WAVES": 8}), ("rows", {"NO_PLANE_GEMM": 1}),
+                       ("two_launch_ln", {"NO_FUSED_CONVT_LN": 1})):      # D_4 / D_7 as plane_gemm + ln_rows (round 5) instead of LayerNorm inside the launch
         e = _engine(hp, W, opts)                    # launch-path options of oph_create_opts
         out[name] = e.ssrn(Y0)
         e.close()
@@ -198,6 +199,7 @@ def test_plane_gemm_wave_forms_and_the_row_kernel_agree(c2):
         assert np.abs(Z - Z0).max() < TOL
     assert np.array_equal(out["waves4"], out["waves8"]) and np.array_equal(out["default"], out["waves4"])
     assert np.abs(out["rows"] - out["default"]).max() < 2e-5
+    assert np.abs(out["two_launch_ln"] - out["default"]).max() < 2e-5       # (pooled statistics instead of a two-pass row: last bits)
 
 
 def test_pipelined_batches_equal_sequential(c2):
