@@ -79,7 +79,7 @@ def test_mel2mag_chunking_is_py2_integer_division():
     calls = []
     orig = O.ssrn
     try:
-        O.ssrn = lambda hp_, Yb, W: (None, calls.append(len(Yb)) or np.zeros((len(Yb), 1, 1), np.float32))
+        O.ssrn = lambda hp_, Yb, W, speakers=None: (None, calls.append(len(Yb)) or np.zeros((len(Yb), 1, 1), np.float32))
         O.synth_mel2mag(hp, None, np.zeros((300, 1, 1), np.float32), batchsize=128)
     finally:
         O.ssrn = orig
