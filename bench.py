@@ -95,6 +95,24 @@ def pin_rank_to_cores(local_rank, world):
     return info
 
 
+def thread_cpu_seconds():
+    """{tid: (comm, user + system seconds)} of this process's threads (Linux /proc): which thread burns the host CPU a rank needs"""
+    out = {}
+    try:
+        tick = os.sysconf("SC_CLK_TCK")
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                f = open("/proc/self/task/%s/stat" % tid).read()
+                comm = f[f.index("(") + 1:f.rindex(")")]
+                rest = f[f.rindex(")") + 2:].split()
+                out[int(tid)] = (comm, (int(rest[11]) + int(rest[12])) / float(tick))
+            except (OSError, ValueError, IndexError):
+                pass
+    except (OSError, ValueError, AttributeError):
+        pass
+    return out
+
+
 class HP(object):
     pass
 
@@ -474,10 +492,15 @@ def main():
     eng.loop_clock(reset=True)                  # ... and the kernel's own first-in / last-out clock stamps
     t0 = time.perf_counter()
     cpu0 = time.process_time()
+    thr0 = thread_cpu_seconds()
     for _ in range(a.steps):
         h2h_step()
     eng.synchronize()
     host_cpu_s = time.process_time() - cpu0         # host CPU this rank burnt driving its GPU (all threads of the process)
+    thr1 = thread_cpu_seconds()
+    t_region = time.perf_counter() - t0
+    # ... and which threads: [name, cores] of the busiest four (the enqueue thread is this one, "python"; the rest belong to the runtime)
+    thr_top = sorted(((c, round((s - thr0.get(tid, (c, 0.0))[1]) / t_region, 3)) for tid, (c, s) in thr1.items()), key=lambda x: -x[1])[:4]
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -504,12 +527,13 @@ def main():
         mine = {"rank": rank, "local_rank": local_rank, "device": eng.device, "host": socket.gethostname(), "pid": os.getpid(),
                 "gpu": torch.cuda.get_device_name(eng.device) if torch.cuda.is_available() else None,
                 "gpu_uuid": str(getattr(torch.cuda.get_device_properties(eng.device), "uuid", "")) if torch.cuda.is_available() else None,
-                "recoveries": eng.counters()["recoveries"], "masked_streams": eng.counters()["masked_streams"]}
+                "recoveries": eng.counters()["recoveries"], "masked_streams": eng.counters()["masked_streams"],
+                "degraded_left": eng.counters()["degraded_left"], "host_threads": thr_top, "cores": host["cores"] and [host["cores"][0], host["cores"][-1]]}
         rank_info = [None] * world
         dist.all_gather_object(rank_info, mine)
     else:
         rank_info = [{"rank": 0, "local_rank": local_rank, "device": eng.device, "recoveries": eng.counters()["recoveries"],
-                      "masked_streams": eng.counters()["masked_streams"]}]
+                      "masked_streams": eng.counters()["masked_streams"], "host_threads": thr_top}]
 
     # Watchdog over everything that follows (the supplementary legs, the per-class profile, the vocoder leg, the CPU baseline): the
     # timed region is over and its numbers are final, so a leg that gets stuck must not cost the run its line -- after

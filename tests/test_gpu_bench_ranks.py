@@ -39,10 +39,11 @@ def test_bench_two_ranks_on_one_gpu():
     assert "all ranks on one GPU" in cfg["parallelism"]
     assert len(cfg["recoveries"]) == 2 and all(n >= 0 for n in cfg["recoveries"])      # per rank; > 0 only when the ranks collided
     # host CPU per rank over the 10 timed steps: REPORTED (DESIGN section 7 has the measured figures per mode); two ranks time-slicing
-    # one GPU is not a production shape and a recovery puts a rank on the per-step launch path, so the only thing asserted is
-    # that the figure is a sane fraction of the region (a throughput-hygiene number must not void the parity record)
-    print("rank_host_cores", cfg["rank_host_cores"], "recoveries", cfg["recoveries"])
-    assert len(cfg["rank_host_cores"]) == 2 and all(0.0 < c < 1.5 for c in cfg["rank_host_cores"]), cfg["rank_host_cores"]
+    # one GPU is not a production shape and a recovery puts a rank on the per-step launch path, so nothing is asserted about
+    # its size (measured on one box: 0.1 - 0.5 of a core on the whole-decode path, 1.5 - 1.8 while a rank is on the per-step paths after a
+    # collision -- the enqueue thread plus a runtime thread; a throughput-hygiene number must not void the parity record)
+    print("rank_host_cores", cfg["rank_host_cores"], "recoveries", cfg["recoveries"], "busiest threads", [r.get("host_threads") for r in cfg["ranks"]])
+    assert len(cfg["rank_host_cores"]) == 2 and all(c > 0.0 for c in cfg["rank_host_cores"]), cfg["rank_host_cores"]
 
 
 def test_bench_line_survives_a_stuck_supplementary_leg():
