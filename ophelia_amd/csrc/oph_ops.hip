@@ -239,7 +239,14 @@ int oph_bench_conv1d_transpose(int device, int B, int T, int Cin, int Cout, int 
     // precision 2 (the SSRN path's default): the input arrives as fp16 hi / lo planes (written by the previous layer's LayerNorm launch),
     // and this layer's LayerNorm launch writes planes for the next layer beside its fp32 rows; precision 5: the round-3 launches
     // (fp32 rows split inside the paired contraction)
-    int pg_dbg = 0;
+    int pg_dbg = 0, ln_dbg = 0;
+    if (precision == 11 || precision == 12) {          // measurement builds: the fused launch without its wait (11) / without its plane stores (12)
+#ifdef OPH_ABLATE
+        ln_dbg = precision == 11 ? 16 : 32; precision = 2;
+#else
+        g_op_error = "precisions 11, 12 exist only in measurement builds of the library (ABLATE)"; return OPH_ERR_UNSUPPORTED;
+#endif
+    }
     if (precision >= 6 && precision <= 9) {
 #ifdef OPH_ABLATE
         pg_dbg = 1 << (precision - 6); precision = 2;
@@ -247,7 +254,7 @@ int oph_bench_conv1d_transpose(int device, int B, int T, int Cin, int Cout, int 
         g_op_error = "precisions 6..9 (ablation builds of plane_gemm) exist only in measurement builds of the library (ABLATE)"; return OPH_ERR_UNSUPPORTED;
 #endif
     }      // measurement only: plane_gemm without its MFMAs / without its operand stream
-    const bool planes = precision == 2;
+    const bool planes = precision == 2 || precision == 10;      // (10: the round-5 form -- the same operands, plane_gemm + ln_rows)
     unsigned short *dxh = nullptr, *dxl = nullptr, *dyh = nullptr, *dyl = nullptr, *kweh = nullptr, *kwel = nullptr, *kwoh = nullptr, *kwol = nullptr;
     if (planes) {
         dxh = c.alloc<unsigned short>((size_t)M * kc); dxl = c.alloc<unsigned short>((size_t)M * kc);
@@ -282,7 +289,7 @@ int oph_bench_conv1d_transpose(int device, int B, int T, int Cin, int Cout, int 
             pg.nalloc = Nalloc; pg.ldh = 2 * Nalloc; pg.ntaps = 2; pg.off[0] = 0; pg.off[1] = -1; pg.convt = 1; pg.dbg = pg_dbg;
             if (fused) {
                 pg.ln_gamma = dg; pg.ln_beta = db; pg.Y = dy; pg.ldy = Cout; pg.Yh = (_Float16*)dyh; pg.Yl = (_Float16*)dyl;
-                pg.ln_stats = dst; pg.ln_epoch = ++epoch; pg.ln_err = derr;
+                pg.ln_stats = dst; pg.ln_epoch = ++epoch; pg.ln_err = derr; pg.dbg = ln_dbg;
                 launch_plane_gemm(pg, c.s);
                 return;
             }

@@ -180,6 +180,14 @@ __global__ __launch_bounds__(64 * WV, 1) void plane_gemm(PlaneGemmArgs a) {     
     float bias_v[TNW];                               // (requested before the K loop: no round trip between the loop and the stores)
 #pragma unroll
     for (int jn = 0; jn < TNW; ++jn) bias_v[jn] = a.bias[CONVT ? n0 + wc * 32 + r32 : n0 + wc * (128 / WC) + jn * 32 + r32];
+    // fused LayerNorm: this thread's 8 channels of the store pass (the same in every iteration) -- gamma / beta requested here, with the bias
+    f32x4 ln_g[2], ln_b[2];
+    if constexpr (LNF) {
+        constexpr int C8 = Cfg::NCOLS / 8, PC8 = BNC / 8;
+        const int ch = n0 + ((tid % C8) % PC8) * 8;
+        ln_g[0] = *(const f32x4*)(a.ln_gamma + ch); ln_g[1] = *(const f32x4*)(a.ln_gamma + ch + 4);
+        ln_b[0] = *(const f32x4*)(a.ln_beta + ch); ln_b[1] = *(const f32x4*)(a.ln_beta + ch + 4);
+    }
     f32x16 acc[2][TNW];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -325,8 +333,9 @@ __global__ __launch_bounds__(64 * WV, 1) void plane_gemm(PlaneGemmArgs a) {     
         constexpr int NG = BNC / 64;                               // 64-channel groups per phase in this workgroup (1: 4 waves, 2: 8 waves)
         static_assert(64 * WV == 256 * NG, "one (row, phase, group) task per thread");
         __shared__ float srow[256][2];                             // mean, rstd per (row, phase)
+        __shared__ float spart[256][NG][2];                        // this workgroup's own partials (its partners' come from memory)
         const int rp = tid / NG, gq = tid % NG, r = rp >> 1, p = rp & 1;
-        const int ngt = a.N >> 6, gt = (n0 >> 6) + gq;             // groups of a row; this thread's
+        const int ngt = a.N >> 6, g0 = n0 >> 6, gt = g0 + gq;      // groups of a row; this workgroup's first; this thread's
         float* const xs = Os + r * LDO + p * BNC + gq * 64;
         float mean_g, m2_g;
         {
@@ -350,7 +359,10 @@ __global__ __launch_bounds__(64 * WV, 1) void plane_gemm(PlaneGemmArgs a) {     
             g[0] = mean_g; g[1] = m2_g; g[2] = __uint_as_float(a.ln_epoch); g[3] = 0.f;
             st_sc1_b128(region, (unsigned)((gt * 256 + rp) * 16), g);
         }
-        // gather the row's ngt partials (its own among them, from memory like the others: the same bits in every form)
+        spart[rp][gq][0] = mean_g; spart[rp][gq][1] = m2_g;
+        __syncthreads();
+        // gather the row's ngt partials: this workgroup's own from LDS (the floats it stored: the same bits), the partners' from memory
+        // (sc1 loads past the L1, until every granule carries this launch's tag)
         float mean = 0.f, rstd = 0.f;
         {
             long long t0 = 0;
@@ -359,11 +371,13 @@ __global__ __launch_bounds__(64 * WV, 1) void plane_gemm(PlaneGemmArgs a) {     
                 bool ok = true;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    if (j < ngt) {
+                    const bool own = j >= g0 && j < g0 + NG;
+                    if (j < ngt && !own) {
                         const f32x4 g = ld_sc1_b128(region, (unsigned)((j * 256 + rp) * 16));
                         gm[j] = g[0]; gq2[j] = g[1];
                         ok = ok && __float_as_uint(g[2]) == a.ln_epoch;
-                    } else { gm[j] = 0.f; gq2[j] = 0.f; }
+                    } else if (own) { gm[j] = spart[rp][(j - g0) & (NG - 1)][0]; gq2[j] = spart[rp][(j - g0) & (NG - 1)][1]; }
+                    else { gm[j] = 0.f; gq2[j] = 0.f; }
                 }
                 bool give_up = false;
                 if (!__all(ok) && it >= 64 && (it & 63) == 0) {
@@ -372,6 +386,9 @@ __global__ __launch_bounds__(64 * WV, 1) void plane_gemm(PlaneGemmArgs a) {     
                     give_up = now - t0 > PG_LN_TIMEOUT_TICKS || __hip_atomic_load(a.ln_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
                     if (give_up && lane == 0) __hip_atomic_store(a.ln_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (pinned host word)
                 }
+#ifdef OPH_ABLATE
+                if (a.dbg & 16) give_up = true;           // measurement: do not wait for the partners (wrong statistics)
+#endif
                 if (__all(ok) || give_up) {
                     float sm = 0.f;
 #pragma unroll
@@ -390,29 +407,36 @@ __global__ __launch_bounds__(64 * WV, 1) void plane_gemm(PlaneGemmArgs a) {     
         }
         if (gq == 0) { srow[rp][0] = mean; srow[rp][1] = rstd; }
         __syncthreads();
-        // ---- normalise, store fp32 rows and the next layer's planes: thread <-> (row, 4 consecutive channels of one phase)
-        constexpr int C4 = NCOLS / 4, ITS = 128 * C4 / (64 * WV), PC4 = BNC / 4;
-        const int c4 = tid % C4;                                   // (64 WV is a multiple of C4: the same columns in every iteration)
-        const int ph = c4 / PC4, ch = n0 + (c4 % PC4) * 4;
-        const f32x4 gv = *(const f32x4*)(a.ln_gamma + ch), bv = *(const f32x4*)(a.ln_beta + ch);
+        // ---- normalise, store fp32 rows and the next layer's planes: thread <-> (row, 8 consecutive channels of one phase): two 16-byte
+        //      fp32 stores and one 16-byte store per plane
+        constexpr int C8 = NCOLS / 8, ITS = 128 * C8 / (64 * WV), PC8 = BNC / 8;
+        const int c8 = tid % C8;                                   // (64 WV is a multiple of C8: the same columns in every iteration)
+        const int ph = c8 / PC8, ch = n0 + (c8 % PC8) * 8;
         const size_t rows2 = (size_t)2 * a.M;
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
-            const int idx = it * 64 * WV + tid, row = idx / C4;
+            const int idx = it * 64 * WV + tid, row = idx / C8;
             if (m0 + row >= a.M) continue;
-            f32x4 v = *(const f32x4*)(Os + row * LDO + c4 * 4);
+            f32x4 v0 = *(const f32x4*)(Os + row * LDO + c8 * 8), v1 = *(const f32x4*)(Os + row * LDO + c8 * 8 + 4);
             const float mu = srow[row * 2 + ph][0], rs = srow[row * 2 + ph][1];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (v[e] - mu) * rs * gv[e] + bv[e];
+            for (int e = 0; e < 4; ++e) { v0[e] = (v0[e] - mu) * rs * ln_g[0][e] + ln_b[0][e]; v1[e] = (v1[e] - mu) * rs * ln_g[1][e] + ln_b[1][e]; }
             const size_t orow = (size_t)2 * (m0 + row) + ph;
-            *(f32x4*)(a.Y + orow * a.ldy + ch) = v;
+            *(f32x4*)(a.Y + orow * a.ldy + ch) = v0;
+            *(f32x4*)(a.Y + orow * a.ldy + ch + 4) = v1;
+#ifdef OPH_ABLATE
+            if (a.dbg & 32) continue;                     // measurement: no plane stores
+#endif
             if (a.Yh) {
-                h16x4 hi, lo;
+                h16x8 hi, lo;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { hi[e] = (h16)v[e]; lo[e] = (h16)(v[e] - (float)hi[e]); }
+                for (int e = 0; e < 4; ++e) {
+                    hi[e] = (h16)v0[e]; lo[e] = (h16)(v0[e] - (float)hi[e]);
+                    hi[4 + e] = (h16)v1[e]; lo[4 + e] = (h16)(v1[e] - (float)hi[4 + e]);
+                }
                 const size_t o = ((size_t)(ch >> 5) * rows2 + orow) * 32 + (ch & 31);
-                *(h16x4*)(a.Yh + o) = hi;
-                *(h16x4*)(a.Yl + o) = lo;
+                *(h16x8*)(a.Yh + o) = hi;
+                *(h16x8*)(a.Yl + o) = lo;
             }
         }
         return;
