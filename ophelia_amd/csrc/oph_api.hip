@@ -7,7 +7,10 @@
 #include "oph_host.h"
 
 #include <mutex>
-#include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 thread_local std::string g_create_error;
 thread_local hipStream_t g_cur = nullptr;    // stream the launch wrappers of THIS host thread target
@@ -64,9 +67,50 @@ std::recursive_mutex& device_mutex(int device) {
     std::lock_guard<std::mutex> lock(g_masked_mutex);
     return g_device_mutex[device];
 }
+// Two PROCESSES of this library on one GPU (two ranks pointed at the same device: a test shape, or a mistake) would dispatch their
+// whole-decode launches workgroup by workgroup onto the same CU partition, each get a part of it, and both run into the 2 s
+// co-residency bound before the ladder saves them (round 5: 12 of 12 such runs).  Prevention instead of recovery: the calls that put
+// work on the device take turns across processes too -- an advisory lock per physical GPU (flock on /dev/shm/ophelia_hip.<pci bus id>.lock),
+// taken with the device's mutex and released with it.  One process per GPU never waits (two system calls per API call); a process
+// that dies releases it; a holder that does not come back within 10 s is no longer waited for (the bounded in-kernel waits and the
+// ladder are still there).  It is advisory: it orders THIS library's processes, not other tenants of the GPU.
+struct GpuTurn { int fd = -2; int depth = 0; };          // fd -2: not opened yet, -1: unavailable
+std::map<int, GpuTurn> g_gpu_turn;                     // (under the device's recursive mutex)
+void gpu_turn_acquire(int device) {
+    GpuTurn& t = g_gpu_turn[device];
+    if (t.depth++ > 0) return;
+    if (t.fd == -2) {
+        char bus[64] = {0}, path[128];
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); snprintf(bus, sizeof bus, "dev%d", device); }
+        for (char* c = bus; *c; ++c) if (*c == ':' || *c == '/' || *c == '.') *c = '_';
+        snprintf(path, sizeof path, "/dev/shm/ophelia_hip.%s.lock", bus);
+        t.fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+        if (t.fd >= 0) (void)fchmod(t.fd, 0666);
+    }
+    if (t.fd < 0) return;
+    for (int i = 0; i < 50000; ++i) {                  // <= 10 s in 200 us naps
+        if (flock(t.fd, LOCK_EX | LOCK_NB) == 0) return;
+        if (errno != EWOULDBLOCK && errno != EINTR) return;
+        struct timespec ts = {0, 200000};
+        nanosleep(&ts, nullptr);
+    }
+    TRACE("another process has held this GPU's turn for 10 s: going on without it");
+}
+void gpu_turn_release(int device) {
+    GpuTurn& t = g_gpu_turn[device];
+    if (--t.depth > 0 || t.fd < 0) return;
+    (void)flock(t.fd, LOCK_UN);
+}
 struct DevGuard {
     std::unique_lock<std::recursive_mutex> lk;
-    explicit DevGuard(const oph_handle* h) { if (h) lk = std::unique_lock<std::recursive_mutex>(device_mutex(h->device)); }
+    int device = -1;
+    explicit DevGuard(const oph_handle* h) {
+        if (!h) return;
+        lk = std::unique_lock<std::recursive_mutex>(device_mutex(h->device));
+        device = h->device;
+        gpu_turn_acquire(device);
+    }
+    ~DevGuard() { if (device >= 0) gpu_turn_release(device); }      // (before lk's destructor releases the mutex: members are destroyed after the body)
 };
 }  // namespace
 
@@ -466,10 +510,12 @@ int oph_fetch_mag(oph_handle* h, float* Z) {
     DevGuard dev_guard(h);
     if (!h || !h->bKV[0] || !Z) { if (h) h->fail("no staged batch / null"); return OPH_ERR_STATE; }
     if (h->sssrn) HIPCHK(h, hipStreamSynchronize(h->sssrn));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    { const int rc = check_convt_ln(h); if (rc) return rc; }
     const oph_dims& m = h->dm;
     HIPCHK(h, hipMemcpyAsync(Z, h->bZ[h->buf], (size_t)h->nB * m.max_T * m.r * m.full_dim * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return check_convt_ln(h);
+    return OPH_OK;
 }
 
 int oph_device_mag(oph_handle* h, const float** d_mag, int64_t* utt_stride, int32_t* B) {
@@ -543,7 +589,7 @@ int oph_run_host(oph_handle* h, int stop_mode, float* K, float* V, float* Y, int
         auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         TRACE("run_host: text / K,V %.3f ms, decode_batch %.3f ms, finish_ssrn enqueue %.3f ms, final syncs %.3f ms", ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3), ms(tp3, clk::now()));
     }
-    return check_convt_ln(h);
+    return check_convt_ln(h, Z);
 }
 
 // ---- host-buffer session calls ---------------------------------------------------------------
@@ -747,7 +793,7 @@ static int ssrn_common(oph_handle* h, const float* Y, int B, int T, float* Z, fl
             HIPCHK(h, hipStreamSynchronize(h->stream));
             HIPCHK(h, hipStreamSynchronize(h->sssrn));
             HIPCHK(h, hipStreamSynchronize(h->scopy));
-            return check_convt_ln(h);
+            return check_convt_ln(h, Z);
         }
         if ((rc = finish_ssrn(h))) return rc;
         return oph_fetch_mag(h, Z);
@@ -765,16 +811,20 @@ static int ssrn_common(oph_handle* h, const float* Y, int B, int T, float* Z, fl
     }
     hipError_t e = hipMemcpyAsync(dY, Y, (size_t)B * T * m.n_mels * 4, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess && spk) e = hipMemcpyAsync(dSpk, spk, (size_t)B * 4, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) {
+    hipError_t es = hipSuccess;
+    for (int attempt = 0; attempt < 2 && e == hipSuccess; ++attempt) {
         launch_pad_rows(dY, m.n_mels, h->actB, ldy, (long long)B * T, m.n_mels, h->stream);
         rc = run_ssrn_on(h, h->actB, ldy, B, T, dZ, 0, dZl, dSpk);
         e = hipMemcpyAsync(Z, dZ, zn * 4, hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess && Z_logits) e = hipMemcpyAsync(Z_logits, dZl, zn * 4, hipMemcpyDeviceToHost, h->stream);
+        es = hipStreamSynchronize(h->stream);
+        if (rc || es != hipSuccess || !h->host_prog || h->host_prog[8] == 0) break;
+        // a fused conv1d_transpose + LayerNorm launch timed out (its workgroups were not co-resident): once more with two launches per layer
+        h->host_prog[8] = 0; h->pg_ln_off = true; h->n_recoveries++;
     }
-    const hipError_t es = hipStreamSynchronize(h->stream);
     hipFree(dY); hipFree(dZ); if (dZl) hipFree(dZl);
     if (e != hipSuccess || es != hipSuccess) { h->fail("ssrn failed: %s", hipGetErrorString(e != hipSuccess ? e : es)); return OPH_ERR_DEVICE; }
-    return rc ? rc : check_convt_ln(h);
+    return rc;
 }
 int oph_ssrn(oph_handle* h, const float* Y, int B, int T, float* Z) { return ssrn_common(h, Y, B, T, Z, nullptr); }
 int oph_ssrn_speakers(oph_handle* h, const float* Y, const int32_t* spk, int B, int T, float* Z, float* Z_logits) {

@@ -128,6 +128,8 @@ struct Options {
                                      // 0 = the launcher's choice); in -DOPH_ABLATE builds 8 also selects the 8-wave forms of the other layers
     bool no_plane_gemm = false;      // NO_PLANE_GEMM: the batched nets' split-fp16 contractions on fp32 rows (conv_gemm_bf16x3) instead of planes (plane_gemm)
     bool no_chain = false;           // NO_CHAIN: the whole-decode launch as dec_loop (generic) even where dec_chain (specialised) fits
+    bool fake_ln_timeout = false;    // -DOPH_ABLATE only: FAKE_LN_TIMEOUT: the fused conv1d_transpose launch raises its time-out word although nothing timed out
+                                     // (fault injection for the redo path: tests/test_gpu_second_client.py)
     bool no_fused_convt_ln = false;  // NO_FUSED_CONVT_LN: conv1d_transpose as plane_gemm + ln_rows (two launches, round 5) instead of LayerNorm inside the launch
     // spec: the option string or NULL.  Returns false (and says why) on a name this build does not know.
     bool read(const char* spec, std::string* why) {
@@ -135,7 +137,7 @@ struct Options {
                                             "NO_LOOP_QW", "NO_PREENCODE", "NO_STREAM_SSRN", "CONE_PREC", "SSRN_PREC", "TEXTENC_PREC", "STREAM_VALUE", "RUN_STAMPS", "SSRN_CHUNK",
                                             "NO_FUSED_CONE", "PG_WAVES", "NO_PLANE_GEMM", "NO_CHAIN", "NO_FUSED_CONVT_LN",
 #ifdef OPH_ABLATE
-                                            "SKIP_CONE", "LOOP_ALONE", "LOOP_DBG",
+                                            "SKIP_CONE", "LOOP_ALONE", "LOOP_DBG", "FAKE_LN_TIMEOUT",
 #endif
         };
         std::map<std::string, std::string> kv;
@@ -166,7 +168,7 @@ struct Options {
         fc_rows = num("CONE_FC_ROWS", -1); fc_insplit = std::max(1, num("CONE_FC_INSPLIT", 2));
         lookahead = num("LOOP_LOOKAHEAD", 8);
         loop_dbg = num("LOOP_DBG", flag("LOOP_ALONE") ? 32 : 0);        // (names a production build has refused above)
-        skip_cone = flag("SKIP_CONE");
+        skip_cone = flag("SKIP_CONE"); fake_ln_timeout = flag("FAKE_LN_TIMEOUT");
         if (const char* sp = str("CU_SPLIT")) { int a_ = 0, b_ = 0; if (sscanf(sp, "%d,%d", &a_, &b_) == 2 && a_ > 0 && b_ > 0) { cu_dec = a_; cu_cone = b_; } }
         no_cu_mask = flag("NO_CU_MASK");
         no_cone_head = flag("NO_CONE_HEAD"); no_loop_qw = flag("NO_LOOP_QW"); no_preencode = flag("NO_PREENCODE");
@@ -436,7 +438,7 @@ void run_dec(oph_handle* h, const DecArgs& a, const Layer& l);
 float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, int ld_in, int B, int T, int wsi, int prec,
                    float* final_out, int final_ld, int final_pad, int* out_ld, long long* out_rows, const BatchedIO& io = BatchedIO());
 int ensure_batched_capacity(oph_handle* h, int B);
-int check_convt_ln(oph_handle* h);
+int check_convt_ln(oph_handle* h, float* z_host = nullptr);       // after a synchronisation: did a fused conv1d_transpose + LayerNorm launch time out?  (redoes SSRN)
 bool convt_ln_fits(const oph_handle* h, int wsi);       // after a synchronisation: did a fused conv1d_transpose + LayerNorm launch time out?
 int run_encode_into(oph_handle* h, const int* dL, const int* dSpk, int B, float* KVdst, hipStream_t stream, int wsi);
 int run_encode(oph_handle* h);

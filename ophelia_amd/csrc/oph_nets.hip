@@ -94,6 +94,7 @@ float* run_batched(oph_handle* h, const std::vector<Layer>& layers, float* in, i
                     pg.ln_gamma = l.g1; pg.ln_beta = l.b1; pg.Y = y; pg.ldy = ldy;
                     if (write_planes) { pg.Yh = (_Float16*)h->actP[wsi ? 1 : 0][flip][0]; pg.Yl = (_Float16*)h->actP[wsi ? 1 : 0][flip][1]; }
                     pg.ln_stats = h->d_pg_stats[wsi ? 1 : 0]; pg.ln_epoch = ++h->pg_epoch; pg.ln_err = h->d_pg_err;
+                    if (h->opt.fake_ln_timeout) pg.dbg = 64;       // (measurement builds: fault injection)
                 }
                 h->pbegin(PC_PLANEGEMM);
                 launch_plane_gemm(pg, g_cur);
@@ -155,13 +156,29 @@ bool convt_ln_fits(const oph_handle* h, int wsi) {
     else { hipDeviceProp_t prop; ncu = hipGetDeviceProperties(&prop, h->device) == hipSuccess ? prop.multiProcessorCount : 0; }
     return ncu / 8 >= 8;
 }
-int check_convt_ln(oph_handle* h) {
+// After a synchronisation of the streams SSRN ran on: did a fused conv1d_transpose + LayerNorm launch of this batch time out (the column
+// tiles of a row tile never saw each other's statistics: workgroups of one launch were not co-resident -- another tenant on the
+// SSRN CUs)?  Its rows are garbage then.  Like the decode's ladder: the batch's SSRN is redone in the two-launch form, which needs no
+// exchange between workgroups (z_host: the host destination the redone rows are copied to, or null), the handle stays on that form, and
+// the event is counted (oph_get_counters[9]).
+int check_convt_ln(oph_handle* h, float* z_host) {
     if (!h->host_prog || h->host_prog[8] == 0) return OPH_OK;
+    for (hipStream_t st : {h->stream, h->sssrn, h->scopy}) if (st) hipStreamSynchronize(st);
     h->host_prog[8] = 0;
-    h->pg_ln_off = true;               // the handle goes on with the two-launch form
-    h->fail("conv1d_transpose + LayerNorm: the column tiles of a row tile never saw each other's statistics (time-out: workgroups of one launch "
-            "were not co-resident); this call's spectrogram is invalid, later calls use the two-launch form");
-    return OPH_ERR_DEVICE;
+    h->pg_ln_off = true;
+    h->n_recoveries++;
+    TRACE("conv1d_transpose + LayerNorm: statistics exchange timed out -- SSRN of this batch is redone with two launches per transposed layer");
+    if (!h->y_resident && !h->bYout[0]) { h->fail("conv1d_transpose + LayerNorm timed out and there are no resident frames to redo SSRN from"); return OPH_ERR_DEVICE; }
+    const bool pip = h->pipelined;
+    h->pipelined = false;              // (the redo runs now, on the API stream)
+    for (Tile& tl : h->tiles) { tl.ssrn_done = 0; tl.z_copied = 0; }
+    float* const saved = h->z_host;
+    h->z_host = z_host;
+    int rc = finish_ssrn(h);
+    h->z_host = saved;
+    h->pipelined = pip;
+    for (hipStream_t st : {h->stream, h->sssrn, h->scopy}) if (st && hipStreamSynchronize(st) != hipSuccess && !rc) { h->fail("SSRN redo failed"); rc = OPH_ERR_DEVICE; }
+    return rc;
 }
 
 int ensure_batched_capacity(oph_handle* h, int B) {

@@ -405,6 +405,9 @@ __global__ __launch_bounds__(64 * WV, 1) void plane_gemm(PlaneGemmArgs a) {     
                 __builtin_amdgcn_s_sleep(1);
             }
         }
+#ifdef OPH_ABLATE
+        if ((a.dbg & 64) && blockIdx.x == 0 && tid == 0) __hip_atomic_store(a.ln_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // fault injection
+#endif
         if (gq == 0) { srow[rp][0] = mean; srow[rp][1] = rstd; }
         __syncthreads();
         // ---- normalise, store fp32 rows and the next layer's planes: thread <-> (row, 8 consecutive channels of one phase): two 16-byte
