@@ -84,3 +84,38 @@ def test_mel2mag_chunking_is_py2_integer_division():
     finally:
         O.ssrn = orig
     assert calls == [150, 150]          # max(1, 300//128) = 2 chunks via array_split
+
+
+def test_conv1d_transpose_is_the_adjoint_of_tf_same_stride2_conv():
+    """From the documented definition rather than from another framework's kernel: tf.layers.conv2d_transpose(kernel (1, 3),
+    strides (1, 2), 'same') is the gradient (linear adjoint) of conv2d over a length-2T input with stride 2 and SAME padding, whose
+    padding rule is out = ceil(in / stride), pad_total = max((out - 1) * stride + k - in, 0), pad_left = pad_total // 2 (= 0 here,
+    1 on the right).  The forward operator is written out as an explicit matrix per (input channel, output channel) pair, transposed,
+    and compared with the oracle's closed form o[2t] = x[t].K0 + x[t-1].K2, o[2t+1] = x[t].K1 (modules.py:209-258, SURVEY [TF-sem])."""
+    rng = np.random.default_rng(7)
+    T, Cin, Cout, k, stride = 9, 5, 4, 3, 2
+    n_in = 2 * T                                        # the forward conv's input length = the transposed conv's output length
+    n_out = -(-n_in // stride)
+    assert n_out == T
+    pad_total = max((n_out - 1) * stride + k - n_in, 0)
+    pad_left = pad_total // 2
+    assert (pad_total, pad_left) == (1, 0)
+    # conv2d_transpose's kernel variable is (1, k, Cout, Cin): filters of the FORWARD conv from Cout-channel input to Cin-channel output
+    Kt = rng.standard_normal((1, k, Cout, Cin)).astype(np.float32)
+    x = rng.standard_normal((1, T, Cin)).astype(np.float32)
+    # forward: y[t, ci] = sum_j sum_co in[2 t + j - pad_left, co] * Kt[0, j, co, ci]   ->   matrix F of shape (T * Cin, 2T * Cout)
+    Fm = np.zeros((T * Cin, n_in * Cout), np.float64)
+    for t in range(T):
+        for j in range(k):
+            p = stride * t + j - pad_left
+            if 0 <= p < n_in:
+                for co in range(Cout):
+                    for ci in range(Cin):
+                        Fm[t * Cin + ci, p * Cout + co] += Kt[0, j, co, ci]
+    raw = (Fm.T @ x[0].reshape(-1).astype(np.float64)).reshape(n_in, Cout)      # the adjoint applied to x
+    W = {"D/conv2d_transpose/kernel": Kt, "D/conv2d_transpose/bias": np.zeros(Cout, np.float32),
+         "D/normalize/gamma": np.ones(Cout, np.float32), "D/normalize/beta": np.zeros(Cout, np.float32)}
+    mine = O.conv1d_transpose(x, W, "D")[0]
+    mu = raw.mean(-1, keepdims=True)
+    ref = (raw - mu) / np.sqrt(((raw - mu) ** 2).mean(-1, keepdims=True) + 1e-12)
+    assert np.abs(mine - ref).max() < 1e-5
