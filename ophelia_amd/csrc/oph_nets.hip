@@ -168,15 +168,18 @@ int check_convt_ln(oph_handle* h, float* z_host) {
     h->pg_ln_off = true;
     h->n_recoveries++;
     TRACE("conv1d_transpose + LayerNorm: statistics exchange timed out -- SSRN of this batch is redone with two launches per transposed layer");
-    if (!h->y_resident && !h->bYout[0]) { h->fail("conv1d_transpose + LayerNorm timed out and there are no resident frames to redo SSRN from"); return OPH_ERR_DEVICE; }
-    const bool pip = h->pipelined;
-    h->pipelined = false;              // (the redo runs now, on the API stream)
+    if (h->pipelined || !h->y_resident) {
+        // (pipelined batches: the frames of the batch whose SSRN tail timed out may already have been replaced by the next decode's --
+        //  nothing to redo it from.  Loud, once: the handle is on the two-launch form from here on.)
+        h->fail("conv1d_transpose + LayerNorm: the statistics exchange timed out (workgroups of one launch were not co-resident) and the batch's "
+                "frames are no longer resident to redo SSRN from: that batch's spectrogram is invalid; later batches use the two-launch form");
+        return OPH_ERR_DEVICE;
+    }
     for (Tile& tl : h->tiles) { tl.ssrn_done = 0; tl.z_copied = 0; }
     float* const saved = h->z_host;
     h->z_host = z_host;
-    int rc = finish_ssrn(h);
+    int rc = finish_ssrn(h);           // (not pipelined: on the API stream, now)
     h->z_host = saved;
-    h->pipelined = pip;
     for (hipStream_t st : {h->stream, h->sssrn, h->scopy}) if (st && hipStreamSynchronize(st) != hipSuccess && !rc) { h->fail("SSRN redo failed"); rc = OPH_ERR_DEVICE; }
     return rc;
 }
