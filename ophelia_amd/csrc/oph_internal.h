@@ -401,6 +401,13 @@ void launch_embed(const int* ids, long long n, const float* table, int units, fl
 void launch_pad_rows(const float* src, int lds_, float* dst, int ldd, long long rows, int C, hipStream_t s);
 void launch_copy_rows_strided(const float* src, long long src_bs, int ld, float* dst, int B, int T, int C, hipStream_t s);   // dst[b*T + t][:C] = src[b*src_bs + t*ld ..]
 void launch_fill_int(int* p, int v, int n, hipStream_t s);
+struct ResetTileArgs {
+    float* buf[3]; size_t n4[3];        // three buffers to zero, lengths in 16-byte units (Yout, Ytm, alignments)
+    int* p; int n_p;                    // prev_max ping-pong
+    int* tends; int n_tends; int max_T; // t_ends = max_T ("not ended")
+    int* ctl;                           // {0, INT_MAX, 0, 0}: n_ended, stop step, error, attention arrivals
+};
+void launch_reset_tile(const ResetTileArgs& a, hipStream_t s);
 void launch_spk_append_rows(float* out, int ldo, long long rows, int T, int col0, const float* table, const int* ids, int dim, hipStream_t s);
 
 }  // namespace oph

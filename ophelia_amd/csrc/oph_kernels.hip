@@ -1643,6 +1643,20 @@ __global__ __launch_bounds__(256) void fill_int_k(int* p, int v, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;
 }
+// A tile's decode state back to "nothing decoded yet" in ONE launch (synthesize.py:157-166: Y, alignments = zeros, prev_max = 0,
+// t_ends = max_T; plus this library's control words): until round 5 four memsets, a fill kernel and a 16-byte copy from the host's
+// stack -- six dependent stream operations of ~7 us each in front of every decode, and a host synchronisation to keep the stack alive.
+__global__ __launch_bounds__(256) void reset_tile_k(ResetTileArgs a) {
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = tid; i < a.n4[0]; i += nth) ((f32x4*)a.buf[0])[i] = z;
+    for (size_t i = tid; i < a.n4[1]; i += nth) ((f32x4*)a.buf[1])[i] = z;
+    for (size_t i = tid; i < a.n4[2]; i += nth) ((f32x4*)a.buf[2])[i] = z;
+    if (tid < (size_t)a.n_p) a.p[tid] = 0;
+    if (tid < (size_t)a.n_tends) a.tends[tid] = a.max_T;
+    if (tid < 4) a.ctl[tid] = tid == 1 ? INT_MAX : 0;
+}
+void launch_reset_tile(const ResetTileArgs& a, hipStream_t s) { hipLaunchKernelGGL(reset_tile_k, dim3(1024), dim3(256), 0, s, a); }
 void launch_fill_int(int* p, int v, int n, hipStream_t s) {
     hipLaunchKernelGGL(fill_int_k, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n);
 }
