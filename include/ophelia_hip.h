@@ -292,8 +292,9 @@ int oph_op_conv1d_transpose(int device, const float* x, int B, int T, int Cin, i
                             const float* beta, float* y /* (B,2T,Cout) */);
 /* The same layer through the launches the SSRN path makes at one of oph_set_precision's arithmetic codes: 0 = fp32-operand
  * MFMA (= oph_op_conv1d_transpose), 1 = split-bf16 x3 (both phases in one launch, then the LayerNorm rows), 2 = split-fp16 x3
- * (the input split into fp16 hi / lo planes as the previous layer's LayerNorm launch writes them in SSRN, both phases as one
- * plane_gemm problem, then the LayerNorm rows). */
+ * (the input split into fp16 hi / lo planes as the previous layer's launch writes them in SSRN, both phases as one plane_gemm
+ * problem with the layer's LayerNorm inside the launch -- round 6; channel counts that are not a multiple of 64 or exceed 1024:
+ * plane_gemm, then the LayerNorm rows). */
 int oph_op_conv1d_transpose_prec(int device, const float* x, int B, int T, int Cin, int Cout,
                                  const float* kernel, const float* bias, const float* gamma,
                                  const float* beta, int precision, float* y /* (B,2T,Cout) */);
@@ -303,10 +304,12 @@ int oph_op_attention(int device, const float* Q, const float* K, const float* V,
                      int64_t* max_attentions /*(B,T)*/);
 /* oph_bench_conv1d_transpose: device-resident timing of the conv1d_transpose launches (SSRN D_4 / D_7) on seeded random
  * data already in HBM -- the measurement behind bench.py's kernel_rooflines.  precision: 0 exact fp32 MFMA, 1 split-bf16 x3,
- * 2 split-fp16 x3 as SSRN runs it (operands arrive as fp16 planes, plane_gemm + LayerNorm rows that write fp32 rows and planes),
+ * 2 split-fp16 x3 as SSRN runs it (operands arrive as fp16 planes; ONE launch: plane_gemm with the LayerNorm inside, fp32 rows and
+ * planes out), 10 the same as round 5 ran it (plane_gemm + LayerNorm rows: two launches),
  * 5 split-fp16 x3 as round 3 ran it (fp32 rows split inside the paired contraction); 3 / 4: precision 5 with two / one of the
- * three products; 6..9: ablation builds of plane_gemm (no MFMAs / no operand stream / no stores / three K blocks) -- measurement only, present
- * only in a library built with -DOPH_ABLATE (OPH_ERR_UNSUPPORTED otherwise).
+ * three products; 6..9: ablation builds of plane_gemm (no MFMAs / no operand stream / no stores / three K blocks), 11 / 12: the fused
+ * launch without its wait for the partners / without its plane stores -- measurement only, present only in a library built with
+ * -DOPH_ABLATE (OPH_ERR_UNSUPPORTED otherwise).
  * Returns the average time of one layer evaluation and its ALGORITHMIC bytes / flops. */
 int oph_bench_conv1d_transpose(int device, int B, int T, int Cin, int Cout, int precision, int warmup, int iters,
                                double* avg_us, double* alg_bytes, double* alg_flops);
